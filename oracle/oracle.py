@@ -1,0 +1,160 @@
+"""ctypes loader for oracle/libisle_oracle.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never from isle_amd/ (the product must not route through the oracle).
+PARITY UNPINNED (see isle_oracle.cpp header and DESIGN.md §Oracle).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libisle_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_csc_create.restype = C.c_void_p
+        L.orc_csc_create.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_csc_destroy.argtypes = [C.c_void_p]
+        L.orc_frobenius.restype = C.c_float
+        L.orc_frobenius.argtypes = [C.c_void_p]
+        L.orc_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleCsc:
+    """Host CSC matrix B (V x D): vals f32[nnz], rows u32[nnz] ascending per column, offs i64[D+1]."""
+
+    def __init__(self, V, D, vals, rows, offs):
+        self.V, self.D = int(V), int(D)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float32)
+        self.rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        self.offs = np.ascontiguousarray(offs, dtype=np.int64)
+        self.nnz = int(self.offs[-1])
+        assert self.offs.shape[0] == self.D + 1 and self.vals.shape[0] == self.nnz
+        self.h = C.c_void_p(lib().orc_csc_create(self.V, self.D, self.nnz, _p(self.vals), _p(self.rows), _p(self.offs)))
+
+    def __del__(self):
+        try:
+            lib().orc_csc_destroy(self.h)
+        except Exception:
+            pass
+
+    def frobenius(self):
+        return float(lib().orc_frobenius(self.h))
+
+    def gram_apply(self, X):
+        """X: (V, b) array (any layout) -> Z = B (B^T X), (V, b)."""
+        X = np.asfortranarray(X, dtype=np.float32)
+        b = X.shape[1]
+        Z = np.empty_like(X, order="F")
+        rc = lib().orc_gram_apply(self.h, _p(X), C.c_int(b), _p(Z))
+        assert rc == 0
+        return Z
+
+    def block_ks(self, nev, blk=10, ncv=None, maxit=100, tol=1e-4, seed=1):
+        ncv = 2 * nev + 10 if ncv is None else ncv
+        ev = np.empty(nev, np.float32)
+        U = np.empty((self.V, nev), np.float32, order="F")
+        nconv, rst, nap = C.c_int(), C.c_int(), C.c_int()
+        rc = lib().orc_block_ks(self.h, nev, ncv, maxit, blk, C.c_float(tol), C.c_uint64(seed), _p(ev), _p(U),
+                                C.byref(nconv), C.byref(rst), C.byref(nap))
+        return dict(rc=rc, evals=ev, U=U, nconv=nconv.value, restarts=rst.value, napplies=nap.value)
+
+    def project(self, U):
+        U = np.asfortranarray(U, dtype=np.float32)
+        k = U.shape[1]
+        P = np.empty((self.D, k), np.float32)
+        n2 = np.empty(self.D, np.float32)
+        lib().orc_project(self.h, _p(U), k, _p(P), _p(n2))
+        return P, n2
+
+    def kmeanspp(self, U, k, inject=None, seed=1):
+        U = np.asfortranarray(U, dtype=np.float32)
+        seeds = np.empty(k, np.uint64)
+        Cl = np.empty((k, k), np.float32)
+        res, rounds = C.c_float(), C.c_int()
+        md = np.empty(self.D, np.float32)
+        inj = None if inject is None else np.ascontiguousarray(inject, dtype=np.uint64)
+        rc = lib().orc_kmeanspp(self.h, _p(U), k, _p(inj), C.c_uint64(seed), _p(seeds), _p(Cl), C.byref(res),
+                                C.byref(rounds), _p(md))
+        return dict(rc=rc, seeds=seeds, C_lowd=Cl, residual=res.value, rounds=rounds.value, min_dist=md)
+
+    def lloyds_projected(self, U, C_lowd, max_reps=10):
+        U = np.asfortranarray(U, dtype=np.float32)
+        k = U.shape[1]
+        Cl = np.array(C_lowd, dtype=np.float32, order="C", copy=True)
+        it = C.c_int()
+        assign = np.empty(self.D, np.uint32)
+        lib().orc_lloyds_projected(self.h, _p(U), k, _p(Cl), max_reps, C.byref(it), _p(assign))
+        return dict(C_lowd=Cl, iters=it.value, assign=assign)
+
+    def lloyds_sparse(self, centers, max_reps=10):
+        """centers: (V, k) Fortran-order (centre c = column c), updated copy returned."""
+        Cn = np.array(centers, dtype=np.float32, order="F", copy=True)
+        k = Cn.shape[1]
+        it = C.c_int()
+        assign = np.empty(self.D, np.uint32)
+        lib().orc_lloyds_sparse(self.h, k, _p(Cn), _p(assign), max_reps, C.byref(it))
+        return dict(centers=Cn, iters=it.value, assign=assign)
+
+
+def lift(U, C_lowd):
+    """centers (V x k, F-order) = U (V x k) * C_lowd^T-as-columns (centre c = row c of C_lowd)."""
+    U = np.asfortranarray(U, dtype=np.float32)
+    V, k = U.shape
+    Cl = np.ascontiguousarray(C_lowd, dtype=np.float32)  # row c = centre c  == col-major k x n with ld = k
+    n = Cl.shape[0]
+    out = np.empty((V, n), np.float32, order="F")
+    lib().orc_lift(_p(U), C.c_uint64(V), k, _p(Cl), k, n, _p(out))
+    return out
+
+
+def block_ks_dense(A, nev, blk=10, ncv=None, maxit=100, tol=1e-4, seed=1):
+    A = np.asfortranarray(A, dtype=np.float32)
+    n = A.shape[0]
+    ncv = 2 * nev + 10 if ncv is None else ncv
+    ev = np.empty(nev, np.float32)
+    U = np.empty((n, nev), np.float32, order="F")
+    nconv, rst, nap = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().orc_block_ks_dense(_p(A), C.c_uint64(n), nev, ncv, maxit, blk, C.c_float(tol), C.c_uint64(seed), _p(ev),
+                                  _p(U), C.byref(nconv), C.byref(rst), C.byref(nap))
+    return dict(rc=rc, evals=ev, U=U, nconv=nconv.value, restarts=rst.value, napplies=nap.value)
+
+
+def eig_sym(S):
+    S = np.asfortranarray(S, dtype=np.float32)
+    n = S.shape[0]
+    e = np.empty(n, np.float32)
+    v = np.empty((n, n), np.float32, order="F")
+    rc = lib().orc_eig_sym(_p(S), C.c_uint64(n), _p(e), _p(v))
+    assert rc == 0
+    return e, v
+
+
+def qr(A):
+    A = np.asfortranarray(A, dtype=np.float32)
+    n, c = A.shape
+    Q = np.zeros((n, c), np.float32, order="F")
+    R = np.zeros(c * c, np.float32)
+    rk = C.c_int()
+    lib().orc_qr(_p(A), C.c_uint64(n), C.c_uint64(c), _p(Q), _p(R), C.byref(rk))
+    r = rk.value
+    return Q[:, :r], R[: r * c].reshape((c, r)).T.copy(), r
