@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — ISLE training hot path (truncated SVD + k-means) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* is one pass of the hot path of ISLETrainer::train() (reference src/trainer.cpp:490-571) over the
+device-resident thresholded matrix B: compute_block_ks -> kmeans_init_on_projected_space ->
+run_lloyds_on_projected_space -> left_multiply_by_U -> run_lloyds, with the reference's hyper-parameters
+(include/hyperparams.h).  Metric = docs/sec = (documents of all ranks) * steps / wall time, inputs already in
+HBM when the timed region starts.  Workload at N = 1: BASELINE.json configs[1] (vocab 50k, 1M docs,
+~100M nnz, k = 200, sample = 0); at N > 1 each rank holds its own 1M-document shard of a larger corpus
+(weak scaling; Gram / centroid sums are all-reduced with RCCL inside libisle_hip.so).
+
+One JSON line on stdout (rank 0).  See DESIGN.md §Measurement for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (vocab, docs per GPU, topics, generator seed)          BASELINE.json configs
+    "c1": (10_000, 50_000, 50, 12345),     # configs[0] (reference's CPU-runnable case)
+    "c2": (50_000, 1_000_000, 200, 2024),  # configs[1]  <- bench default
+    "c3shard": (100_000, 1_250_000, 1000, 31337),  # one GPU's share of configs[2]
+    "tiny": (2_000, 5_000, 10, 0),
+}
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # host control plane only
+
+    from isle_amd import HotPath
+    from tools.synth import Corpus, effective_cpus
+
+    V, D_per, k, seed = WORKLOADS[args.workload]
+
+    def allreduce_np(a):
+        if dist is not None:
+            t = torch.from_numpy(a)
+            dist.all_reduce(t)
+        return a
+
+    # ---------------- synthetic input (not timed): planted-topic Zipf corpus -> thresholded B ------------
+    t0 = time.time()
+    corp = Corpus(V, D_per, k, seed, doc_base=rank * D_per)
+    nnz_A = corp.nnz_A
+    B = corp.threshold(k, free_A=True, allreduce=allreduce_np if dist is not None else None)
+    del corp
+    t_gen = time.time() - t0
+    D_loc, nnz_loc = B["D"], B["nnz"]
+    counts = np.zeros(world, np.int64)
+    counts[rank] = D_loc
+    allreduce_np(counts)
+    doc_offset = int(counts[:rank].sum())
+    D_glob = int(counts.sum())
+    tot = np.array([nnz_loc, nnz_A], np.int64)
+    allreduce_np(tot)
+    nnz_glob = int(tot[0])
+    log("[rank %d] corpus: V=%d docs=%d (global %d) nnz(A)=%d nnz(B)=%d  generated in %.1fs" %
+        (rank, V, D_loc, D_glob, nnz_A, nnz_loc, t_gen))
+
+    hp = HotPath(local_rank)
+    if world > 1:
+        uid = [HotPath.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        hp.comm_init(world, rank, uid[0])
+    hp.upload_csc(V, B["vals"], B["rows"], B["offs"], doc_offset=doc_offset, docs_global=D_glob)
+
+    def step(i):
+        r = hp.compute_block_ks(k, seed=1 + i, allow_noconv=True)
+        g = hp.kmeans_init_on_projected_space(k, rng_seed=1 + i)
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = hp.run_lloyds(k, fetch_centers=True)  # the trainer consumes centers + partition (trainer.cpp:563-575)
+        return dict(ks=r, kmpp_rounds=g["rounds"], lp_iters=lp["iters"], ls_iters=ls["iters"], assign=ls["assign"])
+
+    def fence():
+        hp.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(local_rank)
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    hp.timing_enable(True)
+    hp.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    tm = hp.timing_get()
+    hp.timing_enable(False)
+    dtt = np.array([dt], np.float64)
+    if dist is not None:
+        t = torch.from_numpy(dtt)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(dtt[0])
+
+    # ---------------- accuracy: size-independent check of the eigenpairs ---------------------------------
+    # |lambda_i - lambda_true| <= ||A u_i - lambda_i u_i||  =>  sigma rel-err <= resid_i / (2 lambda_i)
+    ev = last["ks"]["evals"].astype(np.float64)
+    U = hp.get_U(k)
+    AU = hp.gram_apply(U[:, :16]) if k > 16 else hp.gram_apply(U)
+    kk = AU.shape[1]
+    resid = np.linalg.norm(AU.astype(np.float64) - U[:, :kk].astype(np.float64) * ev[:kk], axis=0) / ev[:kk]
+    sizes = np.bincount(last["assign"], minlength=k).astype(np.int64)
+    allreduce_np(sizes)
+
+    if rank != 0:
+        return
+
+    steps = args.steps
+    ms_per_step = 1e3 * dt / steps
+    value = D_glob * steps / dt
+
+    # ---------------- roofline of the dominant sparse kernel family (Gram apply) --------------------------
+    b = 10 if k > 10 else 1
+    n_apply = tm["gram_pass1"][1]
+    t_apply_ms = (tm["gram_pass1"][0] + tm["gram_pass2"][0]) / max(n_apply, 1)
+    # bytes per application = 8*nnz + 8*(D+1) + 2*4*V*b   (this rank's shard)
+    alg_bytes = 8.0 * nnz_loc + 8.0 * (D_loc + 1) + 8.0 * V * b
+    achieved = alg_bytes / (t_apply_ms * 1e-3) / 1e9 if n_apply else 0.0
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(args.workload, {}).get("gram_apply_hbm_bytes_per_launch")
+    except Exception:
+        pass
+    device_ms = {f: round(v[0] / steps, 3) for f, v in tm.items() if v[1]}
+
+    # ---------------- CPU baseline: the oracle ("port") on a bounded sample of the same work --------------
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import OracleCsc
+        cores = effective_cpus()
+        tc0 = time.time()
+        o = OracleCsc(V, D_loc, B["vals"], B["rows"], B["offs"])
+        X = np.random.default_rng(0).standard_normal((V, b)).astype(np.float32)
+        o.gram_apply(X)
+        t1 = time.time()
+        reps = 2
+        for _ in range(reps):
+            o.gram_apply(X)
+        t_apply_cpu = (time.time() - t1) / reps
+        t1 = time.time()
+        kr = o.kmeanspp(U, k, seed=1, max_rounds=3)
+        t_round_cpu = (time.time() - t1) / max(kr["rounds"], 1)
+        C0 = np.ascontiguousarray(o.project(U)[0][:k])  # any k points as centres: cost per iteration is data-independent
+        t1 = time.time()
+        o.lloyds_projected(U, C0, max_reps=1)
+        ta = time.time() - t1
+        t1 = time.time()
+        o.lloyds_projected(U, C0, max_reps=2)
+        t_lp_cpu = max(time.time() - t1 - ta, 1e-9)
+        from oracle.oracle import lift
+        cen = lift(U, C0)
+        t1 = time.time()
+        o.lloyds_sparse(cen, max_reps=1)
+        ta = time.time() - t1
+        t1 = time.time()
+        o.lloyds_sparse(cen, max_reps=2)
+        t_ls_cpu = max(time.time() - t1 - ta, 1e-9)
+        n_app = last["ks"]["napplies"]
+        est = (n_app * t_apply_cpu + last["kmpp_rounds"] * t_round_cpu + last["lp_iters"] * t_lp_cpu +
+               last["ls_iters"] * t_ls_cpu)
+        cpu = {
+            "value": round(D_loc / est, 1), "unit": "docs/sec", "cores": cores, "kind": "port",
+            "sample": ("same-work extrapolation on the full-size matrix: measured 1 Gram-apply (%.3fs), 1 k-means++ round "
+                       "(%.3fs), 1 projected-Lloyd iteration (%.3fs), 1 sparse-Lloyd iteration (%.3fs) of oracle/ "
+                       "(OpenMP, %d threads), scaled by the counts the GPU run executed (%d applies, %d rounds, %d+%d "
+                       "iterations); orthogonalisation/QR/EVD time of the CPU eigensolver NOT included (upper bound on CPU "
+                       "docs/s); sampling took %.0fs" %
+                       (t_apply_cpu, t_round_cpu, t_lp_cpu, t_ls_cpu, cores, n_app, last["kmpp_rounds"], last["lp_iters"],
+                        last["ls_iters"], time.time() - tc0)),
+        }
+
+    out = {
+        "metric": "docs/sec end-to-end ISLETrain hot path (SVD+k-means)",
+        "value": round(value, 1),
+        "unit": "docs/sec",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic planted-topic Zipf corpus (%s): vocab=%d, docs=%d (%d per GPU), nnz(A)=%d, nnz(B)=%d, "
+                        "num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
+                        % (args.workload, V, D_glob, D_per, int(tot[1]), nnz_glob, k),
+            "block_ks": {"nev": k, "ncv": 2 * k + 10, "blk": b, "tol": 1e-4, "maxit": 100,
+                         "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"]},
+            "kmeans": {"kmpp_rounds": last["kmpp_rounds"], "lloyd_projected_iters": last["lp_iters"],
+                       "lloyd_sparse_iters": last["ls_iters"], "nonempty_clusters": int((sizes > 0).sum())},
+            "parallelism": "docs column-sharded x%d, RCCL all-reduce" % world if world > 1 else "single GPU",
+        },
+        "accuracy": {"sigma_rel_err_bound": float(np.max(resid) / 2.0), "checked_pairs": int(kk),
+                     "note": "|sigma-sigma_true|/sigma <= ||A u - lambda u|| / (2 lambda), residual computed with the HIP Gram apply"},
+        "roofline": {"bound": "hbm", "kernel": "gram_apply = gram_pass1_k + gram_pass2_k (Z = B(B^T X), b=%d)" % b,
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},
+        "device_ms_per_step": device_ms,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/* include/isle_hip.h — C ABI of libisle_hip.so: the MI355X (gfx950) implementation of ISLE's
+ * training hot path (truncated SVD of the thresholded word-document matrix B by restarted block
+ * Krylov-Schur on B*B^T, k-means++ / Lloyd in the projected space, lift, Lloyd on sparse B).
+ *
+ * This is the drop-in boundary: each entry point replaces one public method of the reference's
+ * ISLE::FPSparseMatrix<float> (or the ProdOp plug-in of BlockKs) — cited per function as
+ * file:line relative to the reference root.  The reference-side binding a maintainer would add
+ * is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 on success or a negative ISLE_E_* code and
+ *    records a message retrievable with isle_hip_last_error(); no exception crosses the ABI.
+ *  - all pointers are HOST pointers owned by the caller unless a name ends in _dev.
+ *  - one context = one GPU = one process (multi-GPU: one process per GPU, documents
+ *    column-sharded; see isle_hip_comm_init).  A context is not thread-safe.
+ *  - matrices named *_colmajor are column-major with leading dimension = number of rows, as
+ *    in the reference (Armadillo fmat / cblas ColMajor).
+ *  - there is NO CPU fallback: without a visible gfx950 device isle_hip_create fails.
+ */
+#ifndef ISLE_HIP_H
+#define ISLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct isle_ctx isle_ctx;
+
+enum {
+  ISLE_OK = 0,
+  ISLE_E_ARG = -1,      /* bad argument / state */
+  ISLE_E_HIP = -2,      /* HIP runtime error */
+  ISLE_E_NOCONV = -3,   /* eigensolver exhausted maxit restarts (Ritz values still returned) */
+  ISLE_E_NUMERIC = -4,  /* breakdown: rank repair / small EVD failed */
+  ISLE_E_COMM = -5      /* RCCL error */
+};
+
+/* ---- context --------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device_id`.  Returns NULL (and prints to stderr) on failure. */
+isle_ctx* isle_hip_create(int device_id);
+void isle_hip_destroy(isle_ctx* ctx);
+const char* isle_hip_last_error(isle_ctx* ctx);
+
+/* Multi-GPU (documents column-sharded, one process per GPU).  rank 0 calls
+ * isle_hip_comm_unique_id (128 bytes), distributes the bytes by any host channel
+ * (bench.py uses torch.distributed), then every rank calls isle_hip_comm_init.
+ * doc_offset / docs_global place this rank's shard in the global column numbering. */
+int isle_hip_comm_unique_id(void* out128);
+int isle_hip_comm_init(isle_ctx* ctx, int world_size, int rank, const void* unique_id128);
+
+/* Contiguous, nnz-balanced document ranges for `parts` shards (pure host function, no GPU):
+ * bounds[p] .. bounds[p+1] are the columns of shard p; bounds has parts+1 entries. */
+int isle_hip_plan_shards(uint64_t num_docs, const int64_t* offsets_CSC, int parts, uint64_t* bounds);
+
+/* ---- input: the matrix B -------------------------------------------------------------- */
+/* Uploads this rank's column shard of B (CSC: vals_CSC / rows_CSC / offsets_CSC of
+ * include/sparseMatrix.h:23-56; rows ascending within a column, as threshold_and_copy builds
+ * them, src/sparseMatrix.cpp:1328-1361).  `num_docs` columns local to this rank;
+ * offsets[0] == 0, offsets[num_docs] == nnz.  rows are the reference's 8-byte word_id_t
+ * (include/types.h:24) in the _u64 flavour, or 4-byte in the _u32 flavour.
+ * doc_offset = global id of local column 0, docs_global = total columns over all ranks
+ * (pass 0 and num_docs for single-GPU). */
+int isle_hip_upload_csc_u64(isle_ctx* ctx, uint64_t vocab_size, uint64_t num_docs, uint64_t nnz,
+                            const float* vals, const uint64_t* rows, const int64_t* offsets,
+                            uint64_t doc_offset, uint64_t docs_global);
+int isle_hip_upload_csc_u32(isle_ctx* ctx, uint64_t vocab_size, uint64_t num_docs, uint64_t nnz,
+                            const float* vals, const uint32_t* rows, const int64_t* offsets,
+                            uint64_t doc_offset, uint64_t docs_global);
+
+/* FPSparseMatrix::frobenius  src/sparseMatrix.cpp:1096-1100  (sum of squares of all entries,
+ * over all ranks). */
+int isle_hip_frobenius(isle_ctx* ctx, float* out);
+
+/* ---- eigensolver ----------------------------------------------------------------------- */
+/* ProdOp::multiply of MKL_SpSpTrProd  include/matUtils.h:336-365:
+ * Z (V x b, col-major) = B * (B^T * X), X V x b col-major, 1 <= b <= 32. */
+int isle_hip_gram_apply(isle_ctx* ctx, const float* X_colmajor, int b, float* Z_colmajor);
+
+/* FPSparseMatrix::compute_block_ks  src/sparseMatrix.cpp:1195-1220  driving
+ * BlockKs<ProdOp>(op, nev, ncv, maxit, blk, tol) init()+compute()
+ * block-ks/restarted_block_ks.h:190-321.  The reference passes
+ * (k, 2k + BLOCK_KS_BLOCK_SIZE, 100, 10, 1e-4) (include/hyperparams.h:38-40).
+ * evals: nev Ritz values, descending (= sigma_i^2).  U (V x nev) stays on the device for the
+ * k-means calls (fetch with isle_hip_get_U).  seed: start-block RNG seed (the reference uses
+ * unseeded rand(); parity does not depend on it).  Returns ISLE_E_NOCONV (not 0) if maxit
+ * restarts were exhausted — the reference reports full convergence in that case
+ * (SURVEY.md App. C #7); evals/U are still the last Ritz pairs.
+ * nconv/restarts/napplies may be NULL. */
+int isle_hip_block_ks(isle_ctx* ctx, int nev, int ncv, int maxit, int blk, float tol, uint64_t seed,
+                      float* evals, int* nconv, int* restarts, int* napplies);
+
+/* U_colmajor (V x nev), what compute_block_ks memcpy's at src/sparseMatrix.cpp:1214. */
+int isle_hip_get_U(isle_ctx* ctx, float* U_colmajor);
+/* Test hook: install a caller-provided U (V x k col-major) instead of running the eigensolver. */
+int isle_hip_set_U(isle_ctx* ctx, const float* U_colmajor, int k);
+
+/* Dense symmetric eigendecomposition used inside truncate() (arma::eig_sym,
+ * block-ks/restarted_block_ks.h:150-161): S n x n col-major symmetric -> evals descending,
+ * vecs col-major.  Exposed for parity tests. */
+int isle_hip_eig_sym(isle_ctx* ctx, const float* S_colmajor, int n, float* evals_desc, float* vecs_colmajor);
+
+/* ---- k-means --------------------------------------------------------------------------- */
+/* FPSparseMatrix::kmeans_init_on_projected_space(k, reps = 1, seeds, centers_coords)
+ * src/sparseMatrix.cpp:2212-2238 -> kmeanspp_on_projected_space :2133-2209.
+ * inject_seeds: NULL, or k global doc ids that replace the D^2 draws (test hook; the round
+ * schedule and min-distance updates still run).  seeds_out: k global doc ids.
+ * C_lowd: k x k, centre c at offset c*k (the reference's centers_lowd).  residual: as
+ * returned by the reference (App. C #9).  rng_seed seeds the host draw RNG (rand() stand-in). */
+int isle_hip_kmeanspp_projected(isle_ctx* ctx, int k, const uint64_t* inject_seeds, uint64_t rng_seed,
+                                uint64_t* seeds_out, float* C_lowd, float* residual, int* rounds);
+
+/* Optional test hook: copies the current min-distance array (local docs) after kmeanspp. */
+int isle_hip_get_min_dist(isle_ctx* ctx, float* min_dist);
+
+/* FPSparseMatrix::run_lloyds_on_projected_space(k, C_lowd, NULL, max_reps)
+ * src/sparseMatrix.cpp:2016-2072.  C_lowd in/out.  assign_out (local docs, may be NULL). */
+int isle_hip_lloyds_projected(isle_ctx* ctx, int k, float* C_lowd, int max_reps, int* iters_run,
+                              uint32_t* assign_out);
+
+/* FPSparseMatrix::left_multiply_by_U_Spectra(out, in, ld_in, ncols)
+ * src/sparseMatrix.cpp:1438-1450: centers (V x ncols col-major) = U (V x k) * in (ld_in x ncols).
+ * centers may be NULL: the result then only stays on the device as the start point of
+ * isle_hip_lloyds_sparse. */
+int isle_hip_lift_centers(isle_ctx* ctx, const float* in, int ld_in, int ncols, float* centers);
+
+/* FPSparseMatrix::run_lloyds(k, centers, closest_docs, max_reps)  src/sparseMatrix.cpp:1690-1746.
+ * centers_in: V x k col-major start centres, or NULL to use the device-resident result of
+ * isle_hip_lift_centers.  centers_out: V x k col-major (may be NULL).  assign: local docs ->
+ * centre index (the caller buckets it into closest_docs[k], ascending doc id). */
+int isle_hip_lloyds_sparse(isle_ctx* ctx, int k, const float* centers_in, float* centers_out,
+                           uint32_t* assign, int max_reps, int* iters_run);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+/* Per-kernel-family device time accumulated with HIP events on the context's stream since the
+ * last reset (only while enabled; enabling adds event records around each launch).
+ * Families: see ISLE_T_* below. */
+enum {
+  ISLE_T_GRAM_PASS1 = 0,   /* Y = B^T X   (CSC gather)            */
+  ISLE_T_GRAM_PASS2 = 1,   /* Z = B Y     (chunked-CSR gather + chunk reduce) */
+  ISLE_T_ORTHO = 2,        /* V^T F, F -= V H                      */
+  ISLE_T_QR = 3,           /* panel QR (Gram, apply)               */
+  ISLE_T_EVD = 4,          /* small symmetric EVD                  */
+  ISLE_T_ROTATE = 5,       /* Ritz rotation / lift GEMM            */
+  ISLE_T_PROJECT = 6,      /* P = U^T B                            */
+  ISLE_T_KMPP = 7,         /* k-means++ rounds                     */
+  ISLE_T_LLOYD_PROJ = 8,   /* projected Lloyd assign + update      */
+  ISLE_T_SPARSE_ASSIGN = 9,/* sparse Lloyd: distances + argmin     */
+  ISLE_T_SPARSE_UPDATE = 10,/* sparse Lloyd: centroid update       */
+  ISLE_T_BAND_BUILD = 11,  /* chunked-CSR copy of B (per solve)   */
+  ISLE_T_COMM = 12,        /* collectives                          */
+  ISLE_T_COUNT = 13
+};
+int isle_hip_timing_enable(isle_ctx* ctx, int on);
+int isle_hip_timing_reset(isle_ctx* ctx);
+/* ms[ISLE_T_COUNT], launches[ISLE_T_COUNT] */
+int isle_hip_timing_get(isle_ctx* ctx, double* ms, uint64_t* launches);
+int isle_hip_synchronize(isle_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISLE_HIP_H */

@@ -1,0 +1,1038 @@
+// isle_amd/csrc/api.cpp — host orchestration behind the C ABI of include/isle_hip.h.
+//
+// The control flow mirrors the reference exactly where it defines the result:
+//   BlockKs::init / expand / truncate / compute   block-ks/restarted_block_ks.h:62-321
+//   kmeanspp_on_projected_space                   src/sparseMatrix.cpp:2133-2209
+//   run_lloyds_on_projected_space / run_lloyds    src/sparseMatrix.cpp:2016-2072 / :1690-1746 (stop rule)
+// All arithmetic on V- or D-sized data runs in the HIP kernels of spmm.hip / dense.hip / kmeans.hip;
+// the host keeps only the small projected matrix H (<= (2k+b) x 2k floats) and scalars.
+// There is no CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// errors, timing
+// ------------------------------------------------------------------------------------------
+int isle_fail(isle_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
+  if (!c->timing) return;
+  if (!c->ev_free.empty()) {
+    ep = c->ev_free.back();
+    c->ev_free.pop_back();
+  } else {
+    if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
+  }
+  ep.fam = fam;
+  on = (hipEventRecord(ep.a, c->stream) == hipSuccess);
+}
+TimeScope::~TimeScope() {
+  if (!on) return;
+  (void)hipEventRecord(ep.b, c->stream);
+  c->ev_used.push_back(ep);
+}
+
+static int drain_events(isle_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& e : c->ev_used) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->t_ms[e.fam] += ms;
+      c->t_n[e.fam] += 1;
+    }
+    c->ev_free.push_back(e);
+  }
+  c->ev_used.clear();
+  return 0;
+}
+
+#define NCCLCHK(ctx, call)                                                                              \
+  do {                                                                                                  \
+    ncclResult_t r__ = (call);                                                                          \
+    if (r__ != ncclSuccess)                                                                             \
+      return isle_fail((ctx), ISLE_E_COMM, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r__)); \
+  } while (0)
+
+template <class T>
+static ncclDataType_t nccl_type();
+template <>
+ncclDataType_t nccl_type<float>() { return ncclFloat; }
+template <>
+ncclDataType_t nccl_type<double>() { return ncclDouble; }
+template <>
+ncclDataType_t nccl_type<int>() { return ncclInt; }
+template <>
+ncclDataType_t nccl_type<uint64_t>() { return ncclUint64; }
+
+template <class T>
+static int allreduce_sum(isle_ctx* c, T* buf, size_t count) {
+  if (!c->comm || c->world == 1) return 0;
+  TimeScope ts(c, ISLE_T_COMM);
+  NCCLCHK(c, ncclAllReduce(buf, buf, count, nccl_type<T>(), ncclSum, c->comm, c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host RNG (rand() stand-in)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct HostRng {
+  uint64_t s;
+  explicit HostRng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+  uint64_t next64() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  uint32_t next31() { return (uint32_t)(next64() >> 33); }
+  double fraction() {  // include/matUtils.h:473-477
+    const double R1 = 2147483648.0;
+    const double lo = (double)next31();
+    const double hi = (double)next31();
+    return (lo + hi * R1) / (R1 * R1);
+  }
+};
+
+struct HMat {  // small col-major float matrix on the host (the projected matrix H)
+  size_t r = 0, c = 0;
+  std::vector<float> a;
+  HMat() {}
+  HMat(size_t r_, size_t c_) : r(r_), c(c_), a(r_ * c_, 0.f) {}
+  float& operator()(size_t i, size_t j) { return a[j * r + i]; }
+  float operator()(size_t i, size_t j) const { return a[j * r + i]; }
+};
+HMat hsub(const HMat& m, size_t r0, size_t c0, size_t r1, size_t c1) {  // inclusive bounds (arma submat)
+  HMat o(r1 - r0 + 1, c1 - c0 + 1);
+  for (size_t j = c0; j <= c1; ++j)
+    for (size_t i = r0; i <= r1; ++i) o(i - r0, j - c0) = m(i, j);
+  return o;
+}
+}  // namespace
+
+static int round4(int k) { return (k + 3) & ~3; }
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+extern "C" isle_ctx* isle_hip_create(int device_id) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "isle_hip_create: no HIP device visible (this library has no CPU fallback)\n");
+    return nullptr;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    fprintf(stderr, "isle_hip_create: device %d out of range (%d devices)\n", device_id, ndev);
+    return nullptr;
+  }
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return nullptr;
+  isle_ctx* c = new isle_ctx;
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  const char* br = getenv("ISLE_CHUNK_COLS");
+  if (br) c->band_rows = (uint32_t)atoi(br);
+  return c;
+}
+
+extern "C" void isle_hip_destroy(isle_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  for (auto& e : c->ev_used) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (auto& e : c->ev_free) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  c->vals.release(); c->rows.release(); c->offs.release();
+  c->bcol.release(); c->bval.release(); c->seg_off.release(); c->Zpart.release();
+  c->Xrm.release(); c->Yrm.release(); c->Zrm.release(); c->Xcm.release(); c->Zcm.release();
+  c->basis.release(); c->Fbuf.release(); c->Tmp.release(); c->part.release(); c->coef.release();
+  c->gram.release(); c->small.release(); c->jacW.release(); c->jacV.release(); c->Wf.release();
+  c->Ucm.release(); c->Urm.release(); c->P.release(); c->pnorm.release(); c->min_dist.release();
+  c->cum.release(); c->scan_blk.release(); c->Cdev.release(); c->cnorm.release(); c->Csum.release();
+  c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release();
+  c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release();
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char* isle_hip_last_error(isle_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int isle_hip_comm_unique_id(void* out128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return ISLE_E_COMM;
+  memcpy(out128, &id, sizeof id);
+  return 0;
+}
+
+extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* uid) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return isle_fail(c, ISLE_E_ARG, "bad world/rank");
+  c->world = world;
+  c->rank = rank;
+  if (world == 1) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, uid, sizeof id);
+  NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
+  return 0;
+}
+
+extern "C" int isle_hip_plan_shards(uint64_t num_docs, const int64_t* offs, int parts, uint64_t* bounds) {
+  if (!offs || !bounds || parts < 1) return ISLE_E_ARG;
+  const int64_t nnz = offs[num_docs];
+  bounds[0] = 0;
+  for (int p = 1; p < parts; ++p) {
+    const int64_t target = (int64_t)(((__int128)nnz * p) / parts);
+    const int64_t* it = std::lower_bound(offs, offs + num_docs + 1, target);
+    uint64_t d = (uint64_t)(it - offs);
+    if (d > num_docs) d = num_docs;
+    if (d < bounds[p - 1]) d = bounds[p - 1];
+    bounds[p] = d;
+  }
+  bounds[parts] = num_docs;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// upload
+// ------------------------------------------------------------------------------------------
+static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* vals, const uint32_t* rows32,
+                         const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (V == 0 || V > 0xfffffff0ull || D > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "vocab/doc count out of range");
+  if (offs[0] != 0 || (uint64_t)offs[D] != nnz) return isle_fail(c, ISLE_E_ARG, "offsets[0] != 0 or offsets[D] != nnz");
+  for (uint64_t d = 0; d < D; ++d) {
+    if (offs[d + 1] < offs[d]) return isle_fail(c, ISLE_E_ARG, "offsets not monotone at column %llu", (unsigned long long)d);
+    for (int64_t i = offs[d]; i < offs[d + 1]; ++i) {
+      if (rows32[i] >= V) return isle_fail(c, ISLE_E_ARG, "row index out of range at %lld", (long long)i);
+      // include/matUtils.h:138-148: columns strictly increasing
+      if (i > offs[d] && rows32[i] <= rows32[i - 1])
+        return isle_fail(c, ISLE_E_ARG, "rows not strictly ascending in column %llu", (unsigned long long)d);
+    }
+  }
+  c->V = V;
+  c->D = D;
+  c->nnz = nnz;
+  c->doc_offset = doc_offset;
+  c->D_global = docs_global ? docs_global : D;
+  HIPCHK(c, c->vals.reserve(nnz ? nnz : 1));
+  HIPCHK(c, c->rows.reserve(nnz ? nnz : 1));
+  HIPCHK(c, c->offs.reserve(D + 1));
+  if (nnz) {
+    HIPCHK(c, hipMemcpy(c->vals.p, vals, nnz * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->rows.p, rows32, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipMemcpy(c->offs.p, offs, (D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  c->band_ready = false;
+  c->P_ready = false;
+  c->U_k = 0;
+  c->centers_ready = false;
+  return 0;
+}
+
+extern "C" int isle_hip_upload_csc_u32(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* vals, const uint32_t* rows,
+                                       const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
+  return upload_common(c, V, D, nnz, vals, rows, offs, doc_offset, docs_global);
+}
+extern "C" int isle_hip_upload_csc_u64(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* vals, const uint64_t* rows,
+                                       const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
+  std::vector<uint32_t> r32(nnz);
+  for (uint64_t i = 0; i < nnz; ++i) {
+    if (rows[i] > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "row index too large");
+    r32[i] = (uint32_t)rows[i];
+  }
+  return upload_common(c, V, D, nnz, vals, r32.data(), offs, doc_offset, docs_global);
+}
+
+extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
+  if (!c || !out) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  double s = 0.0;
+  ISLECHK(k_frobenius(c, &s));
+  if (c->comm && c->world > 1) {
+    HIPCHK(c, c->gram.reserve(1024));
+    HIPCHK(c, hipMemcpyAsync(c->gram.p, &s, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ISLECHK(allreduce_sum<double>(c, c->gram.p, 1));
+    HIPCHK(c, hipMemcpyAsync(&s, c->gram.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  *out = (float)s;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Gram apply on device pointers: Zcm (V x b col-major) = B (B^T Xcm)
+// ------------------------------------------------------------------------------------------
+static int panel_width(int b) { return 4 * ((b + 3) / 4); }  // b <= 16 -> BP in {4, 8, 12, 16}
+
+// One panel of at most 16 columns (the R x (BP+1) LDS tile of pass 2 is sized for BP <= 16).
+static int gram_apply_panel(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
+  const int BP = panel_width(b);
+  HIPCHK(c, c->Xrm.reserve((size_t)c->V * BP));
+  HIPCHK(c, c->Zrm.reserve((size_t)c->V * BP));
+  HIPCHK(c, c->Yrm.reserve((size_t)(c->D ? c->D : 1) * BP));
+  ISLECHK(k_pack_rm(c, Xcm, c->V, b, BP, c->Xrm.p));
+  ISLECHK(k_gram_pass1(c, BP));
+  ISLECHK(k_gram_pass2(c, BP));
+  ISLECHK(allreduce_sum<float>(c, c->Zrm.p, (size_t)c->V * BP));
+  ISLECHK(k_unpack_cm(c, c->Zrm.p, c->V, b, BP, Zcm));
+  return 0;
+}
+
+static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
+  if (b < 1 || b > 32) return isle_fail(c, ISLE_E_ARG, "gram_apply: b = %d not in [1, 32]", b);
+  for (int j0 = 0; j0 < b; j0 += 16)
+    ISLECHK(gram_apply_panel(c, Xcm + (size_t)j0 * c->V, std::min(16, b - j0), Zcm + (size_t)j0 * c->V));
+  return 0;
+}
+
+extern "C" int isle_hip_gram_apply(isle_ctx* c, const float* X, int b, float* Z) {
+  if (!c || !X || !Z) return ISLE_E_ARG;
+  if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->V * b;
+  HIPCHK(c, c->Xcm.reserve(n));
+  HIPCHK(c, c->Zcm.reserve(n));
+  HIPCHK(c, hipMemcpy(c->Xcm.p, X, n * sizeof(float), hipMemcpyHostToDevice));
+  ISLECHK(gram_apply_dev(c, c->Xcm.p, b, c->Zcm.p));
+  HIPCHK(c, hipMemcpyAsync(Z, c->Zcm.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Panel QR: rank-revealing CholQR2 on an fp64 Gram matrix.
+// utils::compute_qr (block-ks/ks_utils.h:43-127) is MGS in double with one DGKS correction and drops
+// columns whose residual norm is < 1e-6.  Cholesky of G = F^T F processed column by column IS that MGS
+// in exact arithmetic (pivot_i^2 = residual norm^2 of column i); a second pass restores orthogonality
+// to working precision.  F: n x w (device, destroyed).  Q: n x rank written to Qdst.  R: rank x w.
+// ------------------------------------------------------------------------------------------
+static int dev_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, std::vector<float>& R, int* rank_out) {
+  std::vector<double> G((size_t)w * w);
+  ISLECHK(k_gram64(c, F, n, w, G.data()));
+  auto g = [&](int i, int j) { return G[(size_t)j * w + i]; };
+  std::vector<double> R1((size_t)w * w, 0.0);  // (row r, col j) at [j*w + r]
+  std::vector<int> piv;
+  for (int i = 0; i < w; ++i) {
+    double s = g(i, i);
+    const int rk = (int)piv.size();
+    for (int r = 0; r < rk; ++r) s -= R1[(size_t)i * w + r] * R1[(size_t)i * w + r];
+    const double nrm = s > 0.0 ? std::sqrt(s) : 0.0;
+    // ks_utils.h:66-69 absolute test, plus a relative guard for what an fp64 Gram matrix can resolve
+    if ((float)nrm < 1e-6f || s <= 1e-13 * g(i, i) * (double)w) continue;
+    for (int j = i; j < w; ++j) {
+      double t = g(i, j);
+      for (int r = 0; r < rk; ++r) t -= R1[(size_t)i * w + r] * R1[(size_t)j * w + r];
+      R1[(size_t)j * w + rk] = t / nrm;
+    }
+    piv.push_back(i);
+  }
+  const int rk = (int)piv.size();
+  *rank_out = rk;
+  R.assign((size_t)rk * w, 0.f);
+  if (rk == 0) return 0;
+  // T1 (w x rk): rows at pivot columns hold inv(R1[:, piv])
+  std::vector<double> Rp((size_t)rk * rk, 0.0), Ri((size_t)rk * rk, 0.0);  // upper triangular, [col*rk + row]
+  for (int a = 0; a < rk; ++a)
+    for (int r = 0; r <= a; ++r) Rp[(size_t)a * rk + r] = R1[(size_t)piv[a] * w + r];
+  auto inv_upper = [&](const std::vector<double>& U, std::vector<double>& X, int m) {
+    std::fill(X.begin(), X.end(), 0.0);
+    for (int j = 0; j < m; ++j) {
+      X[(size_t)j * m + j] = 1.0 / U[(size_t)j * m + j];
+      for (int i = j - 1; i >= 0; --i) {
+        double s = 0.0;
+        for (int t = i + 1; t <= j; ++t) s += U[(size_t)t * m + i] * X[(size_t)j * m + t];
+        X[(size_t)j * m + i] = -s / U[(size_t)i * m + i];
+      }
+    }
+  };
+  inv_upper(Rp, Ri, rk);
+  std::vector<float> T1((size_t)w * rk, 0.f);
+  for (int cc = 0; cc < rk; ++cc)
+    for (int a = 0; a < rk; ++a) T1[(size_t)cc * w + piv[a]] = (float)Ri[(size_t)cc * rk + a];
+  ISLECHK(k_apply_T(c, F, n, w, T1.data(), rk, Qdst));
+  // second pass
+  std::vector<double> G2((size_t)rk * rk);
+  ISLECHK(k_gram64(c, Qdst, n, rk, G2.data()));
+  std::vector<double> R2((size_t)rk * rk, 0.0), R2i((size_t)rk * rk, 0.0);
+  for (int i = 0; i < rk; ++i) {
+    double s = G2[(size_t)i * rk + i];
+    for (int r = 0; r < i; ++r) s -= R2[(size_t)i * rk + r] * R2[(size_t)i * rk + r];
+    if (!(s > 0.0)) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
+    const double nrm = std::sqrt(s);
+    R2[(size_t)i * rk + i] = nrm;
+    for (int j = i + 1; j < rk; ++j) {
+      double t = G2[(size_t)j * rk + i];
+      for (int r = 0; r < i; ++r) t -= R2[(size_t)i * rk + r] * R2[(size_t)j * rk + r];
+      R2[(size_t)j * rk + i] = t / nrm;
+    }
+  }
+  inv_upper(R2, R2i, rk);
+  std::vector<float> T2((size_t)rk * rk);
+  for (size_t i = 0; i < T2.size(); ++i) T2[i] = (float)R2i[i];
+  ISLECHK(k_apply_T(c, Qdst, n, rk, T2.data(), rk, Qdst));
+  // R = R2 * R1   (rk x w)
+  for (int j = 0; j < w; ++j)
+    for (int r = 0; r < rk; ++r) {
+      double s = 0.0;
+      for (int t = r; t < rk; ++t) s += R2[(size_t)t * rk + r] * R1[(size_t)j * w + t];
+      R[(size_t)j * rk + r] = (float)s;
+    }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Restarted block Krylov-Schur
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Ks {
+  isle_ctx* c;
+  size_t nev, ncv, maxit, blk;
+  uint64_t dim;
+  float tol;
+  HMat H;
+  size_t vcols = 0, nconv = 0, n_restarts = 0, last_j = 0;
+  long napplies = 0;
+  uint64_t seed, draws = 0;
+  float* Vb() { return c->basis.p; }
+  float* col(size_t j) { return c->basis.p + j * dim; }
+
+  int randu(float* F, size_t cols) { return k_randu(c, F, dim * cols, seed + 0x1000 * (++draws)); }
+
+  // orthogonalise F (dim x w) against the first m basis columns, `passes` times; coefficient blocks kept on device
+  int ortho(float* F, int w, size_t m, int passes) {
+    HIPCHK(c, c->coef.reserve(3 * (c->basis.cap / dim) * 32));
+    for (int p = 0; p < passes; ++p) {
+      float* cf = c->coef.p + (size_t)p * m * w;
+      ISLECHK(k_vtf(c, Vb(), dim, (int)m, F, w, cf));
+      ISLECHK(k_update(c, F, dim, w, Vb(), (int)m, cf));
+    }
+    return 0;
+  }
+
+  // rank repair shared by init (:238-258) and expand (:106-132)
+  int repair(size_t& nvecs, size_t target, size_t width) {
+    size_t tries = 0;
+    while (nvecs < target && tries < 100) {
+      tries++;
+      ISLECHK(randu(c->Fbuf.p, width));
+      ISLECHK(ortho(c->Fbuf.p, (int)width, nvecs, 2));
+      std::vector<float> R2;
+      int rk2 = 0;
+      const size_t room = target - nvecs;
+      // Q lands in Tmp first: only `room` columns may be appended
+      ISLECHK(dev_qr(c, c->Fbuf.p, dim, (int)width, c->Tmp.p, R2, &rk2));
+      const size_t take = std::min<size_t>((size_t)rk2, room);
+      if (take) HIPCHK(c, hipMemcpyAsync(col(nvecs), c->Tmp.p, take * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      nvecs += take;
+    }
+    if (nvecs < target) return isle_fail(c, ISLE_E_NUMERIC, "unable to find new starting basis for Arnoldi expansion");
+    return 0;
+  }
+
+  int apply(const float* X, float* Z) {
+    napplies++;
+    return gram_apply_dev(c, X, (int)blk, Z);
+  }
+
+  int init() {  // :203-259
+    std::vector<float> R;
+    int rank = 0;
+    do {
+      ISLECHK(randu(c->Fbuf.p, blk));
+      ISLECHK(dev_qr(c, c->Fbuf.p, dim, (int)blk, col(0), R, &rank));
+    } while ((size_t)rank < blk);
+    float* V1 = c->Fbuf.p;
+    ISLECHK(apply(col(0), V1));
+    ISLECHK(ortho(V1, (int)blk, blk, 2));  // H = V^T V1; V1 -= V H; C = V^T V1; H += C; V1 -= V C
+    std::vector<float> hc(2 * blk * blk);
+    HIPCHK(c, hipMemcpyAsync(hc.data(), c->coef.p, hc.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    ISLECHK(dev_qr(c, V1, dim, (int)blk, col(blk), R, &rank));  // synchronises the stream
+    H = HMat(2 * blk, blk);
+    for (size_t j = 0; j < blk; ++j) {
+      for (size_t i = 0; i < blk; ++i) H(i, j) = hc[j * blk + i] + hc[blk * blk + j * blk + i];
+      for (int i = 0; i < rank; ++i) H(blk + i, j) = R[j * rank + i];
+    }
+    vcols = blk + rank;
+    if ((size_t)rank < blk) ISLECHK(repair(vcols, 2 * blk, blk - rank));
+    vcols = 2 * blk;
+    return 0;
+  }
+
+  int expand() {  // :62-136
+    while (H.r < ncv) {
+      const size_t m = H.r;
+      float* F = c->Fbuf.p;
+      ISLECHK(apply(col(H.c), F));
+      ISLECHK(ortho(F, (int)blk, m, 3));  // CGS + 2 DGKS passes (:83-91)
+      std::vector<float> hc(3 * m * blk);
+      HIPCHK(c, hipMemcpyAsync(hc.data(), c->coef.p, hc.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      std::vector<float> R;
+      int rk = 0;
+      ISLECHK(dev_qr(c, F, dim, (int)blk, col(H.c + blk), R, &rk));  // synchronises
+      HMat Hn(m + blk, H.c + blk);
+      for (size_t j = 0; j < H.c; ++j)
+        for (size_t i = 0; i < m; ++i) Hn(i, j) = H(i, j);
+      for (size_t j = 0; j < blk; ++j)
+        for (size_t i = 0; i < m; ++i) {
+          float h = hc[j * m + i];
+          h = h + hc[m * blk + j * m + i];
+          h = h + hc[2 * m * blk + j * m + i];
+          Hn(i, H.c + j) = h;
+        }
+      for (size_t j = 0; j < blk; ++j)
+        for (int i = 0; i < rk; ++i) Hn(m + i, H.c + j) = R[j * rk + i];
+      H = Hn;
+      if ((size_t)rk < blk) {
+        size_t nvecs = H.c + rk;
+        ISLECHK(repair(nvecs, H.r, blk - rk));
+      }
+    }
+    vcols = H.r;
+    return 0;
+  }
+
+  int truncate() {  // :138-187
+    const size_t n = H.c - nconv;
+    HMat subH = hsub(H, nconv, nconv, H.c - 1, H.c - 1);
+    std::vector<float> eH(n), vH(n * n);
+    HIPCHK(c, c->Wf.reserve(n * n));
+    ISLECHK(k_jacobi_eig(c, subH.a.data(), (int)n, eH.data(), c->Wf.p));
+    HIPCHK(c, hipMemcpyAsync(vH.data(), c->Wf.p, n * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    const size_t keep = nev - nconv;
+    // V = [ V(:, :nconv) | V(:, nconv : ncols-blk) * vH(:, :keep) | V(:, tail blk) ]
+    ISLECHK(k_gemm_nn(c, col(nconv), dim, (int)n, c->Wf.p, (int)n, (int)keep, c->Tmp.p));
+    HIPCHK(c, hipMemcpyAsync(c->Fbuf.p, col(vcols - blk), blk * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(col(nconv), c->Tmp.p, keep * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(col(nev), c->Fbuf.p, blk * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    vcols = nev + blk;
+    // Transform H (:169-184)
+    auto vh = [&](size_t i, size_t j) { return vH[j * n + i]; };
+    HMat last = hsub(H, H.r - blk, H.c - blk, H.r - 1, H.c - 1);  // blk x blk
+    HMat newrows(blk, keep);
+    for (size_t j = 0; j < keep; ++j)
+      for (size_t t = 0; t < blk; ++t) {
+        const float v = vh(n - blk + t, j);
+        for (size_t i = 0; i < blk; ++i) newrows(i, j) += last(i, t) * v;
+      }
+    HMat top;
+    if (nconv > 0) {
+      top = HMat(nconv, keep);
+      for (size_t j = 0; j < keep; ++j)
+        for (size_t t = 0; t < n; ++t) {
+          const float v = vh(t, j);
+          for (size_t i = 0; i < nconv; ++i) top(i, j) += H(i, nconv + t) * v;
+        }
+    }
+    HMat Hn(nev + blk, nev);
+    for (size_t j = 0; j < nconv; ++j) {  // locked columns keep their entries (rows < nev from the old H; residual rows too)
+      for (size_t i = 0; i < nev; ++i) Hn(i, j) = H(i, j);
+      for (size_t i = 0; i < blk; ++i) Hn(nev + i, j) = H(nev + i, j);
+    }
+    for (size_t j = nconv; j < nev; ++j) {
+      Hn(j, j) = eH[j - nconv];
+      for (size_t i = 0; i < blk; ++i) Hn(nev + i, j) = newrows(i, j - nconv);
+      for (size_t i = 0; i < nconv; ++i) Hn(i, j) = top(i, j - nconv);
+    }
+    H = Hn;
+    return 0;
+  }
+
+  size_t first_unconverged(bool divide) const {  // :278-293
+    for (size_t j = 0; j < H.c; ++j) {
+      float s = 0.f;
+      for (size_t i = H.r - blk; i < H.r; ++i) s += H(i, j) * H(i, j);
+      float nrm = std::sqrt(s);
+      if (divide) nrm = nrm / H(j, j);
+      if (nrm >= tol) return j;
+    }
+    return H.c;
+  }
+
+  int compute() {  // :261-321
+    n_restarts = 0;
+    nconv = 0;
+    ISLECHK(expand());
+    while (n_restarts < maxit) {
+      ISLECHK(truncate());
+      const size_t j = first_unconverged(true);
+      last_j = j;
+      if (j == H.c) {
+        nconv = H.c;
+        break;
+      }
+      nconv = j;
+      ++n_restarts;
+      ISLECHK(expand());
+    }
+    return 0;
+  }
+};
+}  // namespace
+
+static int install_U(isle_ctx* c, const float* Ucm_dev, int k) {
+  c->ldk = round4(k);
+  HIPCHK(c, c->Ucm.reserve((size_t)c->V * k));
+  HIPCHK(c, c->Urm.reserve((size_t)c->V * c->ldk));
+  if (Ucm_dev != c->Ucm.p)
+    HIPCHK(c, hipMemcpyAsync(c->Ucm.p, Ucm_dev, (size_t)c->V * k * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->Urm.p, 0, (size_t)c->V * c->ldk * sizeof(float), c->stream));
+  ISLECHK(k_transpose(c, c->Ucm.p, c->V, k, c->V, c->Urm.p, c->ldk));  // compute_U_rowmajor :1223-1231
+  c->U_k = k;
+  c->P_ready = false;
+  c->centers_ready = false;
+  return 0;
+}
+
+extern "C" int isle_hip_block_ks(isle_ctx* c, int nev, int ncv, int maxit, int blk, float tol, uint64_t seed, float* evals, int* nconv,
+                                 int* restarts, int* napplies) {
+  if (!c || !evals) return ISLE_E_ARG;
+  if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (nev < 1 || blk < 1 || blk > 32) return isle_fail(c, ISLE_E_ARG, "bad nev/blk");
+  Ks ks;
+  ks.c = c;
+  ks.nev = nev;
+  ks.ncv = ncv;
+  ks.maxit = maxit;
+  ks.blk = (blk < nev) ? blk : 1;  // block-ks/restarted_block_ks.h:198
+  ks.dim = c->V;
+  ks.tol = tol;
+  ks.seed = seed;
+  if ((size_t)ncv < (size_t)nev + 2 * ks.blk || (uint64_t)ncv + ks.blk > c->V)
+    return isle_fail(c, ISLE_E_ARG, "need nev + 2*blk <= ncv and ncv + blk <= vocab_size (nev=%d ncv=%d blk=%zu V=%llu)", nev, ncv,
+                     ks.blk, (unsigned long long)c->V);
+  if ((ncv - nev) % ks.blk != 0 || ncv % ks.blk != 0)
+    return isle_fail(c, ISLE_E_ARG, "nev and ncv - nev must be multiples of the block size (reference asserts the same implicitly)");
+  HIPCHK(c, c->basis.reserve((size_t)c->V * (ncv + ks.blk)));
+  HIPCHK(c, c->Fbuf.reserve((size_t)c->V * ks.blk));
+  HIPCHK(c, c->Tmp.reserve((size_t)c->V * std::max<size_t>(nev, ks.blk)));
+  c->band_ready = false;  // the operator (CSR copy) is rebuilt per solve, as in src/sparseMatrix.cpp:1199
+  ISLECHK(ks.init());
+  ISLECHK(ks.compute());
+  int rc = 0;
+  size_t nc = ks.nconv;
+  if (ks.n_restarts == (size_t)maxit) {
+    // The reference recomputes residuals from the expanded H without dividing (:303-317) and always
+    // ends up reporting nev; we report non-convergence instead but return the same Ritz pairs.
+    nc = std::min(ks.last_j, (size_t)nev);
+    if (nc < (size_t)nev) rc = ISLE_E_NOCONV;
+  }
+  nc = std::min(nc, (size_t)nev);
+  for (int i = 0; i < nev; ++i) evals[i] = ks.H(i, i);  // src/sparseMatrix.cpp:1212-1213
+  if (nconv) *nconv = (int)nc;
+  if (restarts) *restarts = (int)ks.n_restarts;
+  if (napplies) *napplies = (int)ks.napplies;
+  ISLECHK(install_U(c, c->basis.p, nev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (rc == ISLE_E_NOCONV) return isle_fail(c, rc, "block KS: %d restarts exhausted, %zu of %d Ritz pairs converged", maxit, nc, nev);
+  return 0;
+}
+
+extern "C" int isle_hip_get_U(isle_ctx* c, float* U) {
+  if (!c || !U || c->U_k == 0) return isle_fail(c, ISLE_E_ARG, "no U available");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(U, c->Ucm.p, (size_t)c->V * c->U_k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int isle_hip_set_U(isle_ctx* c, const float* U, int k) {
+  if (!c || !U || k < 1 || c->V == 0) return isle_fail(c, ISLE_E_ARG, "set_U: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->Ucm.reserve((size_t)c->V * k));
+  HIPCHK(c, hipMemcpy(c->Ucm.p, U, (size_t)c->V * k * sizeof(float), hipMemcpyHostToDevice));
+  ISLECHK(install_U(c, c->Ucm.p, k));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int isle_hip_eig_sym(isle_ctx* c, const float* S, int n, float* evals, float* vecs) {
+  if (!c || !S || !evals || !vecs || n < 1) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->Wf.reserve((size_t)n * n));
+  ISLECHK(k_jacobi_eig(c, S, n, evals, c->Wf.p));
+  HIPCHK(c, hipMemcpy(vecs, c->Wf.p, (size_t)n * n * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// k-means in the projected space
+// ------------------------------------------------------------------------------------------
+static int ensure_P(isle_ctx* c, int k) {
+  if (c->U_k != k) return isle_fail(c, ISLE_E_ARG, "U has %d columns, k = %d (run isle_hip_block_ks / set_U first)", c->U_k, k);
+  if (c->P_ready) return 0;
+  const size_t D = c->D ? c->D : 1;
+  HIPCHK(c, c->P.reserve(D * c->ldk));
+  HIPCHK(c, c->pnorm.reserve(D));
+  ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p));
+  c->P_ready = true;
+  return 0;
+}
+
+// dst (n x ldk, device) <- P rows of the given GLOBAL doc ids (owner contributes, others zero, then all-reduce)
+static int fetch_rows(isle_ctx* c, const uint64_t* ids, int n, float* dst) {
+  if (n == 0) return 0;
+  const bool multi = c->comm && c->world > 1;
+  if (multi) HIPCHK(c, hipMemsetAsync(dst, 0, (size_t)n * c->ldk * sizeof(float), c->stream));
+  for (int i = 0; i < n; ++i) {
+    const uint64_t g = ids[i];
+    if (g >= c->doc_offset && g < c->doc_offset + c->D)
+      HIPCHK(c, hipMemcpyAsync(dst + (size_t)i * c->ldk, c->P.p + (size_t)(g - c->doc_offset) * c->ldk, (size_t)c->ldk * sizeof(float),
+                               hipMemcpyDeviceToDevice, c->stream));
+    else if (!multi)
+      return isle_fail(c, ISLE_E_ARG, "seed doc id %llu out of range", (unsigned long long)g);
+  }
+  if (multi) ISLECHK(allreduce_sum<float>(c, dst, (size_t)n * c->ldk));
+  return 0;
+}
+
+extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* inject, uint64_t rng_seed, uint64_t* seeds_out,
+                                           float* C_lowd, float* residual, int* rounds_out) {
+  if (!c || !seeds_out || !C_lowd || k < 1) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((uint64_t)k > c->D_global) return isle_fail(c, ISLE_E_ARG, "k > number of documents");
+  ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2144
+  const uint64_t D = c->D, Dg = c->D_global;
+  const int ldk = c->ldk;
+  const bool multi = c->comm && c->world > 1;
+  HIPCHK(c, c->min_dist.reserve(D ? D : 1));
+  HIPCHK(c, c->cum.reserve(D + 1));
+  HIPCHK(c, c->Cdev.reserve((size_t)k * ldk));
+  HIPCHK(c, c->gram.reserve(1024));
+  HIPCHK(c, c->small.reserve(4096));
+  ISLECHK(k_fill_f32(c, c->min_dist.p, D, 3.402823466e+38f));  // FP_MAX :2148
+  HostRng rng(rng_seed);
+  std::vector<uint64_t> centers;
+  const uint64_t first = inject ? inject[0] : (uint64_t)(((size_t)rng.next31() * (size_t)84619573) % (size_t)Dg);  // :2150
+  centers.push_back(first);
+  ISLECHK(fetch_rows(c, &first, 1, c->Cdev.p));
+  int new_added = 1, rounds = 0;
+  double grand = 0.0, last_md = 0.0;
+  const int maxdraw = 2 + (int)std::ceil(std::sqrt((double)k));
+  std::vector<double> dice(maxdraw);
+  std::vector<uint64_t> drawn(maxdraw);
+  while ((int)centers.size() < k) {
+    rounds++;
+    ISLECHK(k_kmpp_update(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p + (centers.size() - new_added) * (size_t)ldk, new_added,
+                          c->min_dist.p));
+    ISLECHK(k_scan_f2d(c, c->min_dist.p, D, c->cum.p));  // :2170-2172 (double, parallel; the reference's is fp32 sequential)
+    // totals (per rank) -> offsets
+    double my[2] = {0.0, 0.0};
+    HIPCHK(c, hipMemcpyAsync(&my[0], c->cum.p + D, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (D > 0) {
+      float lm = 0.f;
+      HIPCHK(c, hipMemcpy(&lm, c->min_dist.p + (D - 1), sizeof(float), hipMemcpyDeviceToHost));
+      my[1] = lm;
+    }
+    std::vector<double> tot(2 * c->world, 0.0);
+    if (multi) {
+      double* dv = c->gram.p;
+      HIPCHK(c, hipMemcpyAsync(dv + 2 * c->world, my, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      {
+        TimeScope ts(c, ISLE_T_COMM);
+        NCCLCHK(c, ncclAllGather(dv + 2 * c->world, dv, 2, ncclDouble, c->comm, c->stream));
+      }
+      HIPCHK(c, hipMemcpyAsync(tot.data(), dv, 2 * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+      tot[0] = my[0];
+      tot[1] = my[1];
+    }
+    grand = 0.0;
+    double my_off = 0.0;
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) my_off = grand;
+      grand += tot[2 * r];
+    }
+    last_md = tot[2 * (c->world - 1) + 1];
+    const int s = (int)centers.size();
+    int ndraw = 0;
+    for (int cc = 0; cc < 1 + std::sqrt((double)(s - 5 > 0 ? s - 5 : 0)); ++cc) ndraw++;  // :2183 (upper bound on draws)
+    ndraw = std::min(ndraw, maxdraw);
+    if (!inject) {
+      // all ranks draw the same dice; the owner of the interval searches its local prefix sums
+      std::vector<double> local(ndraw, -1.0);
+      for (int i = 0; i < ndraw; ++i) {
+        dice[i] = grand * rng.fraction();  // :2184
+        const double x = dice[i] - my_off;
+        const bool mine = (x >= 0.0 && x < my[0]) || (c->world == 1);
+        local[i] = mine ? std::min(std::max(x, 0.0), my[0]) : -1.0;
+      }
+      double* dd = c->gram.p + 64;
+      uint64_t* od = (uint64_t*)(c->gram.p + 128);
+      HIPCHK(c, hipMemcpy(dd, local.data(), ndraw * sizeof(double), hipMemcpyHostToDevice));
+      ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
+      HIPCHK(c, hipMemcpyAsync(drawn.data(), od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (int i = 0; i < ndraw; ++i) {
+        if (local[i] < 0.0 || D == 0) drawn[i] = 0;
+        else drawn[i] = std::min<uint64_t>(drawn[i], D - 1) + c->doc_offset + 1;  // +1: zero means "not mine"
+      }
+      if (multi) {
+        HIPCHK(c, hipMemcpy(od, drawn.data(), ndraw * sizeof(uint64_t), hipMemcpyHostToDevice));
+        ISLECHK(allreduce_sum<uint64_t>(c, od, ndraw));
+        HIPCHK(c, hipMemcpyAsync(drawn.data(), od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+      }
+      for (int i = 0; i < ndraw; ++i) drawn[i] = drawn[i] ? drawn[i] - 1 : 0;
+    }
+    new_added = 0;
+    std::vector<uint64_t> fresh;
+    for (int cc = 0; cc < ndraw && (int)centers.size() < k; ++cc) {
+      const uint64_t nc = inject ? inject[centers.size()] : drawn[cc];
+      if (std::find(centers.begin(), centers.end(), nc) == centers.end()) {  // duplicates skipped, not redrawn :2189
+        centers.push_back(nc);
+        fresh.push_back(nc);
+        new_added++;
+      }
+    }
+    if (new_added) ISLECHK(fetch_rows(c, fresh.data(), new_added, c->Cdev.p + (centers.size() - new_added) * (size_t)ldk));
+    if (inject && new_added == 0) return isle_fail(c, ISLE_E_ARG, "injected seeds contain duplicates");
+    if (rounds > 100 * k) return isle_fail(c, ISLE_E_NUMERIC, "k-means++ cannot find %d distinct seeds", k);
+  }
+  // best_centers_coords[c] = U^T b_seed[c]  (:2232-2234)
+  std::vector<float> Ch((size_t)k * ldk);
+  HIPCHK(c, hipMemcpyAsync(Ch.data(), c->Cdev.p, Ch.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int cc = 0; cc < k; ++cc) {
+    seeds_out[cc] = centers[cc];
+    memcpy(C_lowd + (size_t)cc * k, Ch.data() + (size_t)cc * ldk, (size_t)k * sizeof(float));
+  }
+  if (residual) *residual = (float)(grand - last_md);  // dist_cumul[num_docs - 1]  (:2208; App. C #9)
+  if (rounds_out) *rounds_out = rounds;
+  return 0;
+}
+
+extern "C" int isle_hip_get_min_dist(isle_ctx* c, float* out) {
+  if (!c || !out) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->D) HIPCHK(c, hipMemcpy(out, c->min_dist.p, c->D * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// The reference's stop rule (src/sparseMatrix.cpp:2044-2064 / :1718-1738): converged when the cluster
+// sizes equal the previous iteration's AND the partition equals the last partition stored on an
+// iteration whose sizes matched.
+namespace {
+struct StopRule {
+  isle_ctx* c;
+  int k;
+  std::vector<long long> prev_sizes;
+  bool have_prev = false;
+  StopRule(isle_ctx* c_, int k_) : c(c_), k(k_), prev_sizes(k_, 0) {}
+  // sizes: GLOBAL cluster sizes of this iteration.  assign: device, local docs.
+  int converged(const std::vector<long long>& sizes, const uint32_t* assign, bool* out) {
+    bool changed = false;
+    for (int i = 0; i < k; ++i)
+      if (prev_sizes[i] != sizes[i]) changed = true;
+    prev_sizes = sizes;
+    if (!changed) {
+      if (!have_prev) {
+        changed = c->D_global > 0;  // prev_closest_docs are k empty lists
+      } else {
+        HIPCHK(c, c->flags.reserve(16));
+        ISLECHK(k_compare_u32(c, assign, c->assign_prev.p, c->D, c->flags.p));
+        ISLECHK(allreduce_sum<int>(c, c->flags.p, 1));
+        int f = 0;
+        HIPCHK(c, hipMemcpyAsync(&f, c->flags.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        changed = f != 0;
+      }
+      HIPCHK(c, c->assign_prev.reserve(c->D ? c->D : 1));
+      if (c->D) HIPCHK(c, hipMemcpyAsync(c->assign_prev.p, assign, c->D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+      have_prev = true;
+    }
+    *out = !changed;
+    return 0;
+  }
+};
+}  // namespace
+
+static int fetch_sizes(isle_ctx* c, int k, std::vector<long long>& sizes) {
+  ISLECHK(allreduce_sum<int>(c, c->counts.p, k));
+  std::vector<int> h(k);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->counts.p, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  sizes.assign(h.begin(), h.end());
+  return 0;
+}
+
+extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int max_reps, int* iters_run, uint32_t* assign_out) {
+  if (!c || !C_lowd || k < 1) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2032
+  const uint64_t D = c->D;
+  const int ldk = c->ldk;
+  HIPCHK(c, c->Cdev.reserve((size_t)k * ldk));
+  HIPCHK(c, c->Csum.reserve((size_t)k * ldk));
+  HIPCHK(c, c->cnorm.reserve(k));
+  HIPCHK(c, c->counts.reserve(k));
+  HIPCHK(c, c->assign.reserve(D ? D : 1));
+  std::vector<float> Ch((size_t)k * ldk, 0.f);
+  for (int cc = 0; cc < k; ++cc) memcpy(Ch.data() + (size_t)cc * ldk, C_lowd + (size_t)cc * k, (size_t)k * sizeof(float));
+  HIPCHK(c, hipMemcpy(c->Cdev.p, Ch.data(), Ch.size() * sizeof(float), hipMemcpyHostToDevice));
+  StopRule stop(c, k);
+  int it = 0;
+  for (; it < max_reps; ++it) {
+    ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
+    ISLECHK(k_proj_assign(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p));      // :1947
+    ISLECHK(k_proj_accumulate(c, c->P.p, D, k, ldk, c->assign.p, c->Csum.p, c->counts.p));              // :1957-1984
+    ISLECHK(allreduce_sum<float>(c, c->Csum.p, (size_t)k * ldk));
+    std::vector<long long> sizes;
+    ISLECHK(fetch_sizes(c, k, sizes));
+    ISLECHK(k_proj_finalize(c, c->Csum.p, c->counts.p, k, ldk, c->Cdev.p));                             // :1988-1992
+    bool conv = false;
+    ISLECHK(stop.converged(sizes, c->assign.p, &conv));
+    if (conv) {
+      ++it;
+      break;
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(Ch.data(), c->Cdev.p, Ch.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (assign_out && D) HIPCHK(c, hipMemcpyAsync(assign_out, c->assign.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int cc = 0; cc < k; ++cc) memcpy(C_lowd + (size_t)cc * k, Ch.data() + (size_t)cc * ldk, (size_t)k * sizeof(float));
+  if (iters_run) *iters_run = it;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// lift + Lloyd on the sparse matrix
+// ------------------------------------------------------------------------------------------
+static int install_centers(isle_ctx* c, int ncols) {  // centers_cm (V x ncols) -> centers_rm (V x ld), zero padded
+  const int ld = round4(ncols);
+  HIPCHK(c, c->centers_rm.reserve((size_t)c->V * ld));
+  HIPCHK(c, hipMemsetAsync(c->centers_rm.p, 0, (size_t)c->V * ld * sizeof(float), c->stream));
+  ISLECHK(k_transpose(c, c->centers_cm.p, c->V, ncols, c->V, c->centers_rm.p, ld));
+  c->centers_ready = true;
+  c->centers_k = ncols;
+  return 0;
+}
+
+extern "C" int isle_hip_lift_centers(isle_ctx* c, const float* in, int ld_in, int ncols, float* centers) {
+  if (!c || !in || ncols < 1) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->U_k == 0 || ld_in < c->U_k) return isle_fail(c, ISLE_E_ARG, "lift: need U and ld_in >= k");
+  HIPCHK(c, c->Csum.reserve((size_t)ld_in * ncols));
+  HIPCHK(c, hipMemcpy(c->Csum.p, in, (size_t)ld_in * ncols * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(c, c->centers_cm.reserve((size_t)c->V * ncols));
+  ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, c->U_k, c->Csum.p, ld_in, ncols, c->centers_cm.p));
+  ISLECHK(install_centers(c, ncols));
+  if (centers) HIPCHK(c, hipMemcpyAsync(centers, c->centers_cm.p, (size_t)c->V * ncols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_in, float* centers_out, uint32_t* assign, int max_reps,
+                                      int* iters_run) {
+  if (!c || k < 1) return ISLE_E_ARG;
+  if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t D = c->D, V = c->V;
+  const int ld = round4(k);
+  if (centers_in) {
+    HIPCHK(c, c->centers_cm.reserve((size_t)V * k));
+    HIPCHK(c, hipMemcpy(c->centers_cm.p, centers_in, (size_t)V * k * sizeof(float), hipMemcpyHostToDevice));
+    ISLECHK(install_centers(c, k));
+  } else if (!c->centers_ready || c->centers_k != k) {
+    return isle_fail(c, ISLE_E_ARG, "lloyds_sparse: no device-resident centres for k = %d (call isle_hip_lift_centers)", k);
+  }
+  HIPCHK(c, c->dnorm.reserve(D ? D : 1));
+  HIPCHK(c, c->cnorm.reserve(k));
+  HIPCHK(c, c->counts.reserve(k));
+  HIPCHK(c, c->assign.reserve(D ? D : 1));
+  ISLECHK(k_doc_norms(c, c->dnorm.p));  // :1680-1687
+  StopRule stop(c, k);
+  int it = 0;
+  for (; it < max_reps; ++it) {
+    {
+      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+      ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, c->cnorm.p));  // :1604
+    }
+    ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p));  // :1606
+    ISLECHK(k_scatter_centers(c, c->assign.p, k, ld, c->centers_rm.p, c->counts.p));               // :1613-1638
+    ISLECHK(allreduce_sum<float>(c, c->centers_rm.p, (size_t)V * ld));
+    std::vector<long long> sizes;
+    ISLECHK(fetch_sizes(c, k, sizes));
+    ISLECHK(k_scale_centers(c, c->centers_rm.p, V, k, ld, c->counts.p));  // :1641-1646
+    bool conv = false;
+    ISLECHK(stop.converged(sizes, c->assign.p, &conv));
+    if (conv) {
+      ++it;
+      break;
+    }
+  }
+  if (assign && D) HIPCHK(c, hipMemcpyAsync(assign, c->assign.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (centers_out) {
+    HIPCHK(c, c->centers_cm.reserve((size_t)V * k));
+    // row-major (V x ld) -> col-major (V x k): view as a k x V col-major matrix with ld_in = ld
+    ISLECHK(k_transpose(c, c->centers_rm.p, k, V, ld, c->centers_cm.p, V));
+    HIPCHK(c, hipMemcpyAsync(centers_out, c->centers_cm.p, (size_t)V * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (iters_run) *iters_run = it;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------
+extern "C" int isle_hip_timing_enable(isle_ctx* c, int on) {
+  if (!c) return ISLE_E_ARG;
+  c->timing = on != 0;
+  return 0;
+}
+extern "C" int isle_hip_timing_reset(isle_ctx* c) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(drain_events(c));
+  for (int i = 0; i < ISLE_T_COUNT; ++i) {
+    c->t_ms[i] = 0.0;
+    c->t_n[i] = 0;
+  }
+  return 0;
+}
+extern "C" int isle_hip_timing_get(isle_ctx* c, double* ms, uint64_t* launches) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(drain_events(c));
+  for (int i = 0; i < ISLE_T_COUNT; ++i) {
+    if (ms) ms[i] = c->t_ms[i];
+    if (launches) launches[i] = c->t_n[i];
+  }
+  return 0;
+}
+extern "C" int isle_hip_synchronize(isle_ctx* c) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}

@@ -1,0 +1,174 @@
+// isle_amd/csrc/common.h — internal declarations shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/isle_hip.h"
+
+#define ISLE_WAVE 64
+
+struct isle_event_pair {
+  hipEvent_t a, b;
+  int fam;
+};
+
+// Device buffer with explicit capacity (grows, never shrinks).
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct isle_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int num_cus = 256;
+
+  // --- communicator (null for single GPU)
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+
+  // --- B (this rank's column shard), CSC
+  uint64_t V = 0, D = 0, nnz = 0, doc_offset = 0, D_global = 0;
+  DevBuf<float> vals;
+  DevBuf<uint32_t> rows;
+  DevBuf<int64_t> offs;
+
+  // --- chunked-CSR copy of B for Z = B*Y (built per eigensolve, like the reference's operator ctor)
+  bool band_ready = false;
+  uint32_t band_rows = 0;  // requested columns per chunk (0 = default), env ISLE_CHUNK_COLS
+  uint32_t nbands = 0;     // number of column chunks (multiple of 8)
+  uint32_t chunk_cols = 0;
+  DevBuf<uint32_t> bcol;   // nnz   doc id
+  DevBuf<float> bval;      // nnz
+  DevBuf<int64_t> seg_off; // nchunks*V + 1
+  DevBuf<float> Zpart;     // nchunks x V x BP partial rows
+
+  // --- gram-apply workspaces
+  DevBuf<float> Xrm, Yrm, Zrm;   // V*BP, D*BP, V*BP
+  DevBuf<float> Xcm, Zcm;        // staging for the host-pointer API
+
+  // --- eigensolver state
+  DevBuf<float> basis;     // V x (ncv + blk) col-major
+  DevBuf<float> Fbuf;      // V x blk
+  DevBuf<float> Tmp;       // V x nev (rotation target)
+  DevBuf<double> part;     // partial reductions
+  DevBuf<float> coef;      // 3 x (m x blk)
+  DevBuf<double> gram;     // blk x blk
+  DevBuf<float> small;     // misc small device scratch
+  DevBuf<double> jacW, jacV;  // n x n each
+  DevBuf<float> Wf;        // n x n float eigenvectors
+  int U_k = 0;             // number of columns of U available
+  DevBuf<float> Ucm;       // V x k col-major  (copy of basis[:, :k])
+  DevBuf<float> Urm;       // V x ldk row-major
+  int ldk = 0;
+
+  // --- k-means state
+  DevBuf<float> P;         // D x ldk
+  DevBuf<float> pnorm;     // D
+  bool P_ready = false;
+  DevBuf<float> min_dist;  // D
+  DevBuf<double> cum;      // D + 1
+  DevBuf<double> scan_blk;
+  DevBuf<float> Cdev;      // k x ldk centres (projected)
+  DevBuf<float> cnorm;     // k
+  DevBuf<float> Csum;      // k x ldk + k
+  DevBuf<uint32_t> assign, assign_prev;
+  DevBuf<int> counts;
+  DevBuf<int> flags;
+  DevBuf<float> centers_rm;   // V x ldk  (word-space centres, row-major)
+  DevBuf<float> centers_cm;   // V x k col-major staging
+  bool centers_ready = false;
+  int centers_k = 0;
+  DevBuf<float> dnorm;     // D   |b_d|^2
+
+  // --- timing
+  bool timing = false;
+  std::vector<isle_event_pair> ev_used;
+  std::vector<isle_event_pair> ev_free;
+  double t_ms[ISLE_T_COUNT] = {0};
+  uint64_t t_n[ISLE_T_COUNT] = {0};
+};
+
+int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return isle_fail((ctx), ISLE_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+  } while (0)
+
+#define ISLECHK(call)            \
+  do {                           \
+    int rc__ = (call);           \
+    if (rc__ != 0) return rc__;  \
+  } while (0)
+
+// RAII timing scope: records an event pair on the stream when timing is enabled.
+struct TimeScope {
+  isle_ctx* c;
+  isle_event_pair ep;
+  bool on;
+  TimeScope(isle_ctx* c_, int fam);
+  ~TimeScope();
+};
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------- kernel launchers (each defined in one .hip file) -------------------------
+// spmm.hip
+int k_pack_rm(isle_ctx* c, const float* Xcm, uint64_t V, int b, int BP, float* Xrm);
+int k_unpack_cm(isle_ctx* c, const float* Zrm, uint64_t V, int b, int BP, float* Zcm);
+int k_gram_pass1(isle_ctx* c, int BP);   // Yrm = B^T Xrm
+int k_gram_pass2(isle_ctx* c, int BP);   // Zrm = B Yrm
+int k_band_build(isle_ctx* c);
+int k_frobenius(isle_ctx* c, double* out_host);
+int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms);
+int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign);
+int k_doc_norms(isle_ctx* c, float* dn);
+int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
+
+// dense.hip
+int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);
+int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef);
+int k_gram64(isle_ctx* c, const float* F, uint64_t n, int b, double* G_host /*b x b col-major*/);
+int k_apply_T(isle_ctx* c, const float* F, uint64_t n, int b, const float* T_host /*b x rk col-major*/, int rk, float* Q);
+int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
+int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C);  // col-major, lda = ldc = M
+int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl
+int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x n col-major*/);
+int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out);  // out[c] = sum_r M[r][c]^2
+int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, const int* counts);
+
+// kmeans.hip
+int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc, float* min_dist);
+int k_scan_f2d(isle_ctx* c, const float* in, uint64_t n, double* cum /*n+1*/);
+int k_search(isle_ctx* c, const double* cum, uint64_t n, const double* dice_dev, int nd, uint64_t* out_dev);
+int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign);
+int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out);
+int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts);
+int k_proj_finalize(isle_ctx* c, const float* Csum, const int* counts, int k, int ldk, float* C);
+int k_count_sizes(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, int* counts);
+int k_compare_u32(isle_ctx* c, const uint32_t* a, const uint32_t* b, uint64_t n, int* flag_dev);
+int k_fill_f32(isle_ctx* c, float* p, uint64_t n, float v);

@@ -1,0 +1,485 @@
+// isle_amd/csrc/dense.hip — tall-skinny panel kernels, f32 MFMA GEMM, small symmetric EVD (gfx950).
+//
+//   k_vtf / k_update      H = V^T F ; F -= V H        block-ks/restarted_block_ks.h:83-91 (CGS + 2x DGKS)
+//   k_gram64 / k_apply_T  panel QR as CholQR2 on an fp64 Gram matrix; stands in for the fp64 MGS of
+//                         utils::compute_qr  block-ks/ks_utils.h:43-127  (rank test kept: see solver.cpp)
+//   k_gemm_nn             C = A B, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): Ritz rotation
+//                         block-ks/restarted_block_ks.h:166-167 and lift src/sparseMatrix.cpp:1446-1449
+//   k_jacobi_eig          one-sided (Hestenes) Jacobi in fp64: arma::eig_sym -> ssyevd
+//                         block-ks/restarted_block_ks.h:150-161
+#include <algorithm>
+
+#include "common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// V^T F : partial products per (row chunk, column group) in double, then a fixed-order reduce.
+// ------------------------------------------------------------------------------------------
+constexpr int VTF_CG = 32;    // basis columns per workgroup (8 per wave)
+// rows per chunk: the F panel chunk [BT][RC] must fit the 64 KB static LDS limit
+constexpr int vtf_rc(int BT) { return BT <= 12 ? 1024 : (BT <= 16 ? 512 : 256); }
+
+template <int BT>
+__global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ Vb, uint64_t n, int m, const float* __restrict__ F,
+                                                      int b, double* __restrict__ part /*[chunk][m][BT]*/) {
+  constexpr int VTF_RC = vtf_rc(BT);
+  __shared__ float Fs[BT][VTF_RC];
+  const uint64_t r0 = (uint64_t)blockIdx.x * VTF_RC;
+  const int rc = (int)min((uint64_t)VTF_RC, n - r0);
+  for (int idx = threadIdx.x; idx < BT * VTF_RC; idx += 256) {
+    const int j = idx / VTF_RC, r = idx - j * VTF_RC;
+    Fs[j][r] = (j < b && r < rc) ? F[(uint64_t)j * n + r0 + r] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int ci = wave; ci < VTF_CG; ci += 4) {
+    const int i = blockIdx.y * VTF_CG + ci;
+    if (i >= m) break;
+    const float* v = Vb + (uint64_t)i * n + r0;
+    double acc[BT];
+#pragma unroll
+    for (int j = 0; j < BT; ++j) acc[j] = 0.0;
+    for (int r = lane; r < rc; r += 64) {
+      const double x = (double)v[r];
+#pragma unroll
+      for (int j = 0; j < BT; ++j) acc[j] = fma(x, (double)Fs[j][r], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      double s = acc[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      acc[j] = s;
+    }
+    if (lane == 0) {
+      double* o = part + ((size_t)blockIdx.x * m + i) * BT;
+#pragma unroll
+      for (int j = 0; j < BT; ++j) o[j] = acc[j];
+    }
+  }
+}
+
+template <class Tout>
+__global__ void vtf_reduce_k(const double* __restrict__ part, int nchunks, int m, int BT, int b, Tout* __restrict__ coef) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * b) return;
+  const int j = idx / m, i = idx - j * m;
+  double s = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) s += part[((size_t)ch * m + i) * BT + j];
+  coef[(size_t)j * m + i] = (Tout)s;
+}
+
+static int bt_of(int b) { return b <= 4 ? 4 : b <= 8 ? 8 : b <= 12 ? 12 : b <= 16 ? 16 : 32; }
+
+template <class Tout>
+static int vtf_impl(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, Tout* out_dev) {
+  if (b > 32 || b < 1) return isle_fail(c, ISLE_E_ARG, "block width %d not in [1,32]", b);
+  const int BT = bt_of(b);
+  const int nchunks = cdiv(n, vtf_rc(BT));
+  HIPCHK(c, c->part.reserve((size_t)nchunks * m * BT));
+  dim3 g(nchunks, cdiv(m, VTF_CG)), blk(256);
+  switch (BT) {
+    case 4: hipLaunchKernelGGL(vtf_partial_k<4>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
+    case 8: hipLaunchKernelGGL(vtf_partial_k<8>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
+    case 12: hipLaunchKernelGGL(vtf_partial_k<12>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
+    case 16: hipLaunchKernelGGL(vtf_partial_k<16>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
+    default: hipLaunchKernelGGL(vtf_partial_k<32>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(vtf_reduce_k<Tout>, dim3(cdiv((long)m * b, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, m, BT, b, out_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef) {
+  TimeScope ts(c, ISLE_T_ORTHO);
+  return vtf_impl<float>(c, Vb, n, m, F, b, coef);
+}
+
+int k_gram64(isle_ctx* c, const float* F, uint64_t n, int b, double* G_host) {
+  TimeScope ts(c, ISLE_T_QR);
+  HIPCHK(c, c->gram.reserve(32 * 32));
+  ISLECHK(vtf_impl<double>(c, F, n, b, F, b, c->gram.p));
+  HIPCHK(c, hipMemcpyAsync(G_host, c->gram.p, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// F[r, :] -= sum_i Vb[r, i] * coef[i, :]        one thread per row, coef tiles staged in LDS
+// ------------------------------------------------------------------------------------------
+constexpr int UPD_TILE = 128;
+template <int BT>
+__global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t n, int b, const float* __restrict__ Vb, int m,
+                                                 const float* __restrict__ coef /*m x b col-major*/) {
+  __shared__ float Cs[UPD_TILE][BT];
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < n;
+  float acc[BT];
+#pragma unroll
+  for (int j = 0; j < BT; ++j) acc[j] = 0.f;
+  for (int i0 = 0; i0 < m; i0 += UPD_TILE) {
+    const int cnt = min(UPD_TILE, m - i0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < UPD_TILE * BT; idx += 256) {
+      const int ii = idx / BT, j = idx - ii * BT;
+      Cs[ii][j] = (ii < cnt && j < b) ? coef[(size_t)j * m + i0 + ii] : 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      const float* v = Vb + (uint64_t)i0 * n + r;
+#pragma unroll 8
+      for (int ii = 0; ii < cnt; ++ii) {
+        const float x = v[(uint64_t)ii * n];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) acc[j] = fmaf(x, Cs[ii][j], acc[j]);
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j)
+      if (j < b) F[(uint64_t)j * n + r] -= acc[j];
+  }
+}
+
+int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef) {
+  TimeScope ts(c, ISLE_T_ORTHO);
+  const int BT = bt_of(b);
+  dim3 g(cdiv(n, 256)), blk(256);
+  switch (BT) {
+    case 4: hipLaunchKernelGGL(update_k<4>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
+    case 8: hipLaunchKernelGGL(update_k<8>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
+    case 12: hipLaunchKernelGGL(update_k<12>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
+    case 16: hipLaunchKernelGGL(update_k<16>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
+    default: hipLaunchKernelGGL(update_k<32>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// Q[r, 0:rk] = F[r, 0:b] * T (b x rk, col-major).  Q may alias F (each thread owns a row).
+__global__ __launch_bounds__(256) void apply_T_k(const float* F, uint64_t n, int b, const float* __restrict__ T, int rk, float* Q) {
+  __shared__ float Ts[32 * 32];
+  for (int idx = threadIdx.x; idx < b * rk; idx += 256) Ts[idx] = T[idx];
+  __syncthreads();
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  float f[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) f[j] = (j < b) ? F[(uint64_t)j * n + r] : 0.f;
+  for (int cc = 0; cc < rk; ++cc) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < b) s = fmaf(f[j], Ts[cc * b + j], s);
+    Q[(uint64_t)cc * n + r] = s;
+  }
+}
+int k_apply_T(isle_ctx* c, const float* F, uint64_t n, int b, const float* T_host, int rk, float* Q) {
+  TimeScope ts(c, ISLE_T_QR);
+  if (rk == 0) return 0;
+  HIPCHK(c, c->small.reserve(4096));
+  HIPCHK(c, hipMemcpyAsync(c->small.p, T_host, (size_t)b * rk * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(apply_T_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, F, n, b, c->small.p, rk, Q);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // T_host is pageable caller memory: do not outlive it
+  return 0;
+}
+
+// uniform [0,1) fill (arma::randu stand-in, block-ks/restarted_block_ks.h:212)
+__global__ void randu_k(float* __restrict__ F, uint64_t count, uint64_t seed) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + (i + 1) * 0xD1342543DE82EF95ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  F[i] = (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed) {
+  hipLaunchKernelGGL(randu_k, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, F, count, seed);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// C (M x N) = A (M x K, lda = M) * B (K x N, ldb), col-major, exact f32 on the matrix cores.
+// Tile 128 (M) x 64 (N) x 16 (K); wave w owns rows [32w, 32w+32) x all 64 columns (2 MFMA tiles).
+// The MFMA is issued "transposed" (its row index = n, its column index = m) so that a lane owns one
+// row m of C and the col-major stores of a wave are 128-B contiguous.
+// ------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 64, GK = 16;
+__global__ __launch_bounds__(256) void gemm_nn_k(const float* __restrict__ A, uint64_t M, int K, const float* __restrict__ B, int ldb,
+                                                  int N, float* __restrict__ C) {
+  __shared__ float As[GK][GM];
+  __shared__ float Bs[GK][GN + 1];
+  const uint64_t m0 = (uint64_t)blockIdx.x * GM;
+  const int n0 = blockIdx.y * GN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  floatx16 acc0 = {0}, acc1 = {0};
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (GK * GM) / 256; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      const int kk = idx / GM, mm = idx - kk * GM;
+      const uint64_t gm = m0 + mm;
+      As[kk][mm] = (gm < M && k0 + kk < K) ? A[(uint64_t)(k0 + kk) * M + gm] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < (GK * GN) / 256; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      const int kk = idx % GK, nn = idx / GK;
+      Bs[kk][nn] = (n0 + nn < N && k0 + kk < K) ? B[(size_t)(n0 + nn) * ldb + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 2) {
+      const float bm = As[kk + h][32 * wave + l31];
+      const float a0 = Bs[kk + h][l31];
+      const float a1 = Bs[kk + h][32 + l31];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bm, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bm, acc1, 0, 0, 0);
+    }
+  }
+  const uint64_t gm = m0 + 32 * wave + l31;
+  if (gm < M) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nn = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n0 + nn < N) C[(uint64_t)(n0 + nn) * M + gm] = acc0[r];
+      if (n0 + 32 + nn < N) C[(uint64_t)(n0 + 32 + nn) * M + gm] = acc1[r];
+    }
+  }
+}
+int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C) {
+  TimeScope ts(c, ISLE_T_ROTATE);
+  if (M == 0 || N == 0) return 0;
+  dim3 g(cdiv(M, GM), cdiv(N, GN)), blk(256);
+  hipLaunchKernelGGL(gemm_nn_k, g, blk, 0, c->stream, A, M, K, B, ldb, N, C);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// in: element (r, cidx) at in[cidx*ld_in + r], r < rows, cidx < cols.  out[r*ld_out + cidx] = in(r, cidx).
+__global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in, uint64_t rows, uint64_t cols, uint64_t ld_in,
+                                                    float* __restrict__ out, uint64_t ld_out) {
+  __shared__ float t[32][33];
+  const uint64_t r0 = (uint64_t)blockIdx.x * 32, c0 = (uint64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int yy = ty; yy < 32; yy += 8) {
+    const uint64_t r = r0 + tx, cc = c0 + yy;
+    t[yy][tx] = (r < rows && cc < cols) ? in[cc * ld_in + r] : 0.f;
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 32; yy += 8) {
+    const uint64_t r = r0 + yy, cc = c0 + tx;
+    if (r < rows && cc < cols) out[r * ld_out + cc] = t[tx][yy];
+  }
+}
+int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out) {
+  if (rows == 0 || cols == 0) return 0;
+  dim3 g(cdiv(rows, 32), cdiv(cols, 32)), blk(256);
+  hipLaunchKernelGGL(transpose_k, g, blk, 0, c->stream, in, rows, cols, ld_in, out, ld_out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// One-sided Jacobi (Hestenes) on W = (S + mu I), V = I, fp64.  Round-robin pairing: n/2 disjoint
+// column pairs per round, one workgroup per pair; n-1 rounds per sweep.
+// ------------------------------------------------------------------------------------------
+__device__ inline double block_sum(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void jacobi_round_k(double* __restrict__ W, double* __restrict__ Vv, int n, int np, int round,
+                                                       double tol, unsigned int* __restrict__ rotated) {
+  __shared__ double sh[8];
+  const int mrot = np - 1;
+  int p, q;
+  if (blockIdx.x == 0) {
+    p = np - 1;
+    q = round % mrot;
+  } else {
+    p = (round + (int)blockIdx.x) % mrot;
+    q = (round - (int)blockIdx.x + mrot) % mrot;
+  }
+  if (p >= n || q >= n) return;
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+  double* wp = W + (size_t)p * n;
+  double* wq = W + (size_t)q * n;
+  double a = 0.0, b = 0.0, g = 0.0;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double x = wp[r], y = wq[r];
+    a = fma(x, x, a);
+    b = fma(y, y, b);
+    g = fma(x, y, g);
+  }
+  a = block_sum(a, sh);
+  b = block_sum(b, sh);
+  g = block_sum(g, sh);
+  if (a == 0.0 || b == 0.0) return;
+  if (fabs(g) <= tol * sqrt(a) * sqrt(b)) return;
+  if (threadIdx.x == 0) atomicAdd(rotated, 1u);
+  const double zeta = (b - a) / (2.0 * g);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cs = 1.0 / sqrt(1.0 + t * t);
+  const double sn = cs * t;
+  double* vp = Vv + (size_t)p * n;
+  double* vq = Vv + (size_t)q * n;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double x = wp[r], y = wq[r];
+    wp[r] = cs * x - sn * y;
+    wq[r] = sn * x + cs * y;
+    const double u = vp[r], v = vq[r];
+    vp[r] = cs * u - sn * v;
+    vq[r] = sn * u + cs * v;
+  }
+}
+
+// lambda_i = sign(v_i . w_i) * |w_i|
+__global__ __launch_bounds__(256) void jacobi_evals_k(const double* __restrict__ W, const double* __restrict__ Vv, int n,
+                                                       double* __restrict__ ev) {
+  __shared__ double sh[8];
+  const int i = blockIdx.x;
+  double nn = 0.0, dd = 0.0;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double w = W[(size_t)i * n + r];
+    nn = fma(w, w, nn);
+    dd = fma(w, Vv[(size_t)i * n + r], dd);
+  }
+  nn = block_sum(nn, sh);
+  dd = block_sum(dd, sh);
+  if (threadIdx.x == 0) ev[i] = (dd < 0.0 ? -1.0 : 1.0) * sqrt(nn);
+}
+
+__global__ void jacobi_gather_k(const double* __restrict__ Vv, int n, const int* __restrict__ order, float* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n * n) return;
+  const int cidx = (int)(idx / n), r = (int)(idx - (size_t)cidx * n);
+  out[idx] = (float)Vv[(size_t)order[cidx] * n + r];
+}
+
+int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev) {
+  TimeScope ts(c, ISLE_T_EVD);
+  if (n <= 0) return 0;
+  const size_t nn = (size_t)n * n;
+  std::vector<double> Wh(nn), Vh(nn, 0.0);
+  // LAPACK 'U' semantics: the upper triangle defines the matrix.
+  double mu = 0.0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) Wh[(size_t)j * n + i] = (i <= j) ? (double)S_host[(size_t)j * n + i] : (double)S_host[(size_t)i * n + j];
+  for (int i = 0; i < n; ++i) {  // Gershgorin: shift so that the matrix is positive semi-definite
+    double off = 0.0;
+    for (int j = 0; j < n; ++j)
+      if (j != i) off += fabs(Wh[(size_t)j * n + i]);
+    mu = std::max(mu, off - Wh[(size_t)i * n + i]);
+  }
+  for (int i = 0; i < n; ++i) {
+    Wh[(size_t)i * n + i] += mu;
+    Vh[(size_t)i * n + i] = 1.0;
+  }
+  HIPCHK(c, c->jacW.reserve(nn));
+  HIPCHK(c, c->jacV.reserve(nn));
+  HIPCHK(c, c->small.reserve((size_t)std::max(4096, n + 64)));
+  HIPCHK(c, c->part.reserve((size_t)n));
+  HIPCHK(c, hipMemcpyAsync(c->jacW.p, Wh.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->jacV.p, Vh.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  unsigned int* rot = (unsigned int*)c->small.p;
+  const int np = (n + 1) & ~1;
+  const double tol = 1e-15 * (double)n;
+  bool converged = (n == 1);
+  for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+    HIPCHK(c, hipMemsetAsync(rot, 0, sizeof(unsigned int), c->stream));
+    for (int round = 0; round < np - 1; ++round)
+      hipLaunchKernelGGL(jacobi_round_k, dim3(np / 2), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, np, round, tol, rot);
+    HIPCHK(c, hipGetLastError());
+    unsigned int nrot = 0;
+    HIPCHK(c, hipMemcpyAsync(&nrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nrot == 0) converged = true;
+  }
+  if (!converged) return isle_fail(c, ISLE_E_NUMERIC, "Jacobi EVD (n=%d) did not converge in 60 sweeps", n);
+  hipLaunchKernelGGL(jacobi_evals_k, dim3(n), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, c->part.p);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> ev(n);
+  HIPCHK(c, hipMemcpyAsync(ev.data(), c->part.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ev[x] > ev[y]; });
+  for (int i = 0; i < n; ++i) evals_host[i] = (float)(ev[order[i]] - mu);
+  int* ord_dev = (int*)(c->small.p + 16);
+  HIPCHK(c, hipMemcpyAsync(ord_dev, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(jacobi_gather_k, dim3(cdiv(nn, 256)), dim3(256), 0, c->stream, c->jacV.p, n, ord_dev, vecs_dev);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // `order` (pageable) must outlive the copy
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums of squares of a row-major matrix (centre norms, src/sparseMatrix.cpp:1575-1584)
+// ------------------------------------------------------------------------------------------
+constexpr int CN_ROWS = 512;
+__global__ __launch_bounds__(256) void colnorm_partial_k(const float* __restrict__ Mrm, uint64_t rows, int k, int ldk,
+                                                          double* __restrict__ part) {
+  const uint64_t r0 = (uint64_t)blockIdx.x * CN_ROWS;
+  const uint64_t r1 = min(rows, r0 + CN_ROWS);
+  for (int cc = threadIdx.x; cc < k; cc += 256) {
+    double s = 0.0;
+    for (uint64_t r = r0; r < r1; ++r) {
+      const double x = (double)Mrm[r * ldk + cc];
+      s = fma(x, x, s);
+    }
+    part[(size_t)blockIdx.x * k + cc] = s;
+  }
+}
+__global__ void colnorm_reduce_k(const double* __restrict__ part, int nchunks, int k, float* __restrict__ out) {
+  const int cc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc >= k) return;
+  double s = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) s += part[(size_t)ch * k + cc];
+  out[cc] = (float)s;
+}
+int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out) {
+  const int nchunks = cdiv(rows, CN_ROWS);
+  HIPCHK(c, c->part.reserve((size_t)nchunks * k));
+  hipLaunchKernelGGL(colnorm_partial_k, dim3(nchunks), dim3(256), 0, c->stream, Mrm, rows, k, ldk, c->part.p);
+  hipLaunchKernelGGL(colnorm_reduce_k, dim3(cdiv(k, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, k, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// centre /= cluster size, true division, empty clusters stay zero (src/sparseMatrix.cpp:1641-1646)
+__global__ void scale_centers_k(float* __restrict__ Crm, uint64_t rows, int k, int ldk, const int* __restrict__ counts) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * (uint64_t)ldk) return;
+  const int cc = (int)(idx % ldk);
+  if (cc < k) {
+    const float div = (float)counts[cc];
+    if (div > 0.0f) Crm[idx] /= div;
+  }
+}
+int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, const int* counts) {
+  TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
+  const uint64_t n = rows * (uint64_t)ldk;
+  hipLaunchKernelGGL(scale_centers_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, Crm, rows, k, ldk, counts);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,454 @@
+// isle_amd/csrc/spmm.hip — sparse kernels of the hot path (gfx950 / wave64).
+//
+//   Gram apply  Z = B (B^T X)      replaces MKL_SpSpTrProd::multiply  include/matUtils.h:336-365
+//     pass 1  Y = B^T X  : CSC gather, one wave per document column, 64/LPE nonzeros per step,
+//                          each lane one float4 of an X row (X is V x BP row-major, L2 resident)
+//     pass 2  Z = B Y    : chunked-CSR copy of B (the reference also builds a CSR copy in the operator
+//                          ctor, matUtils.h:103-106): same gather kernel, one wave per (column chunk, row);
+//                          chunks are pinned to XCDs so that a chunk's slice of Y is served from one L2.
+//                          (An LDS-tile scatter with ds_add_f32 was measured first: 7.0 ms per apply at C2
+//                          against 1.9 ms with plain LDS stores — LDS float atomics are ~4 clk per lane on
+//                          gfx950 — so the scatter form was dropped; see DESIGN.md.)
+//   k-wide SpMM  out_d = sum_i val_i * M[row_i, :]   (M = U or centres, V x ldk row-major)
+//     replaces FPSparseMatrix::multiply_with  src/sparseMatrix.cpp:1749-1782  with fused epilogues:
+//       PROJECT: P = B^T U and |P_d|^2   (UT_times_docs :1785, compute_projected_docs_l2sq :1888)
+//       ASSIGN : argmin_c | |b_d|^2 + |C_c|^2 - 2 b_d^T C_c |   (distsq_docs_to_centers :1494,
+//                closest_centers :1553; cblas_isamin semantics = first index of min |x|)
+//   centroid scatter-add  (lloyds_iter :1631-1638)
+#include <cstdlib>
+
+#include "common.h"
+#include "scan.h"
+
+// ------------------------------------------------------------------------------------------
+// layout helpers
+// ------------------------------------------------------------------------------------------
+__global__ void pack_rm_k(const float* __restrict__ Xcm, uint64_t V, int b, int BP, float* __restrict__ Xrm) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= V * (uint64_t)BP) return;
+  const uint64_t r = idx / BP;
+  const int j = (int)(idx - r * BP);
+  Xrm[idx] = (j < b) ? Xcm[(uint64_t)j * V + r] : 0.f;
+}
+__global__ void unpack_cm_k(const float* __restrict__ Zrm, uint64_t V, int b, int BP, float* __restrict__ Zcm) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= V * (uint64_t)b) return;
+  const int j = (int)(idx / V);
+  const uint64_t r = idx - (uint64_t)j * V;
+  Zcm[idx] = Zrm[r * BP + j];
+}
+int k_pack_rm(isle_ctx* c, const float* Xcm, uint64_t V, int b, int BP, float* Xrm) {
+  const uint64_t n = V * (uint64_t)BP;
+  hipLaunchKernelGGL(pack_rm_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, Xcm, V, b, BP, Xrm);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_unpack_cm(isle_ctx* c, const float* Zrm, uint64_t V, int b, int BP, float* Zcm) {
+  const uint64_t n = V * (uint64_t)b;
+  hipLaunchKernelGGL(unpack_cm_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, Zrm, V, b, BP, Zcm);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+__device__ inline float4 f4_fma(float s, float4 a, float4 acc) {
+  acc.x = fmaf(s, a.x, acc.x);
+  acc.y = fmaf(s, a.y, acc.y);
+  acc.z = fmaf(s, a.z, acc.z);
+  acc.w = fmaf(s, a.w, acc.w);
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Segment gather-reduce:  Out[seg, :] = sum_{i in [offs[seg], offs[seg+1])} vals[i] * In[idx[i], :]
+// One wave per segment, 64/LPE nonzeros per step, each lane one float4 of an In row.
+//   pass 1 (Y = B^T X): segment = document column of the CSC, idx = word id, In = X (V x BP, L2 resident)
+//   pass 2 (Z = B Y)  : segment = (column chunk, word row) of the chunked-CSR copy, idx = doc id,
+//                       In = Y; a chunk's slice of Y (<= ~1.5 MB) stays in ONE XCD's L2 because the
+//                       workgroups of chunk c are the ones with blockIdx % 8 == c % 8 (XCD_MAP).
+// No atomics anywhere: per-chunk partial rows go to a slab that reduce_chunks_k sums in chunk order.
+// ------------------------------------------------------------------------------------------
+template <int LPE, bool XCD_MAP>
+__global__ __launch_bounds__(256) void seg_gather_k(const float* __restrict__ vals, const uint32_t* __restrict__ idx,
+                                                     const int64_t* __restrict__ offs, const float4* __restrict__ In,
+                                                     float4* __restrict__ Out, uint32_t nseg /*per group*/, uint32_t ngroups) {
+  constexpr int EPW = 64 / LPE;
+  const int lane = threadIdx.x & 63;
+  const uint32_t w = threadIdx.x >> 6;
+  size_t seg;
+  if (!XCD_MAP) {
+    const uint32_t sid = blockIdx.x * 4 + w;
+    if (sid >= nseg) return;
+    seg = sid;
+  } else {
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const uint32_t bpc = (nseg + 3) / 4;
+    const uint32_t grp = 8 * (j / bpc) + xcd;
+    const uint32_t r = 4 * (j % bpc) + w;
+    if (grp >= ngroups || r >= nseg) return;
+    seg = (size_t)grp * nseg + r;
+  }
+  const int e = lane / LPE;
+  const int q = lane - e * LPE;
+  const bool active = e < EPW;
+  const int64_t beg = offs[seg], end = offs[seg + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    int64_t i = beg + e;
+    for (; i + 3 * EPW < end; i += 4 * EPW) {  // four nonzeros in flight per lane
+      const uint32_t r0 = __builtin_nontemporal_load(&idx[i]), r1 = __builtin_nontemporal_load(&idx[i + EPW]);
+      const uint32_t r2 = __builtin_nontemporal_load(&idx[i + 2 * EPW]), r3 = __builtin_nontemporal_load(&idx[i + 3 * EPW]);
+      const float v0 = __builtin_nontemporal_load(&vals[i]), v1 = __builtin_nontemporal_load(&vals[i + EPW]);
+      const float v2 = __builtin_nontemporal_load(&vals[i + 2 * EPW]), v3 = __builtin_nontemporal_load(&vals[i + 3 * EPW]);
+      const float4 x0 = In[(size_t)r0 * LPE + q];
+      const float4 x1 = In[(size_t)r1 * LPE + q];
+      const float4 x2 = In[(size_t)r2 * LPE + q];
+      const float4 x3 = In[(size_t)r3 * LPE + q];
+      acc = f4_fma(v0, x0, acc);
+      acc = f4_fma(v1, x1, acc);
+      acc = f4_fma(v2, x2, acc);
+      acc = f4_fma(v3, x3, acc);
+    }
+    for (; i < end; i += EPW) {
+      const uint32_t r0 = __builtin_nontemporal_load(&idx[i]);
+      const float v0 = __builtin_nontemporal_load(&vals[i]);
+      acc = f4_fma(v0, In[(size_t)r0 * LPE + q], acc);
+    }
+  }
+  // reduce over the entry slots; the lowest slot of every aligned group is always exact
+#pragma unroll
+  for (int m = 1; m < EPW; m <<= 1) {
+    const int pe = e ^ m;
+    const bool ok = active && (pe < EPW);
+    const int src = ok ? pe * LPE + q : lane;
+    const float ox = __shfl(acc.x, src), oy = __shfl(acc.y, src), oz = __shfl(acc.z, src), ow = __shfl(acc.w, src);
+    if (ok) {
+      acc.x += ox;
+      acc.y += oy;
+      acc.z += oz;
+      acc.w += ow;
+    }
+  }
+  if (e == 0) Out[seg * LPE + q] = acc;
+}
+
+int k_gram_pass1(isle_ctx* c, int BP) {
+  TimeScope ts(c, ISLE_T_GRAM_PASS1);
+  const uint32_t D = (uint32_t)c->D;
+  if (D == 0) return 0;
+  dim3 g(cdiv(D, 4)), b(256);
+  const float4* X = (const float4*)c->Xrm.p;
+  float4* Y = (float4*)c->Yrm.p;
+#define L1(L) hipLaunchKernelGGL((seg_gather_k<L, false>), g, b, 0, c->stream, c->vals.p, c->rows.p, c->offs.p, X, Y, D, 1u)
+  switch (BP / 4) {
+    case 1: L1(1); break;
+    case 2: L1(2); break;
+    case 3: L1(3); break;
+    case 4: L1(4); break;
+    default: return isle_fail(c, ISLE_E_ARG, "unsupported panel width BP=%d", BP);
+  }
+#undef L1
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Chunked-CSR copy of B for pass 2: cell (chunk, row) holds the row's nonzeros whose column lies in the
+// chunk.  Stands in for the CSR copy the reference builds in the operator constructor
+// (mkl_scsrcsc, include/matUtils.h:103-106).  Counts are exact; the order inside a cell follows the
+// placement atomics (so the fp32 summation order of pass 2 may differ between runs, by rounding only).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_count_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint32_t D,
+                                                    uint32_t V, uint32_t Cc, uint32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= D) return;
+  const size_t base = (size_t)(d / Cc) * V;
+  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) atomicAdd(&cnt[base + rows[i]], 1u);
+}
+__global__ __launch_bounds__(256) void csr_fill_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
+                                                   const int64_t* __restrict__ offs, uint32_t D, uint32_t V, uint32_t Cc,
+                                                   const int64_t* __restrict__ seg_off, uint32_t* __restrict__ fill,
+                                                   uint32_t* __restrict__ ccol, float* __restrict__ cval) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= D) return;
+  const size_t base = (size_t)(d / Cc) * V;
+  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+    const size_t cell = base + rows[i];
+    const int64_t pos = seg_off[cell] + atomicAdd(&fill[cell], 1u);
+    ccol[pos] = d;
+    cval[pos] = vals[i];
+  }
+}
+
+int k_band_build(isle_ctx* c) {
+  if (c->band_ready) return 0;
+  TimeScope ts(c, ISLE_T_BAND_BUILD);
+  const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
+  // chunk size: a chunk's slice of Y (Cc x 16 floats) should sit comfortably in a 4 MiB XCD L2
+  uint32_t Cc = c->band_rows ? c->band_rows : 32768;
+  uint32_t nch = (uint32_t)((D + Cc - 1) / Cc);
+  nch = (nch + 7) & ~7u;  // a multiple of the 8 XCDs
+  if (nch == 0) nch = 8;
+  Cc = (D + nch - 1) / nch;
+  if (Cc == 0) Cc = 1;
+  c->nbands = nch;
+  c->chunk_cols = Cc;
+  const size_t ncell = (size_t)nch * V;
+  HIPCHK(c, c->bcol.reserve(c->nnz ? c->nnz : 1));
+  HIPCHK(c, c->bval.reserve(c->nnz ? c->nnz : 1));
+  HIPCHK(c, c->seg_off.reserve(ncell + 1));
+  uint32_t* cnt = nullptr;
+  int64_t* blk = nullptr;
+  HIPCHK(c, hipMalloc((void**)&cnt, ncell * sizeof(uint32_t)));
+  HIPCHK(c, hipMalloc((void**)&blk, isle_scan::scan_scratch_elems(ncell) * sizeof(int64_t)));
+  HIPCHK(c, hipMemsetAsync(cnt, 0, ncell * sizeof(uint32_t), c->stream));
+  if (D) hipLaunchKernelGGL(csr_count_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->rows.p, c->offs.p, D, V, Cc, cnt);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, cnt, ncell, c->seg_off.p, blk)));
+  HIPCHK(c, hipMemsetAsync(cnt, 0, ncell * sizeof(uint32_t), c->stream));
+  if (D)
+    hipLaunchKernelGGL(csr_fill_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, D, V, Cc, c->seg_off.p,
+                       cnt, c->bcol.p, c->bval.p);
+  HIPCHK(c, hipGetLastError());
+  int64_t total = 0;
+  HIPCHK(c, hipMemcpyAsync(&total, c->seg_off.p + ncell, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(cnt);
+  (void)hipFree(blk);
+  if ((uint64_t)total != c->nnz)
+    return isle_fail(c, ISLE_E_NUMERIC, "operator build: placed %lld of %llu nonzeros", (long long)total, (unsigned long long)c->nnz);
+  c->band_ready = true;
+  return 0;
+}
+
+// Z[row, :] = sum_chunk part[chunk][row][:]   (fixed chunk order)
+__global__ __launch_bounds__(256) void reduce_chunks_k(const float4* __restrict__ part, uint32_t nch, size_t n4 /*V*LPE*/,
+                                                        float4* __restrict__ Z) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = part[i];
+  for (uint32_t ch = 1; ch < nch; ++ch) {
+    const float4 p = part[(size_t)ch * n4 + i];
+    s.x += p.x;
+    s.y += p.y;
+    s.z += p.z;
+    s.w += p.w;
+  }
+  Z[i] = s;
+}
+
+int k_gram_pass2(isle_ctx* c, int BP) {
+  ISLECHK(k_band_build(c));
+  TimeScope ts(c, ISLE_T_GRAM_PASS2);
+  const uint32_t V = (uint32_t)c->V;
+  const uint32_t nch = c->nbands;
+  const int LPE = BP / 4;
+  HIPCHK(c, c->Zpart.reserve((size_t)nch * V * BP));
+  const uint32_t bpc = (V + 3) / 4;
+  dim3 g(8 * (nch / 8) * bpc), b(256);
+  const float4* Y = (const float4*)c->Yrm.p;
+  float4* Pt = (float4*)c->Zpart.p;
+#define L2(L) hipLaunchKernelGGL((seg_gather_k<L, true>), g, b, 0, c->stream, c->bval.p, c->bcol.p, c->seg_off.p, Y, Pt, V, nch)
+  switch (LPE) {
+    case 1: L2(1); break;
+    case 2: L2(2); break;
+    case 3: L2(3); break;
+    case 4: L2(4); break;
+    default: return isle_fail(c, ISLE_E_ARG, "unsupported panel width BP=%d", BP);
+  }
+#undef L2
+  HIPCHK(c, hipGetLastError());
+  const size_t n4 = (size_t)V * LPE;
+  hipLaunchKernelGGL(reduce_chunks_k, dim3(cdiv(n4, 256)), dim3(256), 0, c->stream, Pt, nch, n4, (float4*)c->Zrm.p);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Frobenius: sum of squares in double, two-stage (deterministic)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ v, uint64_t n, double* __restrict__ part) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const double x = (double)v[i];
+    s += x * x;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+int k_frobenius(isle_ctx* c, double* out_host) {
+  const int nb = 1024;
+  HIPCHK(c, c->part.reserve(nb));
+  hipLaunchKernelGGL(sumsq_k, dim3(nb), dim3(256), 0, c->stream, c->vals.p, c->nnz, c->part.p);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> h(nb);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->part.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s = 0.0;
+  for (double x : h) s += x;
+  *out_host = s;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// k-wide SpMM, one wave per document; lane owns float4 chunks {lane + 64*it} of the output row
+// ------------------------------------------------------------------------------------------
+enum { WIDE_PROJECT = 0, WIDE_ASSIGN = 1 };
+
+template <int NIT, int MODE>
+__global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
+                                                    const int64_t* __restrict__ offs, const float4* __restrict__ M, int nq,
+                                                    int k, uint32_t D, float4* __restrict__ P, float* __restrict__ norms,
+                                                    const float* __restrict__ cn, const float* __restrict__ dn,
+                                                    uint32_t* __restrict__ assign) {
+  const int lane = threadIdx.x & 63;
+  uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  d = __builtin_amdgcn_readfirstlane(d);
+  if (d >= D) return;
+  const int64_t beg = offs[d], end = offs[d + 1];
+  float4 acc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t base = beg; base < end; base += 64) {
+    const int cnt = (int)min((int64_t)64, end - base);
+    const uint32_t myrow = (lane < cnt) ? rows[base + lane] : 0u;
+    const float myval = (lane < cnt) ? vals[base + lane] : 0.f;
+#pragma unroll 4
+    for (int e = 0; e < cnt; ++e) {
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)myrow, e);
+      const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), e));
+      const float4* mr = M + (size_t)r * nq;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int cidx = lane + 64 * it;
+        if (cidx < nq) acc[it] = f4_fma(v, mr[cidx], acc[it]);
+      }
+    }
+  }
+  if (MODE == WIDE_PROJECT) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int cidx = lane + 64 * it;
+      if (cidx < nq) {
+        P[(size_t)d * nq + cidx] = acc[it];
+        s += acc[it].x * acc[it].x + acc[it].y * acc[it].y + acc[it].z * acc[it].z + acc[it].w * acc[it].w;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) norms[d] = s;
+  } else {
+    const float dnd = dn[d];
+    float best = 3.4e38f;
+    uint32_t bidx = 0xffffffffu;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int cidx = lane + 64 * it;
+      if (cidx < nq) {
+        const float a[4] = {acc[it].x, acc[it].y, acc[it].z, acc[it].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = 4 * cidx + j;
+          if (cc < k) {
+            const float dist = fabsf((-2.0f * a[j] + cn[cc]) + dnd);
+            if (dist < best) {  // ascending cc per lane -> first index wins ties
+              best = dist;
+              bidx = (uint32_t)cc;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const uint32_t oi = __shfl_xor(bidx, off);
+      if (ob < best || (ob == best && oi < bidx)) {
+        best = ob;
+        bidx = oi;
+      }
+    }
+    if (lane == 0) assign[d] = bidx;
+  }
+}
+
+template <int MODE>
+static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms, const float* cn, const float* dn,
+                       uint32_t* assign) {
+  const uint32_t D = (uint32_t)c->D;
+  if (D == 0) return 0;
+  const int nq = ldk / 4;
+  const int nit = cdiv(nq, 64);
+  dim3 g(cdiv(D, 4)), b(256);
+#define LW(N)                                                                                                              \
+  hipLaunchKernelGGL((spmm_wide_k<N, MODE>), g, b, 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Mrm, nq, k, D, \
+                     (float4*)P, norms, cn, dn, assign)
+  if (nit <= 1) LW(1);
+  else if (nit <= 2) LW(2);
+  else if (nit <= 4) LW(4);
+  else if (nit <= 8) LW(8);
+  else return isle_fail(c, ISLE_E_ARG, "k = %d too large (max 2048)", k);
+#undef LW
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms) {
+  TimeScope ts(c, ISLE_T_PROJECT);
+  return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr);
+}
+int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign);
+}
+
+// |b_d|^2  (compute_docs_l2sq  src/sparseMatrix.cpp:1680-1687)
+__global__ __launch_bounds__(256) void doc_norms_k(const float* __restrict__ vals, const int64_t* __restrict__ offs, uint32_t D,
+                                                    float* __restrict__ dn) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= D) return;
+  float s = 0.f;
+  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) s = fmaf(vals[i], vals[i], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) dn[d] = s;
+}
+int k_doc_norms(isle_ctx* c, float* dn) {
+  const uint32_t D = (uint32_t)c->D;
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(doc_norms_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->offs.p, D, dn);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// centre[c] += b_d for every member d  (src/sparseMatrix.cpp:1631-1638); Crm is V x ldk row-major
+__global__ __launch_bounds__(256) void scatter_centers_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
+                                                          const int64_t* __restrict__ offs, uint32_t D,
+                                                          const uint32_t* __restrict__ assign, int ldk, float* __restrict__ Crm,
+                                                          int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= D) return;
+  const uint32_t cc = assign[d];
+  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) atomicAdd(&Crm[(size_t)rows[i] * ldk + cc], vals[i]);
+  if (lane == 0) atomicAdd(&counts[cc], 1);
+}
+int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts) {
+  TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
+  const uint32_t D = (uint32_t)c->D;
+  HIPCHK(c, hipMemsetAsync(Crm, 0, (size_t)c->V * ldk * sizeof(float), c->stream));
+  HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)k * sizeof(int), c->stream));
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(scatter_centers_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, D, assign, ldk,
+                     Crm, counts);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

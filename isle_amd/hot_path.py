@@ -1,0 +1,184 @@
+"""Python binding of the C ABI (one object = one isle_ctx = one GPU).
+
+Method names follow the reference methods they replace (ISLE::FPSparseMatrix<float>,
+/root/reference include/sparseMatrix.h:242-466); see include/isle_hip.h for the contract.
+numpy arrays in, numpy arrays out; all device work happens inside libisle_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import IsleHipError, load_library
+
+TIMING_FAMILIES = ["gram_pass1", "gram_pass2", "ortho", "qr", "evd", "rotate", "project", "kmpp", "lloyd_proj",
+                   "sparse_assign", "sparse_update", "op_build", "comm"]
+
+BLOCK_KS_MAX_ITERS = 100      # include/hyperparams.h:38
+BLOCK_KS_BLOCK_SIZE = 10      # include/hyperparams.h:39
+BLOCK_KS_TOLERANCE = 1e-4     # include/hyperparams.h:40
+MAX_KMEANS_LOWD_REPS = 10     # include/hyperparams.h:60
+MAX_KMEANS_REPS = 10          # include/hyperparams.h:68
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HotPath:
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = self._lib.isle_hip_create(device)
+        if not self._h:
+            raise IsleHipError("isle_hip_create(%d) failed: no usable HIP device (no CPU fallback exists)" % device)
+        self.V = self.D = self.nnz = 0
+        self.doc_offset = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.isle_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise IsleHipError("isle_hip error %d: %s" % (rc, self._lib.isle_hip_last_error(self._h).decode()))
+        return rc
+
+    # ---- multi-GPU ------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = np.zeros(128, np.uint8)
+        rc = load_library().isle_hip_comm_unique_id(_p(buf))
+        if rc != 0:
+            raise IsleHipError("ncclGetUniqueId failed")
+        return buf
+
+    def comm_init(self, world, rank, uid):
+        uid = np.ascontiguousarray(uid, np.uint8)
+        self._chk(self._lib.isle_hip_comm_init(self._h, world, rank, _p(uid)))
+
+    @staticmethod
+    def plan_shards(offs, parts):
+        offs = np.ascontiguousarray(offs, np.int64)
+        bounds = np.zeros(parts + 1, np.uint64)
+        rc = load_library().isle_hip_plan_shards(offs.shape[0] - 1, _p(offs), parts, _p(bounds))
+        if rc != 0:
+            raise IsleHipError("plan_shards failed")
+        return bounds
+
+    # ---- input ----------------------------------------------------------------------------
+    def upload_csc(self, V, vals, rows, offs, doc_offset=0, docs_global=0):
+        vals = np.ascontiguousarray(vals, np.float32)
+        offs = np.ascontiguousarray(offs, np.int64)
+        D = offs.shape[0] - 1
+        nnz = int(offs[-1])
+        if rows.dtype == np.uint64:
+            rows = np.ascontiguousarray(rows)
+            fn = self._lib.isle_hip_upload_csc_u64
+        else:
+            rows = np.ascontiguousarray(rows, np.uint32)
+            fn = self._lib.isle_hip_upload_csc_u32
+        self._chk(fn(self._h, V, D, nnz, _p(vals), _p(rows), _p(offs), doc_offset, docs_global))
+        self.V, self.D, self.nnz, self.doc_offset = int(V), D, nnz, int(doc_offset)
+        self.D_global = int(docs_global) if docs_global else D
+
+    def frobenius(self):
+        out = C.c_float()
+        self._chk(self._lib.isle_hip_frobenius(self._h, C.byref(out)))
+        return out.value
+
+    # ---- eigensolver ----------------------------------------------------------------------
+    def gram_apply(self, X):
+        X = np.asfortranarray(X, dtype=np.float32)
+        assert X.shape[0] == self.V
+        Z = np.empty_like(X, order="F")
+        self._chk(self._lib.isle_hip_gram_apply(self._h, _p(X), X.shape[1], _p(Z)))
+        return Z
+
+    def compute_block_ks(self, num_topics, blk=BLOCK_KS_BLOCK_SIZE, ncv=None, maxit=BLOCK_KS_MAX_ITERS,
+                         tol=BLOCK_KS_TOLERANCE, seed=1, allow_noconv=False):
+        """FPSparseMatrix::compute_block_ks(num_topics, evalues) — src/sparseMatrix.cpp:1195-1220."""
+        ncv = 2 * num_topics + BLOCK_KS_BLOCK_SIZE if ncv is None else ncv
+        ev = np.empty(num_topics, np.float32)
+        nconv, rst, nap = C.c_int(), C.c_int(), C.c_int()
+        rc = self._lib.isle_hip_block_ks(self._h, num_topics, ncv, maxit, blk, tol, seed, _p(ev), C.byref(nconv), C.byref(rst),
+                                         C.byref(nap))
+        self._chk(rc, allow=(-3,) if allow_noconv else ())
+        return dict(rc=rc, evals=ev, nconv=nconv.value, restarts=rst.value, napplies=nap.value)
+
+    def get_U(self, k):
+        U = np.empty((self.V, k), np.float32, order="F")
+        self._chk(self._lib.isle_hip_get_U(self._h, _p(U)))
+        return U
+
+    def set_U(self, U):
+        U = np.asfortranarray(U, dtype=np.float32)
+        self._chk(self._lib.isle_hip_set_U(self._h, _p(U), U.shape[1]))
+
+    def eig_sym(self, S):
+        S = np.asfortranarray(S, dtype=np.float32)
+        n = S.shape[0]
+        e = np.empty(n, np.float32)
+        v = np.empty((n, n), np.float32, order="F")
+        self._chk(self._lib.isle_hip_eig_sym(self._h, _p(S), n, _p(e), _p(v)))
+        return e, v
+
+    # ---- k-means --------------------------------------------------------------------------
+    def kmeans_init_on_projected_space(self, k, inject_seeds=None, rng_seed=1):
+        seeds = np.empty(k, np.uint64)
+        Cl = np.empty((k, k), np.float32)
+        res, rounds = C.c_float(), C.c_int()
+        inj = None if inject_seeds is None else np.ascontiguousarray(inject_seeds, np.uint64)
+        self._chk(self._lib.isle_hip_kmeanspp_projected(self._h, k, _p(inj), rng_seed, _p(seeds), _p(Cl), C.byref(res),
+                                                       C.byref(rounds)))
+        return dict(seeds=seeds, C_lowd=Cl, residual=res.value, rounds=rounds.value)
+
+    def get_min_dist(self):
+        md = np.empty(self.D, np.float32)
+        self._chk(self._lib.isle_hip_get_min_dist(self._h, _p(md)))
+        return md
+
+    def run_lloyds_on_projected_space(self, k, C_lowd, max_reps=MAX_KMEANS_LOWD_REPS):
+        Cl = np.array(C_lowd, dtype=np.float32, order="C", copy=True)
+        it = C.c_int()
+        assign = np.empty(self.D, np.uint32)
+        self._chk(self._lib.isle_hip_lloyds_projected(self._h, k, _p(Cl), max_reps, C.byref(it), _p(assign)))
+        return dict(C_lowd=Cl, iters=it.value, assign=assign)
+
+    def left_multiply_by_U(self, C_lowd, fetch=True):
+        """centers (V x n, F-order) = U * C_lowd^T, centre c = row c of C_lowd (ld_in = k)."""
+        Cl = np.ascontiguousarray(C_lowd, dtype=np.float32)
+        n, k = Cl.shape
+        out = np.empty((self.V, n), np.float32, order="F") if fetch else None
+        self._chk(self._lib.isle_hip_lift_centers(self._h, _p(Cl), k, n, _p(out)))
+        return out
+
+    def run_lloyds(self, k, centers=None, max_reps=MAX_KMEANS_REPS, fetch_centers=True):
+        cin = None if centers is None else np.asfortranarray(centers, dtype=np.float32)
+        cout = np.empty((self.V, k), np.float32, order="F") if fetch_centers else None
+        assign = np.empty(self.D, np.uint32)
+        it = C.c_int()
+        self._chk(self._lib.isle_hip_lloyds_sparse(self._h, k, _p(cin), _p(cout), _p(assign), max_reps, C.byref(it)))
+        return dict(centers=cout, assign=assign, iters=it.value)
+
+    # ---- measurement ------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._chk(self._lib.isle_hip_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self._lib.isle_hip_timing_reset(self._h))
+
+    def timing_get(self):
+        n = len(TIMING_FAMILIES)
+        ms = np.zeros(n, np.float64)
+        cnt = np.zeros(n, np.uint64)
+        self._chk(self._lib.isle_hip_timing_get(self._h, _p(ms), _p(cnt)))
+        return {f: (float(ms[i]), int(cnt[i])) for i, f in enumerate(TIMING_FAMILIES)}
+
+    def synchronize(self):
+        self._chk(self._lib.isle_hip_synchronize(self._h))

@@ -727,7 +727,7 @@ struct KmState {
 // inject: if non-null, k doc ids that replace the draws (the seeding kernel is then
 // exercised only for its min_dist updates); rounds follow the same schedule.
 static float kmeanspp(const Csc& m, const fvec& Urm, size_t k, const uint64_t* inject, Rng& rng,
-                      std::vector<uint64_t>& centers, int* rounds_out, fvec* min_dist_out) {
+                      std::vector<uint64_t>& centers, int* rounds_out, fvec* min_dist_out, int max_rounds = 0) {
   const uint64_t D = m.D;
   fvec pl2;
   projected_docs_l2sq(m, Urm, k, pl2);
@@ -742,6 +742,7 @@ static float kmeanspp(const Csc& m, const fvec& Urm, size_t k, const uint64_t* i
   const uint64_t Db = 1 << 14;
   fvec dist;
   while (centers.size() < k) {
+    if (max_rounds > 0 && rounds >= max_rounds) break;  // bench-only: bounded sample of rounds
     rounds++;
     const size_t n = (size_t)new_added;
     const float* newC = &coords[(centers.size() - n) * k];
@@ -1033,15 +1034,15 @@ int orc_project(void* h, const float* Ucm, int k, float* P, float* norms) {
 
 // src/sparseMatrix.cpp:2212-2238 kmeans_init_on_projected_space (KMEANS_INIT_REPS = 1)
 int orc_kmeanspp(void* h, const float* Ucm, int k, const uint64_t* inject, uint64_t seed, uint64_t* seeds_out,
-                 float* C_lowd, float* residual, int* rounds, float* min_dist_out) {
+                 float* C_lowd, float* residual, int* rounds, float* min_dist_out, int max_rounds) {
   Csc* m = (Csc*)h;
   fvec Urm;
   to_rowmajor(Ucm, m->V, k, Urm);
   Rng rng(seed);
   std::vector<uint64_t> centers;
   fvec md;
-  const float res = kmeanspp(*m, Urm, k, inject, rng, centers, rounds, &md);
-  if (centers.size() != (size_t)k) return 1;
+  const float res = kmeanspp(*m, Urm, k, inject, rng, centers, rounds, &md, max_rounds);
+  if (centers.size() != (size_t)k) return max_rounds > 0 ? 2 : 1;
   for (int c = 0; c < k; ++c) {
     seeds_out[c] = centers[c];
     multiply_with(*m, centers[c], centers[c] + 1, Urm.data(), C_lowd + (size_t)c * k, k);  // :2232-2234

@@ -10,6 +10,22 @@ import subprocess
 
 import numpy as np
 
+
+def effective_cpus():
+    """min(affinity, cgroup CPU quota): the GPU boxes show 256 logical CPUs behind a 16-CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -86,7 +102,7 @@ class OracleCsc:
         lib().orc_project(self.h, _p(U), k, _p(P), _p(n2))
         return P, n2
 
-    def kmeanspp(self, U, k, inject=None, seed=1):
+    def kmeanspp(self, U, k, inject=None, seed=1, max_rounds=0):
         U = np.asfortranarray(U, dtype=np.float32)
         seeds = np.empty(k, np.uint64)
         Cl = np.empty((k, k), np.float32)
@@ -94,7 +110,7 @@ class OracleCsc:
         md = np.empty(self.D, np.float32)
         inj = None if inject is None else np.ascontiguousarray(inject, dtype=np.uint64)
         rc = lib().orc_kmeanspp(self.h, _p(U), k, _p(inj), C.c_uint64(seed), _p(seeds), _p(Cl), C.byref(res),
-                                C.byref(rounds), _p(md))
+                                C.byref(rounds), _p(md), C.c_int(max_rounds))
         return dict(rc=rc, seeds=seeds, C_lowd=Cl, residual=res.value, rounds=rounds.value, min_dist=md)
 
     def lloyds_projected(self, U, C_lowd, max_reps=10):

@@ -6,6 +6,23 @@ import ctypes as C
 import os
 import subprocess
 
+
+def effective_cpus():
+    """CPUs this process may really use: min(affinity, cgroup quota).  The GPU boxes expose 256
+    logical CPUs behind a 16-CPU cgroup quota; OpenMP's default of 256 threads is catastrophic there."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,7 +41,12 @@ def _lib():
             build()
         L = C.CDLL(path)
         L.synth_generate.restype = C.c_void_p
-        L.synth_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint64]
+        L.synth_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64]
+        L.synth_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.synth_hist.restype = C.c_void_p
+        L.synth_hist.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.synth_apply.restype = C.c_uint64
+        L.synth_apply.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.synth_from_csc.restype = C.c_void_p
         L.synth_from_csc.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.synth_threshold.restype = C.c_uint64
@@ -52,10 +74,10 @@ def _arr(ptr, n, dtype):
 class Corpus:
     """A = counts (V x D CSC) and, after threshold(k), B (V x D_B CSC) as ISLE's trainer would build it."""
 
-    def __init__(self, V, D, K, seed, zipf_s=1.05, L0=130.0, dom_w=0.8, _handle=None):
+    def __init__(self, V, D, K, seed, zipf_s=1.05, L0=130.0, dom_w=0.8, doc_base=0, _handle=None):
         self.V, self.D, self.K = int(V), int(D), int(K)
         self._h = _handle if _handle is not None else C.c_void_p(
-            _lib().synth_generate(self.V, self.D, self.K, zipf_s, L0, dom_w, seed))
+            _lib().synth_generate(self.V, self.D, self.K, zipf_s, L0, dom_w, seed, doc_base))
         self.nnz_A = int(_lib().synth_nnz_A(self._h))
 
     @classmethod
@@ -80,10 +102,27 @@ class Corpus:
     def planted(self):
         return _arr(_lib().synth_dom(self._h), self.D, np.uint32)
 
-    def threshold(self, k, free_A=False):
-        """Returns dict(V, D, nnz, vals, rows, offs, original_cols, zetas) for B."""
+    def threshold(self, k, free_A=False, allreduce=None):
+        """Returns dict(V, D, nnz, vals, rows, offs, original_cols, zetas) for B.
+
+        allreduce: optional callable(np.ndarray int64/uint32) -> summed-in-place over all shards; lets a
+        column-sharded corpus use GLOBAL avg_doc_sz / nz_docs / per-word histograms (the thresholds depend
+        on the whole corpus: src/sparseMatrix.cpp:357-485)."""
         L = _lib()
-        nnz = int(L.synth_threshold(self._h, k))
+        if allreduce is None:
+            nnz = int(L.synth_threshold(self._h, k))
+        else:
+            st = np.zeros(2, np.uint64)
+            L.synth_stats(self._h, st.ctypes.data, st.ctypes.data + 8)
+            st64 = st.astype(np.int64)
+            allreduce(st64)
+            mv = C.c_uint32()
+            hp_ = L.synth_hist(self._h, int(st64[0]), int(st64[1]), C.byref(mv))
+            n = self.V * (mv.value + 1)
+            buf = (C.c_char * (n * 4)).from_address(hp_)
+            hist = np.frombuffer(buf, dtype=np.int32, count=n)  # view onto the C++ buffer, reduced in place
+            allreduce(hist)
+            nnz = int(L.synth_apply(self._h, k, int(st64[1])))
         Db = int(L.synth_docs_B(self._h))
         out = dict(V=self.V, D=Db, nnz=nnz,
                    vals=_arr(L.synth_B_vals(self._h), nnz, np.float32),

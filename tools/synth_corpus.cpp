@@ -56,7 +56,7 @@ struct Corpus {
 
 extern "C" {
 
-void* synth_generate(uint64_t V, uint64_t D, uint32_t K, double zipf_s, double L0, double dom_w, uint64_t seed) {
+void* synth_generate(uint64_t V, uint64_t D, uint32_t K, double zipf_s, double L0, double dom_w, uint64_t seed, uint64_t doc_base) {
   Corpus* c = new Corpus;
   c->V = V;
   c->D = D;
@@ -93,7 +93,7 @@ void* synth_generate(uint64_t V, uint64_t D, uint32_t K, double zipf_s, double L
     auto& rr = crow[ch];
     auto& cc = ccnt[ch];
     for (uint64_t d = ch * CH; d < std::min(D, (uint64_t)(ch + 1) * CH); ++d) {
-      Rng r((seed + 77) * 0xD1342543DE82EF95ull + d * 0x9E3779B97F4A7C15ull);
+      Rng r((seed + 77) * 0xD1342543DE82EF95ull + (d + doc_base) * 0x9E3779B97F4A7C15ull);
       double L = std::exp(std::log(L0) + 0.4 * r.normal());
       L = std::min(2000.0, std::max(30.0, L));
       const uint32_t len = (uint32_t)L;
@@ -145,16 +145,33 @@ void* synth_from_csc(uint64_t V, uint64_t D, const float* counts, const uint32_t
   return c;
 }
 
-// Thresholding for num_topics = k.  Returns nnz(B).
-uint64_t synth_threshold(void* h, uint32_t k) {
+// ---- thresholding, in phases so that a column-sharded corpus can all-reduce the global statistics ----
+struct ThreshState {
+  std::vector<float> rnd;
+  std::vector<uint32_t> hist;
+  uint32_t maxv = 0;
+};
+static ThreshState g_ts;  // one corpus at a time per process (bench/test tool)
+
+// phase A: local token count and non-empty docs
+void synth_stats(void* h, uint64_t* tokens, uint64_t* nz_docs) {
   Corpus* c = (Corpus*)h;
-  const uint64_t V = c->V, D = c->D;
-  const uint64_t nnz = c->offs[D];
-  uint64_t tokens = 0, nz_docs = 0;
-  for (uint64_t i = 0; i < nnz; ++i) tokens += (uint64_t)c->counts[i];
-  for (uint64_t d = 0; d < D; ++d) nz_docs += (c->offs[d + 1] > c->offs[d]);
-  const float avg = (float)(tokens / std::max<uint64_t>(nz_docs, 1));  // src/sparseMatrix.cpp:98
-  std::vector<float> rnd(nnz);
+  const uint64_t D = c->D, nnz = c->offs[D];
+  uint64_t t = 0, nz = 0;
+  for (uint64_t i = 0; i < nnz; ++i) t += (uint64_t)c->counts[i];
+  for (uint64_t d = 0; d < D; ++d) nz += (c->offs[d + 1] > c->offs[d]);
+  *tokens = t;
+  *nz_docs = nz;
+}
+
+// phase B: rounded normalised counts with the GLOBAL avg_doc_sz; returns the local per-word histogram
+// (V x (maxv+1) uint32) for the caller to all-reduce in place.
+uint32_t* synth_hist(void* h, uint64_t tokens_global, uint64_t nzdocs_global, uint32_t* maxv_out) {
+  Corpus* c = (Corpus*)h;
+  const uint64_t V = c->V, D = c->D, nnz = c->offs[D];
+  const float avg = (float)(tokens_global / std::max<uint64_t>(nzdocs_global, 1));  // src/sparseMatrix.cpp:98
+  g_ts.rnd.resize(nnz);
+  std::vector<float>& rnd = g_ts.rnd;
 #pragma omp parallel for schedule(dynamic, 4096)
   for (int64_t d = 0; d < (int64_t)D; ++d) {
     float sum = 0.f;
@@ -162,13 +179,25 @@ uint64_t synth_threshold(void* h, uint32_t k) {
     for (int64_t i = c->offs[d]; i < c->offs[d + 1]; ++i)
       rnd[i] = std::round(avg * (c->counts[i] / sum));  // :158 then :1345 / :371
   }
-  // per-word histogram of rounded values (>0)
   const uint32_t maxv = (uint32_t)avg + 2;
-  std::vector<uint32_t> hist((size_t)V * (maxv + 1), 0);
+  g_ts.maxv = maxv;
+  g_ts.hist.assign((size_t)V * (maxv + 1), 0);
   for (uint64_t i = 0; i < nnz; ++i) {
     uint32_t v = (uint32_t)std::min<float>(rnd[i], (float)maxv);
-    if (v > 0) hist[(size_t)c->rows[i] * (maxv + 1) + v]++;
+    if (v > 0) g_ts.hist[(size_t)c->rows[i] * (maxv + 1) + v]++;
   }
+  *maxv_out = maxv;
+  return g_ts.hist.data();
+}
+
+// phase C: zetas from the (global) histogram, then B.  Returns nnz(B).
+uint64_t synth_apply(void* h, uint32_t k, uint64_t nzdocs_global) {
+  Corpus* c = (Corpus*)h;
+  const uint64_t V = c->V, D = c->D;
+  const uint64_t nz_docs = nzdocs_global;
+  const uint32_t maxv = g_ts.maxv;
+  const std::vector<uint32_t>& hist = g_ts.hist;
+  const std::vector<float>& rnd = g_ts.rnd;
   uint64_t count_gr = (uint64_t)(1.0 * (float)nz_docs / (2.0 * (float)k));               // :367
   uint64_t count_eq = (uint64_t)std::ceil(3.0 * (1.0 / 60.0) * 1.0 * (float)nz_docs / (float)k);  // :368
   if (count_gr == 0) count_gr = 1;
@@ -245,7 +274,18 @@ uint64_t synth_threshold(void* h, uint32_t k) {
       }
     }
   }
+  std::vector<float>().swap(g_ts.rnd);
+  std::vector<uint32_t>().swap(g_ts.hist);
   return bnnz;
+}
+
+// single-process convenience: all three phases
+uint64_t synth_threshold(void* h, uint32_t k) {
+  uint64_t t, nz;
+  uint32_t mv;
+  synth_stats(h, &t, &nz);
+  (void)synth_hist(h, t, nz, &mv);
+  return synth_apply(h, k, nz);
 }
 
 uint64_t synth_nnz_A(void* h) { return ((Corpus*)h)->offs.back(); }
