@@ -172,9 +172,9 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   c->Xrm.release(); c->Yrm.release(); c->Zrm.release(); c->Xcm.release(); c->Zcm.release();
   c->basis.release(); c->Fbuf.release(); c->Tmp.release(); c->part.release(); c->coef.release();
   c->gram.release(); c->small.release(); c->jacW.release(); c->jacV.release(); c->Wf.release();
-  c->Ucm.release(); c->Urm.release(); c->P.release(); c->pnorm.release(); c->min_dist.release();
+  c->Ucm.release(); c->Urm.release(); c->P.release(); c->Pt.release(); c->pnorm.release(); c->min_dist.release();
   c->cum.release(); c->scan_blk.release(); c->Cdev.release(); c->cnorm.release(); c->Csum.release();
-  c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release();
+  c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release(); c->members.release(); c->moff.release();
   c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -251,6 +251,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   HIPCHK(c, hipMemcpy(c->offs.p, offs, (D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   c->band_ready = false;
   c->P_ready = false;
+  c->Pt_ready = false;
   c->U_k = 0;
   c->centers_ready = false;
   return 0;
@@ -607,6 +608,7 @@ static int install_U(isle_ctx* c, const float* Ucm_dev, int k) {
   ISLECHK(k_transpose(c, c->Ucm.p, c->V, k, c->V, c->Urm.p, c->ldk));  // compute_U_rowmajor :1223-1231
   c->U_k = k;
   c->P_ready = false;
+  c->Pt_ready = false;
   c->centers_ready = false;
   return 0;
 }
@@ -693,6 +695,7 @@ static int ensure_P(isle_ctx* c, int k) {
   HIPCHK(c, c->pnorm.reserve(D));
   ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p));
   c->P_ready = true;
+  c->Pt_ready = false;
   return 0;
 }
 
@@ -889,6 +892,12 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   if (!c || !C_lowd || k < 1) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2032
+  if (!c->Pt_ready && c->ldk <= 256 && c->D) {  // coordinate-major copy for the register-resident assignment kernel
+    TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+    HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
+    ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
+    c->Pt_ready = true;
+  }
   const uint64_t D = c->D;
   const int ldk = c->ldk;
   HIPCHK(c, c->Cdev.reserve((size_t)k * ldk));
@@ -904,6 +913,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   for (; it < max_reps; ++it) {
     ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
     ISLECHK(k_proj_assign(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p));      // :1947
+    ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
     ISLECHK(k_proj_accumulate(c, c->P.p, D, k, ldk, c->assign.p, c->Csum.p, c->counts.p));              // :1957-1984
     ISLECHK(allreduce_sum<float>(c, c->Csum.p, (size_t)k * ldk));
     std::vector<long long> sizes;
@@ -978,7 +988,8 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, c->cnorm.p));  // :1604
     }
     ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p));  // :1606
-    ISLECHK(k_scatter_centers(c, c->assign.p, k, ld, c->centers_rm.p, c->counts.p));               // :1613-1638
+    ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
+    ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p));                          // :1613-1638
     ISLECHK(allreduce_sum<float>(c, c->centers_rm.p, (size_t)V * ld));
     std::vector<long long> sizes;
     ISLECHK(fetch_sizes(c, k, sizes));

@@ -87,6 +87,8 @@ struct isle_ctx {
   DevBuf<float> P;         // D x ldk
   DevBuf<float> pnorm;     // D
   bool P_ready = false;
+  DevBuf<float> Pt;        // ldk x D coordinate-major copy (projected assignment), only for ldk <= 256
+  bool Pt_ready = false;
   DevBuf<float> min_dist;  // D
   DevBuf<double> cum;      // D + 1
   DevBuf<double> scan_blk;
@@ -95,6 +97,8 @@ struct isle_ctx {
   DevBuf<float> Csum;      // k x ldk + k
   DevBuf<uint32_t> assign, assign_prev;
   DevBuf<int> counts;
+  DevBuf<uint32_t> members;  // documents grouped by centre
+  DevBuf<int> moff;          // k+1 offsets, k cursors
   DevBuf<int> flags;
   DevBuf<float> centers_rm;   // V x ldk  (word-space centres, row-major)
   DevBuf<float> centers_cm;   // V x k col-major staging
@@ -148,6 +152,7 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign);
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
+int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);
 
 // dense.hip
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);

@@ -8,11 +8,14 @@
 //   k_proj_assign      projected_closest_centers (f32 MFMA distance tiles + fused isamin)  :1852-1871
 //   k_proj_accumulate  centroid sums (saxpy loop)               src/sparseMatrix.cpp:1975-1992
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "scan.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int CS_ITEMS = 16;  // documents per thread in the histogram-style kernels
 
 // ------------------------------------------------------------------------------------------
 // min_dist[d] = min(min_dist[d], max(|p_d|^2 + |c|^2 - 2 p_d.c, 0)) over the nc newest centres.
@@ -178,8 +181,101 @@ __global__ __launch_bounds__(256) void proj_assign_k(const float* __restrict__ P
   }
   if (h == 0 && myd < D) assign[myd] = bidx;
 }
+// Register-resident variant for ldk <= 256: every lane keeps its half-row of P (KH = ldk/2 coordinates: MFMA k-slot h
+// of step i carries coordinate h*KH + i) in registers for the whole kernel, so P is read from HBM exactly once per
+// iteration; centres stream through LDS in slabs of 2 x 16 coordinates and all centre tiles accumulate side by side.
+constexpr int PR_SL = 16;
+template <int KHMAX, int CTMAX>
+__global__ __launch_bounds__(256) void proj_assign_reg_k(const float* __restrict__ Pt /*ldk x D*/, const float* __restrict__ pn, uint32_t D, int k,
+                                                          int ldk, const float* __restrict__ C, const float* __restrict__ cn,
+                                                          uint32_t* __restrict__ assign) {
+  extern __shared__ float Cs[];  // [2][kpad][PR_SL + 1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int KH = ldk >> 1;
+  const int kpad = (k + 31) & ~31;
+  const int CT = kpad >> 5;
+  const uint32_t myd = blockIdx.x * 128 + 32 * wave + l31;
+  float p[KHMAX];
+  {
+    // coordinate-major copy of P: 32 consecutive documents per coordinate = one 128-B line per half-wave
+    const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
+#pragma unroll
+    for (int i = 0; i < KHMAX; ++i) p[i] = (i < KH && myd < D) ? col[(size_t)i * D] : 0.f;
+  }
+  floatx16 acc[CTMAX];
+#pragma unroll
+  for (int t = 0; t < CTMAX; ++t) acc[t] = (floatx16){0};
+#pragma unroll
+  for (int s = 0; s < KHMAX / PR_SL; ++s) {
+    if (s * PR_SL < KH) {
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 2 * kpad * PR_SL; idx += 256) {
+        const int ii = idx % PR_SL;
+        const int cc = (idx / PR_SL) % kpad;
+        const int hh = idx / (PR_SL * kpad);
+        const int coord = s * PR_SL + ii;
+        Cs[(hh * kpad + cc) * (PR_SL + 1) + ii] = (cc < k && coord < KH) ? C[(size_t)cc * ldk + hh * KH + coord] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < CTMAX; ++t) {
+        if (t < CT) {
+          const float* cb = &Cs[(h * kpad + 32 * t + l31) * (PR_SL + 1)];
+#pragma unroll
+          for (int ii = 0; ii < PR_SL; ++ii) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[ii], p[s * PR_SL + ii], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float nd = (myd < D) ? pn[myd] : 0.f;
+  float best = 3.4e38f;
+  uint32_t bidx = 0xffffffffu;
+#pragma unroll
+  for (int t = 0; t < CTMAX; ++t) {
+    if (t < CT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (cc < k) {
+          const float dist = fabsf((-2.0f * acc[t][r] + cn[cc]) + nd);
+          if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
+            best = dist;
+            bidx = (uint32_t)cc;
+          }
+        }
+      }
+    }
+  }
+  const float ob = __shfl_xor(best, 32);
+  const uint32_t oi = __shfl_xor(bidx, 32);
+  if (ob < best || (ob == best && oi < bidx)) {
+    best = ob;
+    bidx = oi;
+  }
+  if (h == 0 && myd < D) assign[myd] = bidx;
+}
+
 int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn,
                   uint32_t* assign) {
+  if (D && ldk <= 256 && k <= 256 && c->Pt_ready && !getenv("ISLE_PROJ_ASSIGN_GENERIC")) {
+    TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+    const int kpad = (k + 31) & ~31;
+    const size_t lds = (size_t)2 * kpad * (PR_SL + 1) * sizeof(float);
+    dim3 g(cdiv(D, 128)), b(256);
+    const int KH = ldk / 2;
+#define LR(KM, CM)                                                                                                       \
+  do {                                                                                                                   \
+    HIPCHK(c, hipFuncSetAttribute((const void*)proj_assign_reg_k<KM, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((proj_assign_reg_k<KM, CM>), g, b, lds, c->stream, c->Pt.p, pn, (uint32_t)D, k, ldk, C, cn, assign);     \
+  } while (0)
+    if (KH <= 32 && kpad <= 64) LR(32, 2);
+    else if (KH <= 64 && kpad <= 128) LR(64, 4);
+    else LR(128, 8);
+#undef LR
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   if (D == 0) return 0;
   hipLaunchKernelGGL(proj_assign_k, dim3(cdiv(D, PA_DOCS)), dim3(256), 0, c->stream, P, pn, (uint32_t)D, k, ldk, C, cn, assign);
@@ -187,23 +283,105 @@ int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   return 0;
 }
 
-// Csum[assign[d]][:] += P[d][:]   (float atomics, contiguous dwords per wave-instruction); counts[c]++
-__global__ __launch_bounds__(256) void proj_accumulate_k(const float* __restrict__ P, uint32_t D, int k, int ldk,
-                                                          const uint32_t* __restrict__ assign, float* __restrict__ Csum,
-                                                          int* __restrict__ counts) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= D) return;
-  const uint32_t cc = assign[d];
-  for (int j = lane; j < k; j += 64) atomicAdd(&Csum[(size_t)cc * ldk + j], P[(size_t)d * ldk + j]);
-  if (lane == 0) atomicAdd(&counts[cc], 1);
+// Member lists: members[off[c] .. off[c+1]) = documents assigned to centre c (order = placement atomics).
+__global__ __launch_bounds__(256) void member_fill_k(const uint32_t* __restrict__ assign, uint32_t D, int k, const int* __restrict__ off,
+                                                      int* __restrict__ cursor, uint32_t* __restrict__ members) {
+  extern __shared__ int sh[];  // hist[k], base[k]
+  int* hist = sh;
+  int* base = sh + k;
+  for (int j = threadIdx.x; j < k; j += 256) hist[j] = 0;
+  __syncthreads();
+  const uint32_t b0 = blockIdx.x * (256 * CS_ITEMS);
+  uint32_t mine[CS_ITEMS];
+  int rank[CS_ITEMS];
+#pragma unroll
+  for (int u = 0; u < CS_ITEMS; ++u) {
+    const uint32_t d = b0 + threadIdx.x + 256 * u;
+    mine[u] = (d < D) ? assign[d] : 0xffffffffu;
+    rank[u] = (d < D) ? atomicAdd(&hist[mine[u]], 1) : 0;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < k; j += 256) base[j] = hist[j] ? off[j] + atomicAdd(&cursor[j], hist[j]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < CS_ITEMS; ++u) {
+    const uint32_t d = b0 + threadIdx.x + 256 * u;
+    if (d < D) members[base[mine[u]] + rank[u]] = d;
+  }
 }
+
+// Csum[c][:] += sum of P rows of the members [j*MC, (j+1)*MC) of centre c.  grid = (chunks, k).
+// Each wave sums whole rows (coalesced 4*k-byte reads), waves are combined in LDS, one atomicAdd per (block, coordinate).
+constexpr int SEG_MC = 256;
+template <int NIT>
+__global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P, int k, int ldk, const int* __restrict__ off,
+                                                      const uint32_t* __restrict__ members, float* __restrict__ Csum) {
+  extern __shared__ float red[];  // 4 x ldk
+  const int cc = blockIdx.y;
+  const int beg = off[cc] + blockIdx.x * SEG_MC;
+  const int end = min(off[cc + 1], beg + SEG_MC);
+  if (beg >= end) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) acc[it] = 0.f;
+  for (int m = beg + wave; m < end; m += 4) {
+    const float* row = P + (size_t)members[m] * ldk;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int j = lane + 64 * it;
+      if (j < k) acc[it] += row[j];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int j = lane + 64 * it;
+    if (j < k) red[wave * ldk + j] = acc[it];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < k; j += 256) {
+    const float sum = (red[j] + red[ldk + j]) + (red[2 * ldk + j] + red[3 * ldk + j]);
+    atomicAdd(&Csum[(size_t)cc * ldk + j], sum);
+  }
+}
+
+// counts must hold the LOCAL cluster sizes (k_count_sizes); sizes_host = the same on the host.
 int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   HIPCHK(c, hipMemsetAsync(Csum, 0, (size_t)k * ldk * sizeof(float), c->stream));
-  HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)k * sizeof(int), c->stream));
   if (D == 0) return 0;
-  hipLaunchKernelGGL(proj_accumulate_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, P, (uint32_t)D, k, ldk, assign, Csum, counts);
+  // local sizes -> host -> offsets (k is small; this sync replaces the one the stop rule needs anyway)
+  std::vector<int> h(k), off(k + 1, 0);
+  HIPCHK(c, hipMemcpyAsync(h.data(), counts, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int mx = 0;
+  for (int i = 0; i < k; ++i) {
+    off[i + 1] = off[i] + h[i];
+    mx = std::max(mx, h[i]);
+  }
+  HIPCHK(c, c->members.reserve(D));
+  HIPCHK(c, c->moff.reserve(2 * (size_t)k + 2));
+  int* offd = c->moff.p;
+  int* cur = c->moff.p + k + 1;
+  HIPCHK(c, hipMemcpyAsync(offd, off.data(), (size_t)(k + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(cur, 0, (size_t)k * sizeof(int), c->stream));
+  hipLaunchKernelGGL(member_fill_k, dim3(cdiv(D, 256 * CS_ITEMS)), dim3(256), 2 * (size_t)k * sizeof(int), c->stream, assign, (uint32_t)D, k,
+                     offd, cur, c->members.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // `off` is pageable host memory
+  if (mx == 0) return 0;
+  dim3 g(cdiv(mx, SEG_MC), k), b(256);
+  const size_t lds = 4 * (size_t)ldk * sizeof(float);
+  const int nit = cdiv(k, 64);
+#define LS(N) hipLaunchKernelGGL(proj_segsum_k<N>, g, b, lds, c->stream, P, k, ldk, offd, c->members.p, Csum)
+  if (nit <= 1) LS(1);
+  else if (nit <= 2) LS(2);
+  else if (nit <= 4) LS(4);
+  else if (nit <= 8) LS(8);
+  else if (nit <= 16) LS(16);
+  else if (nit <= 32) LS(32);
+  else return isle_fail(c, ISLE_E_ARG, "k too large");
+#undef LS
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -223,14 +401,25 @@ int k_proj_finalize(isle_ctx* c, const float* Csum, const int* counts, int k, in
   return 0;
 }
 
-__global__ __launch_bounds__(256) void count_sizes_k(const uint32_t* __restrict__ assign, uint64_t D, int* __restrict__ counts) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < D) atomicAdd(&counts[assign[i]], 1);
+// cluster sizes: per-workgroup histogram in LDS, one global atomic per (workgroup, non-empty bin)
+__global__ __launch_bounds__(256) void count_sizes_k(const uint32_t* __restrict__ assign, uint64_t D, int k, int* __restrict__ counts) {
+  extern __shared__ int hist[];
+  for (int j = threadIdx.x; j < k; j += 256) hist[j] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * (256 * CS_ITEMS);
+#pragma unroll
+  for (int u = 0; u < CS_ITEMS; ++u) {
+    const uint64_t i = base + threadIdx.x + 256 * u;
+    if (i < D) atomicAdd(&hist[assign[i]], 1);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < k; j += 256)
+    if (hist[j]) atomicAdd(&counts[j], hist[j]);
 }
 int k_count_sizes(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, int* counts) {
   HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)k * sizeof(int), c->stream));
   if (D == 0) return 0;
-  hipLaunchKernelGGL(count_sizes_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, assign, D, counts);
+  hipLaunchKernelGGL(count_sizes_k, dim3(cdiv(D, 256 * CS_ITEMS)), dim3(256), (size_t)k * sizeof(int), c->stream, assign, D, k, counts);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -452,3 +452,40 @@ int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+
+// Centroid sums without global atomics: Crm[w][c] = sum over the nonzeros (w, d) with assign[d] == c of B[w,d].
+// One wave per vocabulary row w walks the row's cells of the chunked-CSR copy and keeps a k-bin histogram in LDS
+// (one ds_add_f32 per nonzero); the finished row of sums is written once, coalesced.
+__global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restrict__ cval, const uint32_t* __restrict__ ccol,
+                                                            const int64_t* __restrict__ seg_off, uint32_t V, uint32_t nch,
+                                                            const uint32_t* __restrict__ assign, int ldk, float* __restrict__ Crm) {
+  extern __shared__ float bins_all[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* bins = bins_all + wave * ldk;
+  const uint32_t w = blockIdx.x * 4 + wave;
+  if (w >= V) return;
+  for (int j = lane; j < ldk; j += 64) bins[j] = 0.f;
+  for (uint32_t ch = 0; ch < nch; ++ch) {
+    const size_t seg = (size_t)ch * V + w;
+    const int64_t beg = seg_off[seg], end = seg_off[seg + 1];
+    for (int64_t i = beg + lane; i < end; i += 64) {
+      const uint32_t d = __builtin_nontemporal_load(&ccol[i]);
+      const float v = __builtin_nontemporal_load(&cval[i]);
+      atomicAdd(&bins[assign[d]], v);
+    }
+  }
+  // LDS ops of one wave complete in order; the wave's own atomics are visible to its later reads
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (int j = lane; j < ldk; j += 64) Crm[(size_t)w * ldk + j] = bins[j];
+}
+
+int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm) {
+  ISLECHK(k_band_build(c));
+  TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
+  const uint32_t V = (uint32_t)c->V;
+  const size_t lds = 4 * (size_t)ldk * sizeof(float);
+  hipLaunchKernelGGL(centers_from_rows_k, dim3(cdiv(V, 4)), dim3(256), lds, c->stream, c->bval.p, c->bcol.p, c->seg_off.p, V, c->nbands,
+                     assign, ldk, Crm);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
