@@ -252,6 +252,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   c->band_ready = false;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->members_valid = false;
   c->U_k = 0;
   c->centers_ready = false;
   return 0;
@@ -987,8 +988,14 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, c->cnorm.p));  // :1604
     }
-    ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p));  // :1606
+    // documents are visited grouped by their previous centre (cache locality of the centre rows); results are order-independent
+    ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p,
+                               c->members_valid ? c->members.p : nullptr));  // :1606
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
+    if (it + 1 < max_reps) {
+      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+      ISLECHK(k_member_lists(c, c->assign.p, D, k, c->counts.p, nullptr));
+    }
     ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p));                          // :1613-1638
     ISLECHK(allreduce_sum<float>(c, c->centers_rm.p, (size_t)V * ld));
     std::vector<long long> sizes;

@@ -99,6 +99,7 @@ struct isle_ctx {
   DevBuf<int> counts;
   DevBuf<uint32_t> members;  // documents grouped by centre
   DevBuf<int> moff;          // k+1 offsets, k cursors
+  bool members_valid = false; // members = a permutation of the local docs grouped by centre
   DevBuf<int> flags;
   DevBuf<float> centers_rm;   // V x ldk  (word-space centres, row-major)
   DevBuf<float> centers_cm;   // V x k col-major staging
@@ -149,7 +150,9 @@ int k_gram_pass2(isle_ctx* c, int BP);   // Zrm = B Yrm
 int k_band_build(isle_ctx* c);
 int k_frobenius(isle_ctx* c, double* out_host);
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms);
-int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign);
+int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
+                       const uint32_t* perm /*nullable: processing order (a permutation of the local docs)*/);
+int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);

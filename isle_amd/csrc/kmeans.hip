@@ -345,30 +345,39 @@ __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P
   }
 }
 
-// counts must hold the LOCAL cluster sizes (k_count_sizes); sizes_host = the same on the host.
-int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts) {
-  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
-  HIPCHK(c, hipMemsetAsync(Csum, 0, (size_t)k * ldk * sizeof(float), c->stream));
-  if (D == 0) return 0;
-  // local sizes -> host -> offsets (k is small; this sync replaces the one the stop rule needs anyway)
+// members = local documents grouped by centre (counts_dev = LOCAL cluster sizes from k_count_sizes).
+int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out) {
   std::vector<int> h(k), off(k + 1, 0);
-  HIPCHK(c, hipMemcpyAsync(h.data(), counts, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h.data(), counts_dev, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int mx = 0;
   for (int i = 0; i < k; ++i) {
     off[i + 1] = off[i] + h[i];
     mx = std::max(mx, h[i]);
   }
-  HIPCHK(c, c->members.reserve(D));
+  if (max_out) *max_out = mx;
+  HIPCHK(c, c->members.reserve(D ? D : 1));
   HIPCHK(c, c->moff.reserve(2 * (size_t)k + 2));
   int* offd = c->moff.p;
   int* cur = c->moff.p + k + 1;
   HIPCHK(c, hipMemcpyAsync(offd, off.data(), (size_t)(k + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(cur, 0, (size_t)k * sizeof(int), c->stream));
-  hipLaunchKernelGGL(member_fill_k, dim3(cdiv(D, 256 * CS_ITEMS)), dim3(256), 2 * (size_t)k * sizeof(int), c->stream, assign, (uint32_t)D, k,
-                     offd, cur, c->members.p);
+  if (D)
+    hipLaunchKernelGGL(member_fill_k, dim3(cdiv(D, 256 * CS_ITEMS)), dim3(256), 2 * (size_t)k * sizeof(int), c->stream, assign, (uint32_t)D, k,
+                       offd, cur, c->members.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // `off` is pageable host memory
+  c->members_valid = true;
+  return 0;
+}
+
+int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  HIPCHK(c, hipMemsetAsync(Csum, 0, (size_t)k * ldk * sizeof(float), c->stream));
+  if (D == 0) return 0;
+  int mx = 0;
+  ISLECHK(k_member_lists(c, assign, D, k, counts, &mx));
+  int* offd = c->moff.p;
   if (mx == 0) return 0;
   dim3 g(cdiv(mx, SEG_MC), k), b(256);
   const size_t lds = 4 * (size_t)ldk * sizeof(float);

@@ -307,11 +307,16 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
                                                     const int64_t* __restrict__ offs, const float4* __restrict__ M, int nq,
                                                     int k, uint32_t D, float4* __restrict__ P, float* __restrict__ norms,
                                                     const float* __restrict__ cn, const float* __restrict__ dn,
-                                                    uint32_t* __restrict__ assign) {
+                                                    uint32_t* __restrict__ assign, const uint32_t* __restrict__ perm) {
   const int lane = threadIdx.x & 63;
-  uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD-contiguous slots: workgroups of one XCD (blockIdx % 8) walk one contiguous eighth of the slot list, so that
+  // with `perm` = documents grouped by their previous centre each L2 keeps re-serving one cluster's hot vocabulary rows
+  const uint32_t nb = gridDim.x, per = (nb + 7) / 8;
+  const uint32_t vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  uint32_t d = vb * 4 + (threadIdx.x >> 6);
   d = __builtin_amdgcn_readfirstlane(d);
-  if (d >= D) return;
+  if (vb >= nb || d >= D) return;
+  if (perm) d = __builtin_amdgcn_readfirstlane(perm[d]);
   const int64_t beg = offs[d], end = offs[d + 1];
   float4 acc[NIT];
 #pragma unroll
@@ -382,15 +387,15 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
 
 template <int MODE>
 static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms, const float* cn, const float* dn,
-                       uint32_t* assign) {
+                       uint32_t* assign, const uint32_t* perm) {
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
   const int nq = ldk / 4;
   const int nit = cdiv(nq, 64);
-  dim3 g(cdiv(D, 4)), b(256);
+  dim3 g(8 * cdiv(cdiv(D, 4), 8)), b(256);  // multiple of 8 so that the XCD slot map is a bijection
 #define LW(N)                                                                                                              \
   hipLaunchKernelGGL((spmm_wide_k<N, MODE>), g, b, 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Mrm, nq, k, D, \
-                     (float4*)P, norms, cn, dn, assign)
+                     (float4*)P, norms, cn, dn, assign, perm)
   if (nit <= 1) LW(1);
   else if (nit <= 2) LW(2);
   else if (nit <= 4) LW(4);
@@ -402,11 +407,12 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
 }
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms) {
   TimeScope ts(c, ISLE_T_PROJECT);
-  return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr);
+  return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr, nullptr);
 }
-int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign) {
+int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
+                       const uint32_t* perm) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
-  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign);
+  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm);
 }
 
 // |b_d|^2  (compute_docs_l2sq  src/sparseMatrix.cpp:1680-1687)
