@@ -291,7 +291,11 @@ extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
 // ------------------------------------------------------------------------------------------
 // Gram apply on device pointers: Zcm (V x b col-major) = B (B^T Xcm)
 // ------------------------------------------------------------------------------------------
-static int panel_width(int b) { return 4 * ((b + 3) / 4); }  // b <= 16 -> BP in {4, 8, 12, 16}
+static int panel_width(int b) {  // b <= 16 -> BP in {4, 8, 12, 16}
+  static const bool p16 = getenv("ISLE_PANEL16") != nullptr;  // experiment: 64-B panel rows
+  if (p16 && b > 8) return 16;
+  return 4 * ((b + 3) / 4);
+}
 
 // One panel of at most 16 columns (the R x (BP+1) LDS tile of pass 2 is sized for BP <= 16).
 static int gram_apply_panel(isle_ctx* c, const float* Xcm, int b, float* Zcm) {

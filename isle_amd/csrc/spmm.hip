@@ -90,30 +90,36 @@ __global__ __launch_bounds__(256) void seg_gather_k(const float* __restrict__ va
   const int e = lane / LPE;
   const int q = lane - e * LPE;
   const bool active = e < EPW;
+  const int es = active ? e : 0;
+  constexpr int NB = EPW * LPE;  // nonzeros per batch: one coalesced (idx, val) load per lane, LPE gather steps
   const int64_t beg = offs[seg], end = offs[seg + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    int64_t i = beg + e;
-    for (; i + 3 * EPW < end; i += 4 * EPW) {  // four nonzeros in flight per lane
-      const uint32_t r0 = __builtin_nontemporal_load(&idx[i]), r1 = __builtin_nontemporal_load(&idx[i + EPW]);
-      const uint32_t r2 = __builtin_nontemporal_load(&idx[i + 2 * EPW]), r3 = __builtin_nontemporal_load(&idx[i + 3 * EPW]);
-      const float v0 = __builtin_nontemporal_load(&vals[i]), v1 = __builtin_nontemporal_load(&vals[i + EPW]);
-      const float v2 = __builtin_nontemporal_load(&vals[i + 2 * EPW]), v3 = __builtin_nontemporal_load(&vals[i + 3 * EPW]);
-      const float4 x0 = In[(size_t)r0 * LPE + q];
-      const float4 x1 = In[(size_t)r1 * LPE + q];
-      const float4 x2 = In[(size_t)r2 * LPE + q];
-      const float4 x3 = In[(size_t)r3 * LPE + q];
-      acc = f4_fma(v0, x0, acc);
-      acc = f4_fma(v1, x1, acc);
-      acc = f4_fma(v2, x2, acc);
-      acc = f4_fma(v3, x3, acc);
-    }
-    for (; i < end; i += EPW) {
-      const uint32_t r0 = __builtin_nontemporal_load(&idx[i]);
-      const float v0 = __builtin_nontemporal_load(&vals[i]);
-      acc = f4_fma(v0, In[(size_t)r0 * LPE + q], acc);
-    }
+  uint32_t ci = 0;
+  float cv = 0.f;
+  if (lane < NB && beg + lane < end) {
+    ci = __builtin_nontemporal_load(&idx[beg + lane]);
+    cv = __builtin_nontemporal_load(&vals[beg + lane]);
   }
+  for (int64_t i0 = beg; i0 < end; i0 += NB) {
+    uint32_t ni = 0;
+    float nv = 0.f;
+    const int64_t i1 = i0 + NB + lane;  // prefetch the next batch while this one is gathered
+    if (lane < NB && i1 < end) {
+      ni = __builtin_nontemporal_load(&idx[i1]);
+      nv = __builtin_nontemporal_load(&vals[i1]);
+    }
+#pragma unroll
+    for (int st = 0; st < LPE; ++st) {
+      if (i0 + st * EPW < end) {  // wave-uniform
+        const uint32_t r = __shfl(ci, st * EPW + es);
+        const float v = __shfl(cv, st * EPW + es);  // 0 beyond the segment end
+        acc = f4_fma(v, In[(size_t)r * LPE + q], acc);
+      }
+    }
+    ci = ni;
+    cv = nv;
+  }
+  if (!active) acc = make_float4(0.f, 0.f, 0.f, 0.f);
   // reduce over the entry slots; the lowest slot of every aligned group is always exact
 #pragma unroll
   for (int m = 1; m < EPW; m <<= 1) {
