@@ -80,7 +80,7 @@ ncclDataType_t nccl_type<uint64_t>() { return ncclUint64; }
 
 template <class T>
 static int allreduce_sum(isle_ctx* c, T* buf, size_t count) {
-  if (!c->comm || c->world == 1) return 0;
+  if (!c->comm) return 0;
   TimeScope ts(c, ISLE_T_COMM);
   NCCLCHK(c, ncclAllReduce(buf, buf, count, nccl_type<T>(), ncclSum, c->comm, c->stream));
   return 0;
@@ -194,7 +194,9 @@ extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* 
   if (!c || world < 1 || rank < 0 || rank >= world) return isle_fail(c, ISLE_E_ARG, "bad world/rank");
   c->world = world;
   c->rank = rank;
-  if (world == 1) return 0;
+  // world == 1 needs no communicator; ISLE_FORCE_COMM=1 creates a 1-rank one anyway so that every RCCL call site
+  // of the sharded path can be exercised on a single GPU (tests/test_gpu_comm_selftest.py)
+  if (world == 1 && !getenv("ISLE_FORCE_COMM")) return 0;
   HIPCHK(c, hipSetDevice(c->device));
   ncclUniqueId id;
   memcpy(&id, uid, sizeof id);
@@ -277,7 +279,7 @@ extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
   HIPCHK(c, hipSetDevice(c->device));
   double s = 0.0;
   ISLECHK(k_frobenius(c, &s));
-  if (c->comm && c->world > 1) {
+  if (c->comm) {
     HIPCHK(c, c->gram.reserve(1024));
     HIPCHK(c, hipMemcpyAsync(c->gram.p, &s, sizeof(double), hipMemcpyHostToDevice, c->stream));
     ISLECHK(allreduce_sum<double>(c, c->gram.p, 1));
@@ -707,7 +709,7 @@ static int ensure_P(isle_ctx* c, int k) {
 // dst (n x ldk, device) <- P rows of the given GLOBAL doc ids (owner contributes, others zero, then all-reduce)
 static int fetch_rows(isle_ctx* c, const uint64_t* ids, int n, float* dst) {
   if (n == 0) return 0;
-  const bool multi = c->comm && c->world > 1;
+  const bool multi = c->comm != nullptr;
   if (multi) HIPCHK(c, hipMemsetAsync(dst, 0, (size_t)n * c->ldk * sizeof(float), c->stream));
   for (int i = 0; i < n; ++i) {
     const uint64_t g = ids[i];
@@ -729,7 +731,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2144
   const uint64_t D = c->D, Dg = c->D_global;
   const int ldk = c->ldk;
-  const bool multi = c->comm && c->world > 1;
+  const bool multi = c->comm != nullptr;
   HIPCHK(c, c->min_dist.reserve(D ? D : 1));
   HIPCHK(c, c->cum.reserve(D + 1));
   HIPCHK(c, c->Cdev.reserve((size_t)k * ldk));
