@@ -289,8 +289,14 @@ int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// One-sided Jacobi (Hestenes) on W = (S + mu I), V = I, fp64.  Round-robin pairing: n/2 disjoint
-// column pairs per round, one workgroup per pair; n-1 rounds per sweep.
+// Block one-sided Jacobi (Hestenes) on W = (S + mu I), V = I, fp64.
+// Columns are grouped in blocks of 16; a round pairs the blocks round-robin and one workgroup owns a pair:
+//   (1) G = [Wa Wb]^T [Wa Wb]  (32 x 32, rows streamed through LDS)
+//   (2) ONE cyclic sweep of two-sided Jacobi rotations on G in LDS (31 inner rounds x 16 disjoint pairs),
+//       accumulating the 32 x 32 rotation product Q  ("cyclic by blocks" ordering of the scalar method)
+//   (3) [Wa Wb] <- [Wa Wb] Q,  [Va Vb] <- [Va Vb] Q
+// n/16 - 1 launches per sweep instead of n - 1 for the scalar method (the scalar kernel was launch-latency
+// bound: 9.4k launches and 58 ms per solve pair at n = 400).
 // ------------------------------------------------------------------------------------------
 __device__ inline double block_sum(double v, double* sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,52 +310,141 @@ __device__ inline double block_sum(double v, double* sh) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void jacobi_round_k(double* __restrict__ W, double* __restrict__ Vv, int n, int np, int round,
-                                                       double tol, unsigned int* __restrict__ rotated) {
-  __shared__ double sh[8];
-  const int mrot = np - 1;
-  int p, q;
-  if (blockIdx.x == 0) {
-    p = np - 1;
-    q = round % mrot;
+constexpr int BJ_W = 16;          // block width
+constexpr int BJ_P = 2 * BJ_W;    // columns per pair
+
+__device__ inline void rr_pair(int nplayers, int round, int slot, int* p, int* q) {
+  const int m = nplayers - 1;
+  if (slot == 0) {
+    *p = nplayers - 1;
+    *q = round % m;
   } else {
-    p = (round + (int)blockIdx.x) % mrot;
-    q = (round - (int)blockIdx.x + mrot) % mrot;
+    *p = (round + slot) % m;
+    *q = (round - slot + m) % m;
   }
-  if (p >= n || q >= n) return;
-  if (p > q) {
-    const int t = p;
-    p = q;
-    q = t;
+}
+
+__global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, double* __restrict__ Vv, int n, int nblk2 /*even*/,
+                                                        int round, double tol, unsigned int* __restrict__ rotated) {
+  __shared__ double T[64][BJ_P + 1];
+  __shared__ double G[BJ_P][BJ_P + 1];
+  __shared__ double Q[BJ_P][BJ_P + 1];
+  __shared__ double rc[BJ_W], rs[BJ_W];
+  __shared__ int rp[BJ_W], rq[BJ_W];
+  __shared__ unsigned int nrot;
+  const int t = threadIdx.x;
+  int A, Bk;
+  rr_pair(nblk2, round, blockIdx.x, &A, &Bk);
+  if (A > Bk) {
+    const int x = A;
+    A = Bk;
+    Bk = x;
   }
-  double* wp = W + (size_t)p * n;
-  double* wq = W + (size_t)q * n;
-  double a = 0.0, b = 0.0, g = 0.0;
-  for (int r = threadIdx.x; r < n; r += 256) {
-    const double x = wp[r], y = wq[r];
-    a = fma(x, x, a);
-    b = fma(y, y, b);
-    g = fma(x, y, g);
+  if (A * BJ_W >= n) return;  // both blocks are padding
+  auto colidx = [&](int cc) { return cc < BJ_W ? A * BJ_W + cc : Bk * BJ_W + (cc - BJ_W); };
+  if (t == 0) nrot = 0;
+  // ---- (1) Gram matrix -------------------------------------------------------------------------
+  const int gi = t >> 3, gj0 = (t & 7) * 4;
+  double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+  for (int r0 = 0; r0 < n; r0 += 64) {
+    __syncthreads();
+    for (int idx = t; idx < 64 * BJ_P; idx += 256) {
+      const int rr = idx & 63, cc = idx >> 6;
+      const int cg = colidx(cc);
+      T[rr][cc] = (r0 + rr < n && cg < n) ? W[(size_t)cg * n + r0 + rr] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) {
+      const double a = T[rr][gi];
+      g0 = fma(a, T[rr][gj0 + 0], g0);
+      g1 = fma(a, T[rr][gj0 + 1], g1);
+      g2 = fma(a, T[rr][gj0 + 2], g2);
+      g3 = fma(a, T[rr][gj0 + 3], g3);
+    }
   }
-  a = block_sum(a, sh);
-  b = block_sum(b, sh);
-  g = block_sum(g, sh);
-  if (a == 0.0 || b == 0.0) return;
-  if (fabs(g) <= tol * sqrt(a) * sqrt(b)) return;
-  if (threadIdx.x == 0) atomicAdd(rotated, 1u);
-  const double zeta = (b - a) / (2.0 * g);
-  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  const double cs = 1.0 / sqrt(1.0 + t * t);
-  const double sn = cs * t;
-  double* vp = Vv + (size_t)p * n;
-  double* vq = Vv + (size_t)q * n;
-  for (int r = threadIdx.x; r < n; r += 256) {
-    const double x = wp[r], y = wq[r];
-    wp[r] = cs * x - sn * y;
-    wq[r] = sn * x + cs * y;
-    const double u = vp[r], v = vq[r];
-    vp[r] = cs * u - sn * v;
-    vq[r] = sn * u + cs * v;
+  G[gi][gj0 + 0] = g0;
+  G[gi][gj0 + 1] = g1;
+  G[gi][gj0 + 2] = g2;
+  G[gi][gj0 + 3] = g3;
+  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) Q[idx / BJ_P][idx % BJ_P] = (idx / BJ_P == idx % BJ_P) ? 1.0 : 0.0;
+  __syncthreads();
+  // ---- (2) one cyclic sweep on G, accumulating Q ------------------------------------------------
+  for (int ir = 0; ir < BJ_P - 1; ++ir) {
+    if (t < BJ_W) {
+      int p, q;
+      rr_pair(BJ_P, ir, t, &p, &q);
+      if (p > q) {
+        const int x = p;
+        p = q;
+        q = x;
+      }
+      const double a = G[p][p], b = G[q][q], gpq = G[p][q];
+      double cs = 1.0, sn = 0.0;
+      if (a > 0.0 && b > 0.0 && fabs(gpq) > tol * sqrt(a) * sqrt(b)) {
+        const double zeta = (b - a) / (2.0 * gpq);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        cs = 1.0 / sqrt(1.0 + tt * tt);
+        sn = cs * tt;
+        atomicAdd(&nrot, 1u);
+      }
+      rp[t] = p;
+      rq[t] = q;
+      rc[t] = cs;
+      rs[t] = sn;
+    }
+    __syncthreads();
+    // columns of G and Q:  M[:, p] = c M[:, p] - s M[:, q];  M[:, q] = s M[:, p] + c M[:, q]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int item = t + 256 * u;
+      const int mat = item >> 9, rem = item & 511;
+      const int pr = rem >> 5, r = rem & 31;
+      const int p = rp[pr], q = rq[pr];
+      const double cs = rc[pr], sn = rs[pr];
+      double(*M)[BJ_P + 1] = mat ? Q : G;
+      const double x = M[r][p], y = M[r][q];
+      M[r][p] = cs * x - sn * y;
+      M[r][q] = sn * x + cs * y;
+    }
+    __syncthreads();
+    // rows of G:  G[p, :] = c G[p, :] - s G[q, :];  G[q, :] = s G[p, :] + c G[q, :]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int item = t + 256 * u;
+      const int pr = item >> 5, cc = item & 31;
+      const int p = rp[pr], q = rq[pr];
+      const double cs = rc[pr], sn = rs[pr];
+      const double x = G[p][cc], y = G[q][cc];
+      G[p][cc] = cs * x - sn * y;
+      G[q][cc] = sn * x + cs * y;
+    }
+    __syncthreads();
+  }
+  if (nrot == 0) return;  // uniform: nothing to apply
+  if (t == 0) atomicAdd(rotated, nrot);
+  // ---- (3) apply Q to the long columns of W and V -----------------------------------------------
+  for (int r = t; r < n; r += 256) {
+#pragma unroll
+    for (int mat = 0; mat < 2; ++mat) {
+      double* M = mat ? Vv : W;
+      double x[BJ_P];
+#pragma unroll
+      for (int j = 0; j < BJ_P; ++j) {
+        const int cg = colidx(j);
+        x[j] = (cg < n) ? M[(size_t)cg * n + r] : 0.0;
+      }
+#pragma unroll 4
+      for (int cc = 0; cc < BJ_P; ++cc) {
+        const int cg = colidx(cc);
+        if (cg < n) {
+          double o = 0.0;
+#pragma unroll
+          for (int j = 0; j < BJ_P; ++j) o = fma(x[j], Q[j][cc], o);
+          M[(size_t)cg * n + r] = o;
+        }
+      }
+    }
   }
 }
 
@@ -402,13 +497,14 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
   HIPCHK(c, hipMemcpyAsync(c->jacW.p, Wh.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->jacV.p, Vh.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
   unsigned int* rot = (unsigned int*)c->small.p;
-  const int np = (n + 1) & ~1;
+  const int nblk = (n + BJ_W - 1) / BJ_W;
+  const int nblk2 = std::max(2, (nblk + 1) & ~1);
   const double tol = 1e-15 * (double)n;
   bool converged = (n == 1);
   for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
     HIPCHK(c, hipMemsetAsync(rot, 0, sizeof(unsigned int), c->stream));
-    for (int round = 0; round < np - 1; ++round)
-      hipLaunchKernelGGL(jacobi_round_k, dim3(np / 2), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, np, round, tol, rot);
+    for (int round = 0; round < nblk2 - 1; ++round)
+      hipLaunchKernelGGL(bjacobi_round_k, dim3(nblk2 / 2), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, nblk2, round, tol, rot);
     HIPCHK(c, hipGetLastError());
     unsigned int nrot = 0;
     HIPCHK(c, hipMemcpyAsync(&nrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
