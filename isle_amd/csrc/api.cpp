@@ -703,6 +703,11 @@ static int ensure_P(isle_ctx* c, int k) {
   ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p));
   c->P_ready = true;
   c->Pt_ready = false;
+  if (c->ldk <= 256 && c->D) {  // coordinate-major copy for the register-resident MFMA distance kernels
+    HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
+    ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
+    c->Pt_ready = true;
+  }
   return 0;
 }
 
@@ -899,12 +904,6 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   if (!c || !C_lowd || k < 1) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2032
-  if (!c->Pt_ready && c->ldk <= 256 && c->D) {  // coordinate-major copy for the register-resident assignment kernel
-    TimeScope ts(c, ISLE_T_LLOYD_PROJ);
-    HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
-    ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
-    c->Pt_ready = true;
-  }
   const uint64_t D = c->D;
   const int ldk = c->ldk;
   HIPCHK(c, c->Cdev.reserve((size_t)k * ldk));

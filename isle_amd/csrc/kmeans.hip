@@ -16,6 +16,10 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int CS_ITEMS = 16;  // documents per thread in the histogram-style kernels
+enum { PR_ARGMIN = 0, PR_MINDIST = 1 };
+template <int MODE>
+static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
+                           float* min_dist, bool* done);
 
 // ------------------------------------------------------------------------------------------
 // min_dist[d] = min(min_dist[d], max(|p_d|^2 + |c|^2 - 2 p_d.c, 0)) over the nc newest centres.
@@ -76,6 +80,11 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   if (D == 0 || nc == 0) return 0;
   HIPCHK(c, c->cnorm.reserve((size_t)std::max(k, nc)));
   ISLECHK(k_rownorms(c, newC, nc, k, ldk, c->cnorm.p));
+  if (nc <= 32) {  // distance tile on the matrix cores: the nc newest centres are one 32-row MFMA tile
+    bool done = false;
+    ISLECHK(launch_proj_reg<PR_MINDIST>(c, D, nc, ldk, newC, c->cnorm.p, pn, nullptr, min_dist, &done));
+    if (done) return 0;
+  }
   const int nit = cdiv(ldk, 64);
   dim3 g(cdiv(D, 4)), b(256);
 #define LK(N) hipLaunchKernelGGL(kmpp_update_k<N>, g, b, 0, c->stream, P, pn, (uint32_t)D, ldk, newC, c->cnorm.p, nc, min_dist)
@@ -185,10 +194,14 @@ __global__ __launch_bounds__(256) void proj_assign_k(const float* __restrict__ P
 // of step i carries coordinate h*KH + i) in registers for the whole kernel, so P is read from HBM exactly once per
 // iteration; centres stream through LDS in slabs of 2 x 16 coordinates and all centre tiles accumulate side by side.
 constexpr int PR_SL = 16;
-template <int KHMAX, int CTMAX>
-__global__ __launch_bounds__(256) void proj_assign_reg_k(const float* __restrict__ Pt /*ldk x D*/, const float* __restrict__ pn, uint32_t D, int k,
-                                                          int ldk, const float* __restrict__ C, const float* __restrict__ cn,
-                                                          uint32_t* __restrict__ assign) {
+// MODE PR_ARGMIN : assign[d] = first index of min |dist|        (Lloyd, cblas_isamin semantics)
+// MODE PR_MINDIST: min_dist[d] = min(min_dist[d], max(dist, 0)) (k-means++ round against the newest <= 32*CTMAX centres)
+template <int NSLAB, int CTMAX, int MODE>
+__global__ __launch_bounds__(256, 2) void proj_assign_reg_k(const float* __restrict__ Pt /*ldk x D*/, const float* __restrict__ pn,
+                                                             uint32_t D, int k, int ldk, const float* __restrict__ C,
+                                                             const float* __restrict__ cn, uint32_t* __restrict__ assign,
+                                                             float* __restrict__ min_dist) {
+  constexpr int KHMAX = NSLAB * PR_SL;
   extern __shared__ float Cs[];  // [2][kpad][PR_SL + 1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -238,10 +251,15 @@ __global__ __launch_bounds__(256) void proj_assign_reg_k(const float* __restrict
       for (int r = 0; r < 16; ++r) {
         const int cc = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (cc < k) {
-          const float dist = fabsf((-2.0f * acc[t][r] + cn[cc]) + nd);
-          if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
-            best = dist;
-            bidx = (uint32_t)cc;
+          const float raw = (-2.0f * acc[t][r] + cn[cc]) + nd;
+          if (MODE == PR_ARGMIN) {
+            const float dist = fabsf(raw);
+            if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
+              best = dist;
+              bidx = (uint32_t)cc;
+            }
+          } else {
+            best = fminf(best, fmaxf(raw, 0.0f));
           }
         }
       }
@@ -249,32 +267,56 @@ __global__ __launch_bounds__(256) void proj_assign_reg_k(const float* __restrict
   }
   const float ob = __shfl_xor(best, 32);
   const uint32_t oi = __shfl_xor(bidx, 32);
-  if (ob < best || (ob == best && oi < bidx)) {
-    best = ob;
-    bidx = oi;
+  if (MODE == PR_ARGMIN) {
+    if (ob < best || (ob == best && oi < bidx)) {
+      best = ob;
+      bidx = oi;
+    }
+    if (h == 0 && myd < D) assign[myd] = bidx;
+  } else {
+    best = fminf(best, ob);
+    if (h == 0 && myd < D) min_dist[myd] = fminf(min_dist[myd], best);
   }
-  if (h == 0 && myd < D) assign[myd] = bidx;
+}
+
+// dispatch over (coordinate slabs, centre tiles); returns false if the shape is not covered
+template <int MODE>
+static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
+                           float* min_dist, bool* done) {
+  *done = false;
+  if (!D || ldk > 256 || k > 256 || !c->Pt_ready) return 0;
+  const int kpad = (k + 31) & ~31;
+  const int ct = kpad / 32;
+  const int nslab = cdiv(ldk / 2, PR_SL);
+  const size_t lds = (size_t)2 * kpad * (PR_SL + 1) * sizeof(float);
+  dim3 g(cdiv(D, 128)), b(256);
+#define LR(NS, CM)                                                                                                            \
+  do {                                                                                                                        \
+    HIPCHK(c, hipFuncSetAttribute((const void*)proj_assign_reg_k<NS, CM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, c->Pt.p, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist); \
+    *done = true;                                                                                                             \
+  } while (0)
+  if (ct <= 1) {
+    if (nslab <= 2) LR(2, 1);
+    else if (nslab <= 4) LR(4, 1);
+    else if (nslab <= 7) LR(7, 1);
+    else LR(8, 1);
+  } else if (ct <= 2 && nslab <= 2) LR(2, 2);
+  else if (ct <= 4 && nslab <= 4) LR(4, 4);
+  else if (ct <= 7 && nslab <= 7) LR(7, 7);
+  else LR(8, 8);
+#undef LR
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 
 int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn,
                   uint32_t* assign) {
-  if (D && ldk <= 256 && k <= 256 && c->Pt_ready && !getenv("ISLE_PROJ_ASSIGN_GENERIC")) {
+  if (!getenv("ISLE_PROJ_ASSIGN_GENERIC")) {
     TimeScope ts(c, ISLE_T_LLOYD_PROJ);
-    const int kpad = (k + 31) & ~31;
-    const size_t lds = (size_t)2 * kpad * (PR_SL + 1) * sizeof(float);
-    dim3 g(cdiv(D, 128)), b(256);
-    const int KH = ldk / 2;
-#define LR(KM, CM)                                                                                                       \
-  do {                                                                                                                   \
-    HIPCHK(c, hipFuncSetAttribute((const void*)proj_assign_reg_k<KM, CM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((proj_assign_reg_k<KM, CM>), g, b, lds, c->stream, c->Pt.p, pn, (uint32_t)D, k, ldk, C, cn, assign);     \
-  } while (0)
-    if (KH <= 32 && kpad <= 64) LR(32, 2);
-    else if (KH <= 64 && kpad <= 128) LR(64, 4);
-    else LR(128, 8);
-#undef LR
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    bool done = false;
+    ISLECHK(launch_proj_reg<PR_ARGMIN>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done));
+    if (done) return 0;
   }
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   if (D == 0) return 0;
