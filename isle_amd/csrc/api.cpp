@@ -171,7 +171,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   c->bcol.release(); c->bval.release(); c->seg_off.release(); c->Zpart.release();
   c->Xrm.release(); c->Yrm.release(); c->Zrm.release(); c->Xcm.release(); c->Zcm.release();
   c->basis.release(); c->Fbuf.release(); c->Tmp.release(); c->part.release(); c->coef.release();
-  c->gram.release(); c->small.release(); c->jacW.release(); c->jacV.release(); c->Wf.release();
+  c->gram.release(); c->small.release(); c->jacW.release(); c->jacV.release(); c->jacS.release(); c->Wf.release();
   c->Ucm.release(); c->Urm.release(); c->P.release(); c->Pt.release(); c->pnorm.release(); c->min_dist.release();
   c->cum.release(); c->scan_blk.release(); c->Cdev.release(); c->cnorm.release(); c->Csum.release();
   c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release(); c->members.release(); c->moff.release();

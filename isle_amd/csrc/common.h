@@ -77,6 +77,7 @@ struct isle_ctx {
   DevBuf<double> gram;     // blk x blk
   DevBuf<float> small;     // misc small device scratch
   DevBuf<double> jacW, jacV;  // n x n each
+  DevBuf<double> jacS;        // per-pair Gram / rotation scratch
   DevBuf<float> Wf;        // n x n float eigenvectors
   int U_k = 0;             // number of columns of U available
   DevBuf<float> Ucm;       // V x k col-major  (copy of basis[:, :k])

@@ -8,6 +8,7 @@
 //   k_jacobi_eig          one-sided (Hestenes) Jacobi in fp64: arma::eig_sym -> ssyevd
 //                         block-ks/restarted_block_ks.h:150-161
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -227,13 +228,15 @@ __global__ __launch_bounds__(256) void gemm_nn_k(const float* __restrict__ A, ui
       const int idx = threadIdx.x + 256 * u;
       const int kk = idx / GM, mm = idx - kk * GM;
       const uint64_t gm = m0 + mm;
-      As[kk][mm] = (gm < M && k0 + kk < K) ? A[(uint64_t)(k0 + kk) * M + gm] : 0.f;
+      const float va = A[(uint64_t)min(k0 + kk, K - 1) * M + min(gm, M - 1)];  // clamped + masked: loads stay unconditional
+      As[kk][mm] = va * ((gm < M && k0 + kk < K) ? 1.f : 0.f);
     }
 #pragma unroll
     for (int u = 0; u < (GK * GN) / 256; ++u) {
       const int idx = threadIdx.x + 256 * u;
       const int kk = idx % GK, nn = idx / GK;
-      Bs[kk][nn] = (n0 + nn < N && k0 + kk < K) ? B[(size_t)(n0 + nn) * ldb + k0 + kk] : 0.f;
+      const float vb = B[(size_t)min(n0 + nn, N - 1) * ldb + min(k0 + kk, K - 1)];
+      Bs[kk][nn] = vb * ((n0 + nn < N && k0 + kk < K) ? 1.f : 0.f);
     }
     __syncthreads();
 #pragma unroll
@@ -324,34 +327,35 @@ __device__ inline void rr_pair(int nplayers, int round, int slot, int* p, int* q
   }
 }
 
-__global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, double* __restrict__ Vv, int n, int nblk2 /*even*/,
-                                                        int round, double tol, unsigned int* __restrict__ rotated) {
-  __shared__ double T[64][BJ_P + 1];
-  __shared__ double G[BJ_P][BJ_P + 1];
-  __shared__ double Q[BJ_P][BJ_P + 1];
-  __shared__ double rc[BJ_W], rs[BJ_W];
-  __shared__ int rp[BJ_W], rq[BJ_W];
-  __shared__ unsigned int nrot;
-  const int t = threadIdx.x;
-  int A, Bk;
-  rr_pair(nblk2, round, blockIdx.x, &A, &Bk);
-  if (A > Bk) {
-    const int x = A;
-    A = Bk;
-    Bk = x;
+// per-pair scratch in global memory: G (32x32 doubles), then Q (32x32 doubles), then a flag
+constexpr int BJ_SCR = 2 * BJ_P * BJ_P + 8;
+constexpr int BJ_ROWS = 64;   // rows per workgroup in the streaming kernels (one LDS tile)
+
+__device__ inline void bj_blocks(int nblk2, int round, int slot, int* A, int* Bk) {
+  rr_pair(nblk2, round, slot, A, Bk);
+  if (*A > *Bk) {
+    const int x = *A;
+    *A = *Bk;
+    *Bk = x;
   }
-  if (A * BJ_W >= n) return;  // both blocks are padding
-  auto colidx = [&](int cc) { return cc < BJ_W ? A * BJ_W + cc : Bk * BJ_W + (cc - BJ_W); };
-  if (t == 0) nrot = 0;
-  // ---- (1) Gram matrix -------------------------------------------------------------------------
+}
+__device__ inline int bj_col(int A, int Bk, int cc) { return cc < BJ_W ? A * BJ_W + cc : Bk * BJ_W + (cc - BJ_W); }
+
+// (1) G[pair] += [Wa Wb]^T [Wa Wb] over this workgroup's rows.  grid = (pairs, row chunks)
+__global__ __launch_bounds__(256) void bj_gram_k(const double* __restrict__ W, int n, int nblk2, int round, double* __restrict__ scr) {
+  __shared__ double T[64][BJ_P + 1];
+  int A, Bk;
+  bj_blocks(nblk2, round, blockIdx.x, &A, &Bk);
+  if (A * BJ_W >= n) return;
+  const int t = threadIdx.x;
   const int gi = t >> 3, gj0 = (t & 7) * 4;
   double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-  for (int r0 = 0; r0 < n; r0 += 64) {
+  const int rbeg = blockIdx.y * BJ_ROWS, rend = min(n, rbeg + BJ_ROWS);
+  for (int r0 = rbeg; r0 < rend; r0 += 64) {
     __syncthreads();
     for (int idx = t; idx < 64 * BJ_P; idx += 256) {
       const int rr = idx & 63, cc = idx >> 6;
-      const int cg = colidx(cc);
-      T[rr][cc] = (r0 + rr < n && cg < n) ? W[(size_t)cg * n + r0 + rr] : 0.0;
+      T[rr][cc] = W[(size_t)bj_col(A, Bk, cc) * n + r0 + rr];  // n is padded: no guards, no branches around loads
     }
     __syncthreads();
 #pragma unroll 8
@@ -363,13 +367,34 @@ __global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, d
       g3 = fma(a, T[rr][gj0 + 3], g3);
     }
   }
-  G[gi][gj0 + 0] = g0;
-  G[gi][gj0 + 1] = g1;
-  G[gi][gj0 + 2] = g2;
-  G[gi][gj0 + 3] = g3;
-  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) Q[idx / BJ_P][idx % BJ_P] = (idx / BJ_P == idx % BJ_P) ? 1.0 : 0.0;
+  double* G = scr + (size_t)blockIdx.x * BJ_SCR + gi * BJ_P + gj0;
+  atomicAdd(G + 0, g0);
+  atomicAdd(G + 1, g1);
+  atomicAdd(G + 2, g2);
+  atomicAdd(G + 3, g3);
+}
+
+// (2) one cyclic sweep of two-sided rotations on G in LDS, Q accumulated; grid = pairs
+__global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, double tol, double abs_tol, double* __restrict__ scr,
+                                                   unsigned int* __restrict__ rotated) {
+  __shared__ double G[BJ_P][BJ_P + 1];
+  __shared__ double Q[BJ_P][BJ_P + 1];
+  __shared__ double rc[BJ_W], rs[BJ_W];
+  __shared__ int rp[BJ_W], rq[BJ_W];
+  __shared__ unsigned int nrot;
+  int A, Bk;
+  bj_blocks(nblk2, round, blockIdx.x, &A, &Bk);
+  if (A * BJ_W >= n) return;
+  const int t = threadIdx.x;
+  double* S = scr + (size_t)blockIdx.x * BJ_SCR;
+  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) {
+    const int i = idx / BJ_P, j = idx % BJ_P;
+    // symmetrise what the atomics accumulated (they add the same products in a different order)
+    G[i][j] = (i <= j) ? S[i * BJ_P + j] : S[j * BJ_P + i];
+    Q[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  if (t == 0) nrot = 0;
   __syncthreads();
-  // ---- (2) one cyclic sweep on G, accumulating Q ------------------------------------------------
   for (int ir = 0; ir < BJ_P - 1; ++ir) {
     if (t < BJ_W) {
       int p, q;
@@ -381,10 +406,19 @@ __global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, d
       }
       const double a = G[p][p], b = G[q][q], gpq = G[p][q];
       double cs = 1.0, sn = 0.0;
-      if (a > 0.0 && b > 0.0 && fabs(gpq) > tol * sqrt(a) * sqrt(b)) {
-        const double zeta = (b - a) / (2.0 * gpq);
-        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        cs = 1.0 / sqrt(1.0 + tt * tt);
+      // relative test between live columns; absolute floor for (numerically) null columns of a singular S + mu I
+      if (a > 0.0 && b > 0.0 && gpq * gpq > tol * tol * a * b && fabs(gpq) > abs_tol) {
+        // tan(theta) only steers the annihilation: fp32 is enough (the sweep repeats); cos must make the rotation
+        // orthogonal to fp64 accuracy, so it gets an fp64 reciprocal square root with Newton refinement
+        const float zf = (float)((b - a) / (2.0 * gpq));
+        const float tf = (zf >= 0.f ? 1.f : -1.f) / (fabsf(zf) + sqrtf(1.f + zf * zf));
+        const double tt = (double)tf;
+        const double u = 1.0 + tt * tt;
+        double y = (double)rsqrtf((float)u);
+        y = y * (1.5 - 0.5 * u * y * y);
+        y = y * (1.5 - 0.5 * u * y * y);
+        y = y * (1.5 - 0.5 * u * y * y);
+        cs = y;
         sn = cs * tt;
         atomicAdd(&nrot, 1u);
       }
@@ -394,7 +428,6 @@ __global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, d
       rs[t] = sn;
     }
     __syncthreads();
-    // columns of G and Q:  M[:, p] = c M[:, p] - s M[:, q];  M[:, q] = s M[:, p] + c M[:, q]
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int item = t + 256 * u;
@@ -408,7 +441,6 @@ __global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, d
       M[r][q] = sn * x + cs * y;
     }
     __syncthreads();
-    // rows of G:  G[p, :] = c G[p, :] - s G[q, :];  G[q, :] = s G[p, :] + c G[q, :]
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int item = t + 256 * u;
@@ -421,98 +453,145 @@ __global__ __launch_bounds__(256) void bjacobi_round_k(double* __restrict__ W, d
     }
     __syncthreads();
   }
-  if (nrot == 0) return;  // uniform: nothing to apply
-  if (t == 0) atomicAdd(rotated, nrot);
-  // ---- (3) apply Q to the long columns of W and V -----------------------------------------------
-  for (int r = t; r < n; r += 256) {
-#pragma unroll
-    for (int mat = 0; mat < 2; ++mat) {
-      double* M = mat ? Vv : W;
-      double x[BJ_P];
-#pragma unroll
-      for (int j = 0; j < BJ_P; ++j) {
-        const int cg = colidx(j);
-        x[j] = (cg < n) ? M[(size_t)cg * n + r] : 0.0;
-      }
-#pragma unroll 4
-      for (int cc = 0; cc < BJ_P; ++cc) {
-        const int cg = colidx(cc);
-        if (cg < n) {
-          double o = 0.0;
-#pragma unroll
-          for (int j = 0; j < BJ_P; ++j) o = fma(x[j], Q[j][cc], o);
-          M[(size_t)cg * n + r] = o;
-        }
-      }
-    }
+  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) S[BJ_P * BJ_P + idx] = Q[idx / BJ_P][idx % BJ_P];
+  if (t == 0) {
+    // store the COUNT (not `nrot ? 1.0 : 0.0`): hipcc 7.2 lowered that select to s_cselect on a stale SCC here and
+    // always wrote 0.0 (seen in the ISA; the rotations were then never applied)
+    S[2 * BJ_P * BJ_P] = (double)nrot;
+    if (nrot) atomicAdd(rotated, nrot);
   }
 }
 
-// lambda_i = sign(v_i . w_i) * |w_i|
-__global__ __launch_bounds__(256) void jacobi_evals_k(const double* __restrict__ W, const double* __restrict__ Vv, int n,
-                                                       double* __restrict__ ev) {
+// (3) [Ma Mb] <- [Ma Mb] Q for M = W and V, one thread per row; grid = (pairs, row chunks)
+__global__ __launch_bounds__(256) void bj_apply_k(double* __restrict__ W, double* __restrict__ Vv, int n, int nblk2, int round,
+                                                   const double* __restrict__ scr) {
+  __shared__ double Q[BJ_P][BJ_P + 1];
+  int A, Bk;
+  bj_blocks(nblk2, round, blockIdx.x, &A, &Bk);
+  if (A * BJ_W >= n) return;
+  const double* S = scr + (size_t)blockIdx.x * BJ_SCR;
+  const int t = threadIdx.x;
+  if (S[2 * BJ_P * BJ_P] == 0.0) return;  // no rotation in this pair (uniform)
+  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) Q[idx / BJ_P][idx % BJ_P] = S[BJ_P * BJ_P + idx];
+  __syncthreads();
+  // thread = (row, group of 8 output columns): Q is read 8x less often from LDS than with one thread per row.
+  // The matrices are zero-padded to a multiple of 64 rows/columns, so no load or store needs a guard (guarded loads
+  // made hipcc branch around every load, wait for each separately and spill: 33 us per launch).
+  const int r = blockIdx.y * BJ_ROWS + (t & 63);
+  const int c0 = (t >> 6) * 8;
+#pragma unroll
+  for (int mat = 0; mat < 2; ++mat) {
+    double* M = mat ? Vv : W;
+    double x[BJ_P];
+#pragma unroll
+    for (int j = 0; j < BJ_P; ++j) x[j] = M[(size_t)bj_col(A, Bk, j) * n + r];
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0, o5 = 0.0, o6 = 0.0, o7 = 0.0;
+#pragma unroll
+    for (int j = 0; j < BJ_P; ++j) {
+      const double xv = x[j];
+      const double* qr = &Q[j][c0];
+      o0 = fma(xv, qr[0], o0);
+      o1 = fma(xv, qr[1], o1);
+      o2 = fma(xv, qr[2], o2);
+      o3 = fma(xv, qr[3], o3);
+      o4 = fma(xv, qr[4], o4);
+      o5 = fma(xv, qr[5], o5);
+      o6 = fma(xv, qr[6], o6);
+      o7 = fma(xv, qr[7], o7);
+    }
+    __syncthreads();  // all four column groups of a row have read x before anyone overwrites it
+    M[(size_t)bj_col(A, Bk, c0 + 0) * n + r] = o0;
+    M[(size_t)bj_col(A, Bk, c0 + 1) * n + r] = o1;
+    M[(size_t)bj_col(A, Bk, c0 + 2) * n + r] = o2;
+    M[(size_t)bj_col(A, Bk, c0 + 3) * n + r] = o3;
+    M[(size_t)bj_col(A, Bk, c0 + 4) * n + r] = o4;
+    M[(size_t)bj_col(A, Bk, c0 + 5) * n + r] = o5;
+    M[(size_t)bj_col(A, Bk, c0 + 6) * n + r] = o6;
+    M[(size_t)bj_col(A, Bk, c0 + 7) * n + r] = o7;
+  }
+}
+
+// lambda_i = sign(v_i . w_i) * |w_i| on the padded (ld = np) matrices
+__global__ __launch_bounds__(256) void bj_evals_k(const double* __restrict__ W, const double* __restrict__ Vv, int n, int np,
+                                                   double* __restrict__ ev) {
   __shared__ double sh[8];
   const int i = blockIdx.x;
   double nn = 0.0, dd = 0.0;
   for (int r = threadIdx.x; r < n; r += 256) {
-    const double w = W[(size_t)i * n + r];
+    const double w = W[(size_t)i * np + r];
     nn = fma(w, w, nn);
-    dd = fma(w, Vv[(size_t)i * n + r], dd);
+    dd = fma(w, Vv[(size_t)i * np + r], dd);
   }
   nn = block_sum(nn, sh);
   dd = block_sum(dd, sh);
   if (threadIdx.x == 0) ev[i] = (dd < 0.0 ? -1.0 : 1.0) * sqrt(nn);
 }
-
-__global__ void jacobi_gather_k(const double* __restrict__ Vv, int n, const int* __restrict__ order, float* __restrict__ out) {
+__global__ void bj_gather_k(const double* __restrict__ Vv, int n, int np, const int* __restrict__ order, float* __restrict__ out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n * n) return;
   const int cidx = (int)(idx / n), r = (int)(idx - (size_t)cidx * n);
-  out[idx] = (float)Vv[(size_t)order[cidx] * n + r];
+  out[idx] = (float)Vv[(size_t)order[cidx] * np + r];
 }
 
 int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev) {
   TimeScope ts(c, ISLE_T_EVD);
   if (n <= 0) return 0;
-  const size_t nn = (size_t)n * n;
-  std::vector<double> Wh(nn), Vh(nn, 0.0);
+  const int np = (n + 63) & ~63;  // zero-padded to whole 64-row tiles / 16-column blocks
+  const size_t nn = (size_t)n * n, npp = (size_t)np * np;
+  std::vector<double> Wh(npp, 0.0), Vh(npp, 0.0);
   // LAPACK 'U' semantics: the upper triangle defines the matrix.
   double mu = 0.0;
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i) Wh[(size_t)j * n + i] = (i <= j) ? (double)S_host[(size_t)j * n + i] : (double)S_host[(size_t)i * n + j];
+    for (int i = 0; i < n; ++i) Wh[(size_t)j * np + i] = (i <= j) ? (double)S_host[(size_t)j * n + i] : (double)S_host[(size_t)i * n + j];
   for (int i = 0; i < n; ++i) {  // Gershgorin: shift so that the matrix is positive semi-definite
     double off = 0.0;
     for (int j = 0; j < n; ++j)
-      if (j != i) off += fabs(Wh[(size_t)j * n + i]);
-    mu = std::max(mu, off - Wh[(size_t)i * n + i]);
+      if (j != i) off += fabs(Wh[(size_t)j * np + i]);
+    mu = std::max(mu, off - Wh[(size_t)i * np + i]);
   }
+  double gscale = 0.0;  // largest squared column norm of W = S + mu I  (<= lambda_max^2)
   for (int i = 0; i < n; ++i) {
-    Wh[(size_t)i * n + i] += mu;
-    Vh[(size_t)i * n + i] = 1.0;
+    Wh[(size_t)i * np + i] += mu;
+    Vh[(size_t)i * np + i] = 1.0;
   }
-  HIPCHK(c, c->jacW.reserve(nn));
-  HIPCHK(c, c->jacV.reserve(nn));
+  for (int j = 0; j < n; ++j) {
+    double s2 = 0.0;
+    for (int i = 0; i < n; ++i) s2 += Wh[(size_t)j * np + i] * Wh[(size_t)j * np + i];
+    gscale = std::max(gscale, s2);
+  }
+  HIPCHK(c, c->jacW.reserve(npp));
+  HIPCHK(c, c->jacV.reserve(npp));
   HIPCHK(c, c->small.reserve((size_t)std::max(4096, n + 64)));
   HIPCHK(c, c->part.reserve((size_t)n));
-  HIPCHK(c, hipMemcpyAsync(c->jacW.p, Wh.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->jacV.p, Vh.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->jacW.p, Wh.data(), npp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->jacV.p, Vh.data(), npp * sizeof(double), hipMemcpyHostToDevice, c->stream));
   unsigned int* rot = (unsigned int*)c->small.p;
-  const int nblk = (n + BJ_W - 1) / BJ_W;
-  const int nblk2 = std::max(2, (nblk + 1) & ~1);
-  const double tol = 1e-15 * (double)n;
+  const int nblk = np / BJ_W;  // even (np is a multiple of 64)
+  // off-diagonal tolerance: eigenvalue errors are quadratic in it, eigenvector errors linear; the results are
+  // rounded to fp32 (1.2e-7) by the caller, so 1e-12 leaves five digits of slack
+  const double tol = 1e-12;
+  const double abs_tol = 1e-14 * (double)n * gscale;
+  const int npairs = nblk / 2;
+  const int nrowch = np / BJ_ROWS;
+  HIPCHK(c, c->jacS.reserve((size_t)npairs * BJ_SCR));
   bool converged = (n == 1);
   for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
     HIPCHK(c, hipMemsetAsync(rot, 0, sizeof(unsigned int), c->stream));
-    for (int round = 0; round < nblk2 - 1; ++round)
-      hipLaunchKernelGGL(bjacobi_round_k, dim3(nblk2 / 2), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, nblk2, round, tol, rot);
+    for (int round = 0; round < nblk - 1; ++round) {
+      HIPCHK(c, hipMemsetAsync(c->jacS.p, 0, (size_t)npairs * BJ_SCR * sizeof(double), c->stream));
+      hipLaunchKernelGGL(bj_gram_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, np, nblk, round, c->jacS.p);
+      hipLaunchKernelGGL(bj_inner_k, dim3(npairs), dim3(256), 0, c->stream, np, nblk, round, tol, abs_tol, c->jacS.p, rot);
+      hipLaunchKernelGGL(bj_apply_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, np, nblk, round, c->jacS.p);
+    }
     HIPCHK(c, hipGetLastError());
     unsigned int nrot = 0;
     HIPCHK(c, hipMemcpyAsync(&nrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("ISLE_DEBUG_EVD")) fprintf(stderr, "[evd n=%d] sweep %d rotations %u\n", n, sweep, nrot);
     if (nrot == 0) converged = true;
   }
   if (!converged) return isle_fail(c, ISLE_E_NUMERIC, "Jacobi EVD (n=%d) did not converge in 60 sweeps", n);
-  hipLaunchKernelGGL(jacobi_evals_k, dim3(n), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, c->part.p);
+  hipLaunchKernelGGL(bj_evals_k, dim3(n), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, n, np, c->part.p);
   HIPCHK(c, hipGetLastError());
   std::vector<double> ev(n);
   HIPCHK(c, hipMemcpyAsync(ev.data(), c->part.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -523,7 +602,7 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
   for (int i = 0; i < n; ++i) evals_host[i] = (float)(ev[order[i]] - mu);
   int* ord_dev = (int*)(c->small.p + 16);
   HIPCHK(c, hipMemcpyAsync(ord_dev, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(jacobi_gather_k, dim3(cdiv(nn, 256)), dim3(256), 0, c->stream, c->jacV.p, n, ord_dev, vecs_dev);
+  hipLaunchKernelGGL(bj_gather_k, dim3(cdiv(nn, 256)), dim3(256), 0, c->stream, c->jacV.p, n, np, ord_dev, vecs_dev);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // `order` (pageable) must outlive the copy
   return 0;

@@ -212,9 +212,12 @@ __global__ __launch_bounds__(256, 2) void proj_assign_reg_k(const float* __restr
   float p[KHMAX];
   {
     // coordinate-major copy of P: 32 consecutive documents per coordinate = one 128-B line per half-wave
+    // clamped addresses + mask multiply: every load is unconditional and independent (a guarded load makes hipcc
+    // branch around each one and wait for it separately)
     const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
+    const float live = (myd < D) ? 1.f : 0.f;
 #pragma unroll
-    for (int i = 0; i < KHMAX; ++i) p[i] = (i < KH && myd < D) ? col[(size_t)i * D] : 0.f;
+    for (int i = 0; i < KHMAX; ++i) p[i] = col[(size_t)min(i, KH - 1) * D] * ((i < KH) ? live : 0.f);
   }
   floatx16 acc[CTMAX];
 #pragma unroll
