@@ -154,13 +154,15 @@ __global__ __launch_bounds__(256) void proj_assign_k(const float* __restrict__ P
         const int idx = threadIdx.x + 256 * u;
         const int row = idx / PA_BK, col = idx - row * PA_BK;
         const uint32_t dd = d0 + row;
-        Ps[row][col] = (dd < D && k0 + col < ldk) ? P[(size_t)dd * ldk + k0 + col] : 0.f;
+        const float pv = P[(size_t)min(dd, D - 1) * ldk + min(k0 + col, ldk - 1)];
+        Ps[row][col] = pv * ((dd < D && k0 + col < ldk) ? 1.f : 0.f);
       }
 #pragma unroll
       for (int u = 0; u < (PA_CT * PA_BK) / 256; ++u) {
         const int idx = threadIdx.x + 256 * u;
         const int row = idx / PA_BK, col = idx - row * PA_BK;
-        Cs[row][col] = (c0 + row < k && k0 + col < ldk) ? C[(size_t)(c0 + row) * ldk + k0 + col] : 0.f;
+        const float cv = C[(size_t)min(c0 + row, k - 1) * ldk + min(k0 + col, ldk - 1)];
+        Cs[row][col] = cv * ((c0 + row < k && k0 + col < ldk) ? 1.f : 0.f);
       }
       __syncthreads();
 #pragma unroll
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void proj_assign_reg_k(const float* __restr
         const int cc = (idx / PR_SL) % kpad;
         const int hh = idx / (PR_SL * kpad);
         const int coord = s * PR_SL + ii;
-        Cs[(hh * kpad + cc) * (PR_SL + 1) + ii] = (cc < k && coord < KH) ? C[(size_t)cc * ldk + hh * KH + coord] : 0.f;
+        const float cv = C[(size_t)min(cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)];  // unconditional, masked below
+        Cs[(hh * kpad + cc) * (PR_SL + 1) + ii] = cv * ((cc < k && coord < KH) ? 1.f : 0.f);
       }
       __syncthreads();
 #pragma unroll

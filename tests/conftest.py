@@ -16,13 +16,13 @@ def pytest_configure(config):
 _CACHE = {}
 
 
-def corpus(V, D, k, seed, K=None):
+def corpus(V, D, k, seed, K=None, sample_rate=0.0):
     """Thresholded synthetic corpus B (dict) + oracle handle, cached per session."""
-    key = (V, D, k, seed, K)
+    key = (V, D, k, seed, K, sample_rate)
     if key not in _CACHE:
         from tools.synth import make_B
         from oracle.oracle import OracleCsc
-        B = make_B(V, D, k, seed, K=K)
+        B = make_B(V, D, k, seed, K=K, sample_rate=sample_rate)
         B["oracle"] = OracleCsc(B["V"], B["D"], B["vals"], B["rows"], B["offs"])
         _CACHE[key] = B
     return _CACHE[key]

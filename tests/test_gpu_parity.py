@@ -195,3 +195,42 @@ def test_full_hot_path_end_to_end(hp, small50):
     planted = B["planted"]
     agree = sum(np.bincount(planted[sg["assign"] == c]).max() for c in range(k) if sizes[c] > 0) / B["D"]
     assert agree >= 0.6
+
+
+def test_config1_size_sigma_and_kmeans(hp):
+    """BASELINE.json configs[0]: vocab 10k, docs 50k, ~5M nnz, k = 50 (the reference's own CPU-runnable case)."""
+    B = corpus(10_000, 50_000, 50, 12345)
+    k = 50
+    upload(hp, B)
+    r = hp.compute_block_ks(k)
+    o = B["oracle"].block_ks(k)
+    assert np.max(np.abs(np.sqrt(r["evals"]) - np.sqrt(o["evals"])) / np.sqrt(o["evals"])) <= 1e-4
+    hp.set_U(o["U"])
+    ko = B["oracle"].kmeanspp(o["U"], k, seed=2)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=ko["seeds"])
+    lo = B["oracle"].lloyds_projected(o["U"], ko["C_lowd"])
+    lg = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    assert lg["iters"] == lo["iters"] and (lg["assign"] == lo["assign"]).mean() >= 0.99
+    from oracle.oracle import lift
+    hp.left_multiply_by_U(lo["C_lowd"], fetch=False)
+    so, sg = B["oracle"].lloyds_sparse(lift(o["U"], lo["C_lowd"])), hp.run_lloyds(k)
+    assert sg["iters"] == so["iters"] and (sg["assign"] == so["assign"]).mean() >= 0.99
+
+
+def test_config4_importance_sampled_matrix(hp):
+    """BASELINE.json configs[3] shape of input: sample=1, sample_rate=0.1 -> B keeps floor(0.1*D)+1 heavy documents;
+    the hot path then runs unchanged on the sampled B (src/trainer.cpp:476-484)."""
+    B = corpus(6000, 40000, 20, 11, sample_rate=0.1)
+    assert B["D"] == 4001
+    k = 20
+    upload(hp, B)
+    r = hp.compute_block_ks(k, allow_noconv=True)
+    o = B["oracle"].block_ks(k)
+    assert np.max(np.abs(np.sqrt(r["evals"]) - np.sqrt(o["evals"])) / np.sqrt(o["evals"])) <= 1e-4
+    X = np.random.default_rng(1).standard_normal((B["V"], 10)).astype(np.float32)
+    assert relerr(hp.gram_apply(X), B["oracle"].gram_apply(X)) <= 1e-5
+    hp.set_U(o["U"])
+    ko = B["oracle"].kmeanspp(o["U"], k, seed=4)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=ko["seeds"])
+    lo, lg = B["oracle"].lloyds_projected(o["U"], ko["C_lowd"]), hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    assert (lg["assign"] == lo["assign"]).mean() >= 0.99

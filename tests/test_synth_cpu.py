@@ -59,3 +59,20 @@ def test_generator_is_deterministic_and_shardable():
     hi = Corpus(500, 200, 4, seed=9, doc_base=200).A()
     assert np.array_equal(np.concatenate([lo[1], hi[1]]), a[1])
     assert np.array_equal(np.concatenate([lo[0], hi[0]]), a[0])
+
+
+def test_importance_sampling_keeps_rate_times_docs_and_prefers_heavy_docs():
+    """sampled_threshold_and_copy (src/sparseMatrix.cpp:1365-1435): floor(rate*D)+1 docs survive (keys >= pivot),
+    weighted toward documents with large sum of zeta."""
+    from tools.synth import make_B
+    full = make_B(1500, 4000, 8, 5)
+    samp = make_B(1500, 4000, 8, 5, sample_rate=0.25)
+    assert samp["D"] == int(np.float32(0.25) * np.float32(4000)) + 1
+    assert np.array_equal(samp["zetas"], full["zetas"])  # thresholds come from the whole corpus
+    # the sampled columns are a subset, copied verbatim
+    pos = np.searchsorted(full["original_cols"], samp["original_cols"])
+    assert np.array_equal(full["original_cols"][pos], samp["original_cols"])
+    lens_full, lens_s = np.diff(full["offs"]), np.diff(samp["offs"])
+    assert np.array_equal(lens_full[pos], lens_s)
+    w_full = np.add.reduceat(full["vals"] ** 2, full["offs"][:-1])  # sum of zeta per doc
+    assert w_full[pos].mean() > 1.05 * w_full.mean()

@@ -46,7 +46,7 @@ def _lib():
         L.synth_hist.restype = C.c_void_p
         L.synth_hist.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         L.synth_apply.restype = C.c_uint64
-        L.synth_apply.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.synth_apply.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_double, C.c_uint64]
         L.synth_from_csc.restype = C.c_void_p
         L.synth_from_csc.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.synth_threshold.restype = C.c_uint64
@@ -102,15 +102,21 @@ class Corpus:
     def planted(self):
         return _arr(_lib().synth_dom(self._h), self.D, np.uint32)
 
-    def threshold(self, k, free_A=False, allreduce=None):
+    def threshold(self, k, free_A=False, allreduce=None, sample_rate=0.0, sample_seed=0):
         """Returns dict(V, D, nnz, vals, rows, offs, original_cols, zetas) for B.
 
         allreduce: optional callable(np.ndarray int64/uint32) -> summed-in-place over all shards; lets a
         column-sharded corpus use GLOBAL avg_doc_sz / nz_docs / per-word histograms (the thresholds depend
         on the whole corpus: src/sparseMatrix.cpp:357-485)."""
         L = _lib()
-        if allreduce is None:
+        if allreduce is None and not sample_rate:
             nnz = int(L.synth_threshold(self._h, k))
+        elif allreduce is None:
+            st = np.zeros(2, np.uint64)
+            L.synth_stats(self._h, st.ctypes.data, st.ctypes.data + 8)
+            mv = C.c_uint32()
+            L.synth_hist(self._h, int(st[0]), int(st[1]), C.byref(mv))
+            nnz = int(L.synth_apply(self._h, k, int(st[1]), float(sample_rate), int(sample_seed)))
         else:
             st = np.zeros(2, np.uint64)
             L.synth_stats(self._h, st.ctypes.data, st.ctypes.data + 8)
@@ -122,7 +128,7 @@ class Corpus:
             buf = (C.c_char * (n * 4)).from_address(hp_)
             hist = np.frombuffer(buf, dtype=np.int32, count=n)  # view onto the C++ buffer, reduced in place
             allreduce(hist)
-            nnz = int(L.synth_apply(self._h, k, int(st64[1])))
+            nnz = int(L.synth_apply(self._h, k, int(st64[1]), 0.0, 0))
         Db = int(L.synth_docs_B(self._h))
         out = dict(V=self.V, D=Db, nnz=nnz,
                    vals=_arr(L.synth_B_vals(self._h), nnz, np.float32),
@@ -135,10 +141,11 @@ class Corpus:
         return out
 
 
-def make_B(V, D, k, seed, K=None, **kw):
-    """Convenience: planted-topic corpus with K (=k by default) topics, thresholded for k topics."""
+def make_B(V, D, k, seed, K=None, sample_rate=0.0, **kw):
+    """Convenience: planted-topic corpus with K (=k by default) topics, thresholded for k topics
+    (sample_rate > 0: ISLE's importance sampling of documents, BASELINE config 4)."""
     c = Corpus(V, D, k if K is None else K, seed, **kw)
-    B = c.threshold(k)
+    B = c.threshold(k, sample_rate=sample_rate, sample_seed=seed)
     B["planted"] = c.planted()[B["original_cols"].astype(np.int64)]
     B["nnz_A"] = c.nnz_A
     return B

@@ -191,7 +191,10 @@ uint32_t* synth_hist(void* h, uint64_t tokens_global, uint64_t nzdocs_global, ui
 }
 
 // phase C: zetas from the (global) histogram, then B.  Returns nnz(B).
-uint64_t synth_apply(void* h, uint32_t k, uint64_t nzdocs_global) {
+// sample_rate in (0,1): importance sampling of documents (sampled_threshold_and_copy, src/sparseMatrix.cpp:1365-1435):
+// weight w_d = sum of zeta over the surviving entries, key = u^(1/w_d), keep keys >= the floor(rate*D)-th largest.
+// (single-process only: the pivot is not all-reduced across shards)
+uint64_t synth_apply(void* h, uint32_t k, uint64_t nzdocs_global, double sample_rate, uint64_t sample_seed) {
   Corpus* c = (Corpus*)h;
   const uint64_t V = c->V, D = c->D;
   const uint64_t nz_docs = nzdocs_global;
@@ -249,6 +252,23 @@ uint64_t synth_apply(void* h, uint32_t k, uint64_t nzdocs_global) {
     for (int64_t i = c->offs[d]; i < c->offs[d + 1]; ++i) n += (rnd[i] >= c->zetas[c->rows[i]]);
     cnt[d + 1] = n;
   }
+  if (sample_rate > 0.0 && sample_rate < 1.0) {
+    std::vector<float> key(D), dice(D);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t d = 0; d < (int64_t)D; ++d) {
+      float w = 0.f;
+      for (int64_t i = c->offs[d]; i < c->offs[d + 1]; ++i)
+        if (rnd[i] >= c->zetas[c->rows[i]]) w += c->zetas[c->rows[i]];                  // :1393-1394
+      Rng r((sample_seed + 1) * 0x9E3779B97F4A7C15ull ^ ((uint64_t)d * 0xD1342543DE82EF95ull));
+      key[d] = (w == 0.f) ? 0.f : (float)std::pow(r.u01(), 1.0 / (double)w);             // :1401-1403
+      dice[d] = key[d];
+    }
+    const size_t nth = (size_t)(sample_rate * (float)D);                                  // :1406-1409
+    std::nth_element(dice.begin(), dice.begin() + nth, dice.end(), std::greater<float>());
+    const float pivot = dice[nth];
+    for (uint64_t d = 0; d < D; ++d)
+      if (!(key[d] >= pivot)) cnt[d + 1] = 0;                                              // select_docs :1413-1415
+  }
   c->original_cols.clear();
   c->boffs.assign(1, 0);
   std::vector<int64_t> src_first;
@@ -285,7 +305,7 @@ uint64_t synth_threshold(void* h, uint32_t k) {
   uint32_t mv;
   synth_stats(h, &t, &nz);
   (void)synth_hist(h, t, nz, &mv);
-  return synth_apply(h, k, nz);
+  return synth_apply(h, k, nz, 0.0, 0);
 }
 
 uint64_t synth_nnz_A(void* h) { return ((Corpus*)h)->offs.back(); }
