@@ -703,7 +703,7 @@ static int ensure_P(isle_ctx* c, int k) {
   ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p));
   c->P_ready = true;
   c->Pt_ready = false;
-  if (c->ldk <= 256 && c->D) {  // coordinate-major copy for the register-resident MFMA distance kernels
+  if (c->D) {  // coordinate-major copy for the register-resident MFMA distance kernels
     HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
     ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
     c->Pt_ready = true;

@@ -199,73 +199,75 @@ constexpr int PR_SL = 16;
 // MODE PR_ARGMIN : assign[d] = first index of min |dist|        (Lloyd, cblas_isamin semantics)
 // MODE PR_MINDIST: min_dist[d] = min(min_dist[d], max(dist, 0)) (k-means++ round against the newest <= 32*CTMAX centres)
 template <int NSLAB, int CTMAX, int MODE>
-__global__ __launch_bounds__(256, 2) void proj_assign_reg_k(const float* __restrict__ Pt /*ldk x D*/, const float* __restrict__ pn,
+__global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void proj_assign_reg_k(const float* __restrict__ Pt /*ldk x D*/, const float* __restrict__ pn,
                                                              uint32_t D, int k, int ldk, const float* __restrict__ C,
                                                              const float* __restrict__ cn, uint32_t* __restrict__ assign,
                                                              float* __restrict__ min_dist) {
-  constexpr int KHMAX = NSLAB * PR_SL;
-  extern __shared__ float Cs[];  // [2][kpad][PR_SL + 1]
+  constexpr int KHC = NSLAB * PR_SL;  // coordinates per lane half held in registers at a time
+  constexpr int CG = CTMAX * 32;      // centres per group (their accumulators live side by side)
+  extern __shared__ float Cs[];       // [2][CG][PR_SL + 1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int KH = ldk >> 1;
-  const int kpad = (k + 31) & ~31;
-  const int CT = kpad >> 5;
   const uint32_t myd = blockIdx.x * 128 + 32 * wave + l31;
-  float p[KHMAX];
-  {
-    // coordinate-major copy of P: 32 consecutive documents per coordinate = one 128-B line per half-wave
-    // clamped addresses + mask multiply: every load is unconditional and independent (a guarded load makes hipcc
-    // branch around each one and wait for it separately)
-    const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
-    const float live = (myd < D) ? 1.f : 0.f;
+  const float live = (myd < D) ? 1.f : 0.f;
+  const float nd = (myd < D) ? pn[myd] : 0.f;
+  const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
+  float best = 3.4e38f;
+  uint32_t bidx = 0xffffffffu;
+  // k <= CG and KH <= KHC (e.g. k = 200) is a single pass: P is then read from HBM exactly once per call.
+  for (int cg0 = 0; cg0 < k; cg0 += CG) {
+    floatx16 acc[CTMAX];
 #pragma unroll
-    for (int i = 0; i < KHMAX; ++i) p[i] = col[(size_t)min(i, KH - 1) * D] * ((i < KH) ? live : 0.f);
-  }
-  floatx16 acc[CTMAX];
+    for (int t = 0; t < CTMAX; ++t) acc[t] = (floatx16){0};
+    for (int kc0 = 0; kc0 < KH; kc0 += KHC) {
+      float p[KHC];
+      // clamped addresses + mask multiply: every load is unconditional and independent (a guarded load makes hipcc
+      // branch around each one and wait for it separately)
 #pragma unroll
-  for (int t = 0; t < CTMAX; ++t) acc[t] = (floatx16){0};
+      for (int i = 0; i < KHC; ++i) p[i] = col[(size_t)min(kc0 + i, KH - 1) * D] * ((kc0 + i < KH) ? live : 0.f);
 #pragma unroll
-  for (int s = 0; s < KHMAX / PR_SL; ++s) {
-    if (s * PR_SL < KH) {
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < 2 * kpad * PR_SL; idx += 256) {
-        const int ii = idx % PR_SL;
-        const int cc = (idx / PR_SL) % kpad;
-        const int hh = idx / (PR_SL * kpad);
-        const int coord = s * PR_SL + ii;
-        const float cv = C[(size_t)min(cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)];  // unconditional, masked below
-        Cs[(hh * kpad + cc) * (PR_SL + 1) + ii] = cv * ((cc < k && coord < KH) ? 1.f : 0.f);
-      }
-      __syncthreads();
+      for (int s = 0; s < NSLAB; ++s) {
+        const int cb0 = kc0 + s * PR_SL;  // first coordinate (within a half) of this slab
+        if (cb0 < KH) {
+          __syncthreads();
+          for (int idx = threadIdx.x; idx < 2 * CG * PR_SL; idx += 256) {
+            const int ii = idx % PR_SL;
+            const int cc = (idx / PR_SL) % CG;
+            const int hh = idx / (PR_SL * CG);
+            const int coord = cb0 + ii;
+            const float cv = C[(size_t)min(cg0 + cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)];  // unconditional, masked below
+            Cs[(hh * CG + cc) * (PR_SL + 1) + ii] = cv * ((cg0 + cc < k && coord < KH) ? 1.f : 0.f);
+          }
+          __syncthreads();
 #pragma unroll
-      for (int t = 0; t < CTMAX; ++t) {
-        if (t < CT) {
-          const float* cb = &Cs[(h * kpad + 32 * t + l31) * (PR_SL + 1)];
+          for (int t = 0; t < CTMAX; ++t) {
+            if (cg0 + 32 * t < k) {
+              const float* cb = &Cs[(h * CG + 32 * t + l31) * (PR_SL + 1)];
 #pragma unroll
-          for (int ii = 0; ii < PR_SL; ++ii) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[ii], p[s * PR_SL + ii], acc[t], 0, 0, 0);
+              for (int ii = 0; ii < PR_SL; ++ii) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[ii], p[s * PR_SL + ii], acc[t], 0, 0, 0);
+            }
+          }
         }
       }
     }
-  }
-  const float nd = (myd < D) ? pn[myd] : 0.f;
-  float best = 3.4e38f;
-  uint32_t bidx = 0xffffffffu;
 #pragma unroll
-  for (int t = 0; t < CTMAX; ++t) {
-    if (t < CT) {
+    for (int t = 0; t < CTMAX; ++t) {
+      if (cg0 + 32 * t < k) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cc = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (cc < k) {
-          const float raw = (-2.0f * acc[t][r] + cn[cc]) + nd;
-          if (MODE == PR_ARGMIN) {
-            const float dist = fabsf(raw);
-            if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
-              best = dist;
-              bidx = (uint32_t)cc;
+        for (int r = 0; r < 16; ++r) {
+          const int cc = cg0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (cc < k) {
+            const float raw = (-2.0f * acc[t][r] + cn[cc]) + nd;
+            if (MODE == PR_ARGMIN) {
+              const float dist = fabsf(raw);
+              if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
+                best = dist;
+                bidx = (uint32_t)cc;
+              }
+            } else {
+              best = fminf(best, fmaxf(raw, 0.0f));
             }
-          } else {
-            best = fminf(best, fmaxf(raw, 0.0f));
           }
         }
       }
@@ -290,14 +292,14 @@ template <int MODE>
 static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
                            float* min_dist, bool* done) {
   *done = false;
-  if (!D || ldk > 256 || k > 256 || !c->Pt_ready) return 0;
+  if (!D || !c->Pt_ready) return 0;
   const int kpad = (k + 31) & ~31;
   const int ct = kpad / 32;
   const int nslab = cdiv(ldk / 2, PR_SL);
-  const size_t lds = (size_t)2 * kpad * (PR_SL + 1) * sizeof(float);
   dim3 g(cdiv(D, 128)), b(256);
 #define LR(NS, CM)                                                                                                            \
   do {                                                                                                                        \
+    const size_t lds = (size_t)2 * (CM * 32) * (PR_SL + 1) * sizeof(float);                                                   \
     HIPCHK(c, hipFuncSetAttribute((const void*)proj_assign_reg_k<NS, CM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, c->Pt.p, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist); \
     *done = true;                                                                                                             \
@@ -306,11 +308,11 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
     if (nslab <= 2) LR(2, 1);
     else if (nslab <= 4) LR(4, 1);
     else if (nslab <= 7) LR(7, 1);
-    else LR(8, 1);
+    else LR(8, 1);  // loops over coordinate chunks of 128 per half when ldk > 256
   } else if (ct <= 2 && nslab <= 2) LR(2, 2);
   else if (ct <= 4 && nslab <= 4) LR(4, 4);
   else if (ct <= 7 && nslab <= 7) LR(7, 7);
-  else LR(8, 8);
+  else LR(8, 8);  // loops over centre groups of 256 and coordinate chunks of 128 per half
 #undef LR
   HIPCHK(c, hipGetLastError());
   return 0;
