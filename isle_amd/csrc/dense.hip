@@ -61,6 +61,61 @@ __global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ V
   }
 }
 
+// Matrix-core variant for the orthogonalisation coefficients (b <= 16): v_mfma_f32_16x16x4_f32 with basis columns
+// on the MFMA row index, panel columns on the MFMA column index and the V rows as the contraction index.  A wave owns
+// 16 basis columns of a 1024-row chunk; per 64 rows every lane loads four float4 of its basis column and four of its
+// panel column (MFMA step s pairs element s of both operands, so any row order inside a group is consistent) and issues
+// 16 MFMAs on two alternating accumulators.  fp32 inside a chunk, fp64 across chunks (vtf_reduce_k).  The fp64 Gram
+// matrix of the panel QR keeps the fp64 VALU kernel above.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int VM_RC = 1024;
+__global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, int m, const float* __restrict__ F, int b,
+                                                   int BT, double* __restrict__ part /*[chunk][m][BT]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int col0 = (blockIdx.y * 4 + wave) * 16;
+  if (col0 >= m) return;
+  const uint64_t r0 = (uint64_t)blockIdx.x * VM_RC;
+  const uint64_t r1 = min(n, r0 + VM_RC);
+  const float* va = Vb + (uint64_t)min(col0 + l15, m - 1) * n;  // clamped: rows of H beyond m are not written
+  const float* fb = F + (uint64_t)min(l15, b - 1) * n;
+  const float bmask = (l15 < b) ? 1.f : 0.f;
+  floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  uint64_t r = r0;
+  if ((n & 3) == 0) {  // columns are 16-byte aligned
+    for (; r + 64 <= r1; r += 64) {
+      float4 av[4], fv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = *(const float4*)(va + r + 16 * u + 4 * g);
+        fv[u] = *(const float4*)(fb + r + 16 * u + 4 * g);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, fv[u].x * bmask, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, fv[u].y * bmask, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, fv[u].z * bmask, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, fv[u].w * bmask, acc1, 0, 0, 0);
+      }
+    }
+  }
+  for (; r < r1; r += 4) {  // tail / unaligned: 4 rows per MFMA, rows beyond the end contribute zeros
+    const uint64_t rr = r + g;
+    const float inr = (rr < r1) ? 1.f : 0.f;
+    const float a = va[min(rr, n - 1)] * inr;
+    const float f = fb[min(rr, n - 1)] * (inr * bmask);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f, acc0, 0, 0, 0);
+  }
+  // C/D layout of the 16x16 tile: column j = lane & 15, row i = 4 * (lane >> 4) + reg
+  if (l15 < BT) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = col0 + 4 * g + reg;
+      if (i < m) part[((size_t)blockIdx.x * m + i) * BT + l15] = (double)(acc0[reg] + acc1[reg]);
+    }
+  }
+}
+
 template <class Tout>
 __global__ void vtf_reduce_k(const double* __restrict__ part, int nchunks, int m, int BT, int b, Tout* __restrict__ coef) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,6 +150,16 @@ static int vtf_impl(isle_ctx* c, const float* Vb, uint64_t n, int m, const float
 
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef) {
   TimeScope ts(c, ISLE_T_ORTHO);
+  if (b <= 16 && m >= 64 && !getenv("ISLE_VTF_VALU")) {  // matrix-core path (enough columns to fill the chip)
+    const int BT = bt_of(b);
+    const int nch = cdiv(n, VM_RC);
+    HIPCHK(c, c->part.reserve((size_t)nch * m * BT));
+    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 64)), dim3(256), 0, c->stream, Vb, n, m, F, b, BT, c->part.p);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(vtf_reduce_k<float>, dim3(cdiv((long)m * b, 256)), dim3(256), 0, c->stream, c->part.p, nch, m, BT, b, coef);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   return vtf_impl<float>(c, Vb, n, m, F, b, coef);
 }
 
