@@ -392,8 +392,10 @@ __device__ inline void rr_pair(int nplayers, int round, int slot, int* p, int* q
   }
 }
 
-// per-pair scratch in global memory: G (32x32 doubles), then Q (32x32 doubles), then a flag
-constexpr int BJ_SCR = 2 * BJ_P * BJ_P + 8;
+// per-pair scratch in global memory: Q (32x32 doubles) and a rotation count; the Gram partials (one 32x32 slab per
+// row chunk, summed in fixed order by bj_inner_k: bitwise reproducible, so replicated solves on several GPUs agree)
+// live in a second buffer
+constexpr int BJ_SCR = BJ_P * BJ_P + 8;
 constexpr int BJ_ROWS = 64;   // rows per workgroup in the streaming kernels (one LDS tile)
 
 __device__ inline void bj_blocks(int nblk2, int round, int slot, int* A, int* Bk) {
@@ -407,7 +409,7 @@ __device__ inline void bj_blocks(int nblk2, int round, int slot, int* A, int* Bk
 __device__ inline int bj_col(int A, int Bk, int cc) { return cc < BJ_W ? A * BJ_W + cc : Bk * BJ_W + (cc - BJ_W); }
 
 // (1) G[pair] += [Wa Wb]^T [Wa Wb] over this workgroup's rows.  grid = (pairs, row chunks)
-__global__ __launch_bounds__(256) void bj_gram_k(const double* __restrict__ W, int n, int nblk2, int round, double* __restrict__ scr) {
+__global__ __launch_bounds__(256) void bj_gram_k(const double* __restrict__ W, int n, int nblk2, int round, double* __restrict__ gpart) {
   __shared__ double T[64][BJ_P + 1];
   int A, Bk;
   bj_blocks(nblk2, round, blockIdx.x, &A, &Bk);
@@ -432,16 +434,16 @@ __global__ __launch_bounds__(256) void bj_gram_k(const double* __restrict__ W, i
       g3 = fma(a, T[rr][gj0 + 3], g3);
     }
   }
-  double* G = scr + (size_t)blockIdx.x * BJ_SCR + gi * BJ_P + gj0;
-  atomicAdd(G + 0, g0);
-  atomicAdd(G + 1, g1);
-  atomicAdd(G + 2, g2);
-  atomicAdd(G + 3, g3);
+  double* G = gpart + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (BJ_P * BJ_P) + gi * BJ_P + gj0;
+  G[0] = g0;
+  G[1] = g1;
+  G[2] = g2;
+  G[3] = g3;
 }
 
 // (2) one cyclic sweep of two-sided rotations on G in LDS, Q accumulated; grid = pairs
-__global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, double tol, double abs_tol, double* __restrict__ scr,
-                                                   unsigned int* __restrict__ rotated) {
+__global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, double tol, double abs_tol, const double* __restrict__ gpart,
+                                                   int nrowch, double* __restrict__ scr, unsigned int* __restrict__ rotated) {
   __shared__ double G[BJ_P][BJ_P + 1];
   __shared__ double Q[BJ_P][BJ_P + 1];
   __shared__ double rc[BJ_W], rs[BJ_W];
@@ -452,10 +454,13 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
   if (A * BJ_W >= n) return;
   const int t = threadIdx.x;
   double* S = scr + (size_t)blockIdx.x * BJ_SCR;
+  const double* gp = gpart + (size_t)blockIdx.x * nrowch * (BJ_P * BJ_P);
   for (int idx = t; idx < BJ_P * BJ_P; idx += 256) {
     const int i = idx / BJ_P, j = idx % BJ_P;
-    // symmetrise what the atomics accumulated (they add the same products in a different order)
-    G[i][j] = (i <= j) ? S[i * BJ_P + j] : S[j * BJ_P + i];
+    const int u = (i <= j) ? i * BJ_P + j : j * BJ_P + i;  // upper triangle defines G (exactly symmetric)
+    double sum = 0.0;
+    for (int ch = 0; ch < nrowch; ++ch) sum += gp[(size_t)ch * (BJ_P * BJ_P) + u];  // fixed order
+    G[i][j] = sum;
     Q[i][j] = (i == j) ? 1.0 : 0.0;
   }
   if (t == 0) nrot = 0;
@@ -518,11 +523,11 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
     }
     __syncthreads();
   }
-  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) S[BJ_P * BJ_P + idx] = Q[idx / BJ_P][idx % BJ_P];
+  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) S[idx] = Q[idx / BJ_P][idx % BJ_P];
   if (t == 0) {
     // store the COUNT (not `nrot ? 1.0 : 0.0`): hipcc 7.2 lowered that select to s_cselect on a stale SCC here and
     // always wrote 0.0 (seen in the ISA; the rotations were then never applied)
-    S[2 * BJ_P * BJ_P] = (double)nrot;
+    S[BJ_P * BJ_P] = (double)nrot;
     if (nrot) atomicAdd(rotated, nrot);
   }
 }
@@ -536,8 +541,8 @@ __global__ __launch_bounds__(256) void bj_apply_k(double* __restrict__ W, double
   if (A * BJ_W >= n) return;
   const double* S = scr + (size_t)blockIdx.x * BJ_SCR;
   const int t = threadIdx.x;
-  if (S[2 * BJ_P * BJ_P] == 0.0) return;  // no rotation in this pair (uniform)
-  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) Q[idx / BJ_P][idx % BJ_P] = S[BJ_P * BJ_P + idx];
+  if (S[BJ_P * BJ_P] == 0.0) return;  // no rotation in this pair (uniform)
+  for (int idx = t; idx < BJ_P * BJ_P; idx += 256) Q[idx / BJ_P][idx % BJ_P] = S[idx];
   __syncthreads();
   // thread = (row, group of 8 output columns): Q is read 8x less often from LDS than with one thread per row.
   // The matrices are zero-padded to a multiple of 64 rows/columns, so no load or store needs a guard (guarded loads
@@ -638,14 +643,14 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
   const double abs_tol = 1e-14 * (double)n * gscale;
   const int npairs = nblk / 2;
   const int nrowch = np / BJ_ROWS;
-  HIPCHK(c, c->jacS.reserve((size_t)npairs * BJ_SCR));
+  HIPCHK(c, c->jacS.reserve((size_t)npairs * BJ_SCR + (size_t)npairs * nrowch * BJ_P * BJ_P));
+  double* gpart = c->jacS.p + (size_t)npairs * BJ_SCR;
   bool converged = (n == 1);
   for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
     HIPCHK(c, hipMemsetAsync(rot, 0, sizeof(unsigned int), c->stream));
     for (int round = 0; round < nblk - 1; ++round) {
-      HIPCHK(c, hipMemsetAsync(c->jacS.p, 0, (size_t)npairs * BJ_SCR * sizeof(double), c->stream));
-      hipLaunchKernelGGL(bj_gram_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, np, nblk, round, c->jacS.p);
-      hipLaunchKernelGGL(bj_inner_k, dim3(npairs), dim3(256), 0, c->stream, np, nblk, round, tol, abs_tol, c->jacS.p, rot);
+      hipLaunchKernelGGL(bj_gram_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, np, nblk, round, gpart);
+      hipLaunchKernelGGL(bj_inner_k, dim3(npairs), dim3(256), 0, c->stream, np, nblk, round, tol, abs_tol, gpart, nrowch, c->jacS.p, rot);
       hipLaunchKernelGGL(bj_apply_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, np, nblk, round, c->jacS.p);
     }
     HIPCHK(c, hipGetLastError());
