@@ -175,7 +175,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   c->Ucm.release(); c->Urm.release(); c->P.release(); c->Pt.release(); c->pnorm.release(); c->min_dist.release();
   c->cum.release(); c->scan_blk.release(); c->Cdev.release(); c->cnorm.release(); c->Csum.release();
   c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release(); c->members.release(); c->moff.release();
-  c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release();
+  c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release(); c->hub.release(); c->hlb.release(); c->active.release(); c->centers_old.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -986,6 +986,17 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   HIPCHK(c, c->counts.reserve(k));
   HIPCHK(c, c->assign.reserve(D ? D : 1));
   ISLECHK(k_doc_norms(c, c->dnorm.p));  // :1680-1687
+  // Hamerly bounds: an exact acceleration of the assignment step (documents whose bounds prove "unchanged" are skipped)
+  const bool hamerly = !getenv("ISLE_NO_HAMERLY");
+  HIPCHK(c, c->hub.reserve(D ? D : 1));
+  HIPCHK(c, c->hlb.reserve(D ? D : 1));
+  HIPCHK(c, c->active.reserve(D + 1));
+  HIPCHK(c, c->centers_old.reserve((size_t)V * ld));
+  HIPCHK(c, c->Csum.reserve((size_t)2 * k + 16));
+  float* delta_dev = c->Csum.p;  // k floats
+  std::vector<float> delta(k, 0.f), cnh(k);
+  uint32_t amax = 0;
+  float d1 = 0.f, d2 = 0.f;
   StopRule stop(c, k);
   int it = 0;
   for (; it < max_reps; ++it) {
@@ -993,19 +1004,56 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, c->cnorm.p));  // :1604
     }
-    // documents are visited grouped by their previous centre (cache locality of the centre rows); results are order-independent
-    ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p,
-                               c->members_valid ? c->members.p : nullptr));  // :1606
+    if (it == 0 || !hamerly) {
+      // documents are visited grouped by their previous centre (cache locality of the centre rows); results are order-independent
+      ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p,
+                                 c->members_valid ? c->members.p : nullptr, nullptr, c->hub.p, c->hlb.p));  // :1606
+    } else {
+      HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      float cn_max = 0.f;
+      for (int i = 0; i < k; ++i) cn_max = std::max(cn_max, cnh[i]);
+      uint32_t* nact = c->active.p + D;
+      ISLECHK(k_hamerly_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, amax, d1, d2,
+                               c->dnorm.p, cn_max, c->active.p, nact));
+      ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->active.p, nact, c->hub.p, c->hlb.p));
+      if (getenv("ISLE_DEBUG_HAMERLY")) {
+        uint32_t na = 0;
+        HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[hamerly] iter %d active %u of %llu  d1 %.4f d2 %.4f\n", it, na, (unsigned long long)D, d1, d2);
+      }
+    }
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
     if (it + 1 < max_reps) {
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_member_lists(c, c->assign.p, D, k, c->counts.p, nullptr));
     }
+    if (hamerly) HIPCHK(c, hipMemcpyAsync(c->centers_old.p, c->centers_rm.p, (size_t)V * ld * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p));                          // :1613-1638
     ISLECHK(allreduce_sum<float>(c, c->centers_rm.p, (size_t)V * ld));
     std::vector<long long> sizes;
     ISLECHK(fetch_sizes(c, k, sizes));
     ISLECHK(k_scale_centers(c, c->centers_rm.p, V, k, ld, c->counts.p));  // :1641-1646
+    if (hamerly && it + 1 < max_reps) {  // centre movements for the next filter
+      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+      ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, delta_dev, c->centers_old.p));
+      HIPCHK(c, hipMemcpyAsync(delta.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      amax = 0;
+      d1 = d2 = 0.f;
+      for (int i = 0; i < k; ++i) {
+        delta[i] = std::sqrt(std::max(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
+        if (delta[i] > d1) {
+          d2 = d1;
+          d1 = delta[i];
+          amax = (uint32_t)i;
+        } else if (delta[i] > d2) {
+          d2 = delta[i];
+        }
+      }
+      HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));
     if (conv) {

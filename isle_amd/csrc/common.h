@@ -107,6 +107,9 @@ struct isle_ctx {
   bool centers_ready = false;
   int centers_k = 0;
   DevBuf<float> dnorm;     // D   |b_d|^2
+  DevBuf<float> hub, hlb;  // D   Hamerly bounds (sparse Lloyd)
+  DevBuf<uint32_t> active; // D + 1 (last = count)
+  DevBuf<float> centers_old;  // V x ldk
 
   // --- timing
   bool timing = false;
@@ -152,7 +155,10 @@ int k_band_build(isle_ctx* c);
 int k_frobenius(isle_ctx* c, double* out_host);
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms);
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
-                       const uint32_t* perm /*nullable: processing order (a permutation of the local docs)*/);
+                       const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
+                       float* ub = nullptr, float* lb = nullptr);
+int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
+                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
@@ -167,7 +173,7 @@ int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C);  // col-major, lda = ldc = M
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl
 int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x n col-major*/);
-int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out);  // out[c] = sum_r M[r][c]^2
+int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out, const float* Sub = nullptr);
 int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, const int* counts);
 
 // kmeans.hip

@@ -682,14 +682,14 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
 // column sums of squares of a row-major matrix (centre norms, src/sparseMatrix.cpp:1575-1584)
 // ------------------------------------------------------------------------------------------
 constexpr int CN_ROWS = 512;
-__global__ __launch_bounds__(256) void colnorm_partial_k(const float* __restrict__ Mrm, uint64_t rows, int k, int ldk,
-                                                          double* __restrict__ part) {
+__global__ __launch_bounds__(256) void colnorm_partial_k(const float* __restrict__ Mrm, const float* __restrict__ Sub /*nullable*/,
+                                                          uint64_t rows, int k, int ldk, double* __restrict__ part) {
   const uint64_t r0 = (uint64_t)blockIdx.x * CN_ROWS;
   const uint64_t r1 = min(rows, r0 + CN_ROWS);
   for (int cc = threadIdx.x; cc < k; cc += 256) {
     double s = 0.0;
     for (uint64_t r = r0; r < r1; ++r) {
-      const double x = (double)Mrm[r * ldk + cc];
+      const double x = (double)Mrm[r * ldk + cc] - (Sub ? (double)Sub[r * ldk + cc] : 0.0);
       s = fma(x, x, s);
     }
     part[(size_t)blockIdx.x * k + cc] = s;
@@ -702,10 +702,11 @@ __global__ void colnorm_reduce_k(const double* __restrict__ part, int nchunks, i
   for (int ch = 0; ch < nchunks; ++ch) s += part[(size_t)ch * k + cc];
   out[cc] = (float)s;
 }
-int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out) {
+// out[c] = sum_r (M[r][c] - Sub[r][c])^2   (Sub nullable: plain column norms)
+int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out, const float* Sub) {
   const int nchunks = cdiv(rows, CN_ROWS);
   HIPCHK(c, c->part.reserve((size_t)nchunks * k));
-  hipLaunchKernelGGL(colnorm_partial_k, dim3(nchunks), dim3(256), 0, c->stream, Mrm, rows, k, ldk, c->part.p);
+  hipLaunchKernelGGL(colnorm_partial_k, dim3(nchunks), dim3(256), 0, c->stream, Mrm, Sub, rows, k, ldk, c->part.p);
   hipLaunchKernelGGL(colnorm_reduce_k, dim3(cdiv(k, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, k, out);
   HIPCHK(c, hipGetLastError());
   return 0;

@@ -313,12 +313,17 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
                                                     const int64_t* __restrict__ offs, const float4* __restrict__ M, int nq,
                                                     int k, uint32_t D, float4* __restrict__ P, float* __restrict__ norms,
                                                     const float* __restrict__ cn, const float* __restrict__ dn,
-                                                    uint32_t* __restrict__ assign, const uint32_t* __restrict__ perm) {
+                                                    uint32_t* __restrict__ assign, const uint32_t* __restrict__ perm,
+                                                    const uint32_t* __restrict__ nslots /*nullable: device-side slot count*/,
+                                                    float* __restrict__ ub, float* __restrict__ lb /*nullable: Hamerly bounds out*/) {
   const int lane = threadIdx.x & 63;
+  if (nslots) D = min(D, *nslots);
   // XCD-contiguous slots: workgroups of one XCD (blockIdx % 8) walk one contiguous eighth of the slot list, so that
   // with `perm` = documents grouped by their previous centre each L2 keeps re-serving one cluster's hot vocabulary rows
+  // (with a device-side slot count only a prefix of the slots is live: keep the plain interleaved map there, or all
+  // live slots would land on one XCD)
   const uint32_t nb = gridDim.x, per = (nb + 7) / 8;
-  const uint32_t vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const uint32_t vb = nslots ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   uint32_t d = vb * 4 + (threadIdx.x >> 6);
   d = __builtin_amdgcn_readfirstlane(d);
   if (vb >= nb || d >= D) return;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
     if (lane == 0) norms[d] = s;
   } else {
     const float dnd = dn[d];
-    float best = 3.4e38f;
+    float best = 3.4e38f, second = 3.4e38f;
     uint32_t bidx = 0xffffffffu;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -371,8 +376,11 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
           if (cc < k) {
             const float dist = fabsf((-2.0f * a[j] + cn[cc]) + dnd);
             if (dist < best) {  // ascending cc per lane -> first index wins ties
+              second = best;
               best = dist;
               bidx = (uint32_t)cc;
+            } else {
+              second = fminf(second, dist);
             }
           }
         }
@@ -381,19 +389,30 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const float ob = __shfl_xor(best, off);
+      const float os = __shfl_xor(second, off);
       const uint32_t oi = __shfl_xor(bidx, off);
       if (ob < best || (ob == best && oi < bidx)) {
+        second = fminf(best, os);
         best = ob;
         bidx = oi;
+      } else {
+        second = fminf(second, ob);
       }
     }
-    if (lane == 0) assign[d] = bidx;
+    if (lane == 0) {
+      assign[d] = bidx;
+      if (ub) {  // Euclidean distances to the closest and second-closest centre
+        ub[d] = sqrtf(best);
+        lb[d] = sqrtf(second);
+      }
+    }
   }
 }
 
 template <int MODE>
 static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms, const float* cn, const float* dn,
-                       uint32_t* assign, const uint32_t* perm) {
+                       uint32_t* assign, const uint32_t* perm, const uint32_t* nslots = nullptr, float* ub = nullptr,
+                       float* lb = nullptr) {
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
   const int nq = ldk / 4;
@@ -401,7 +420,7 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
   dim3 g(8 * cdiv(cdiv(D, 4), 8)), b(256);  // multiple of 8 so that the XCD slot map is a bijection
 #define LW(N)                                                                                                              \
   hipLaunchKernelGGL((spmm_wide_k<N, MODE>), g, b, 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Mrm, nq, k, D, \
-                     (float4*)P, norms, cn, dn, assign, perm)
+                     (float4*)P, norms, cn, dn, assign, perm, nslots, ub, lb)
   if (nit <= 1) LW(1);
   else if (nit <= 2) LW(2);
   else if (nit <= 4) LW(4);
@@ -416,9 +435,9 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
   return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr, nullptr);
 }
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
-                       const uint32_t* perm) {
+                       const uint32_t* perm, const uint32_t* nslots, float* ub, float* lb) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
-  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm);
+  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm, nslots, ub, lb);
 }
 
 // |b_d|^2  (compute_docs_l2sq  src/sparseMatrix.cpp:1680-1687)
@@ -498,6 +517,38 @@ int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, flo
   const size_t lds = 4 * (size_t)ldk * sizeof(float);
   hipLaunchKernelGGL(centers_from_rows_k, dim3(cdiv(V, 4)), dim3(256), lds, c->stream, c->bval.p, c->bcol.p, c->seg_off.p, V, c->nbands,
                      assign, ldk, Crm);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// Hamerly's bounds for Lloyd on the sparse matrix (an EXACT acceleration: a document is skipped only when its bounds
+// prove that its closest centre cannot have changed).  ub = distance to the assigned centre, lb = distance to the
+// second-closest; after the centres move by delta[c], ub grows by delta[assigned] and lb shrinks by the largest movement
+// of any other centre.  Documents with ub + slack >= lb - slack are appended to `active` and re-evaluated against all
+// centres.  slack covers the fp32 cancellation error of |b|^2 + |c|^2 - 2 b.c under the square root.
+__global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restrict__ order, uint32_t D, const uint32_t* __restrict__ assign,
+                                                         float* __restrict__ ub, float* __restrict__ lb, const float* __restrict__ delta,
+                                                         uint32_t amax, float d1, float d2, const float* __restrict__ dn, float cn_max,
+                                                         uint32_t* __restrict__ active, uint32_t* __restrict__ nactive) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= D) return;
+  const uint32_t d = order ? order[i] : i;
+  const uint32_t a = assign[d];
+  const float u = ub[d] + delta[a];
+  const float l = lb[d] - (a == amax ? d2 : d1);
+  ub[d] = u;
+  lb[d] = l;
+  const float slack = 2e-3f * sqrtf(dn[d] + cn_max) + 1e-6f;
+  if (u + slack >= l - slack) active[atomicAdd(nactive, 1u)] = d;
+}
+int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
+                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  const uint32_t D = (uint32_t)c->D;
+  HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(hamerly_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, lb, delta_dev, amax, d1, d2, dn,
+                     cn_max, active, nactive);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
