@@ -175,7 +175,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   c->Ucm.release(); c->Urm.release(); c->P.release(); c->Pt.release(); c->pnorm.release(); c->min_dist.release();
   c->cum.release(); c->scan_blk.release(); c->Cdev.release(); c->cnorm.release(); c->Csum.release();
   c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release(); c->members.release(); c->moff.release();
-  c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release(); c->hub.release(); c->hlb.release(); c->active.release(); c->centers_old.release();
+  c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release(); c->hub.release(); c->hlb.release(); c->active.release(); c->centers_old.release(); c->Pa.release(); c->pna.release(); c->Cold.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -914,17 +914,67 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   std::vector<float> Ch((size_t)k * ldk, 0.f);
   for (int cc = 0; cc < k; ++cc) memcpy(Ch.data() + (size_t)cc * ldk, C_lowd + (size_t)cc * k, (size_t)k * sizeof(float));
   HIPCHK(c, hipMemcpy(c->Cdev.p, Ch.data(), Ch.size() * sizeof(float), hipMemcpyHostToDevice));
+  // Hamerly bounds (exact skip of documents whose closest centre provably did not change), as in the sparse Lloyd
+  const bool hamerly = !getenv("ISLE_NO_HAMERLY") && c->Pt_ready;
+  if (hamerly) {
+    HIPCHK(c, c->hub.reserve(D ? D : 1));
+    HIPCHK(c, c->hlb.reserve(D ? D : 1));
+    HIPCHK(c, c->active.reserve(D + 1));
+    HIPCHK(c, c->Pa.reserve((size_t)(D ? D : 1) * ldk));
+    HIPCHK(c, c->pna.reserve(D ? D : 1));
+    HIPCHK(c, c->Cold.reserve((size_t)k * ldk + k));
+  }
+  float* delta_dev = hamerly ? c->Cold.p + (size_t)k * ldk : nullptr;
+  std::vector<float> delta(k, 0.f), cnh(k);
+  uint32_t amax = 0;
+  float d1 = 0.f, d2 = 0.f;
   StopRule stop(c, k);
   int it = 0;
   for (; it < max_reps; ++it) {
     ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
-    ISLECHK(k_proj_assign(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p));      // :1947
+    if (it == 0 || !hamerly) {
+      ISLECHK(k_proj_assign(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p,
+                            hamerly ? c->hub.p : nullptr, hamerly ? c->hlb.p : nullptr));                // :1947
+    } else {
+      HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      float cn_max = 0.f;
+      for (int i = 0; i < k; ++i) cn_max = std::max(cn_max, cnh[i]);
+      uint32_t* nact = c->active.p + D;
+      ISLECHK(k_hamerly_filter(c, nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, amax, d1, d2, c->pnorm.p, cn_max, c->active.p, nact,
+                               ISLE_T_LLOYD_PROJ));
+      uint32_t na = 0;
+      HIPCHK(c, hipMemcpyAsync(&na, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      ISLECHK(k_proj_assign_active(c, c->P.p, c->pnorm.p, k, ldk, c->Cdev.p, c->cnorm.p, c->active.p, na, c->Pa.p, c->pna.p, c->assign.p,
+                                   c->hub.p, c->hlb.p));
+    }
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
     ISLECHK(k_proj_accumulate(c, c->P.p, D, k, ldk, c->assign.p, c->Csum.p, c->counts.p));              // :1957-1984
     ISLECHK(allreduce_sum<float>(c, c->Csum.p, (size_t)k * ldk));
     std::vector<long long> sizes;
     ISLECHK(fetch_sizes(c, k, sizes));
+    if (hamerly) HIPCHK(c, hipMemcpyAsync(c->Cold.p, c->Cdev.p, (size_t)k * ldk * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     ISLECHK(k_proj_finalize(c, c->Csum.p, c->counts.p, k, ldk, c->Cdev.p));                             // :1988-1992
+    if (hamerly && it + 1 < max_reps) {
+      ISLECHK(k_rownorms_diff(c, c->Cdev.p, c->Cold.p, k, k, ldk, delta_dev));
+      HIPCHK(c, hipMemcpyAsync(delta.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      amax = 0;
+      d1 = d2 = 0.f;
+      for (int i = 0; i < k; ++i) {
+        delta[i] = std::sqrt(std::max(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;
+        if (delta[i] > d1) {
+          d2 = d1;
+          d1 = delta[i];
+          amax = (uint32_t)i;
+        } else if (delta[i] > d2) {
+          d2 = delta[i];
+        }
+      }
+      HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));
     if (conv) {

@@ -110,6 +110,7 @@ struct isle_ctx {
   DevBuf<float> hub, hlb;  // D   Hamerly bounds (sparse Lloyd)
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<float> centers_old;  // V x ldk
+  DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
 
   // --- timing
   bool timing = false;
@@ -158,7 +159,8 @@ int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const floa
                        const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
                        float* ub = nullptr, float* lb = nullptr);
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
-                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive);
+                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive,
+                     int fam = ISLE_T_SPARSE_ASSIGN);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
@@ -180,7 +182,11 @@ int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, cons
 int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc, float* min_dist);
 int k_scan_f2d(isle_ctx* c, const float* in, uint64_t n, double* cum /*n+1*/);
 int k_search(isle_ctx* c, const double* cum, uint64_t n, const double* dice_dev, int nd, uint64_t* out_dev);
-int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign);
+int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
+                  float* ub = nullptr, float* lb = nullptr);
+int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, int ldk, const float* C, const float* cn,
+                         const uint32_t* active, uint32_t n, float* Pa, float* pna, uint32_t* assign, float* ub, float* lb);
+int k_rownorms_diff(isle_ctx* c, const float* A, const float* B, int rows, int k, int ldk, float* out);
 int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out);
 int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts);
 int k_proj_finalize(isle_ctx* c, const float* Csum, const int* counts, int k, int ldk, float* C);

@@ -19,7 +19,8 @@ constexpr int CS_ITEMS = 16;  // documents per thread in the histogram-style ker
 enum { PR_ARGMIN = 0, PR_MINDIST = 1 };
 template <int MODE>
 static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
-                           float* min_dist, bool* done);
+                           float* min_dist, bool* done, const float* Pt = nullptr, const uint32_t* map = nullptr, float* ub = nullptr,
+                           float* lb = nullptr);
 
 // ------------------------------------------------------------------------------------------
 // min_dist[d] = min(min_dist[d], max(|p_d|^2 + |c|^2 - 2 p_d.c, 0)) over the nc newest centres.
@@ -66,6 +67,27 @@ __global__ __launch_bounds__(256) void rownorms_k(const float* __restrict__ M, i
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) out[r] = s;
+}
+// out[r] = sum_j (A[r][j] - B[r][j])^2 : squared movement of every projected centre
+__global__ __launch_bounds__(256) void rownorms_diff_k(const float* __restrict__ A, const float* __restrict__ B, int rows, int k, int ldk,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int j = lane; j < k; j += 64) {
+    const float x = A[(size_t)r * ldk + j] - B[(size_t)r * ldk + j];
+    s = fmaf(x, x, s);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[r] = s;
+}
+int k_rownorms_diff(isle_ctx* c, const float* A, const float* B, int rows, int k, int ldk, float* out) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(rownorms_diff_k, dim3(cdiv(rows, 4)), dim3(256), 0, c->stream, A, B, rows, k, ldk, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out) {
   if (rows == 0) return 0;
@@ -202,7 +224,8 @@ template <int NSLAB, int CTMAX, int MODE>
 __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void proj_assign_reg_k(const float* __restrict__ Pt /*ldk x D*/, const float* __restrict__ pn,
                                                              uint32_t D, int k, int ldk, const float* __restrict__ C,
                                                              const float* __restrict__ cn, uint32_t* __restrict__ assign,
-                                                             float* __restrict__ min_dist) {
+                                                             float* __restrict__ min_dist, const uint32_t* __restrict__ map,
+                                                             float* __restrict__ ub, float* __restrict__ lb) {
   constexpr int KHC = NSLAB * PR_SL;  // coordinates per lane half held in registers at a time
   constexpr int CG = CTMAX * 32;      // centres per group (their accumulators live side by side)
   extern __shared__ float Cs[];       // [2][CG][PR_SL + 1]
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
   const float live = (myd < D) ? 1.f : 0.f;
   const float nd = (myd < D) ? pn[myd] : 0.f;
   const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
-  float best = 3.4e38f;
+  float best = 3.4e38f, second = 3.4e38f;
   uint32_t bidx = 0xffffffffu;
   // k <= CG and KH <= KHC (e.g. k = 200) is a single pass: P is then read from HBM exactly once per call.
   for (int cg0 = 0; cg0 < k; cg0 += CG) {
@@ -262,8 +285,11 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
             if (MODE == PR_ARGMIN) {
               const float dist = fabsf(raw);
               if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
+                second = best;
                 best = dist;
                 bidx = (uint32_t)cc;
+              } else {
+                second = fminf(second, dist);
               }
             } else {
               best = fminf(best, fmaxf(raw, 0.0f));
@@ -274,13 +300,24 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
     }
   }
   const float ob = __shfl_xor(best, 32);
+  const float os = __shfl_xor(second, 32);
   const uint32_t oi = __shfl_xor(bidx, 32);
   if (MODE == PR_ARGMIN) {
     if (ob < best || (ob == best && oi < bidx)) {
+      second = fminf(best, os);
       best = ob;
       bidx = oi;
+    } else {
+      second = fminf(second, ob);
     }
-    if (h == 0 && myd < D) assign[myd] = bidx;
+    if (h == 0 && myd < D) {
+      const uint32_t dst = map ? map[myd] : myd;  // compacted (active-list) launches write through the slot -> doc map
+      assign[dst] = bidx;
+      if (ub) {
+        ub[dst] = sqrtf(best);
+        lb[dst] = sqrtf(second);
+      }
+    }
   } else {
     best = fminf(best, ob);
     if (h == 0 && myd < D) min_dist[myd] = fminf(min_dist[myd], best);
@@ -290,9 +327,10 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
 // dispatch over (coordinate slabs, centre tiles); returns false if the shape is not covered
 template <int MODE>
 static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
-                           float* min_dist, bool* done) {
+                           float* min_dist, bool* done, const float* Pt, const uint32_t* map, float* ub, float* lb) {
   *done = false;
   if (!D || !c->Pt_ready) return 0;
+  if (!Pt) Pt = c->Pt.p;
   const int kpad = (k + 31) & ~31;
   const int ct = kpad / 32;
   const int nslab = cdiv(ldk / 2, PR_SL);
@@ -301,7 +339,7 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
   do {                                                                                                                        \
     const size_t lds = (size_t)2 * (CM * 32) * (PR_SL + 1) * sizeof(float);                                                   \
     HIPCHK(c, hipFuncSetAttribute((const void*)proj_assign_reg_k<NS, CM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, c->Pt.p, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist); \
+    hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, Pt, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist, map, ub, lb); \
     *done = true;                                                                                                             \
   } while (0)
   if (ct <= 1) {
@@ -318,14 +356,53 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
   return 0;
 }
 
+// Compacts the projected rows of the active documents into a coordinate-major panel (ldk x n) so that the
+// register-resident kernel can run on them unchanged: Pa[j * n + i] = P[active[i] * ldk + j], pna[i] = pn[active[i]].
+__global__ __launch_bounds__(256) void compact_rows_k(const float* __restrict__ P, const float* __restrict__ pn, int ldk,
+                                                       const uint32_t* __restrict__ active, uint32_t n, float* __restrict__ Pa,
+                                                       float* __restrict__ pna) {
+  __shared__ float t[32][33];
+  const uint32_t i0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j0 = 0; j0 < ldk; j0 += 32) {
+    __syncthreads();
+    for (int yy = ty; yy < 32; yy += 8) {  // row yy of the tile = active doc i0+yy, coordinates j0..j0+31 (coalesced 128 B)
+      const uint32_t i = i0 + yy;
+      const uint32_t d = active[min(i, n - 1)];
+      t[yy][tx] = P[(size_t)d * ldk + min(j0 + tx, ldk - 1)];
+    }
+    __syncthreads();
+    for (int yy = ty; yy < 32; yy += 8) {
+      const int j = j0 + yy;
+      const uint32_t i = i0 + tx;
+      if (j < ldk && i < n) Pa[(size_t)j * n + i] = t[tx][yy];
+    }
+  }
+  if (threadIdx.x < 32 && i0 + threadIdx.x < n) pna[i0 + threadIdx.x] = pn[active[i0 + threadIdx.x]];
+}
+
+// assignment of the n active documents (Hamerly); results are written through `active` into assign / ub / lb
+int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, int ldk, const float* C, const float* cn,
+                         const uint32_t* active, uint32_t n, float* Pa, float* pna, uint32_t* assign, float* ub, float* lb) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(compact_rows_k, dim3(cdiv(n, 32)), dim3(256), 0, c->stream, P, pn, ldk, active, n, Pa, pna);
+  HIPCHK(c, hipGetLastError());
+  bool done = false;
+  ISLECHK(launch_proj_reg<PR_ARGMIN>(c, n, k, ldk, C, cn, pna, assign, nullptr, &done, Pa, active, ub, lb));
+  if (!done) return isle_fail(c, ISLE_E_ARG, "projected assignment: register kernel unavailable");
+  return 0;
+}
+
 int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn,
-                  uint32_t* assign) {
+                  uint32_t* assign, float* ub, float* lb) {
   if (!getenv("ISLE_PROJ_ASSIGN_GENERIC")) {
     TimeScope ts(c, ISLE_T_LLOYD_PROJ);
     bool done = false;
-    ISLECHK(launch_proj_reg<PR_ARGMIN>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done));
+    ISLECHK(launch_proj_reg<PR_ARGMIN>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done, nullptr, nullptr, ub, lb));
     if (done) return 0;
   }
+  if (ub) return isle_fail(c, ISLE_E_ARG, "generic projected assignment has no bounds output");
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   if (D == 0) return 0;
   hipLaunchKernelGGL(proj_assign_k, dim3(cdiv(D, PA_DOCS)), dim3(256), 0, c->stream, P, pn, (uint32_t)D, k, ldk, C, cn, assign);

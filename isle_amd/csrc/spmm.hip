@@ -542,8 +542,8 @@ __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restri
   if (u + slack >= l - slack) active[atomicAdd(nactive, 1u)] = d;
 }
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
-                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive) {
-  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive, int fam) {
+  TimeScope ts(c, fam);
   const uint32_t D = (uint32_t)c->D;
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
