@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-upstream", action="store_true", help="skip the (untimed-region) device thresholding check")
+    ap.add_argument("--blk", type=int, default=0, help="experiment: block size of the eigensolver (0 = the reference's 10)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,7 +79,11 @@ def main():
     t0 = time.time()
     corp = Corpus(V, D_per, k, seed, doc_base=rank * D_per)
     nnz_A = corp.nnz_A
+    upstream = world == 1 and not args.no_upstream
+    A_host = corp.A() if upstream else None
+    t_thr0 = time.time()
     B = corp.threshold(k, free_A=True, allreduce=allreduce_np if dist is not None else None)
+    t_thr_cpu = time.time() - t_thr0
     del corp
     t_gen = time.time() - t0
     D_loc, nnz_loc = B["D"], B["nnz"]
@@ -100,7 +106,10 @@ def main():
     hp.upload_csc(V, B["vals"], B["rows"], B["offs"], doc_offset=doc_offset, docs_global=D_glob)
 
     def step(i):
-        r = hp.compute_block_ks(k, seed=1 + i, allow_noconv=True)
+        if args.blk:
+            r = hp.compute_block_ks(k, blk=args.blk, ncv=2 * k + args.blk, seed=1 + i, allow_noconv=True)
+        else:
+            r = hp.compute_block_ks(k, seed=1 + i, allow_noconv=True)
         g = hp.kmeans_init_on_projected_space(k, rng_seed=1 + i)
         lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
         hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
@@ -151,7 +160,7 @@ def main():
     value = D_glob * steps / dt
 
     # ---------------- roofline of the dominant sparse kernel family (Gram apply) --------------------------
-    b = 10 if k > 10 else 1
+    b = (args.blk or 10) if k > 10 else 1
     n_apply = tm["gram_pass1"][1]
     t_apply_ms = (tm["gram_pass1"][0] + tm["gram_pass2"][0]) / max(n_apply, 1)
     # bytes per application = 8*nnz + 8*(D+1) + 2*4*V*b   (this rank's shard)
@@ -211,6 +220,30 @@ def main():
                         last["ls_iters"], time.time() - tc0)),
         }
 
+    # ---------------- upstream stage (outside the timed region): A -> B on the device, checked against the CPU B --------
+    up = None
+    if upstream:
+        cntA, rowsA, offsA = A_host
+        t1 = time.perf_counter()
+        hp.upload_counts(V, cntA, rowsA, offsA)
+        t_up = time.perf_counter() - t1
+        hp.timing_enable(True)
+        hp.timing_reset()
+        t1 = time.perf_counter()
+        hp.threshold(k)
+        hp.synchronize()
+        t_thr = time.perf_counter() - t1
+        tm2 = hp.timing_get()
+        hp.timing_enable(False)
+        got = hp.get_B()
+        same = all(np.array_equal(got[x], B[x]) for x in ("vals", "rows", "offs", "original_cols", "zetas"))
+        up = {"stage": "thresholding A -> B on the device (normalize_docs + compute_thresholds + threshold_and_copy)",
+              "wall_ms": round(t_thr * 1e3, 3), "device_ms": round(tm2["threshold"][0], 3),
+              "GB_per_s_over_A": round(12.0 * nnz_A / max(tm2["threshold"][0], 1e-9) / 1e6, 1),
+              "h2d_upload_ms": round(t_up * 1e3, 1), "cpu_port_ms": round(t_thr_cpu * 1e3, 1), "cpu_cores": effective_cpus(),
+              "identical_to_cpu": bool(same)}
+        del got, A_host
+
     out = {
         "metric": "docs/sec end-to-end ISLETrain hot path (SVD+k-means)",
         "value": round(value, 1),
@@ -242,6 +275,7 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},
         "device_ms_per_step": device_ms,
         "cpu_baseline": cpu,
+        "upstream": up,
     }
     print(json.dumps(out), flush=True)
 

@@ -70,6 +70,37 @@ int isle_hip_upload_csc_u32(isle_ctx* ctx, uint64_t vocab_size, uint64_t num_doc
                             const float* vals, const uint32_t* rows, const int64_t* offsets,
                             uint64_t doc_offset, uint64_t docs_global);
 
+/* ---- upstream stage: thresholding on the device ------------------- */
+/* Uploads this rank's column shard of A, the word-document COUNT matrix in CSC as
+ * SparseMatrix<T>::populate_CSC builds it (src/sparseMatrix.cpp:58-133: rows ascending within a
+ * column, duplicates merged, counts > 0).  doc_offset / docs_global as for isle_hip_upload_csc. */
+int isle_hip_upload_counts_u32(isle_ctx* ctx, uint64_t vocab_size, uint64_t num_docs, uint64_t nnz,
+                               const float* counts, const uint32_t* rows, const int64_t* offsets,
+                               uint64_t doc_offset, uint64_t docs_global);
+
+/* normalize_docs (src/sparseMatrix.cpp:136-167) + list_word_freqs / compute_thresholds (:289-485)
+ * + FPSparseMatrix(A, zetas) = threshold_and_copy (:1285-1361), or sampled_threshold_and_copy
+ * (:1365-1435) when 0 < sample_rate < 1 — what ISLETrainer::train does at src/trainer.cpp:430-485.
+ * B is built in device memory and becomes the context's matrix exactly as if it had been passed
+ * to isle_hip_upload_csc (empty columns removed; its doc_offset / docs_global follow from the
+ * shards' surviving column counts).  Thresholds use the GLOBAL corpus (token total, non-empty
+ * documents and per-word histograms are all-reduced).  Sampling is single-rank only; its keys
+ * are drawn on the host from sample_seed (the reference uses unseeded rand()).
+ * Outputs (any may be NULL): docs_kept / nnz_kept describe this rank's shard of B;
+ * entries_above_threshold is the global count before sampling (the reference's log line);
+ * avg_doc_sz as computed at src/sparseMatrix.cpp:98. */
+int isle_hip_threshold(isle_ctx* ctx, uint64_t num_topics, double sample_rate, uint64_t sample_seed,
+                       uint64_t* docs_kept, uint64_t* nnz_kept, uint64_t* entries_above_threshold,
+                       float* avg_doc_sz);
+
+/* Copies the context's B (and, after isle_hip_threshold, original_cols[D] = global column of A
+ * behind each column of B and zetas[V]) to the host; any pointer may be NULL.  Sizes: query with
+ * isle_hip_shape. */
+int isle_hip_get_B(isle_ctx* ctx, float* vals, uint32_t* rows, int64_t* offsets,
+                   uint64_t* original_cols, float* zetas);
+int isle_hip_shape(isle_ctx* ctx, uint64_t* vocab_size, uint64_t* num_docs, uint64_t* nnz,
+                   uint64_t* doc_offset, uint64_t* docs_global);
+
 /* FPSparseMatrix::frobenius  src/sparseMatrix.cpp:1096-1100  (sum of squares of all entries,
  * over all ranks). */
 int isle_hip_frobenius(isle_ctx* ctx, float* out);
@@ -151,7 +182,8 @@ enum {
   ISLE_T_SPARSE_UPDATE = 10,/* sparse Lloyd: centroid update       */
   ISLE_T_BAND_BUILD = 11,  /* chunked-CSR copy of B (per solve)   */
   ISLE_T_COMM = 12,        /* collectives                          */
-  ISLE_T_COUNT = 13
+  ISLE_T_THRESHOLD = 13,   /* A -> B thresholding (upstream stage) */
+  ISLE_T_COUNT = 14
 };
 int isle_hip_timing_enable(isle_ctx* ctx, int on);
 int isle_hip_timing_reset(isle_ctx* ctx);

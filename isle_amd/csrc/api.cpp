@@ -77,6 +77,8 @@ template <>
 ncclDataType_t nccl_type<int>() { return ncclInt; }
 template <>
 ncclDataType_t nccl_type<uint64_t>() { return ncclUint64; }
+template <>
+ncclDataType_t nccl_type<uint32_t>() { return ncclUint32; }
 
 template <class T>
 static int allreduce_sum(isle_ctx* c, T* buf, size_t count) {
@@ -257,6 +259,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   c->members_valid = false;
   c->U_k = 0;
   c->centers_ready = false;
+  c->b_from_threshold = false;
   return 0;
 }
 
@@ -272,6 +275,203 @@ extern "C" int isle_hip_upload_csc_u64(isle_ctx* c, uint64_t V, uint64_t D, uint
     r32[i] = (uint32_t)rows[i];
   }
   return upload_common(c, V, D, nnz, vals, r32.data(), offs, doc_offset, docs_global);
+}
+
+// ------------------------------------------------------------------------------------------
+// upstream stage: A -> B on the device
+// ------------------------------------------------------------------------------------------
+extern "C" int isle_hip_upload_counts_u32(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* counts, const uint32_t* rows,
+                                          const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (V == 0 || V > 0xfffffff0ull || D > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "vocab/doc count out of range");
+  if (offs[0] != 0 || (uint64_t)offs[D] != nnz) return isle_fail(c, ISLE_E_ARG, "offsets[0] != 0 or offsets[D] != nnz");
+  for (uint64_t d = 0; d < D; ++d) {
+    if (offs[d + 1] < offs[d]) return isle_fail(c, ISLE_E_ARG, "offsets not monotone at column %llu", (unsigned long long)d);
+    for (int64_t i = offs[d]; i < offs[d + 1]; ++i) {
+      if (rows[i] >= V) return isle_fail(c, ISLE_E_ARG, "row index out of range at %lld", (long long)i);
+      if (i > offs[d] && rows[i] <= rows[i - 1])
+        return isle_fail(c, ISLE_E_ARG, "rows not strictly ascending in column %llu", (unsigned long long)d);
+      if (!(counts[i] > 0.f)) return isle_fail(c, ISLE_E_ARG, "count not positive at %lld", (long long)i);
+    }
+  }
+  c->a_V = V;
+  c->a_D = D;
+  c->a_nnz = nnz;
+  c->a_doc_offset = doc_offset;
+  c->a_D_global = docs_global ? docs_global : D;
+  HIPCHK(c, c->a_cnt.reserve(nnz ? nnz : 1));
+  HIPCHK(c, c->a_rows.reserve(nnz ? nnz : 1));
+  HIPCHK(c, c->a_offs.reserve(D + 1));
+  if (nnz) {
+    HIPCHK(c, hipMemcpy(c->a_cnt.p, counts, nnz * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->a_rows.p, rows, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipMemcpy(c->a_offs.p, offs, (D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  c->a_ready = true;
+  return 0;
+}
+
+extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sample_rate, uint64_t sample_seed, uint64_t* docs_kept,
+                                  uint64_t* nnz_kept, uint64_t* entries_above, float* avg_out) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->a_ready) return isle_fail(c, ISLE_E_ARG, "threshold: no count matrix uploaded");
+  if (num_topics == 0) return isle_fail(c, ISLE_E_ARG, "threshold: num_topics == 0");
+  const bool sampling = sample_rate > 0.0 && sample_rate < 1.0;
+  if (sampling && c->world > 1) return isle_fail(c, ISLE_E_ARG, "threshold: document sampling is single-rank only");
+  const uint64_t V = c->a_V, D = c->a_D;
+
+  // corpus statistics (src/sparseMatrix.cpp:92-99), global
+  HIPCHK(c, c->a_scan.reserve(isle_scan_scratch(D) + 4));
+  uint64_t* st_dev = (uint64_t*)c->a_scan.p;
+  ISLECHK(k_th_stats(c, st_dev));
+  ISLECHK(allreduce_sum<uint64_t>(c, st_dev, 2));
+  uint64_t st[2];
+  HIPCHK(c, hipMemcpyAsync(st, st_dev, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint64_t tokens = st[0], nz_docs = st[1];
+  const float avg = (float)(tokens / std::max<uint64_t>(nz_docs, 1));  // :98, integer division
+  if (avg_out) *avg_out = avg;
+  const uint64_t maxv64 = (uint64_t)avg + 2;
+  if (maxv64 > 65535) return isle_fail(c, ISLE_E_ARG, "threshold: average document size %g too large", (double)avg);
+  const uint32_t maxv = (uint32_t)maxv64;
+
+  // rounded normalised counts + per-word value histogram, global
+  HIPCHK(c, c->a_q.reserve(c->a_nnz ? c->a_nnz : 1));
+  HIPCHK(c, c->a_hist.reserve((size_t)V * (maxv + 1)));
+  ISLECHK(k_th_round_hist(c, avg, maxv));
+  ISLECHK(allreduce_sum<uint32_t>(c, c->a_hist.p, (size_t)V * (maxv + 1)));
+
+  // thresholds  (src/sparseMatrix.cpp:367-368)
+  uint64_t count_gr = (uint64_t)(1.0 * (float)nz_docs / (2.0 * (float)num_topics));
+  uint64_t count_eq = (uint64_t)std::ceil(3.0 * (1.0 / 60.0) * 1.0 * (float)nz_docs / (float)num_topics);
+  if (count_gr == 0) count_gr = 1;
+  if (count_eq == 0) count_eq = 1;
+  HIPCHK(c, c->zetas.reserve(V));
+  ISLECHK(k_th_zetas(c, maxv, count_gr, count_eq));
+
+  // survivors per document
+  HIPCHK(c, c->a_kept.reserve(D ? D : 1));
+  if (sampling) HIPCHK(c, c->a_wgt.reserve(D ? D : 1));
+  ISLECHK(k_th_count(c, sampling));
+  ISLECHK(k_th_scans(c));
+  int64_t above_local = 0;
+  HIPCHK(c, hipMemcpyAsync(&above_local, c->a_off_all.p + D, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (entries_above) {
+    uint64_t g = (uint64_t)above_local;
+    if (c->comm) {
+      HIPCHK(c, hipMemcpyAsync(st_dev, &g, sizeof(g), hipMemcpyHostToDevice, c->stream));
+      ISLECHK(allreduce_sum<uint64_t>(c, st_dev, 1));
+      HIPCHK(c, hipMemcpyAsync(&g, st_dev, sizeof(g), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *entries_above = g;
+  }
+
+  if (sampling && D) {  // sampled_threshold_and_copy, src/sparseMatrix.cpp:1383-1415 (keys on the host, like the reference)
+    std::vector<float> wgt(D), key(D), dice(D);
+    HIPCHK(c, hipMemcpy(wgt.data(), c->a_wgt.p, D * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint64_t d = 0; d < D; ++d) {
+      uint64_t z = (sample_seed + 1) * 0x9E3779B97F4A7C15ull ^ (d * 0xD1342543DE82EF95ull);
+      z += 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z = z ^ (z >> 31);
+      const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+      key[d] = (wgt[d] == 0.f) ? 0.f : (float)std::pow(u, 1.0 / (double)wgt[d]);
+      dice[d] = key[d];
+    }
+    const size_t nth = std::min<size_t>((size_t)((float)sample_rate * (float)D), D - 1);
+    std::nth_element(dice.begin(), dice.begin() + nth, dice.end(), std::greater<float>());
+    const float pivot = dice[nth];
+    std::vector<uint8_t> drop(D);
+    for (uint64_t d = 0; d < D; ++d) drop[d] = !(key[d] >= pivot);
+    DevBuf<uint8_t> drop_dev;
+    HIPCHK(c, drop_dev.reserve(D));
+    HIPCHK(c, hipMemcpy(drop_dev.p, drop.data(), D, hipMemcpyHostToDevice));
+    int rc = k_th_drop(c, drop_dev.p);
+    if (rc == 0) rc = k_th_scans(c);
+    (void)hipStreamSynchronize(c->stream);
+    drop_dev.release();
+    ISLECHK(rc);
+  }
+
+  int64_t tail[2];  // nnz(B), columns of B (local)
+  HIPCHK(c, hipMemcpyAsync(&tail[0], c->a_off_all.p + D, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&tail[1], c->a_col_of.p + D, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint64_t bnnz = (uint64_t)tail[0], Db = (uint64_t)tail[1];
+
+  // placement of this shard in B's global column numbering
+  uint64_t b_off = 0, b_glob = Db;
+  if (c->comm) {
+    DevBuf<uint64_t> all;
+    HIPCHK(c, all.reserve((size_t)c->world + 1));
+    HIPCHK(c, hipMemcpyAsync(all.p + c->world, &Db, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    {
+      TimeScope ts(c, ISLE_T_COMM);
+      NCCLCHK(c, ncclAllGather(all.p + c->world, all.p, 1, ncclUint64, c->comm, c->stream));
+    }
+    std::vector<uint64_t> h(c->world);
+    HIPCHK(c, hipMemcpyAsync(h.data(), all.p, c->world * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    all.release();
+    b_glob = 0;
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) b_off = b_glob;
+      b_glob += h[r];
+    }
+  }
+
+  c->V = V;
+  c->D = Db;
+  c->nnz = bnnz;
+  c->doc_offset = b_off;
+  c->D_global = b_glob;
+  HIPCHK(c, c->vals.reserve(bnnz ? bnnz : 1));
+  HIPCHK(c, c->rows.reserve(bnnz ? bnnz : 1));
+  HIPCHK(c, c->offs.reserve(Db + 1));
+  HIPCHK(c, c->original_cols.reserve(Db ? Db : 1));
+  if (D == 0) HIPCHK(c, hipMemsetAsync(c->offs.p, 0, sizeof(int64_t), c->stream));
+  ISLECHK(k_th_emit(c, c->a_doc_offset));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->band_ready = false;
+  c->P_ready = false;
+  c->Pt_ready = false;
+  c->members_valid = false;
+  c->U_k = 0;
+  c->centers_ready = false;
+  c->b_from_threshold = true;
+  if (docs_kept) *docs_kept = Db;
+  if (nnz_kept) *nnz_kept = bnnz;
+  return 0;
+}
+
+extern "C" int isle_hip_shape(isle_ctx* c, uint64_t* V, uint64_t* D, uint64_t* nnz, uint64_t* doc_offset, uint64_t* docs_global) {
+  if (!c) return ISLE_E_ARG;
+  if (V) *V = c->V;
+  if (D) *D = c->D;
+  if (nnz) *nnz = c->nnz;
+  if (doc_offset) *doc_offset = c->doc_offset;
+  if (docs_global) *docs_global = c->D_global;
+  return 0;
+}
+
+extern "C" int isle_hip_get_B(isle_ctx* c, float* vals, uint32_t* rows, int64_t* offs, uint64_t* original_cols, float* zetas) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "get_B: no matrix");
+  if ((original_cols || zetas) && !c->b_from_threshold)
+    return isle_fail(c, ISLE_E_ARG, "get_B: original_cols / zetas exist only after isle_hip_threshold");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (vals && c->nnz) HIPCHK(c, hipMemcpy(vals, c->vals.p, c->nnz * sizeof(float), hipMemcpyDeviceToHost));
+  if (rows && c->nnz) HIPCHK(c, hipMemcpy(rows, c->rows.p, c->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (offs) HIPCHK(c, hipMemcpy(offs, c->offs.p, (c->D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (original_cols && c->D) HIPCHK(c, hipMemcpy(original_cols, c->original_cols.p, c->D * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (zetas) HIPCHK(c, hipMemcpy(zetas, c->zetas.p, c->V * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
 }
 
 extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
@@ -293,14 +493,11 @@ extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
 // ------------------------------------------------------------------------------------------
 // Gram apply on device pointers: Zcm (V x b col-major) = B (B^T Xcm)
 // ------------------------------------------------------------------------------------------
-static int panel_width(int b) {  // b <= 16 -> BP in {4, 8, 12, 16}
-  static const bool p16 = getenv("ISLE_PANEL16") != nullptr;  // experiment: 64-B panel rows
-  if (p16 && b > 8) return 16;
-  return 4 * ((b + 3) / 4);
-}
+static int panel_width(int b) { return 4 * ((b + 3) / 4); }  // BP in {4, 8, ..., 32}: one float4 lane per 4 columns
 
-// One panel of at most 16 columns (the R x (BP+1) LDS tile of pass 2 is sized for BP <= 16).
-static int gram_apply_panel(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
+// Zcm (V x b col-major) = B (B^T Xcm) on device pointers, 1 <= b <= 32, one pass over both copies of B per call.
+static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
+  if (b < 1 || b > 32) return isle_fail(c, ISLE_E_ARG, "gram_apply: b = %d not in [1, 32]", b);
   const int BP = panel_width(b);
   HIPCHK(c, c->Xrm.reserve((size_t)c->V * BP));
   HIPCHK(c, c->Zrm.reserve((size_t)c->V * BP));
@@ -310,13 +507,6 @@ static int gram_apply_panel(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
   ISLECHK(k_gram_pass2(c, BP));
   ISLECHK(allreduce_sum<float>(c, c->Zrm.p, (size_t)c->V * BP));
   ISLECHK(k_unpack_cm(c, c->Zrm.p, c->V, b, BP, Zcm));
-  return 0;
-}
-
-static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
-  if (b < 1 || b > 32) return isle_fail(c, ISLE_E_ARG, "gram_apply: b = %d not in [1, 32]", b);
-  for (int j0 = 0; j0 < b; j0 += 16)
-    ISLECHK(gram_apply_panel(c, Xcm + (size_t)j0 * c->V, std::min(16, b - j0), Zcm + (size_t)j0 * c->V));
   return 0;
 }
 

@@ -54,6 +54,21 @@ struct isle_ctx {
   DevBuf<uint32_t> rows;
   DevBuf<int64_t> offs;
 
+  // --- A (word-document counts, this rank's column shard) and the thresholding workspaces (threshold.hip)
+  uint64_t a_V = 0, a_D = 0, a_nnz = 0, a_doc_offset = 0, a_D_global = 0;
+  bool a_ready = false;
+  DevBuf<float> a_cnt;
+  DevBuf<uint32_t> a_rows;
+  DevBuf<int64_t> a_offs;
+  DevBuf<uint16_t> a_q;        // rounded normalised counts, clamped to maxv
+  DevBuf<uint32_t> a_hist;     // V x (maxv + 1)
+  DevBuf<uint32_t> a_kept, a_flag;
+  DevBuf<float> a_wgt;
+  DevBuf<int64_t> a_off_all, a_col_of, a_scan;
+  DevBuf<float> zetas;             // V
+  DevBuf<uint64_t> original_cols;  // D (B column -> global document id of A)
+  bool b_from_threshold = false;
+
   // --- chunked-CSR copy of B for Z = B*Y (built per eigensolve, like the reference's operator ctor)
   bool band_ready = false;
   uint32_t band_rows = 0;  // requested columns per chunk (0 = default), env ISLE_CHUNK_COLS
@@ -144,6 +159,7 @@ struct TimeScope {
   ~TimeScope();
 };
 
+static inline uint64_t isle_scan_scratch(uint64_t n) { return (n + 4095) / 4096 + 1; }  // = isle_scan::scan_scratch_elems
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------- kernel launchers (each defined in one .hip file) -------------------------
@@ -165,6 +181,15 @@ int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);
+
+// threshold.hip
+int k_th_stats(isle_ctx* c, uint64_t* tokens_nz_dev);
+int k_th_round_hist(isle_ctx* c, float avg, uint32_t maxv);
+int k_th_zetas(isle_ctx* c, uint32_t maxv, uint64_t count_gr, uint64_t count_eq);
+int k_th_count(isle_ctx* c, bool with_weights);
+int k_th_drop(isle_ctx* c, const uint8_t* drop_dev);
+int k_th_scans(isle_ctx* c);
+int k_th_emit(isle_ctx* c, uint64_t doc_base);
 
 // dense.hip
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);

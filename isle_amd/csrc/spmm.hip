@@ -150,6 +150,10 @@ int k_gram_pass1(isle_ctx* c, int BP) {
     case 2: L1(2); break;
     case 3: L1(3); break;
     case 4: L1(4); break;
+    case 5: L1(5); break;
+    case 6: L1(6); break;
+    case 7: L1(7); break;
+    case 8: L1(8); break;
     default: return isle_fail(c, ISLE_E_ARG, "unsupported panel width BP=%d", BP);
   }
 #undef L1
@@ -261,6 +265,10 @@ int k_gram_pass2(isle_ctx* c, int BP) {
     case 2: L2(2); break;
     case 3: L2(3); break;
     case 4: L2(4); break;
+    case 5: L2(5); break;
+    case 6: L2(6); break;
+    case 7: L2(7); break;
+    case 8: L2(8); break;
     default: return isle_fail(c, ISLE_E_ARG, "unsupported panel width BP=%d", BP);
   }
 #undef L2

@@ -205,7 +205,7 @@ inline void threshold(const Csc& A, float avg_doc_sz, uint64_t nz_docs, uint64_t
       key[d] = (wgt == 0.f) ? 0.f : (float)std::pow(u, 1.0 / (double)wgt);  // :1401-1403
       dice[d] = key[d];
     }
-    const size_t nth = (size_t)((float)sample_rate * (float)D);  // :1406-1409
+    const size_t nth = std::min<size_t>((size_t)((float)sample_rate * (float)D), D - 1);  // :1406-1409
     std::nth_element(dice.begin(), dice.begin() + nth, dice.end(), std::greater<float>());
     const float pivot = dice[nth];
     std::printf("sampling docs: pivot: %g\n", pivot);

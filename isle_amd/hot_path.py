@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import IsleHipError, load_library
 
 TIMING_FAMILIES = ["gram_pass1", "gram_pass2", "ortho", "qr", "evd", "rotate", "project", "kmpp", "lloyd_proj",
-                   "sparse_assign", "sparse_update", "op_build", "comm"]
+                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold"]
 
 BLOCK_KS_MAX_ITERS = 100      # include/hyperparams.h:38
 BLOCK_KS_BLOCK_SIZE = 10      # include/hyperparams.h:39
@@ -86,6 +86,42 @@ class HotPath:
         self._chk(fn(self._h, V, D, nnz, _p(vals), _p(rows), _p(offs), doc_offset, docs_global))
         self.V, self.D, self.nnz, self.doc_offset = int(V), D, nnz, int(doc_offset)
         self.D_global = int(docs_global) if docs_global else D
+
+    # ---- upstream stage: thresholding on the device ---------------------------------------
+    def upload_counts(self, V, counts, rows, offs, doc_offset=0, docs_global=0):
+        """A = word-document counts in CSC (SparseMatrix::populate_CSC, src/sparseMatrix.cpp:58-133)."""
+        counts = np.ascontiguousarray(counts, np.float32)
+        rows = np.ascontiguousarray(rows, np.uint32)
+        offs = np.ascontiguousarray(offs, np.int64)
+        D = offs.shape[0] - 1
+        self._chk(self._lib.isle_hip_upload_counts_u32(self._h, V, D, int(offs[-1]), _p(counts), _p(rows), _p(offs),
+                                                       doc_offset, docs_global))
+
+    def threshold(self, num_topics, sample_rate=0.0, sample_seed=0):
+        """normalize_docs + compute_thresholds + (sampled_)threshold_and_copy on the device
+        (src/trainer.cpp:430-485); B becomes this context's matrix.  Returns a dict of scalars."""
+        dk, nk, ab = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        avg = C.c_float()
+        self._chk(self._lib.isle_hip_threshold(self._h, int(num_topics), float(sample_rate), int(sample_seed),
+                                               C.byref(dk), C.byref(nk), C.byref(ab), C.byref(avg)))
+        V, D, nnz, off, glob = (C.c_uint64() for _ in range(5))
+        self._chk(self._lib.isle_hip_shape(self._h, C.byref(V), C.byref(D), C.byref(nnz), C.byref(off), C.byref(glob)))
+        self.V, self.D, self.nnz = int(V.value), int(D.value), int(nnz.value)
+        self.doc_offset, self.D_global = int(off.value), int(glob.value)
+        return dict(docs_kept=int(dk.value), nnz_kept=int(nk.value), entries_above_threshold=int(ab.value),
+                    avg_doc_sz=float(avg.value))
+
+    def get_B(self, with_threshold_outputs=True):
+        """Host copy of the context's B: dict(V, D, nnz, vals, rows, offs[, original_cols, zetas])."""
+        out = dict(V=self.V, D=self.D, nnz=self.nnz, vals=np.empty(self.nnz, np.float32), rows=np.empty(self.nnz, np.uint32),
+                   offs=np.empty(self.D + 1, np.int64))
+        oc = ze = None
+        if with_threshold_outputs:
+            oc = out["original_cols"] = np.empty(self.D, np.uint64)
+            ze = out["zetas"] = np.empty(self.V, np.float32)
+        self._chk(self._lib.isle_hip_get_B(self._h, _p(out["vals"]), _p(out["rows"]), _p(out["offs"]),
+                                           _p(oc) if oc is not None else None, _p(ze) if ze is not None else None))
+        return out
 
     def frobenius(self):
         out = C.c_float()

@@ -263,7 +263,7 @@ uint64_t synth_apply(void* h, uint32_t k, uint64_t nzdocs_global, double sample_
       key[d] = (w == 0.f) ? 0.f : (float)std::pow(r.u01(), 1.0 / (double)w);             // :1401-1403
       dice[d] = key[d];
     }
-    const size_t nth = (size_t)(sample_rate * (float)D);                                  // :1406-1409
+    const size_t nth = std::min<size_t>((size_t)((float)sample_rate * (float)D), D - 1);  // :1406-1409 (FPTYPE product)
     std::nth_element(dice.begin(), dice.begin() + nth, dice.end(), std::greater<float>());
     const float pivot = dice[nth];
     for (uint64_t d = 0; d < D; ++d)
