@@ -3,7 +3,7 @@
 //   ISLETrain <tdf_file> <vocab_file> <output_dir> <vocab_size> <num_docs> <max_entries> <num_topics>
 //             <apply tf-idf(0/1)> <sample(0/1)> <sample_rate> <edge topics(0/1)> <max_edge_topics>
 //
-// Runs ingest -> thresholding (host, prestage.h) -> the hot path src/trainer.cpp:490-571 on the GPU, and writes into
+// Runs ingest (host, prestage.h) -> thresholding (device) -> the hot path src/trainer.cpp:490-571 on the GPU, and writes into
 // the reference's log directory (src/utils.cpp:28-48) diagnosticLog.txt / timerLog.txt with the reference's line
 // formats for these phases.  What comes AFTER the hot path in the reference (catchwords, topic model,
 // M_hat_catch_sparse, edge topics: SURVEY §8f next-3) is not built yet: the partition and centres are written to
@@ -119,18 +119,18 @@ int main(int argv, char** argc) {
     std::cout << "Entries in sparse matrix: " << A.offs[num_docs] << std::endl << "Average document size: " << avg_doc_sz << std::endl;
     log.next_time_secs("Populating CSC");
 
-    prestage::Thresholded T;
-    prestage::threshold(A, avg_doc_sz, nz_docs, num_topics, sample ? (double)sample_rate : 0.0, 0, T);
+    // src/trainer.cpp:430-485 on the device: thresholds from the whole corpus, B built in HBM
+    std::vector<uint32_t> rows32(A.rows.begin(), A.rows.end());
+    std::vector<doc_id_t> original_cols;
+    uint64_t entries_above_threshold = 0;
+    FPSparseMatrixHip* B_fl_CSC = FPSparseMatrixHip::from_counts(vocab_size, num_docs, A.vals.data(), rows32.data(), A.offs.data(), num_topics,
+                                                                 sample ? (double)sample_rate : 0.0, original_cols, nullptr,
+                                                                 &entries_above_threshold);
+    std::vector<uint32_t>().swap(rows32);
     log.next_time_secs("Computing thresholds");
-    log.print("Number of entries above threshold: " + std::to_string(T.entries_above_threshold) + "\n");
-    std::cout << (sample ? "After sampling docs: cols remaining: " : "Columns remaining after thresholding: ") << T.B.D << "\n";
+    log.print("Number of entries above threshold: " + std::to_string(entries_above_threshold) + "\n");
+    std::cout << (sample ? "After sampling docs: cols remaining: " : "Columns remaining after thresholding: ") << B_fl_CSC->num_docs() << "\n";
     log.next_time_secs("Creating thresholded and scaled matrix");
-
-    FPSparseMatrixHip* B_fl_CSC = new FPSparseMatrixHip(vocab_size, T.B.D);
-    B_fl_CSC->allocate((offset_t)T.B.vals.size());
-    std::copy(T.B.vals.begin(), T.B.vals.end(), B_fl_CSC->vals_CSC);
-    std::copy(T.B.rows.begin(), T.B.rows.end(), B_fl_CSC->rows_CSC);
-    std::copy(T.B.offs.begin(), T.B.offs.end(), B_fl_CSC->offsets_CSC);
 
     // ---- src/trainer.cpp:490-571 -----------------------------------------------------------------
     log.print("Frob(B_fl_CSC): " + std::to_string(B_fl_CSC->frobenius()) + "\n");
@@ -172,7 +172,7 @@ int main(int argv, char** argc) {
     if (closest_docs_sizes_sum != B_fl_CSC->num_docs()) throw std::runtime_error("partition incomplete");  // :567-570
     log.next_time_secs("k-means on B");
     for (doc_id_t topic = 0; topic != num_topics; ++topic)  // :573-575
-      for (auto d = closest_docs[topic].begin(); d < closest_docs[topic].end(); ++d) *d = T.original_cols[*d];
+      for (auto d = closest_docs[topic].begin(); d < closest_docs[topic].end(); ++d) *d = original_cols[*d];
     // ---------------------------------------------------------------------------------------------
 
     {

@@ -71,6 +71,36 @@ class FPSparseMatrixHip {
   }
   FPSparseMatrixHip(const FPSparseMatrixHip&) = delete;
 
+  // Device-side equivalent of SparseMatrix::normalize_docs + compute_thresholds (src/sparseMatrix.cpp:136-167, :357-485)
+  // followed by FPSparseMatrix(A_sp, true) + threshold_and_copy / sampled_threshold_and_copy (:1285-1435), i.e. what
+  // ISLETrainer::train does at src/trainer.cpp:430-485.  `counts`/`rows`/`offsets` are A_sp's CSC (populate_CSC layout).
+  // B is built in device memory (the host CSC pointers of the returned object stay NULL); original_cols maps its columns
+  // back to A's, zetas (optional) receives the per-word thresholds.
+  static FPSparseMatrixHip* from_counts(word_id_t vocab_size, doc_id_t num_docs, const float* counts, const uint32_t* rows,
+                                        const offset_t* offsets, doc_id_t num_topics, double sample_rate,
+                                        std::vector<doc_id_t>& original_cols, std::vector<FPTYPE>* zetas = nullptr,
+                                        uint64_t* entries_above_threshold = nullptr, float* avg_doc_sz = nullptr, int device = 0) {
+    FPSparseMatrixHip* B = new FPSparseMatrixHip(vocab_size, 0, device);
+    try {
+      B->check(isle_hip_upload_counts_u32(B->ctx_, vocab_size, num_docs, (uint64_t)offsets[num_docs], counts, rows, offsets, 0, num_docs),
+               "upload_counts");
+      uint64_t docs_kept = 0, nnz_kept = 0;
+      B->check(isle_hip_threshold(B->ctx_, num_topics, sample_rate, 0, &docs_kept, &nnz_kept, entries_above_threshold, avg_doc_sz),
+               "threshold");
+      B->num_docs_ = docs_kept;
+      B->nnzs_ = (offset_t)nnz_kept;
+      B->uploaded_ = true;
+      original_cols.resize(docs_kept);
+      static_assert(sizeof(doc_id_t) == sizeof(uint64_t), "doc_id_t is 8 bytes (include/types.h:25)");
+      if (zetas) zetas->resize(vocab_size);
+      B->check(isle_hip_get_B(B->ctx_, nullptr, nullptr, nullptr, (uint64_t*)original_cols.data(), zetas ? zetas->data() : nullptr), "get_B");
+    } catch (...) {
+      delete B;
+      throw;
+    }
+    return B;
+  }
+
   void allocate(offset_t nnzs) {  // SparseMatrix::allocate
     delete[] vals_CSC;
     delete[] rows_CSC;
