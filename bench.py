@@ -105,15 +105,26 @@ def main():
         hp.comm_init(world, rank, uid[0])
     hp.upload_csc(V, B["vals"], B["rows"], B["offs"], doc_offset=doc_offset, docs_global=D_glob)
 
+    phase_wall = {"block_ks": 0.0, "kmeanspp": 0.0, "lloyd_projected": 0.0, "lift": 0.0, "lloyd_sparse": 0.0}
+
     def step(i):
+        t = [time.perf_counter()]
         if args.blk:
             r = hp.compute_block_ks(k, blk=args.blk, ncv=2 * k + args.blk, seed=1 + i, allow_noconv=True)
         else:
             r = hp.compute_block_ks(k, seed=1 + i, allow_noconv=True)
+        t.append(time.perf_counter())
         g = hp.kmeans_init_on_projected_space(k, rng_seed=1 + i)
+        t.append(time.perf_counter())
         lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        t.append(time.perf_counter())
         hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        t.append(time.perf_counter())
         ls = hp.run_lloyds(k, fetch_centers=True)  # the trainer consumes centers + partition (trainer.cpp:563-575)
+        t.append(time.perf_counter())
+        if i >= 0:
+            for j, name in enumerate(phase_wall):
+                phase_wall[name] += t[j + 1] - t[j]
         return dict(ks=r, kmpp_rounds=g["rounds"], lp_iters=lp["iters"], ls_iters=ls["iters"], assign=ls["assign"])
 
     def fence():
@@ -274,6 +285,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},
         "device_ms_per_step": device_ms,
+        "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
         "cpu_baseline": cpu,
         "upstream": up,
     }

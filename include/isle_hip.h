@@ -164,6 +164,39 @@ int isle_hip_lift_centers(isle_ctx* ctx, const float* in, int ld_in, int ncols, 
 int isle_hip_lloyds_sparse(isle_ctx* ctx, int k, const float* centers_in, float* centers_out,
                            uint32_t* assign, int max_reps, int* iters_run);
 
+/* ---- downstream stage: catchwords, topic model, edge topics ---
+ * These operate on the count matrix A left in device memory by isle_hip_upload_counts_u32 (single
+ * rank only for now) and on the partition of B's columns, mapped back to A's documents through
+ * original_cols exactly as src/trainer.cpp:572-575 does.
+ *
+ * isle_hip_catchwords = SparseMatrix::rth_highest_element for every topic (src/sparseMatrix.cpp:491-524,
+ * called at src/trainer.cpp:586-590) + SparseMatrix::find_catchwords (:573-595).
+ *   assign: this context's B columns -> topic (what isle_hip_lloyds_sparse returned), or NULL to use
+ *           the partition still resident from the last isle_hip_lloyds_sparse call.
+ *   r:      the rank of src/trainer.cpp:579-583 (>= 1).   rho: rho_c (include/hyperparams.h:11).
+ *   thresholds (nullable): vocab x num_topics column-major, the reference's catchword_thresholds.
+ *   catch_topic (nullable): vocab entries, the topic a word is a catchword of or -1 (the rule admits
+ *           at most one topic per word); catchwords[t] of the reference = { w : catch_topic[w] == t }
+ *           ascending. */
+int isle_hip_catchwords(isle_ctx* ctx, int num_topics, const uint32_t* assign, uint64_t r, double rho,
+                        float* thresholds, int32_t* catch_topic, uint64_t* num_catchwords);
+
+/* SparseMatrix::construct_topic_model (src/sparseMatrix.cpp:597-838) after isle_hip_catchwords.
+ *   rank_threshold: src/sparseMatrix.cpp:720.
+ *   model (nullable): vocab x num_topics column-major, L1-normalised topic vectors (DenseMatrix Model).
+ *   model_threshold (nullable): num_topics.  top1/top2 (nullable): per document of A, the two heaviest
+ *   catchword topics (top_topic_pairs, :687-708) or -1/-1.  doc_topic_sums (nullable): number of
+ *   non-zero (document, topic) catchword sums; fetch them with isle_hip_get_doc_topic_sums. */
+int isle_hip_topic_model(isle_ctx* ctx, int num_topics, uint64_t rank_threshold, float* model,
+                         float* model_threshold, int32_t* top1, int32_t* top2, uint64_t* doc_topic_sums);
+/* doc_offsets: docs(A) + 1 entries; topic / val: doc_topic_sums entries, (document, topic) ascending. */
+int isle_hip_get_doc_topic_sums(isle_ctx* ctx, int64_t* doc_offsets, uint32_t* topic, float* val);
+
+/* The FPaxpy pair of ISLETrainer::construct_edge_topics_v2 (src/trainer.cpp:1152-1159) on the
+ * device-resident Model: edge[:, e] = primary_ratio * Model[:, pairs[2e]] +
+ * (1 - primary_ratio) * Model[:, pairs[2e+1]]; edge is vocab x n column-major. */
+int isle_hip_edge_topics(isle_ctx* ctx, const int64_t* pairs, int n, float primary_ratio, float* edge);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* Per-kernel-family device time accumulated with HIP events on the context's stream since the
  * last reset (only while enabled; enabling adds event records around each launch).
@@ -183,7 +216,8 @@ enum {
   ISLE_T_BAND_BUILD = 11,  /* chunked-CSR copy of B (per solve)   */
   ISLE_T_COMM = 12,        /* collectives                          */
   ISLE_T_THRESHOLD = 13,   /* A -> B thresholding (upstream stage) */
-  ISLE_T_COUNT = 14
+  ISLE_T_POST = 14,        /* catchwords / topic model / edge topics (downstream stage) */
+  ISLE_T_COUNT = 15
 };
 int isle_hip_timing_enable(isle_ctx* ctx, int on);
 int isle_hip_timing_reset(isle_ctx* ctx);

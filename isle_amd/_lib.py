@@ -20,6 +20,10 @@ SYMBOLS = {
     "isle_hip_threshold": (_I, [_P, _U64, C.c_double, _U64, _P, _P, _P, _P]),
     "isle_hip_get_B": (_I, [_P, _P, _P, _P, _P, _P]),
     "isle_hip_shape": (_I, [_P, _P, _P, _P, _P, _P]),
+    "isle_hip_catchwords": (_I, [_P, _I, _P, _U64, C.c_double, _P, _P, _P]),
+    "isle_hip_topic_model": (_I, [_P, _I, _U64, _P, _P, _P, _P, _P]),
+    "isle_hip_get_doc_topic_sums": (_I, [_P, _P, _P, _P]),
+    "isle_hip_edge_topics": (_I, [_P, _P, _I, _F, _P]),
     "isle_hip_frobenius": (_I, [_P, _P]),
     "isle_hip_gram_apply": (_I, [_P, _P, _I, _P]),
     "isle_hip_block_ks": (_I, [_P, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P]),

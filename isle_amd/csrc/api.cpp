@@ -259,6 +259,9 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   c->members_valid = false;
   c->U_k = 0;
   c->centers_ready = false;
+  c->assign_valid = false;
+  c->p_catch_ready = false;
+  c->p_model_ready = false;
   c->b_from_threshold = false;
   return 0;
 }
@@ -309,6 +312,9 @@ extern "C" int isle_hip_upload_counts_u32(isle_ctx* c, uint64_t V, uint64_t D, u
   }
   HIPCHK(c, hipMemcpy(c->a_offs.p, offs, (D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   c->a_ready = true;
+  c->a_avg_valid = false;
+  c->p_catch_ready = false;
+  c->p_model_ready = false;
   return 0;
 }
 
@@ -333,6 +339,8 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   const uint64_t tokens = st[0], nz_docs = st[1];
   const float avg = (float)(tokens / std::max<uint64_t>(nz_docs, 1));  // :98, integer division
   if (avg_out) *avg_out = avg;
+  c->a_avg = avg;
+  c->a_avg_valid = true;
   const uint64_t maxv64 = (uint64_t)avg + 2;
   if (maxv64 > 65535) return isle_fail(c, ISLE_E_ARG, "threshold: average document size %g too large", (double)avg);
   const uint32_t maxv = (uint32_t)maxv64;
@@ -443,6 +451,9 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   c->members_valid = false;
   c->U_k = 0;
   c->centers_ready = false;
+  c->assign_valid = false;
+  c->p_catch_ready = false;
+  c->p_model_ready = false;
   c->b_from_threshold = true;
   if (docs_kept) *docs_kept = Db;
   if (nnz_kept) *nnz_kept = bnnz;
@@ -471,6 +482,125 @@ extern "C" int isle_hip_get_B(isle_ctx* c, float* vals, uint32_t* rows, int64_t*
   if (offs) HIPCHK(c, hipMemcpy(offs, c->offs.p, (c->D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
   if (original_cols && c->D) HIPCHK(c, hipMemcpy(original_cols, c->original_cols.p, c->D * sizeof(uint64_t), hipMemcpyDeviceToHost));
   if (zetas) HIPCHK(c, hipMemcpy(zetas, c->zetas.p, c->V * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// downstream stage: catchwords, topic model, edge topics
+// ------------------------------------------------------------------------------------------
+static int post_prepare(isle_ctx* c, const char* who) {
+  if (!c->a_ready) return isle_fail(c, ISLE_E_ARG, "%s: no count matrix uploaded (isle_hip_upload_counts_u32)", who);
+  if (c->world > 1) return isle_fail(c, ISLE_E_ARG, "%s: single-rank only", who);
+  return 0;
+}
+
+extern "C" int isle_hip_catchwords(isle_ctx* c, int num_topics, const uint32_t* assign, uint64_t r, double rho, float* thresholds,
+                                   int32_t* catch_topic, uint64_t* num_catchwords) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(post_prepare(c, "catchwords"));
+  if (num_topics < 1) return isle_fail(c, ISLE_E_ARG, "catchwords: num_topics < 1");
+  if (r < 1 || r > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "catchwords: rank r = %llu out of range (too few documents per topic?)",
+                                                    (unsigned long long)r);
+  const bool identity = !c->b_from_threshold;
+  if (identity && c->D != c->a_D) return isle_fail(c, ISLE_E_ARG, "catchwords: B was uploaded separately and its columns do not match A's");
+  if (assign) {
+    for (uint64_t j = 0; j < c->D; ++j)
+      if (assign[j] >= (uint32_t)num_topics) return isle_fail(c, ISLE_E_ARG, "catchwords: assign[%llu] out of range", (unsigned long long)j);
+    HIPCHK(c, c->assign.reserve(c->D ? c->D : 1));
+    if (c->D) HIPCHK(c, hipMemcpy(c->assign.p, assign, c->D * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->assign_valid = true;
+    c->members_valid = false;
+  } else if (!c->assign_valid) {
+    return isle_fail(c, ISLE_E_ARG, "catchwords: no partition resident (run isle_hip_lloyds_sparse or pass assign)");
+  }
+  if (!c->a_avg_valid) {  // B came from the host: the corpus statistics were never computed here
+    HIPCHK(c, c->a_scan.reserve(isle_scan_scratch(c->a_D) + 4));
+    ISLECHK(k_th_stats(c, (uint64_t*)c->a_scan.p));
+    uint64_t st[2];
+    HIPCHK(c, hipMemcpyAsync(st, c->a_scan.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->a_avg = (float)(st[0] / std::max<uint64_t>(st[1], 1));
+    c->a_avg_valid = true;
+  }
+  ISLECHK(k_post_normalize(c, c->a_avg));
+  ISLECHK(k_post_cluster_of(c, c->assign.p, identity));
+  HIPCHK(c, c->counts.reserve(num_topics));
+  ISLECHK(k_count_sizes(c, c->assign.p, c->D, num_topics, c->counts.p));
+  ISLECHK(k_post_catch_thresholds(c, (uint32_t)num_topics, (uint32_t)r, c->counts.p));
+  uint64_t nc = 0;
+  ISLECHK(k_post_find_catchwords(c, (uint32_t)num_topics, rho, &nc));
+  if (num_catchwords) *num_catchwords = nc;
+  c->p_k = num_topics;
+  c->p_catch_ready = true;
+  c->p_model_ready = false;
+  if (thresholds) {
+    HIPCHK(c, c->p_segvals.reserve((size_t)c->a_V * num_topics));
+    ISLECHK(k_post_thr_colmajor(c, (uint32_t)num_topics, c->p_segvals.p));
+    HIPCHK(c, hipMemcpyAsync(thresholds, c->p_segvals.p, (size_t)c->a_V * num_topics * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (catch_topic) HIPCHK(c, hipMemcpyAsync(catch_topic, c->p_catch.p, c->a_V * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int isle_hip_topic_model(isle_ctx* c, int num_topics, uint64_t rank_threshold, float* model, float* model_threshold, int32_t* top1,
+                                    int32_t* top2, uint64_t* doc_topic_sums) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(post_prepare(c, "topic_model"));
+  if (!c->p_catch_ready || c->p_k != num_topics) return isle_fail(c, ISLE_E_ARG, "topic_model: run isle_hip_catchwords(num_topics = %d) first", num_topics);
+  if (rank_threshold < 1 || rank_threshold > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "topic_model: rank_threshold out of range");  // :721
+  uint64_t n = 0;
+  ISLECHK(k_post_doc_topic_sums(c, (uint32_t)num_topics, &n));
+  ISLECHK(k_post_model_thresholds(c, (uint32_t)num_topics, (uint32_t)rank_threshold));
+  ISLECHK(k_post_model(c, (uint32_t)num_topics));
+  c->p_model_ready = true;
+  if (doc_topic_sums) *doc_topic_sums = n;
+  if (model) HIPCHK(c, hipMemcpyAsync(model, c->p_model.p, (size_t)c->a_V * num_topics * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (model_threshold) HIPCHK(c, hipMemcpyAsync(model_threshold, c->p_mthr.p, num_topics * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (top1 && c->a_D) HIPCHK(c, hipMemcpyAsync(top1, c->p_top1.p, c->a_D * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (top2 && c->a_D) HIPCHK(c, hipMemcpyAsync(top2, c->p_top2.p, c->a_D * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int isle_hip_get_doc_topic_sums(isle_ctx* c, int64_t* doc_offsets, uint32_t* topic, float* val) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->p_model_ready) return isle_fail(c, ISLE_E_ARG, "get_doc_topic_sums: run isle_hip_topic_model first");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (doc_offsets) HIPCHK(c, hipMemcpy(doc_offsets, c->p_dts_off.p, (c->a_D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (topic && c->p_dts_n) HIPCHK(c, hipMemcpy(topic, c->p_dts_topic.p, c->p_dts_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (val && c->p_dts_n) HIPCHK(c, hipMemcpy(val, c->p_dts_val.p, c->p_dts_n * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int isle_hip_edge_topics(isle_ctx* c, const int64_t* pairs, int n, float primary_ratio, float* edge) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->p_model_ready) return isle_fail(c, ISLE_E_ARG, "edge_topics: run isle_hip_topic_model first");
+  if (n < 0 || (n && (!pairs || !edge))) return isle_fail(c, ISLE_E_ARG, "edge_topics: bad arguments");
+  if (n == 0) return 0;
+  for (int e = 0; e < 2 * n; ++e)
+    if (pairs[e] < 0 || pairs[e] >= c->p_k) return isle_fail(c, ISLE_E_ARG, "edge_topics: topic id %lld out of range", (long long)pairs[e]);
+  DevBuf<int64_t> pd;
+  DevBuf<float> ed;
+  HIPCHK(c, pd.reserve(2 * (size_t)n));
+  hipError_t e1 = ed.reserve((size_t)c->a_V * n);
+  if (e1 != hipSuccess) {
+    pd.release();
+    HIPCHK(c, e1);
+  }
+  int rc = 0;
+  hipError_t he = hipMemcpy(pd.p, pairs, 2 * (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (he == hipSuccess) rc = k_post_edge(c, pd.p, n, primary_ratio, (float)(1.0 - (double)primary_ratio), ed.p);
+  if (he == hipSuccess && rc == 0) he = hipStreamSynchronize(c->stream);
+  if (he == hipSuccess && rc == 0) he = hipMemcpy(edge, ed.p, (size_t)c->a_V * n * sizeof(float), hipMemcpyDeviceToHost);
+  pd.release();
+  ed.release();
+  ISLECHK(rc);
+  HIPCHK(c, he);
   return 0;
 }
 
@@ -1101,6 +1231,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   HIPCHK(c, c->cnorm.reserve(k));
   HIPCHK(c, c->counts.reserve(k));
   HIPCHK(c, c->assign.reserve(D ? D : 1));
+  c->assign_valid = false;
   std::vector<float> Ch((size_t)k * ldk, 0.f);
   for (int cc = 0; cc < k; ++cc) memcpy(Ch.data() + (size_t)cc * ldk, C_lowd + (size_t)cc * k, (size_t)k * sizeof(float));
   HIPCHK(c, hipMemcpy(c->Cdev.p, Ch.data(), Ch.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1225,6 +1356,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   HIPCHK(c, c->cnorm.reserve(k));
   HIPCHK(c, c->counts.reserve(k));
   HIPCHK(c, c->assign.reserve(D ? D : 1));
+  c->assign_valid = false;
   ISLECHK(k_doc_norms(c, c->dnorm.p));  // :1680-1687
   // Hamerly bounds: an exact acceleration of the assignment step (documents whose bounds prove "unchanged" are skipped)
   const bool hamerly = !getenv("ISLE_NO_HAMERLY");
@@ -1301,6 +1433,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       break;
     }
   }
+  c->assign_valid = true;  // the partition stays resident for isle_hip_catchwords
   if (assign && D) HIPCHK(c, hipMemcpyAsync(assign, c->assign.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   if (centers_out) {
     HIPCHK(c, c->centers_cm.reserve((size_t)V * k));

@@ -68,6 +68,30 @@ struct isle_ctx {
   DevBuf<float> zetas;             // V
   DevBuf<uint64_t> original_cols;  // D (B column -> global document id of A)
   bool b_from_threshold = false;
+  float a_avg = 0.f;               // avg_doc_sz of the whole corpus (src/sparseMatrix.cpp:98)
+  bool a_avg_valid = false;
+
+  // --- downstream stage (post.hip): catchwords, topic model, edge topics
+  DevBuf<float> a_nv;              // normalised values of A
+  DevBuf<int32_t> p_cluster_of;    // a_D
+  DevBuf<uint32_t> p_cnt, p_min, p_slot;   // V x k, word-major
+  DevBuf<float> p_thr;             // V x k, word-major catchword thresholds
+  DevBuf<uint64_t> p_seg_id, p_seg_off, p_counters;
+  DevBuf<uint32_t> p_seg_len, p_seg_rank, p_seg_cur;
+  DevBuf<float> p_segvals;
+  DevBuf<int32_t> p_catch;         // V: topic the word is a catchword of, or -1
+  DevBuf<uint32_t> p_nz;
+  DevBuf<int64_t> p_dts_off;       // a_D + 1
+  DevBuf<uint32_t> p_dts_topic;
+  DevBuf<float> p_dts_val;
+  uint64_t p_dts_n = 0;
+  DevBuf<int32_t> p_top1, p_top2;  // a_D
+  DevBuf<uint32_t> p_tcnt;
+  DevBuf<int64_t> p_toff;
+  DevBuf<float> p_mthr;            // k
+  DevBuf<float> p_model;           // V x k col-major
+  int p_k = 0;                     // num_topics of the last catchword pass
+  bool p_catch_ready = false, p_model_ready = false, assign_valid = false;
 
   // --- chunked-CSR copy of B for Z = B*Y (built per eigensolve, like the reference's operator ctor)
   bool band_ready = false;
@@ -190,6 +214,17 @@ int k_th_count(isle_ctx* c, bool with_weights);
 int k_th_drop(isle_ctx* c, const uint8_t* drop_dev);
 int k_th_scans(isle_ctx* c);
 int k_th_emit(isle_ctx* c, uint64_t doc_base);
+
+// post.hip
+int k_post_normalize(isle_ctx* c, float avg);
+int k_post_cluster_of(isle_ctx* c, const uint32_t* assign_dev, bool identity);
+int k_post_catch_thresholds(isle_ctx* c, uint32_t k, uint32_t r, const int* sizes_dev);
+int k_post_find_catchwords(isle_ctx* c, uint32_t k, double rho, uint64_t* ncatch_host);
+int k_post_thr_colmajor(isle_ctx* c, uint32_t k, float* out_dev);
+int k_post_doc_topic_sums(isle_ctx* c, uint32_t k, uint64_t* n_out);
+int k_post_model_thresholds(isle_ctx* c, uint32_t k, uint32_t rank);
+int k_post_model(isle_ctx* c, uint32_t k);
+int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, float* edge_dev);
 
 // dense.hip
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);

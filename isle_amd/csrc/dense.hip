@@ -446,8 +446,6 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
                                                    int nrowch, double* __restrict__ scr, unsigned int* __restrict__ rotated) {
   __shared__ double G[BJ_P][BJ_P + 1];
   __shared__ double Q[BJ_P][BJ_P + 1];
-  __shared__ double rc[BJ_W], rs[BJ_W];
-  __shared__ int rp[BJ_W], rq[BJ_W];
   __shared__ unsigned int nrot;
   int A, Bk;
   bj_blocks(nblk2, round, blockIdx.x, &A, &Bk);
@@ -465,22 +463,37 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
   }
   if (t == 0) nrot = 0;
   __syncthreads();
+  // Thread (bi, bj) owns the 2x2 block G[{p_i,q_i}][{p_j,q_j}] of rotation pairs i and j, and two rows of Q's column
+  // pair i.  Every thread derives the two rotations it needs from G's diagonal blocks itself (redundant arithmetic, but
+  // no separate parameter phase): a round is read -> barrier -> write -> barrier.
+  const int bi = t >> 4, bj = t & 15;
+  unsigned int my_rot = 0;
   for (int ir = 0; ir < BJ_P - 1; ++ir) {
-    if (t < BJ_W) {
-      int p, q;
-      rr_pair(BJ_P, ir, t, &p, &q);
-      if (p > q) {
-        const int x = p;
-        p = q;
-        q = x;
-      }
+    int pi, qi, pj, qj;
+    rr_pair(BJ_P, ir, bi, &pi, &qi);
+    rr_pair(BJ_P, ir, bj, &pj, &qj);
+    if (pi > qi) {
+      const int x = pi;
+      pi = qi;
+      qi = x;
+    }
+    if (pj > qj) {
+      const int x = pj;
+      pj = qj;
+      qj = x;
+    }
+    double cs[2], sn[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int p = w ? pj : pi, q = w ? qj : qi;
       const double a = G[p][p], b = G[q][q], gpq = G[p][q];
-      double cs = 1.0, sn = 0.0;
+      cs[w] = 1.0;
+      sn[w] = 0.0;
       // relative test between live columns; absolute floor for (numerically) null columns of a singular S + mu I
       if (a > 0.0 && b > 0.0 && gpq * gpq > tol * tol * a * b && fabs(gpq) > abs_tol) {
         // tan(theta) only steers the annihilation: fp32 is enough (the sweep repeats); cos must make the rotation
         // orthogonal to fp64 accuracy, so it gets an fp64 reciprocal square root with Newton refinement
-        const float zf = (float)((b - a) / (2.0 * gpq));
+        const float zf = (float)(b - a) / (float)(2.0 * gpq);
         const float tf = (zf >= 0.f ? 1.f : -1.f) / (fabsf(zf) + sqrtf(1.f + zf * zf));
         const double tt = (double)tf;
         const double u = 1.0 + tt * tt;
@@ -488,41 +501,30 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
         y = y * (1.5 - 0.5 * u * y * y);
         y = y * (1.5 - 0.5 * u * y * y);
         y = y * (1.5 - 0.5 * u * y * y);
-        cs = y;
-        sn = cs * tt;
-        atomicAdd(&nrot, 1u);
+        cs[w] = y;
+        sn[w] = y * tt;
+        if (w == 0 && bj == 0) ++my_rot;
       }
-      rp[t] = p;
-      rq[t] = q;
-      rc[t] = cs;
-      rs[t] = sn;
     }
+    const double x00 = G[pi][pj], x01 = G[pi][qj], x10 = G[qi][pj], x11 = G[qi][qj];
+    const int r0 = bj * 2;
+    const double q0p = Q[r0][pi], q0q = Q[r0][qi], q1p = Q[r0 + 1][pi], q1q = Q[r0 + 1][qi];
+    // columns (pair j), then rows (pair i):  G <- J_i^T (G J_j)
+    const double y00 = cs[1] * x00 - sn[1] * x01, y01 = sn[1] * x00 + cs[1] * x01;
+    const double y10 = cs[1] * x10 - sn[1] * x11, y11 = sn[1] * x10 + cs[1] * x11;
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int item = t + 256 * u;
-      const int mat = item >> 9, rem = item & 511;
-      const int pr = rem >> 5, r = rem & 31;
-      const int p = rp[pr], q = rq[pr];
-      const double cs = rc[pr], sn = rs[pr];
-      double(*M)[BJ_P + 1] = mat ? Q : G;
-      const double x = M[r][p], y = M[r][q];
-      M[r][p] = cs * x - sn * y;
-      M[r][q] = sn * x + cs * y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int item = t + 256 * u;
-      const int pr = item >> 5, cc = item & 31;
-      const int p = rp[pr], q = rq[pr];
-      const double cs = rc[pr], sn = rs[pr];
-      const double x = G[p][cc], y = G[q][cc];
-      G[p][cc] = cs * x - sn * y;
-      G[q][cc] = sn * x + cs * y;
-    }
+    G[pi][pj] = cs[0] * y00 - sn[0] * y10;
+    G[qi][pj] = sn[0] * y00 + cs[0] * y10;
+    G[pi][qj] = cs[0] * y01 - sn[0] * y11;
+    G[qi][qj] = sn[0] * y01 + cs[0] * y11;
+    Q[r0][pi] = cs[0] * q0p - sn[0] * q0q;
+    Q[r0][qi] = sn[0] * q0p + cs[0] * q0q;
+    Q[r0 + 1][pi] = cs[0] * q1p - sn[0] * q1q;
+    Q[r0 + 1][qi] = sn[0] * q1p + cs[0] * q1q;
     __syncthreads();
   }
+  if (my_rot) atomicAdd(&nrot, my_rot);
+  __syncthreads();
   for (int idx = t; idx < BJ_P * BJ_P; idx += 256) S[idx] = Q[idx / BJ_P][idx % BJ_P];
   if (t == 0) {
     // store the COUNT (not `nrot ? 1.0 : 0.0`): hipcc 7.2 lowered that select to s_cselect on a stale SCC here and

@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import IsleHipError, load_library
 
 TIMING_FAMILIES = ["gram_pass1", "gram_pass2", "ortho", "qr", "evd", "rotate", "project", "kmpp", "lloyd_proj",
-                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold"]
+                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post"]
 
 BLOCK_KS_MAX_ITERS = 100      # include/hyperparams.h:38
 BLOCK_KS_BLOCK_SIZE = 10      # include/hyperparams.h:39
@@ -122,6 +122,44 @@ class HotPath:
         self._chk(self._lib.isle_hip_get_B(self._h, _p(out["vals"]), _p(out["rows"]), _p(out["offs"]),
                                            _p(oc) if oc is not None else None, _p(ze) if ze is not None else None))
         return out
+
+    # ---- downstream stage: catchwords, topic model, edge topics ---------------------------
+    def find_catchwords(self, num_topics, r, assign=None, rho=1.1, fetch_thresholds=True):
+        """rth_highest_element per topic + find_catchwords (src/trainer.cpp:586-627).
+        -> dict(thresholds (V,k) F-order or None, catch_topic int32[V], num_catchwords)."""
+        V = self.V
+        thr = np.empty((V, num_topics), np.float32, order="F") if fetch_thresholds else None
+        ct = np.empty(V, np.int32)
+        n = C.c_uint64()
+        a = None if assign is None else np.ascontiguousarray(assign, np.uint32)
+        self._chk(self._lib.isle_hip_catchwords(self._h, int(num_topics), _p(a), int(r), float(rho), _p(thr), _p(ct), C.byref(n)))
+        return dict(thresholds=thr, catch_topic=ct, num_catchwords=int(n.value))
+
+    def construct_topic_model(self, num_topics, rank_threshold, num_docs_A, fetch_sums=True):
+        """SparseMatrix::construct_topic_model (src/sparseMatrix.cpp:597-838) on the device."""
+        V = self.V
+        M = np.empty((V, num_topics), np.float32, order="F")
+        mt = np.empty(num_topics, np.float32)
+        t1 = np.empty(num_docs_A, np.int32)
+        t2 = np.empty(num_docs_A, np.int32)
+        n = C.c_uint64()
+        self._chk(self._lib.isle_hip_topic_model(self._h, int(num_topics), int(rank_threshold), _p(M), _p(mt), _p(t1), _p(t2), C.byref(n)))
+        out = dict(model=M, model_threshold=mt, top1=t1, top2=t2, num_sums=int(n.value))
+        if fetch_sums:
+            off = np.empty(num_docs_A + 1, np.int64)
+            tp = np.empty(out["num_sums"], np.uint32)
+            va = np.empty(out["num_sums"], np.float32)
+            self._chk(self._lib.isle_hip_get_doc_topic_sums(self._h, _p(off), _p(tp), _p(va)))
+            out.update(dts_off=off, dts_topic=tp, dts_val=va)
+        return out
+
+    def edge_topics(self, pairs, primary_ratio=0.7):
+        """FPaxpy pair of construct_edge_topics_v2 (src/trainer.cpp:1152-1159): pairs (n,2) -> (V,n) F-order."""
+        pairs = np.ascontiguousarray(pairs, np.int64).reshape(-1, 2)
+        n = pairs.shape[0]
+        E = np.empty((self.V, n), np.float32, order="F")
+        self._chk(self._lib.isle_hip_edge_topics(self._h, _p(pairs), n, float(primary_ratio), _p(E)))
+        return E
 
     def frobenius(self):
         out = C.c_float()

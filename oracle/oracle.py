@@ -174,3 +174,103 @@ def qr(A):
     lib().orc_qr(_p(A), C.c_uint64(n), C.c_uint64(c), _p(Q), _p(R), C.byref(rk))
     r = rk.value
     return Q[:, :r], R[: r * c].reshape((c, r)).T.copy(), r
+
+
+# ---- stage downstream of the hot path and edge topics (8a a19): isle_post_oracle.cpp -----------
+W0_C, EPS2_C, EPS3_C, RHO_C = 1.0, 1.0 / 3.0, 5.0, 1.1       # include/hyperparams.h:8-12
+EDGE_TOPIC_MIN_DOCS, EDGE_TOPIC_PRIMARY_RATIO = 1, 0.7       # include/hyperparams.h:77-79
+
+
+def catchword_rank(num_docs, num_topics, sample_rate=None):
+    """r of src/trainer.cpp:579-583 (float operands, double arithmetic)."""
+    x = EPS2_C * W0_C * float(np.float32(num_docs))
+    if sample_rate is not None:
+        x = x * float(np.float32(sample_rate))
+    return int(np.floor(x / float(np.float32(2.0 * num_topics))))
+
+
+def model_rank_threshold(num_docs, num_topics):
+    """rank_threshold of src/sparseMatrix.cpp:720."""
+    return int(EPS3_C * W0_C * float(np.float32(num_docs)) / (float(np.float32(num_topics)) * 2.0))
+
+
+def post_normalize(offs, counts, avg_doc_sz):
+    offs = np.ascontiguousarray(offs, np.int64)
+    counts = np.ascontiguousarray(counts, np.float32)
+    nv = np.empty_like(counts)
+    L = lib()
+    L.orc_post_normalize.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_post_normalize(offs.shape[0] - 1, _p(offs), _p(counts), float(avg_doc_sz), _p(nv))
+    return nv
+
+
+def post_catch_thresholds(V, offs, rows, nv, cluster_of, k, r):
+    """-> thresholds (V, k) Fortran-ordered (catchword_thresholds of src/trainer.cpp:586-590)."""
+    offs = np.ascontiguousarray(offs, np.int64)
+    rows = np.ascontiguousarray(rows, np.uint32)
+    nv = np.ascontiguousarray(nv, np.float32)
+    cl = np.ascontiguousarray(cluster_of, np.int32)
+    thr = np.empty((V, k), np.float32, order="F")
+    L = lib()
+    L.orc_post_catch_thresholds.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_uint64, C.c_void_p]
+    L.orc_post_catch_thresholds(V, offs.shape[0] - 1, k, _p(offs), _p(rows), _p(nv), _p(cl), int(r), _p(thr))
+    return thr
+
+
+def post_find_catchwords(thr, rho=RHO_C):
+    thr = np.asfortranarray(thr, np.float32)
+    V, k = thr.shape
+    ct = np.empty(V, np.int32)
+    L = lib()
+    L.orc_post_find_catchwords.restype = C.c_int64
+    L.orc_post_find_catchwords.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p, C.c_double, C.c_void_p]
+    n = L.orc_post_find_catchwords(V, k, _p(thr), float(rho), _p(ct))
+    assert n >= 0, "a word qualified as catchword of two topics"
+    return ct
+
+
+def post_topic_model(V, offs, rows, nv, cluster_of, catch_topic, k, rank_threshold):
+    """-> dict(model (V,k) F-order, dts_doc, dts_topic, dts_val, model_threshold, top1, top2)."""
+    offs = np.ascontiguousarray(offs, np.int64)
+    rows = np.ascontiguousarray(rows, np.uint32)
+    nv = np.ascontiguousarray(nv, np.float32)
+    cl = np.ascontiguousarray(cluster_of, np.int32)
+    ct = np.ascontiguousarray(catch_topic, np.int32)
+    D = offs.shape[0] - 1
+    M = np.empty((V, k), np.float32, order="F")
+    L = lib()
+    L.orc_post_topic_model.restype = C.c_void_p
+    L.orc_post_topic_model.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint64, C.c_void_p]
+    L.orc_post_dts_size.restype = C.c_uint64
+    L.orc_post_dts_size.argtypes = [C.c_void_p]
+    L.orc_post_dts_get.argtypes = [C.c_void_p] * 7
+    L.orc_post_free.argtypes = [C.c_void_p]
+    h = C.c_void_p(L.orc_post_topic_model(V, D, k, _p(offs), _p(rows), _p(nv), _p(cl), _p(ct), int(rank_threshold), _p(M)))
+    n = int(L.orc_post_dts_size(h))
+    out = dict(model=M, dts_doc=np.empty(n, np.uint64), dts_topic=np.empty(n, np.uint32), dts_val=np.empty(n, np.float32),
+               model_threshold=np.empty(k, np.float32), top1=np.empty(D, np.int32), top2=np.empty(D, np.int32))
+    L.orc_post_dts_get(h, _p(out["dts_doc"]), _p(out["dts_topic"]), _p(out["dts_val"]), _p(out["model_threshold"]),
+                       _p(out["top1"]), _p(out["top2"]))
+    L.orc_post_free(h)
+    return out
+
+
+def post_edge_topics(model, top1, top2, max_edge_topics, want_edge=True):
+    model = np.asfortranarray(model, np.float32)
+    V, k = model.shape
+    t1 = np.ascontiguousarray(top1, np.int32)
+    t2 = np.ascontiguousarray(top2, np.int32)
+    cap = int(max_edge_topics)
+    pairs = np.zeros((cap, 3), np.int64)
+    L = lib()
+    L.orc_post_edge_topics.restype = C.c_uint64
+    L.orc_post_edge_topics.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
+                                       C.c_void_p, C.c_void_p]
+    # the count is not known before the call: size Edge for the worst case the caller allows
+    ncap = min(cap, k * k)
+    edge = np.zeros((V, ncap), np.float32, order="F") if want_edge else None
+    pairs = np.zeros((ncap, 3), np.int64)
+    n = int(L.orc_post_edge_topics(V, t1.shape[0], _p(t1), _p(t2), ncap, EDGE_TOPIC_MIN_DOCS, _p(model),
+                                   EDGE_TOPIC_PRIMARY_RATIO, _p(pairs), _p(edge)))
+    return pairs[:n], (edge[:, :n] if want_edge else None)
