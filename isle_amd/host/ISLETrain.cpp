@@ -5,9 +5,9 @@
 //
 // Runs ingest (host, prestage.h) -> thresholding (device) -> the hot path src/trainer.cpp:490-571 on the GPU, and writes into
 // the reference's log directory (src/utils.cpp:28-48) diagnosticLog.txt / timerLog.txt with the reference's line
-// formats for these phases.  What comes AFTER the hot path in the reference (catchwords, topic model,
-// M_hat_catch_sparse, edge topics: SURVEY §8f next-3) is not built yet: the partition and centres are written to
-// HotPathClusters.tsv / HotPathSingularValues.txt instead and the program says so.
+// formats for these phases, then catchwords, the topic model and (optionally) edge topics on the device
+// (src/trainer.cpp:577-654, :673-693) and the reference's output files M_hat_catch_sparse, TopWordsPerTopic_catch.txt,
+// EdgeModel_sparse.  Extra files: HotPathClusters.tsv / HotPathSingularValues.txt (partition and singular values).
 #include <sys/stat.h>
 
 #include <chrono>
@@ -64,6 +64,54 @@ std::string log_dir_name(uint64_t num_topics, const std::string& base, bool samp
   if (sample_docs) s += "_Rate_" + std::to_string(sample_rate);
   return base + "/" + s;
 }
+// DenseMatrix::write_to_file_as_sparse (src/denseMatrix.cpp:155-186, mmap branch) with MMappedOutput::concat_int /
+// concat_float (include/utils.h:405-478): "<topic>\t<word>\t<weight>\n", 1-based, entries <= 1e-8 skipped, the weight
+// written as integer part, '.', then SIX digits produced by repeated multiplication in FPTYPE — truncated, not rounded
+// (the before_dec / after_dec arguments of concat_float never reach ftoa_mv).
+void write_dense_as_sparse(const std::string& filename, const float* M, uint64_t vocab_size, uint64_t ncols) {
+  std::string buf;
+  buf.reserve(1 << 24);
+  FILE* f = std::fopen(filename.c_str(), "wb");
+  if (!f) throw std::runtime_error("cannot open " + filename);
+  char tmp[64];
+  for (uint64_t topic = 0; topic < ncols; ++topic)
+    for (uint64_t word = 0; word < vocab_size; ++word) {
+      float num = M[topic * vocab_size + word];
+      if (!(num > 0.00000001f)) continue;
+      buf += std::to_string(topic + 1);
+      buf += '\t';
+      buf += std::to_string(word + 1);
+      buf += '\t';
+      int i = 0;
+      unsigned int num_int = (unsigned int)num;
+      if (num_int == 0) {
+        tmp[i++] = '0';
+      } else {
+        char rev[16];
+        int n = 0;
+        for (int d = 0; d < 6 && num_int > 0; ++d) {
+          rev[n++] = (char)('0' + num_int % 10);
+          num_int /= 10;
+        }
+        while (n) tmp[i++] = rev[--n];
+      }
+      tmp[i++] = '.';
+      float frac = num - (float)((int)num);
+      for (int d = 0; d < 6; ++d) {
+        frac *= 10;
+        tmp[i++] = (char)('0' + (int)frac);
+        frac -= (int)frac;
+      }
+      tmp[i++] = '\n';
+      buf.append(tmp, (size_t)i);
+      if (buf.size() > (1u << 24) - 256) {
+        std::fwrite(buf.data(), 1, buf.size(), f);
+        buf.clear();
+      }
+    }
+  std::fwrite(buf.data(), 1, buf.size(), f);
+  std::fclose(f);
+}
 }  // namespace
 
 int main(int argv, char** argc) {
@@ -86,7 +134,6 @@ int main(int argv, char** argc) {
   const bool sample = atoi(argc[9]);
   const FPTYPE sample_rate = (FPTYPE)atof(argc[10]);
   const bool compute_edge_topics = atoi(argc[11]);
-  (void)vocab_file;
 
   try {
     const std::string log_dir = log_dir_name(num_topics, output_dir, sample, sample_rate, tf_idf);
@@ -183,8 +230,102 @@ int main(int argv, char** argc) {
       sv << std::setprecision(9);
       for (doc_id_t t = 0; t < num_topics; ++t) sv << std::sqrt(evalues[t]) << "\n";
     }
-    log.print("NOTE: catchwords / topic model / M_hat_catch_sparse / edge topics are not built in this implementation yet;\n"
-              "      wrote HotPathClusters.tsv and HotPathSingularValues.txt (hot path src/trainer.cpp:490-571 complete).\n");
+
+    // ---- src/trainer.cpp:577-654: catchwords and the topic model, on the device ------------------
+    uint64_t r;  // :579-583
+    if (sample)
+      r = (uint64_t)std::floor(ISLE_EPS2_C * ISLE_W0_C * (FPTYPE)num_docs * sample_rate / (FPTYPE)(2.0 * num_topics));
+    else
+      r = (uint64_t)std::floor(ISLE_EPS2_C * ISLE_W0_C * (FPTYPE)num_docs / (FPTYPE)(2.0 * num_topics));
+    FPTYPE* catchword_thresholds = new FPTYPE[(size_t)vocab_size * num_topics];
+    std::vector<word_id_t>* catchwords = new std::vector<word_id_t>[num_topics];
+    B_fl_CSC->find_catchwords(num_topics, r, catchword_thresholds, catchwords);
+    log.next_time_secs("Collecting word freqs in clusters");
+    log.next_time_secs("Finding catchwords for clusters");
+    FPTYPE* Model = new FPTYPE[(size_t)vocab_size * num_topics];
+    std::vector<std::tuple<int, int, doc_id_t>> top_topic_pairs;
+    B_fl_CSC->construct_topic_model(Model, num_topics, num_docs, compute_edge_topics ? &top_topic_pairs : NULL);
+    log.next_time_secs("Constructing topic vectors");
+
+    // ---- output_cluster_summary (src/trainer.cpp:776-826) -------------------------------------------
+    std::vector<std::string> vocab_words;
+    {  // create_vocab_list, src/utils.cpp:6-25
+      std::ifstream in(vocab_file);
+      std::string word;
+      while (in.good() && !in.eof() && vocab_words.size() < vocab_size) {
+        in >> word;
+        vocab_words.push_back(word);
+      }
+      vocab_words.resize(vocab_size);
+    }
+    const word_id_t ntop = std::min<word_id_t>(10, vocab_size);  // max(DEFAULT_COHERENCE_NUM_WORDS, 10), :781-783
+    std::vector<std::vector<std::pair<word_id_t, FPTYPE>>> topwords(num_topics);
+    for (doc_id_t t = 0; t < num_topics; ++t) {  // DenseMatrix::find_n_top_words, src/denseMatrix.cpp:92-107 (ties: lower word id first)
+      std::vector<std::pair<word_id_t, FPTYPE>>& tw = topwords[t];
+      tw.reserve(vocab_size);
+      for (word_id_t w = 0; w < vocab_size; ++w) tw.push_back(std::make_pair(w, Model[(size_t)t * vocab_size + w]));
+      std::stable_sort(tw.begin(), tw.end(), [](const std::pair<word_id_t, FPTYPE>& l, const std::pair<word_id_t, FPTYPE>& r2) { return l.second > r2.second; });
+      if (tw[ntop - 1].second == (FPTYPE)0.0) std::cout << "\n ==== WARNING: top words in topic " << t << " have zero weight\n\n";
+      tw.resize(ntop);
+    }
+    for (doc_id_t t = 0; t < num_topics; ++t) {
+      std::ostringstream o;
+      o << "\n---------- Topic: " << t << ", Cluster_size: " << closest_docs[t].size() << " -----------\n";
+      o << "Catchwords:\n";  // include/logUtils.h:49-64
+      for (word_id_t w : catchwords[t]) o << vocab_words[w] << ":" << w << "(" << catchword_thresholds[(size_t)t * vocab_size + w] << ") ";
+      o << "\n";
+      o << "\n#Top words: " << topwords[t].size() << "\n";  // src/denseMatrix.cpp:110-121
+      for (auto& tw : topwords[t]) o << vocab_words[tw.first] << ":" << tw.first << "(" << tw.second << ") ";
+      o << "\n\n";
+      log.diag << o.str();
+    }
+    log.diag << "\n---------------------------\n";
+    log.print("\n Avg coherence: " + std::to_string(0.0f) + "\n\n");
+    {  // LogUtils::print_cluster_details, include/logUtils.h:66-99
+      std::vector<std::pair<int, doc_id_t>> cluster_sizes;
+      for (doc_id_t t = 0; t < num_topics; ++t) cluster_sizes.push_back(std::make_pair((int)closest_docs[t].size(), t));
+      std::stable_sort(cluster_sizes.begin(), cluster_sizes.end(),
+                       [](const std::pair<int, doc_id_t>& l, const std::pair<int, doc_id_t>& r2) { return l.first < r2.first; });
+      std::ostringstream o;
+      int catchless = 0;
+      for (doc_id_t i = 0; i < num_topics; ++i) {
+        const doc_id_t t = cluster_sizes[i].second;
+        o << std::setw(12) << std::left << "Cluster" << t << std::setw(12) << std::left << "  size:" << cluster_sizes[i].first << std::setw(15)
+          << std::left << "  distsq_sum:" << 0 << std::setw(15) << std::left << "  raw_coh:" << 0 << std::setw(15) << std::left << "  flt_coh:" << 0
+          << "  #catchwords: " << catchwords[t].size() << std::endl;
+        if (catchwords[t].size() == 0) catchless++;
+      }
+      o << "\n#Topics with no catchwords: " << catchless << "(" << num_topics << ")" << std::endl;
+      log.print(o.str());
+    }
+    log.next_time_secs("Output summary");
+
+    // ---- write_model_to_file (src/trainer.cpp:656-662) ----------------------------------------------
+    auto write_top_words = [&]() {  // output_top_words, :855-868
+      std::ofstream out_top_words(log_dir + "/TopWordsPerTopic_catch.txt");
+      for (doc_id_t t = 0; t < num_topics; ++t) {
+        for (auto& tw : topwords[t]) out_top_words << vocab_words[tw.first] << "\t";
+        out_top_words << std::endl;
+      }
+      log.next_time_secs("Writing top words to file");
+    };
+    write_top_words();
+    write_dense_as_sparse(log_dir + "/M_hat_catch_sparse", Model, vocab_size, num_topics);  // output_model(true), :831-838
+    log.next_time_secs("Output model");
+    write_top_words();
+    log.next_time_secs("Output topwords");
+
+    if (compute_edge_topics) {  // train_edge_topics + write_edgemodel_to_file, :673-693
+      std::vector<std::tuple<int, int, uint64_t>> selected_pairs;
+      std::vector<FPTYPE> EdgeModel;
+      B_fl_CSC->construct_edge_topics(top_topic_pairs, atoi(argc[12]), selected_pairs, EdgeModel);
+      log.next_time_secs("Constructing edge topic model");
+      write_dense_as_sparse(log_dir + "/EdgeModel_sparse", EdgeModel.data(), vocab_size, selected_pairs.size());
+      log.next_time_secs("Output edge model");
+    }
+    delete[] catchword_thresholds;
+    delete[] catchwords;
+    delete[] Model;
     log.total("TVSD");
     delete[] centers;
     delete[] closest_docs;

@@ -11,7 +11,9 @@
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/isle_hip.h"
@@ -28,6 +30,12 @@ typedef float FPTYPE;
 #define ISLE_BLOCK_KS_MAX_ITERS 100
 #define ISLE_BLOCK_KS_BLOCK_SIZE 10
 #define ISLE_BLOCK_KS_TOLERANCE 1e-4f
+#define ISLE_W0_C (1.0)            // :8
+#define ISLE_EPS2_C (1.0 / 3.0)    // :10
+#define ISLE_RHO_C (1.1)           // :11
+#define ISLE_EPS3_C (5.0)          // :12
+#define ISLE_EDGE_TOPIC_MIN_DOCS 1          // :77
+#define ISLE_EDGE_TOPIC_PRIMARY_RATIO 0.7   // :79
 
 class FPSparseMatrixHip {
   word_id_t vocab_size_;
@@ -184,6 +192,73 @@ class FPSparseMatrixHip {
     if (iters < max_reps) std::cout << "Lloyds converged\n";
     fill_partition(assign.data(), closest_docs, num_centers);
     return 0.0f;
+  }
+
+  // ---- the stage after the hot path, on the count matrix this object was built from (from_counts) --------------------
+  // src/trainer.cpp:577-627: A_sp->rth_highest_element(r, closest_docs[t], ...) for every topic, then
+  // A_sp->find_catchwords(num_topics, catchword_thresholds, catchwords).  The partition is the one run_lloyds left on the
+  // device (its closest_docs, mapped through original_cols exactly as :572-575 does).
+  void find_catchwords(const doc_id_t num_topics, const uint64_t r, FPTYPE* catchword_thresholds /*vocab x topics, col-major*/,
+                       std::vector<word_id_t>* catchwords /*[num_topics]*/) {
+    std::vector<int32_t> catch_topic(vocab_size_);
+    uint64_t n = 0;
+    check(isle_hip_catchwords(ctx_, (int)num_topics, nullptr, r, ISLE_RHO_C, catchword_thresholds, catch_topic.data(), &n), "find_catchwords");
+    for (doc_id_t t = 0; t < num_topics; ++t) catchwords[t].clear();
+    for (word_id_t w = 0; w < vocab_size_; ++w)
+      if (catch_topic[w] >= 0) catchwords[catch_topic[w]].push_back(w);
+  }
+  // A_sp->construct_topic_model(Model, num_topics, closest_docs, catchwords, ..., &top_topic_pairs, ...)
+  // src/sparseMatrix.cpp:597-838; rank_threshold as at :720.
+  void construct_topic_model(FPTYPE* Model /*vocab x topics, col-major*/, const doc_id_t num_topics, const doc_id_t num_docs_A,
+                             std::vector<std::tuple<int, int, doc_id_t>>* top_topic_pairs) {
+    const uint64_t rank_threshold = (doc_id_t)(ISLE_EPS3_C * ISLE_W0_C * (FPTYPE)num_docs_A / ((FPTYPE)num_topics * 2.0));
+    std::vector<int32_t> t1, t2;
+    if (top_topic_pairs) {
+      t1.resize(num_docs_A);
+      t2.resize(num_docs_A);
+    }
+    check(isle_hip_topic_model(ctx_, (int)num_topics, rank_threshold, Model, nullptr, top_topic_pairs ? t1.data() : nullptr,
+                               top_topic_pairs ? t2.data() : nullptr, nullptr),
+          "construct_topic_model");
+    if (top_topic_pairs) {
+      top_topic_pairs->clear();
+      for (doc_id_t d = 0; d < num_docs_A; ++d)
+        if (t1[d] >= 0 && t2[d] >= 0) top_topic_pairs->push_back(std::make_tuple((int)t1[d], (int)t2[d], d));
+    }
+  }
+  // ISLETrainer::construct_edge_topics_v2 (src/trainer.cpp:1116-1167): pair selection on the host, the FPaxpy pair on the
+  // device.  Ties in the count ordering are broken by (primary, secondary) ascending (the reference's sort is unstable).
+  void construct_edge_topics(std::vector<std::tuple<int, int, doc_id_t>>& top_topic_pairs, const int max_edge_topics,
+                             std::vector<std::tuple<int, int, uint64_t>>& selected_pairs, std::vector<FPTYPE>& EdgeModel /*vocab x #edge*/) {
+    auto lt = [](const std::tuple<int, int, doc_id_t>& l, const std::tuple<int, int, doc_id_t>& r) {
+      return std::get<0>(l) < std::get<0>(r) || (std::get<0>(l) == std::get<0>(r) && std::get<1>(l) < std::get<1>(r));
+    };
+    std::sort(top_topic_pairs.begin(), top_topic_pairs.end(), lt);
+    selected_pairs.clear();
+    for (size_t i = 0; i < top_topic_pairs.size();) {
+      size_t j = i;
+      while (j < top_topic_pairs.size() && !lt(top_topic_pairs[i], top_topic_pairs[j])) ++j;
+      if ((int64_t)(j - i) >= ISLE_EDGE_TOPIC_MIN_DOCS)
+        selected_pairs.push_back(std::make_tuple(std::get<0>(top_topic_pairs[i]), std::get<1>(top_topic_pairs[i]), (uint64_t)(j - i)));
+      i = j;
+    }
+    std::cout << "#Candidates for edge topics: " << selected_pairs.size() << std::endl;
+    std::stable_sort(selected_pairs.begin(), selected_pairs.end(),
+                     [](const std::tuple<int, int, uint64_t>& l, const std::tuple<int, int, uint64_t>& r) { return std::get<2>(l) > std::get<2>(r); });
+    if ((int64_t)selected_pairs.size() > (int64_t)max_edge_topics) {
+      std::cout << "Edge topic threshold: " << std::get<2>(selected_pairs[max_edge_topics]) << std::endl;
+      selected_pairs.resize(max_edge_topics);
+    }
+    std::cout << "#Edge topics: " << selected_pairs.size() << std::endl;
+    std::vector<int64_t> pq(2 * selected_pairs.size());
+    for (size_t e = 0; e < selected_pairs.size(); ++e) {
+      pq[2 * e] = std::get<0>(selected_pairs[e]);
+      pq[2 * e + 1] = std::get<1>(selected_pairs[e]);
+    }
+    EdgeModel.assign((size_t)vocab_size_ * selected_pairs.size(), 0.f);
+    check(isle_hip_edge_topics(ctx_, pq.data(), (int)selected_pairs.size(), (float)ISLE_EDGE_TOPIC_PRIMARY_RATIO, EdgeModel.data()),
+          "construct_edge_topics");
+    std::cout << "Completed edge topic construction" << std::endl;
   }
 };
 
