@@ -253,7 +253,27 @@ def main():
               "GB_per_s_over_A": round(12.0 * nnz_A / max(tm2["threshold"][0], 1e-9) / 1e6, 1),
               "h2d_upload_ms": round(t_up * 1e3, 1), "cpu_port_ms": round(t_thr_cpu * 1e3, 1), "cpu_cores": effective_cpus(),
               "identical_to_cpu": bool(same)}
-        del got, A_host
+        del got
+        # downstream stage on the partition the last timed step left on the device ... after re-running the hot path on the
+        # device-built B (identical to the uploaded one), outside the timed region
+        from oracle.oracle import catchword_rank, model_rank_threshold
+        step(-100)
+        hp.timing_enable(True)
+        hp.timing_reset()
+        t1 = time.perf_counter()
+        cw = hp.find_catchwords(k, catchword_rank(D_per, k), fetch_thresholds=False)
+        t_cw = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        tmo = hp.construct_topic_model(k, model_rank_threshold(D_per, k), D_per, fetch_sums=False)
+        t_tm = time.perf_counter() - t1
+        tm3 = hp.timing_get()
+        hp.timing_enable(False)
+        down = {"stage": "catchwords + topic model on the device (src/trainer.cpp:577-654)",
+                "catchwords_wall_ms": round(t_cw * 1e3, 3), "topic_model_wall_ms": round(t_tm * 1e3, 3),
+                "device_ms": round(tm3["post"][0], 3), "num_catchwords": cw["num_catchwords"],
+                "doc_topic_sums": tmo["num_sums"], "model_columns_sum_to_one": bool(np.allclose(np.abs(tmo["model"]).sum(0), 1.0, rtol=1e-3))}
+        up["downstream"] = down
+        del A_host
 
     out = {
         "metric": "docs/sec end-to-end ISLETrain hot path (SVD+k-means)",
