@@ -78,6 +78,21 @@ int isle_hip_upload_counts_u32(isle_ctx* ctx, uint64_t vocab_size, uint64_t num_
                                const float* counts, const uint32_t* rows, const int64_t* offsets,
                                uint64_t doc_offset, uint64_t docs_global);
 
+/* tdf ingest on the device: DocWordEntriesReader::fill_doc_word_entries
+ * (include/utils.h:158-228) + the sort / de-duplication of ISLETrainer::finalize_data
+ * (src/trainer.cpp:236-247) + SparseMatrix::populate_CSC (src/sparseMatrix.cpp:58-87).
+ * `text`: the bytes of a tdf file ("<doc> <word> <count>" per line, 1-based ids, blanks or tabs between
+ * fields, optional '\r', last newline optional).  The result is this context's count matrix, exactly
+ * as if it had been passed to isle_hip_upload_counts_u32 (single rank: doc_offset 0).  max_entries:
+ * the reference asserts the file holds exactly that many lines; 0 = do not check.  Of several
+ * lines with the same (doc, word) the first in the file survives (the reference keeps an unspecified
+ * one).  entries_read / nnz (nullable): lines parsed / entries after de-duplication. */
+int isle_hip_ingest_tdf(isle_ctx* ctx, const char* text, uint64_t nbytes, uint64_t vocab_size, uint64_t num_docs,
+                        uint64_t max_entries, uint64_t* entries_read, uint64_t* nnz);
+/* Copies the context's count matrix to the host (any pointer may be NULL); nnz via the call above
+ * or offsets[num_docs]. */
+int isle_hip_get_A(isle_ctx* ctx, float* counts, uint32_t* rows, int64_t* offsets);
+
 /* normalize_docs (src/sparseMatrix.cpp:136-167) + list_word_freqs / compute_thresholds (:289-485)
  * + FPSparseMatrix(A, zetas) = threshold_and_copy (:1285-1361), or sampled_threshold_and_copy
  * (:1365-1435) when 0 < sample_rate < 1 — what ISLETrainer::train does at src/trainer.cpp:430-485.
@@ -217,7 +232,8 @@ enum {
   ISLE_T_COMM = 12,        /* collectives                          */
   ISLE_T_THRESHOLD = 13,   /* A -> B thresholding (upstream stage) */
   ISLE_T_POST = 14,        /* catchwords / topic model / edge topics (downstream stage) */
-  ISLE_T_COUNT = 15
+  ISLE_T_INGEST = 15,      /* tdf text -> count matrix */
+  ISLE_T_COUNT = 16
 };
 int isle_hip_timing_enable(isle_ctx* ctx, int on);
 int isle_hip_timing_reset(isle_ctx* ctx);

@@ -17,6 +17,8 @@ SYMBOLS = {
     "isle_hip_upload_csc_u64": (_I, [_P, _U64, _U64, _U64, _P, _P, _P, _U64, _U64]),
     "isle_hip_upload_csc_u32": (_I, [_P, _U64, _U64, _U64, _P, _P, _P, _U64, _U64]),
     "isle_hip_upload_counts_u32": (_I, [_P, _U64, _U64, _U64, _P, _P, _P, _U64, _U64]),
+    "isle_hip_ingest_tdf": (_I, [_P, _P, _U64, _U64, _U64, _U64, _P, _P]),
+    "isle_hip_get_A": (_I, [_P, _P, _P, _P]),
     "isle_hip_threshold": (_I, [_P, _U64, C.c_double, _U64, _P, _P, _P, _P]),
     "isle_hip_get_B": (_I, [_P, _P, _P, _P, _P, _P]),
     "isle_hip_shape": (_I, [_P, _P, _P, _P, _P, _P]),

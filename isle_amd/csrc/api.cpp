@@ -318,6 +318,52 @@ extern "C" int isle_hip_upload_counts_u32(isle_ctx* c, uint64_t V, uint64_t D, u
   return 0;
 }
 
+extern "C" int isle_hip_ingest_tdf(isle_ctx* c, const char* text, uint64_t nbytes, uint64_t V, uint64_t D, uint64_t max_entries,
+                                   uint64_t* entries_read, uint64_t* nnz) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->world > 1) return isle_fail(c, ISLE_E_ARG, "ingest_tdf: single-rank only");
+  if (V == 0 || V > 0xfffffff0ull || D == 0 || D > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "ingest_tdf: vocab/doc count out of range");
+  if (nbytes && !text) return isle_fail(c, ISLE_E_ARG, "ingest_tdf: null text");
+  c->a_ready = false;
+  DevBuf<unsigned char> td;
+  HIPCHK(c, td.reserve(nbytes + 16));
+  hipError_t he = nbytes ? hipMemcpy(td.p, text, nbytes, hipMemcpyHostToDevice) : hipSuccess;
+  uint64_t nread = 0, err[2] = {0, 0};
+  int rc = 0;
+  if (he == hipSuccess) rc = k_ingest_tdf(c, td.p, nbytes, V, D, &nread, err);
+  (void)hipStreamSynchronize(c->stream);
+  td.release();
+  HIPCHK(c, he);
+  ISLECHK(rc);
+  if (err[0]) {
+    static const char* what[] = {"", "bad character", "more than three fields", "fewer than three fields", "doc/word id is 0 or exceeds <num_docs>/<vocab_size>"};
+    return isle_fail(c, ISLE_E_ARG, "ingest_tdf: %s on line %llu", what[err[0] < 5 ? err[0] : 0], (unsigned long long)(err[1] + 1));
+  }
+  if (max_entries && nread != max_entries)  // include/utils.h:227
+    return isle_fail(c, ISLE_E_ARG, "ingest_tdf: file has %llu entries, <max_entries> says %llu", (unsigned long long)nread, (unsigned long long)max_entries);
+  c->a_doc_offset = 0;
+  c->a_D_global = D;
+  c->a_ready = true;
+  c->a_avg_valid = false;
+  c->p_catch_ready = false;
+  c->p_model_ready = false;
+  if (entries_read) *entries_read = nread;
+  if (nnz) *nnz = c->a_nnz;
+  return 0;
+}
+
+extern "C" int isle_hip_get_A(isle_ctx* c, float* counts, uint32_t* rows, int64_t* offs) {
+  if (!c) return ISLE_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->a_ready) return isle_fail(c, ISLE_E_ARG, "get_A: no count matrix");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (counts && c->a_nnz) HIPCHK(c, hipMemcpy(counts, c->a_cnt.p, c->a_nnz * sizeof(float), hipMemcpyDeviceToHost));
+  if (rows && c->a_nnz) HIPCHK(c, hipMemcpy(rows, c->a_rows.p, c->a_nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (offs) HIPCHK(c, hipMemcpy(offs, c->a_offs.p, (c->a_D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sample_rate, uint64_t sample_seed, uint64_t* docs_kept,
                                   uint64_t* nnz_kept, uint64_t* entries_above, float* avg_out) {
   if (!c) return ISLE_E_ARG;

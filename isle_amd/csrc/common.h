@@ -215,6 +215,9 @@ int k_th_drop(isle_ctx* c, const uint8_t* drop_dev);
 int k_th_scans(isle_ctx* c);
 int k_th_emit(isle_ctx* c, uint64_t doc_base);
 
+// ingest.hip
+int k_ingest_tdf(isle_ctx* c, const unsigned char* text_dev, uint64_t n, uint64_t V, uint64_t D, uint64_t* entries_read, uint64_t* err_out);
+
 // post.hip
 int k_post_normalize(isle_ctx* c, float avg);
 int k_post_cluster_of(isle_ctx* c, const uint32_t* assign_dev, bool identity);

@@ -3,7 +3,7 @@
 //   ISLETrain <tdf_file> <vocab_file> <output_dir> <vocab_size> <num_docs> <max_entries> <num_topics>
 //             <apply tf-idf(0/1)> <sample(0/1)> <sample_rate> <edge topics(0/1)> <max_edge_topics>
 //
-// Runs ingest (host, prestage.h) -> thresholding (device) -> the hot path src/trainer.cpp:490-571 on the GPU, and writes into
+// Runs ingest (device) -> thresholding (device) -> the hot path src/trainer.cpp:490-571 on the GPU, and writes into
 // the reference's log directory (src/utils.cpp:28-48) diagnosticLog.txt / timerLog.txt with the reference's line
 // formats for these phases, then catchwords, the topic model and (optionally) edge topics on the device
 // (src/trainer.cpp:577-654, :673-693) and the reference's output files M_hat_catch_sparse, TopWordsPerTopic_catch.txt,
@@ -142,12 +142,25 @@ int main(int argv, char** argc) {
     else std::cerr << "Subdir exists already" << std::endl;
     Logs log(log_dir);
 
-    std::vector<prestage::DocWordEntry> entries;
-    prestage::read_tdf(tdf_file, (uint64_t)max_entries, entries);
+    // ---- ingest (include/utils.h:96-229; src/trainer.cpp:232-371) and thresholding (:430-485), both on the device --------
+    std::vector<char> text;
+    {
+      FILE* f = std::fopen(tdf_file.c_str(), "rb");
+      if (!f) throw std::runtime_error("cannot open tdf file " + tdf_file);
+      std::fseek(f, 0, SEEK_END);
+      const long sz = std::ftell(f);
+      std::fseek(f, 0, SEEK_SET);
+      text.resize((size_t)sz);
+      if (sz && std::fread(text.data(), 1, (size_t)sz, f) != (size_t)sz) {
+        std::fclose(f);
+        throw std::runtime_error("short read on " + tdf_file);
+      }
+      std::fclose(f);
+    }
     {
       std::ostringstream s;  // src/trainer.cpp:130-143
       s << "\n<<<<<<<<<<<<\t" << tdf_file << "\t>>>>>>>>>>>>\n\n"
-        << std::setfill('.') << std::setw(10) << std::left << std::setw(15) << std::left << "#Entries" << entries.size() << "\n"
+        << std::setfill('.') << std::setw(10) << std::left << std::setw(15) << std::left << "#Entries" << max_entries << "\n"
         << std::setw(15) << std::left << "#Words" << vocab_size << "\n"
         << std::setw(15) << std::left << "#Docs" << num_docs << "\n"
         << std::setw(15) << std::left << "#Topics" << num_topics << "\n"
@@ -159,21 +172,17 @@ int main(int argv, char** argc) {
       log.print(s.str());
     }
     log.next_time_secs("Reading file Entries");
-    prestage::Csc A;
-    float avg_doc_sz = 0.f;
-    uint64_t nz_docs = 0;
-    prestage::build_A(entries, vocab_size, num_docs, A, &avg_doc_sz, &nz_docs);
-    std::cout << "Entries in sparse matrix: " << A.offs[num_docs] << std::endl << "Average document size: " << avg_doc_sz << std::endl;
-    log.next_time_secs("Populating CSC");
-
-    // src/trainer.cpp:430-485 on the device: thresholds from the whole corpus, B built in HBM
-    std::vector<uint32_t> rows32(A.rows.begin(), A.rows.end());
     std::vector<doc_id_t> original_cols;
-    uint64_t entries_above_threshold = 0;
-    FPSparseMatrixHip* B_fl_CSC = FPSparseMatrixHip::from_counts(vocab_size, num_docs, A.vals.data(), rows32.data(), A.offs.data(), num_topics,
-                                                                 sample ? (double)sample_rate : 0.0, original_cols, nullptr,
-                                                                 &entries_above_threshold);
-    std::vector<uint32_t>().swap(rows32);
+    uint64_t entries_in_A = 0, entries_above_threshold = 0;
+    float avg_doc_sz = 0.f;
+    FPSparseMatrixHip* B_fl_CSC = FPSparseMatrixHip::from_tdf(vocab_size, num_docs, text.data(), text.size(), max_entries, num_topics,
+                                                              sample ? (double)sample_rate : 0.0, original_cols, &entries_in_A,
+                                                              &entries_above_threshold, &avg_doc_sz);
+    std::vector<char>().swap(text);
+    log.next_time_secs("Sorting entries");
+    log.next_time_secs("De-duplicating entries");
+    std::cout << "Entries in sparse matrix: " << entries_in_A << std::endl << "Average document size: " << avg_doc_sz << std::endl;
+    log.next_time_secs("Populating CSC");
     log.next_time_secs("Computing thresholds");
     log.print("Number of entries above threshold: " + std::to_string(entries_above_threshold) + "\n");
     std::cout << (sample ? "After sampling docs: cols remaining: " : "Columns remaining after thresholding: ") << B_fl_CSC->num_docs() << "\n";

@@ -60,6 +60,19 @@ class FPSparseMatrixHip {
     for (doc_id_t d = 0; d < num_docs_; ++d) closest_docs[assign[d]].push_back(d);  // ascending, as :1669-1672
   }
 
+  void threshold_on_device(doc_id_t num_topics, double sample_rate, std::vector<doc_id_t>& original_cols, std::vector<FPTYPE>* zetas,
+                           uint64_t* entries_above_threshold, float* avg_doc_sz) {
+    uint64_t docs_kept = 0, nnz_kept = 0;
+    check(isle_hip_threshold(ctx_, num_topics, sample_rate, 0, &docs_kept, &nnz_kept, entries_above_threshold, avg_doc_sz), "threshold");
+    num_docs_ = docs_kept;
+    nnzs_ = (offset_t)nnz_kept;
+    uploaded_ = true;
+    original_cols.resize(docs_kept);
+    static_assert(sizeof(doc_id_t) == sizeof(uint64_t), "doc_id_t is 8 bytes (include/types.h:25)");
+    if (zetas) zetas->resize(vocab_size_);
+    check(isle_hip_get_B(ctx_, nullptr, nullptr, nullptr, (uint64_t*)original_cols.data(), zetas ? zetas->data() : nullptr), "get_B");
+  }
+
  public:
   // the reference re-exports these as public (include/sparseMatrix.h:216,227-230)
   FPTYPE* vals_CSC = nullptr;
@@ -92,16 +105,25 @@ class FPSparseMatrixHip {
     try {
       B->check(isle_hip_upload_counts_u32(B->ctx_, vocab_size, num_docs, (uint64_t)offsets[num_docs], counts, rows, offsets, 0, num_docs),
                "upload_counts");
-      uint64_t docs_kept = 0, nnz_kept = 0;
-      B->check(isle_hip_threshold(B->ctx_, num_topics, sample_rate, 0, &docs_kept, &nnz_kept, entries_above_threshold, avg_doc_sz),
-               "threshold");
-      B->num_docs_ = docs_kept;
-      B->nnzs_ = (offset_t)nnz_kept;
-      B->uploaded_ = true;
-      original_cols.resize(docs_kept);
-      static_assert(sizeof(doc_id_t) == sizeof(uint64_t), "doc_id_t is 8 bytes (include/types.h:25)");
-      if (zetas) zetas->resize(vocab_size);
-      B->check(isle_hip_get_B(B->ctx_, nullptr, nullptr, nullptr, (uint64_t*)original_cols.data(), zetas ? zetas->data() : nullptr), "get_B");
+      B->threshold_on_device(num_topics, sample_rate, original_cols, zetas, entries_above_threshold, avg_doc_sz);
+    } catch (...) {
+      delete B;
+      throw;
+    }
+    return B;
+  }
+
+  // The same with the ingest on the device as well: `text` holds the bytes of the tdf file
+  // (DocWordEntriesReader::fill_doc_word_entries include/utils.h:158-228, the sort / de-duplication of
+  // ISLETrainer::finalize_data src/trainer.cpp:236-247 and SparseMatrix::populate_CSC src/sparseMatrix.cpp:58-87).
+  static FPSparseMatrixHip* from_tdf(word_id_t vocab_size, doc_id_t num_docs, const char* text, uint64_t nbytes, offset_t max_entries,
+                                     doc_id_t num_topics, double sample_rate, std::vector<doc_id_t>& original_cols,
+                                     uint64_t* entries_in_A = nullptr, uint64_t* entries_above_threshold = nullptr, float* avg_doc_sz = nullptr,
+                                     int device = 0) {
+    FPSparseMatrixHip* B = new FPSparseMatrixHip(vocab_size, 0, device);
+    try {
+      B->check(isle_hip_ingest_tdf(B->ctx_, text, nbytes, vocab_size, num_docs, (uint64_t)max_entries, nullptr, entries_in_A), "ingest_tdf");
+      B->threshold_on_device(num_topics, sample_rate, original_cols, nullptr, entries_above_threshold, avg_doc_sz);
     } catch (...) {
       delete B;
       throw;

@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import IsleHipError, load_library
 
 TIMING_FAMILIES = ["gram_pass1", "gram_pass2", "ortho", "qr", "evd", "rotate", "project", "kmpp", "lloyd_proj",
-                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post"]
+                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post", "ingest"]
 
 BLOCK_KS_MAX_ITERS = 100      # include/hyperparams.h:38
 BLOCK_KS_BLOCK_SIZE = 10      # include/hyperparams.h:39
@@ -96,6 +96,23 @@ class HotPath:
         D = offs.shape[0] - 1
         self._chk(self._lib.isle_hip_upload_counts_u32(self._h, V, D, int(offs[-1]), _p(counts), _p(rows), _p(offs),
                                                        doc_offset, docs_global))
+        self._a_shape = (int(V), D, int(offs[-1]))
+
+    def ingest_tdf(self, text, vocab_size, num_docs, max_entries=0):
+        """tdf text (bytes) -> the context's count matrix A, on the device (include/utils.h:158-228,
+        src/trainer.cpp:236-247, src/sparseMatrix.cpp:58-87).  -> dict(entries_read, nnz)."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        nr, nz = C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.isle_hip_ingest_tdf(self._h, _p(buf) if buf.size else None, int(buf.size), int(vocab_size), int(num_docs),
+                                                int(max_entries), C.byref(nr), C.byref(nz)))
+        self._a_shape = (int(vocab_size), int(num_docs), int(nz.value))
+        return dict(entries_read=int(nr.value), nnz=int(nz.value))
+
+    def get_A(self):
+        V, D, nnz = self._a_shape
+        cnt, rows, offs = np.empty(nnz, np.float32), np.empty(nnz, np.uint32), np.empty(D + 1, np.int64)
+        self._chk(self._lib.isle_hip_get_A(self._h, _p(cnt), _p(rows), _p(offs)))
+        return cnt, rows, offs
 
     def threshold(self, num_topics, sample_rate=0.0, sample_seed=0):
         """normalize_docs + compute_thresholds + (sampled_)threshold_and_copy on the device
