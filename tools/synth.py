@@ -99,6 +99,16 @@ class Corpus:
         return (_arr(L.synth_A_counts(self._h), self.nnz_A, np.float32), _arr(L.synth_A_rows(self._h), self.nnz_A, np.uint32),
                 _arr(L.synth_A_offs(self._h), self.D + 1, np.int64))
 
+    def tdf_bytes(self):
+        """The corpus as tdf text ("<doc> <word> <count>\\n", 1-based ids) in a uint8 array."""
+        L = _lib()
+        L.synth_tdf_bytes.restype = C.c_uint64
+        L.synth_tdf_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        buf = np.empty(self.nnz_A * 26 + 16, np.uint8)
+        n = int(L.synth_tdf_bytes(self._h, buf.ctypes.data, buf.size))
+        assert n > 0
+        return buf[:n]
+
     def planted(self):
         return _arr(_lib().synth_dom(self._h), self.D, np.uint32)
 

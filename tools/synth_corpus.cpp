@@ -309,6 +309,42 @@ uint64_t synth_threshold(void* h, uint32_t k) {
 }
 
 uint64_t synth_nnz_A(void* h) { return ((Corpus*)h)->offs.back(); }
+
+// tdf text of A ("<doc> <word> <count>\n", 1-based) into out[cap]; returns the number of bytes (0 if cap is too small).
+uint64_t synth_tdf_bytes(void* h, char* out, uint64_t cap) {
+  Corpus* c = (Corpus*)h;
+  const uint64_t D = c->D;
+  std::vector<uint64_t> start(D + 1, 0);
+  auto digits = [](uint64_t x) { int n = 1; while (x >= 10) { x /= 10; ++n; } return (uint64_t)n; };
+#pragma omp parallel for schedule(dynamic, 4096)
+  for (int64_t d = 0; d < (int64_t)D; ++d) {
+    uint64_t b = 0;
+    for (int64_t i = c->offs[d]; i < c->offs[d + 1]; ++i) b += digits(d + 1) + digits((uint64_t)c->rows[i] + 1) + digits((uint64_t)c->counts[i]) + 3;
+    start[d + 1] = b;
+  }
+  for (uint64_t d = 0; d < D; ++d) start[d + 1] += start[d];
+  if (start[D] > cap) return 0;
+  auto put = [](char* p, uint64_t x) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + x % 10); x /= 10; } while (x);
+    for (int j = 0; j < n; ++j) p[j] = tmp[n - 1 - j];
+    return p + n;
+  };
+#pragma omp parallel for schedule(dynamic, 4096)
+  for (int64_t d = 0; d < (int64_t)D; ++d) {
+    char* p = out + start[d];
+    for (int64_t i = c->offs[d]; i < c->offs[d + 1]; ++i) {
+      p = put(p, (uint64_t)d + 1);
+      *p++ = ' ';
+      p = put(p, (uint64_t)c->rows[i] + 1);
+      *p++ = ' ';
+      p = put(p, (uint64_t)c->counts[i]);
+      *p++ = '\n';
+    }
+  }
+  return start[D];
+}
 uint64_t synth_docs_B(void* h) { return ((Corpus*)h)->Db; }
 const float* synth_A_counts(void* h) { return ((Corpus*)h)->counts.data(); }
 const uint32_t* synth_A_rows(void* h) { return ((Corpus*)h)->rows.data(); }
