@@ -30,6 +30,7 @@ WORKLOADS = {
     "c1": (10_000, 50_000, 50, 12345),     # configs[0] (reference's CPU-runnable case)
     "c2": (50_000, 1_000_000, 200, 2024),  # configs[1]  <- bench default
     "c3shard": (100_000, 1_250_000, 1000, 31337),  # one GPU's share of configs[2]
+    "c3full": (100_000, 10_000_000, 1000, 31337),  # ALL of configs[2] on one GPU (fits: ~110 GB of 288 GB)
     "tiny": (2_000, 5_000, 10, 0),
 }
 

@@ -23,6 +23,14 @@ hp = HotPath(0)
 import os
 if os.environ.get("ISLE_FORCE_COMM"):
     hp.comm_init(1, 0, HotPath.comm_unique_id())
+from tools.synth import Corpus
+cc = Corpus(1500, 4000, 10, 5)
+cnt, rows, offs = cc.A()
+hp.upload_counts(1500, cnt, rows, offs, doc_offset=0, docs_global=4000)
+ti = hp.threshold(10)   # all-reduce of corpus statistics + histogram, all-gather of surviving column counts
+Bd = hp.get_B()
+thr_sig = [Bd["D"], Bd["nnz"], int(Bd["rows"].astype(np.int64).sum()), float(Bd["vals"].astype(np.float64).sum()),
+           int(Bd["original_cols"].astype(np.int64).sum()), ti["entries_above_threshold"], hp.doc_offset, hp.D_global]
 hp.upload_csc(B["V"], B["vals"], B["rows"], B["offs"], doc_offset=0, docs_global=B["D"])
 X = np.random.default_rng(0).standard_normal((B["V"], 10)).astype(np.float32)
 Z = hp.gram_apply(X)
@@ -35,7 +43,7 @@ free = hp.kmeans_init_on_projected_space(k, rng_seed=9)
 lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
 hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
 ls = hp.run_lloyds(k)
-print(json.dumps(dict(fro=hp.frobenius(), Z=float(np.abs(Z).sum()), ev=r["evals"].tolist(), seeds=free["seeds"].tolist(),
+print(json.dumps(dict(fro=hp.frobenius(), thr=thr_sig, Z=float(np.abs(Z).sum()), ev=r["evals"].tolist(), seeds=free["seeds"].tolist(),
                       res=g["residual"], lp_it=lp["iters"], lp_assign=lp["assign"].tolist(), ls_it=ls["iters"],
                       ls_assign=ls["assign"].tolist(), cen=float(np.abs(ls["centers"]).sum()))))
 ''' % (ROOT, ROOT)
@@ -56,6 +64,7 @@ def run(force):
 def test_one_rank_communicator_is_the_identity():
     a, b = run(False), run(True)
     assert abs(a["fro"] - b["fro"]) <= 1e-6 * a["fro"]
+    assert a["thr"] == b["thr"]
     assert abs(a["Z"] - b["Z"]) <= 1e-5 * a["Z"]
     assert np.allclose(a["ev"], b["ev"], rtol=1e-5)
     assert a["seeds"] == b["seeds"]  # same host RNG, same D^2 prefix sums -> same draws
