@@ -708,76 +708,11 @@ extern "C" int isle_hip_gram_apply(isle_ctx* c, const float* X, int b, float* Z)
 // to working precision.  F: n x w (device, destroyed).  Q: n x rank written to Qdst.  R: rank x w.
 // ------------------------------------------------------------------------------------------
 static int dev_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, std::vector<float>& R, int* rank_out) {
-  std::vector<double> G((size_t)w * w);
-  ISLECHK(k_gram64(c, F, n, w, G.data()));
-  auto g = [&](int i, int j) { return G[(size_t)j * w + i]; };
-  std::vector<double> R1((size_t)w * w, 0.0);  // (row r, col j) at [j*w + r]
-  std::vector<int> piv;
-  for (int i = 0; i < w; ++i) {
-    double s = g(i, i);
-    const int rk = (int)piv.size();
-    for (int r = 0; r < rk; ++r) s -= R1[(size_t)i * w + r] * R1[(size_t)i * w + r];
-    const double nrm = s > 0.0 ? std::sqrt(s) : 0.0;
-    // ks_utils.h:66-69 absolute test, plus a relative guard for what an fp64 Gram matrix can resolve
-    if ((float)nrm < 1e-6f || s <= 1e-13 * g(i, i) * (double)w) continue;
-    for (int j = i; j < w; ++j) {
-      double t = g(i, j);
-      for (int r = 0; r < rk; ++r) t -= R1[(size_t)i * w + r] * R1[(size_t)j * w + r];
-      R1[(size_t)j * w + rk] = t / nrm;
-    }
-    piv.push_back(i);
-  }
-  const int rk = (int)piv.size();
+  std::vector<float> Rfull((size_t)w * w, 0.f);
+  int rk = 0;
+  ISLECHK(k_panel_qr(c, F, n, w, Qdst, Rfull.data(), &rk));
   *rank_out = rk;
-  R.assign((size_t)rk * w, 0.f);
-  if (rk == 0) return 0;
-  // T1 (w x rk): rows at pivot columns hold inv(R1[:, piv])
-  std::vector<double> Rp((size_t)rk * rk, 0.0), Ri((size_t)rk * rk, 0.0);  // upper triangular, [col*rk + row]
-  for (int a = 0; a < rk; ++a)
-    for (int r = 0; r <= a; ++r) Rp[(size_t)a * rk + r] = R1[(size_t)piv[a] * w + r];
-  auto inv_upper = [&](const std::vector<double>& U, std::vector<double>& X, int m) {
-    std::fill(X.begin(), X.end(), 0.0);
-    for (int j = 0; j < m; ++j) {
-      X[(size_t)j * m + j] = 1.0 / U[(size_t)j * m + j];
-      for (int i = j - 1; i >= 0; --i) {
-        double s = 0.0;
-        for (int t = i + 1; t <= j; ++t) s += U[(size_t)t * m + i] * X[(size_t)j * m + t];
-        X[(size_t)j * m + i] = -s / U[(size_t)i * m + i];
-      }
-    }
-  };
-  inv_upper(Rp, Ri, rk);
-  std::vector<float> T1((size_t)w * rk, 0.f);
-  for (int cc = 0; cc < rk; ++cc)
-    for (int a = 0; a < rk; ++a) T1[(size_t)cc * w + piv[a]] = (float)Ri[(size_t)cc * rk + a];
-  ISLECHK(k_apply_T(c, F, n, w, T1.data(), rk, Qdst));
-  // second pass
-  std::vector<double> G2((size_t)rk * rk);
-  ISLECHK(k_gram64(c, Qdst, n, rk, G2.data()));
-  std::vector<double> R2((size_t)rk * rk, 0.0), R2i((size_t)rk * rk, 0.0);
-  for (int i = 0; i < rk; ++i) {
-    double s = G2[(size_t)i * rk + i];
-    for (int r = 0; r < i; ++r) s -= R2[(size_t)i * rk + r] * R2[(size_t)i * rk + r];
-    if (!(s > 0.0)) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
-    const double nrm = std::sqrt(s);
-    R2[(size_t)i * rk + i] = nrm;
-    for (int j = i + 1; j < rk; ++j) {
-      double t = G2[(size_t)j * rk + i];
-      for (int r = 0; r < i; ++r) t -= R2[(size_t)i * rk + r] * R2[(size_t)j * rk + r];
-      R2[(size_t)j * rk + i] = t / nrm;
-    }
-  }
-  inv_upper(R2, R2i, rk);
-  std::vector<float> T2((size_t)rk * rk);
-  for (size_t i = 0; i < T2.size(); ++i) T2[i] = (float)R2i[i];
-  ISLECHK(k_apply_T(c, Qdst, n, rk, T2.data(), rk, Qdst));
-  // R = R2 * R1   (rk x w)
-  for (int j = 0; j < w; ++j)
-    for (int r = 0; r < rk; ++r) {
-      double s = 0.0;
-      for (int t = r; t < rk; ++t) s += R2[(size_t)t * rk + r] * R1[(size_t)j * w + t];
-      R[(size_t)j * rk + r] = (float)s;
-    }
+  R.assign(Rfull.begin(), Rfull.begin() + (size_t)rk * w);
   return 0;
 }
 

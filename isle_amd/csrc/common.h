@@ -114,6 +114,9 @@ struct isle_ctx {
   DevBuf<double> part;     // partial reductions
   DevBuf<float> coef;      // 3 x (m x blk)
   DevBuf<double> gram;     // blk x blk
+  DevBuf<double> pq_part, pq_R1;  // panel QR: partial Gram matrices, first triangular factor
+  DevBuf<float> pq_T;             // panel QR: T (32 x 32) and R (32 x 32)
+  DevBuf<int> pq_meta;            // panel QR: rank, status, pivots
   DevBuf<float> small;     // misc small device scratch
   DevBuf<double> jacW, jacV;  // n x n each
   DevBuf<double> jacS;        // per-pair Gram / rotation scratch
@@ -233,6 +236,7 @@ int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, 
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef);
 int k_gram64(isle_ctx* c, const float* F, uint64_t n, int b, double* G_host /*b x b col-major*/);
+int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
 int k_apply_T(isle_ctx* c, const float* F, uint64_t n, int b, const float* T_host /*b x rk col-major*/, int rk, float* Q);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C);  // col-major, lda = ldc = M

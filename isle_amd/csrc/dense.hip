@@ -254,6 +254,215 @@ int k_apply_T(isle_ctx* c, const float* F, uint64_t n, int b, const float* T_hos
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Panel QR entirely on the device: rank-revealing CholQR2 on an fp64 Gram matrix (stands in for the fp64 MGS of
+// utils::compute_qr, block-ks/ks_utils.h:43-127, same drop rule :66-69).  Per pass: pqr_gram_k (partial Gram matrices
+// of 256-row slabs, fp64) -> pqr_factor_k (fixed-order reduction, Cholesky with column dropping, triangular inverse;
+// pass 2 also forms R = R2 R1) -> pqr_apply_k (Q = F T).  The rank lives in device memory between the kernels; the host
+// reads rank, status and R once at the end.
+// ------------------------------------------------------------------------------------------
+constexpr int PQ_ROWS = 256;
+constexpr int PQ_W = 32;  // widest panel
+constexpr int PQ_SUB = 2;  // 256-row slabs per workgroup of pqr_gram_k
+
+__global__ __launch_bounds__(256) void pqr_gram_k(const float* __restrict__ F, uint64_t n, int wmax, const int* __restrict__ w_dev,
+                                                   double* __restrict__ part /*[block][PQ_W*PQ_W]*/) {
+  __shared__ float Ft[PQ_W][PQ_ROWS + 1];
+  const int w = w_dev ? *w_dev : wmax;
+  // this thread's outputs (upper triangle only); at most 4 for w = 32
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int sub = 0; sub < PQ_SUB; ++sub) {
+    const uint64_t r0 = ((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS;
+    if (r0 >= n) break;
+    const int rc = (int)min((uint64_t)PQ_ROWS, n - r0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < w * PQ_ROWS; idx += 256) {
+      const int j = idx / PQ_ROWS, r = idx - j * PQ_ROWS;
+      Ft[j][r] = (r < rc) ? F[(uint64_t)j * n + r0 + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = threadIdx.x + 256 * q;
+      if (o >= w * w) break;
+      const int i = o / w, j = o - i * w;
+      if (j < i) continue;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains, combined in a fixed order
+#pragma unroll 4
+      for (int r = 0; r < PQ_ROWS; r += 4) {
+        s0 = fma((double)Ft[i][r], (double)Ft[j][r], s0);
+        s1 = fma((double)Ft[i][r + 1], (double)Ft[j][r + 1], s1);
+        s2 = fma((double)Ft[i][r + 2], (double)Ft[j][r + 2], s2);
+        s3 = fma((double)Ft[i][r + 3], (double)Ft[j][r + 3], s3);
+      }
+      acc[q] += (s0 + s1) + (s2 + s3);
+    }
+  }
+  double* out = part + (size_t)blockIdx.x * (PQ_W * PQ_W);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = threadIdx.x + 256 * q;
+    if (o >= w * w) break;
+    const int i = o / w, j = o - i * w;
+    if (j >= i) out[j * w + i] = acc[q];
+  }
+}
+
+// meta: [0] rank, [1] status (0 ok, 1 second Gram matrix not positive definite), [2..2+PQ_W) pivots
+__global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ part, int nparts, int wmax, int pass, double* __restrict__ R1g /*PQ_W*PQ_W*/,
+                                                     int* __restrict__ meta, float* __restrict__ T /*PQ_W*PQ_W*/, float* __restrict__ Rout) {
+  __shared__ double G[PQ_W][PQ_W + 1];
+  __shared__ double Rm[PQ_W][PQ_W + 1];  // Rm[r][col]: row r of the triangular factor
+  __shared__ double X[PQ_W][PQ_W + 1];
+  __shared__ int piv[PQ_W];
+  __shared__ int sh_rk, sh_bad;
+  __shared__ double sh_nrm;
+  const int t = threadIdx.x;
+  const int w = (pass == 1) ? wmax : meta[0];
+  for (int o = t; o < w * w; o += 256) {
+    const int i = o / w, j = o - i * w;  // G(i, j), upper triangle stored at [j*w + i]
+    const int u = (i <= j) ? j * w + i : i * w + j;
+    double s = 0.0;
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {  // eight loads in flight, summed in index order
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; p < nparts; ++p) s += part[(size_t)p * (PQ_W * PQ_W) + u];
+    G[i][j] = s;
+  }
+  for (int o = t; o < PQ_W * PQ_W; o += 256) {
+    Rm[o / PQ_W][o % PQ_W] = 0.0;
+    X[o / PQ_W][o % PQ_W] = 0.0;
+    T[o] = 0.f;
+  }
+  if (t == 0) {
+    sh_rk = 0;
+    sh_bad = 0;
+  }
+  __syncthreads();
+  for (int i = 0; i < w; ++i) {
+    const int rk = sh_rk;
+    double tj = 0.0;
+    if (t < w) {
+      tj = G[i][t];
+      for (int r = 0; r < rk; ++r) tj -= Rm[r][i] * Rm[r][t];
+    }
+    if (t == i) {
+      const double s = tj;
+      double nrm = s > 0.0 ? sqrt(s) : 0.0;
+      bool drop;
+      if (pass == 1) {
+        // ks_utils.h:66-69 absolute test, plus a relative guard for what an fp64 Gram matrix can resolve
+        drop = ((float)nrm < 1e-6f) || (s <= 1e-13 * G[i][i] * (double)w);
+      } else {
+        drop = false;
+        if (!(s > 0.0)) {
+          sh_bad = 1;
+          nrm = 1.0;
+        }
+      }
+      sh_nrm = drop ? 0.0 : nrm;
+    }
+    __syncthreads();
+    const double nrm = sh_nrm;
+    if (nrm != 0.0) {
+      if (t < w) Rm[rk][t] = (t >= i) ? tj / nrm : 0.0;
+      if (t == 0) {
+        piv[rk] = i;
+        sh_rk = rk + 1;
+      }
+    }
+    __syncthreads();
+  }
+  const int rk = sh_rk;
+  // X = inverse of the rk x rk upper-triangular U(a, b) = Rm[a][piv[b]]; lane = column
+  if (t < rk) {
+    const int j = t;
+    X[j][j] = 1.0 / Rm[j][piv[j]];
+    for (int i = j - 1; i >= 0; --i) {
+      double s = 0.0;
+      for (int q = i + 1; q <= j; ++q) s += Rm[i][piv[q]] * X[q][j];
+      X[i][j] = -s / Rm[i][piv[i]];
+    }
+  }
+  __syncthreads();
+  // T (w x rk, col-major): rows at the pivot columns hold X
+  for (int o = t; o < rk * rk; o += 256) {
+    const int cc = o / rk, a = o - cc * rk;
+    T[cc * w + piv[a]] = (float)X[a][cc];
+  }
+  if (pass == 1) {
+    for (int o = t; o < PQ_W * PQ_W; o += 256) R1g[o] = Rm[o / PQ_W][o % PQ_W];  // R1g[r * PQ_W + col]
+    if (t == 0) {
+      meta[0] = rk;
+      meta[1] = 0;
+    }
+    if (t < PQ_W) meta[2 + t] = (t < rk) ? piv[t] : -1;
+  } else {
+    // R (rk x w1, [j*rk + r]) = R2 R1;  w1 = wmax
+    for (int o = t; o < rk * wmax; o += 256) {
+      const int j = o / rk, r = o - j * rk;
+      double s = 0.0;
+      for (int q = r; q < rk; ++q) s += Rm[r][q] * R1g[q * PQ_W + j];
+      Rout[o] = (float)s;
+    }
+    if (t == 0) meta[1] = sh_bad;
+  }
+}
+
+// Q[r, 0:rk] = F[r, 0:b] * T (b x rk col-major), rk (and b in pass 2) read from device memory.  Q may alias F.
+__global__ __launch_bounds__(256) void pqr_apply_k(const float* F, uint64_t n, int bmax, int pass, const float* __restrict__ T, const int* __restrict__ meta,
+                                                    float* Q) {
+  __shared__ float Ts[PQ_W * PQ_W];
+  const int rk = meta[0];
+  const int b = (pass == 1) ? bmax : rk;
+  for (int idx = threadIdx.x; idx < b * rk; idx += 256) Ts[idx] = T[idx];
+  __syncthreads();
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  float f[PQ_W];
+#pragma unroll
+  for (int j = 0; j < PQ_W; ++j) f[j] = (j < b) ? F[(uint64_t)j * n + r] : 0.f;
+  for (int cc = 0; cc < rk; ++cc) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PQ_W; ++j)
+      if (j < b) s = fmaf(f[j], Ts[cc * b + j], s);
+    Q[(uint64_t)cc * n + r] = s;
+  }
+}
+
+// F: n x w (device, destroyed).  Q: n x rank at Qdst.  R_host: room for w*w floats, rank x w as [j*rank + r].
+int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* rank_out) {
+  TimeScope ts(c, ISLE_T_QR);
+  if (w < 1 || w > PQ_W) return isle_fail(c, ISLE_E_ARG, "panel QR: width %d not in [1, %d]", w, PQ_W);
+  const int nparts = cdiv((long)n, PQ_ROWS * PQ_SUB);
+  HIPCHK(c, c->pq_part.reserve((size_t)nparts * PQ_W * PQ_W));
+  HIPCHK(c, c->pq_R1.reserve(PQ_W * PQ_W));
+  HIPCHK(c, c->pq_T.reserve(2 * PQ_W * PQ_W));
+  HIPCHK(c, c->pq_meta.reserve(2 + PQ_W));
+  float* Rout = c->pq_T.p + PQ_W * PQ_W;
+  const dim3 rows(cdiv((long)n, 256));
+  hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, F, n, w, (const int*)nullptr, c->pq_part.p);
+  hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 1, c->pq_R1.p, c->pq_meta.p, c->pq_T.p, Rout);
+  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, F, n, w, 1, c->pq_T.p, c->pq_meta.p, Qdst);
+  hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, Qdst, n, w, c->pq_meta.p, c->pq_part.p);
+  hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, c->pq_meta.p, c->pq_T.p, Rout);
+  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, c->pq_meta.p, Qdst);
+  HIPCHK(c, hipGetLastError());
+  int meta[2];
+  HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
+  *rank_out = meta[0];
+  return 0;
+}
+
 // uniform [0,1) fill (arma::randu stand-in, block-ks/restarted_block_ks.h:212)
 __global__ void randu_k(float* __restrict__ F, uint64_t count, uint64_t seed) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
