@@ -206,7 +206,6 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
                      int fam = ISLE_T_SPARSE_ASSIGN);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
 int k_doc_norms(isle_ctx* c, float* dn);
-int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts);
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);
 
 // threshold.hip
@@ -235,9 +234,7 @@ int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, 
 // dense.hip
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef);
-int k_gram64(isle_ctx* c, const float* F, uint64_t n, int b, double* G_host /*b x b col-major*/);
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
-int k_apply_T(isle_ctx* c, const float* F, uint64_t n, int b, const float* T_host /*b x rk col-major*/, int rk, float* Q);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C);  // col-major, lda = ldc = M
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl

@@ -1,7 +1,7 @@
 // isle_amd/csrc/dense.hip — tall-skinny panel kernels, f32 MFMA GEMM, small symmetric EVD (gfx950).
 //
 //   k_vtf / k_update      H = V^T F ; F -= V H        block-ks/restarted_block_ks.h:83-91 (CGS + 2x DGKS)
-//   k_gram64 / k_apply_T  panel QR as CholQR2 on an fp64 Gram matrix; stands in for the fp64 MGS of
+//   k_panel_qr            panel QR as CholQR2 on an fp64 Gram matrix, all on the device; stands in for the fp64 MGS of
 //                         utils::compute_qr  block-ks/ks_utils.h:43-127  (rank test kept: see solver.cpp)
 //   k_gemm_nn             C = A B, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): Ritz rotation
 //                         block-ks/restarted_block_ks.h:166-167 and lift src/sparseMatrix.cpp:1446-1449
@@ -163,15 +163,6 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
   return vtf_impl<float>(c, Vb, n, m, F, b, coef);
 }
 
-int k_gram64(isle_ctx* c, const float* F, uint64_t n, int b, double* G_host) {
-  TimeScope ts(c, ISLE_T_QR);
-  HIPCHK(c, c->gram.reserve(32 * 32));
-  ISLECHK(vtf_impl<double>(c, F, n, b, F, b, c->gram.p));
-  HIPCHK(c, hipMemcpyAsync(G_host, c->gram.p, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
-}
-
 // ------------------------------------------------------------------------------------------
 // F[r, :] -= sum_i Vb[r, i] * coef[i, :]        one thread per row, coef tiles staged in LDS
 // ------------------------------------------------------------------------------------------
@@ -222,35 +213,6 @@ int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, c
     default: hipLaunchKernelGGL(update_k<32>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
   }
   HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-// Q[r, 0:rk] = F[r, 0:b] * T (b x rk, col-major).  Q may alias F (each thread owns a row).
-__global__ __launch_bounds__(256) void apply_T_k(const float* F, uint64_t n, int b, const float* __restrict__ T, int rk, float* Q) {
-  __shared__ float Ts[32 * 32];
-  for (int idx = threadIdx.x; idx < b * rk; idx += 256) Ts[idx] = T[idx];
-  __syncthreads();
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
-  float f[32];
-#pragma unroll
-  for (int j = 0; j < 32; ++j) f[j] = (j < b) ? F[(uint64_t)j * n + r] : 0.f;
-  for (int cc = 0; cc < rk; ++cc) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j)
-      if (j < b) s = fmaf(f[j], Ts[cc * b + j], s);
-    Q[(uint64_t)cc * n + r] = s;
-  }
-}
-int k_apply_T(isle_ctx* c, const float* F, uint64_t n, int b, const float* T_host, int rk, float* Q) {
-  TimeScope ts(c, ISLE_T_QR);
-  if (rk == 0) return 0;
-  HIPCHK(c, c->small.reserve(4096));
-  HIPCHK(c, hipMemcpyAsync(c->small.p, T_host, (size_t)b * rk * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(apply_T_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, F, n, b, c->small.p, rk, Q);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // T_host is pageable caller memory: do not outlive it
   return 0;
 }
 

@@ -468,31 +468,7 @@ int k_doc_norms(isle_ctx* c, float* dn) {
   return 0;
 }
 
-// centre[c] += b_d for every member d  (src/sparseMatrix.cpp:1631-1638); Crm is V x ldk row-major
-__global__ __launch_bounds__(256) void scatter_centers_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
-                                                          const int64_t* __restrict__ offs, uint32_t D,
-                                                          const uint32_t* __restrict__ assign, int ldk, float* __restrict__ Crm,
-                                                          int* __restrict__ counts) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= D) return;
-  const uint32_t cc = assign[d];
-  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) atomicAdd(&Crm[(size_t)rows[i] * ldk + cc], vals[i]);
-  if (lane == 0) atomicAdd(&counts[cc], 1);
-}
-int k_scatter_centers(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, int* counts) {
-  TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
-  const uint32_t D = (uint32_t)c->D;
-  HIPCHK(c, hipMemsetAsync(Crm, 0, (size_t)c->V * ldk * sizeof(float), c->stream));
-  HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)k * sizeof(int), c->stream));
-  if (D == 0) return 0;
-  hipLaunchKernelGGL(scatter_centers_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, D, assign, ldk,
-                     Crm, counts);
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-// Centroid sums without global atomics: Crm[w][c] = sum over the nonzeros (w, d) with assign[d] == c of B[w,d].
+// centre[c] += b_d for every member d  (src/sparseMatrix.cpp:1631-1638), without global atomics: Crm[w][c] = sum over the nonzeros (w, d) with assign[d] == c of B[w,d].
 // One wave per vocabulary row w walks the row's cells of the chunked-CSR copy and keeps a k-bin histogram in LDS
 // (one ds_add_f32 per nonzero); the finished row of sums is written once, coalesced.
 __global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restrict__ cval, const uint32_t* __restrict__ ccol,
