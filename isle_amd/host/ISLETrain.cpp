@@ -273,7 +273,10 @@ int main(int argv, char** argc) {
       std::vector<std::pair<word_id_t, FPTYPE>>& tw = topwords[t];
       tw.reserve(vocab_size);
       for (word_id_t w = 0; w < vocab_size; ++w) tw.push_back(std::make_pair(w, Model[(size_t)t * vocab_size + w]));
-      std::stable_sort(tw.begin(), tw.end(), [](const std::pair<word_id_t, FPTYPE>& l, const std::pair<word_id_t, FPTYPE>& r2) { return l.second > r2.second; });
+      // heaviest first, lower word id first among equal weights (what a stable sort of the word-ordered list gives)
+      std::partial_sort(tw.begin(), tw.begin() + ntop, tw.end(), [](const std::pair<word_id_t, FPTYPE>& l, const std::pair<word_id_t, FPTYPE>& r2) {
+        return l.second > r2.second || (l.second == r2.second && l.first < r2.first);
+      });
       if (tw[ntop - 1].second == (FPTYPE)0.0) std::cout << "\n ==== WARNING: top words in topic " << t << " have zero weight\n\n";
       tw.resize(ntop);
     }
