@@ -1,0 +1,17 @@
+// isle_amd/csrc/hamerly.h — conservative Hamerly bounds from computed squared distances.
+//
+// A squared distance is evaluated as (|b|^2 + |c|^2) - 2 b.c in fp32; with n <= ~1600 products the absolute error is at
+// most E = 1e-4 * (|b|^2 + |c|^2) (linear worst case n * eps * (|b|^2 + |c|^2); the typical error is 1000x smaller).
+// For the distance itself |sqrt(x + e) - sqrt(x)| <= min(sqrt(E), E / sqrt(x)): tiny for documents far from a centre,
+// sqrt(E) only when the distance itself is at the cancellation level.  The upper bound is widened and the lower bound
+// narrowed by that amount when they are stored, so the filter needs no further slack.
+#pragma once
+#include <hip/hip_runtime.h>
+
+__device__ inline void hamerly_store_bounds(float best_sq, float second_sq, float norm_sum /* |b|^2 + max |c|^2 */, float* ub, float* lb) {
+  const float E = 1e-4f * norm_sum;
+  const float sE = sqrtf(E);
+  const float u = sqrtf(best_sq), l = sqrtf(second_sq);
+  *ub = u + fminf(sE, E / fmaxf(u, 1e-30f));
+  *lb = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+}

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "common.h"
+#include "hamerly.h"
 #include "scan.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
   const float live = (myd < D) ? 1.f : 0.f;
   const float nd = (myd < D) ? pn[myd] : 0.f;
   const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
-  float best = 3.4e38f, second = 3.4e38f;
+  float best = 3.4e38f, second = 3.4e38f, cmax = 0.f;
   uint32_t bidx = 0xffffffffu;
   // k <= CG and KH <= KHC (e.g. k = 200) is a single pass: P is then read from HBM exactly once per call.
   for (int cg0 = 0; cg0 < k; cg0 += CG) {
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
         for (int r = 0; r < 16; ++r) {
           const int cc = cg0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (cc < k) {
+            cmax = fmaxf(cmax, cn[cc]);
             const float raw = (-2.0f * acc[t][r] + cn[cc]) + nd;
             if (MODE == PR_ARGMIN) {
               const float dist = fabsf(raw);
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
   const float ob = __shfl_xor(best, 32);
   const float os = __shfl_xor(second, 32);
   const uint32_t oi = __shfl_xor(bidx, 32);
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
   if (MODE == PR_ARGMIN) {
     if (ob < best || (ob == best && oi < bidx)) {
       second = fminf(best, os);
@@ -313,10 +316,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
     if (h == 0 && myd < D) {
       const uint32_t dst = map ? map[myd] : myd;  // compacted (active-list) launches write through the slot -> doc map
       assign[dst] = bidx;
-      if (ub) {
-        ub[dst] = sqrtf(best);
-        lb[dst] = sqrtf(second);
-      }
+      if (ub) hamerly_store_bounds(best, second, nd + cmax, &ub[dst], &lb[dst]);
     }
   } else {
     best = fminf(best, ob);

@@ -315,6 +315,7 @@ int k_frobenius(isle_ctx* c, double* out_host) {
 // k-wide SpMM, one wave per document; lane owns float4 chunks {lane + 64*it} of the output row
 // ------------------------------------------------------------------------------------------
 enum { WIDE_PROJECT = 0, WIDE_ASSIGN = 1 };
+#include "hamerly.h"
 
 template <int NIT, int MODE>
 __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
     if (lane == 0) norms[d] = s;
   } else {
     const float dnd = dn[d];
-    float best = 3.4e38f, second = 3.4e38f;
+    float best = 3.4e38f, second = 3.4e38f, cmax = 0.f;
     uint32_t bidx = 0xffffffffu;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
         for (int j = 0; j < 4; ++j) {
           const int cc = 4 * cidx + j;
           if (cc < k) {
+            cmax = fmaxf(cmax, cn[cc]);
             const float dist = fabsf((-2.0f * a[j] + cn[cc]) + dnd);
             if (dist < best) {  // ascending cc per lane -> first index wins ties
               second = best;
@@ -407,12 +409,13 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
         second = fminf(second, ob);
       }
     }
+    if (ub) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+    }
     if (lane == 0) {
       assign[d] = bidx;
-      if (ub) {  // Euclidean distances to the closest and second-closest centre
-        ub[d] = sqrtf(best);
-        lb[d] = sqrtf(second);
-      }
+      if (ub) hamerly_store_bounds(best, second, dnd + cmax, &ub[d], &lb[d]);
     }
   }
 }
@@ -506,10 +509,10 @@ int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, flo
 }
 
 // Hamerly's bounds for Lloyd on the sparse matrix (an EXACT acceleration: a document is skipped only when its bounds
-// prove that its closest centre cannot have changed).  ub = distance to the assigned centre, lb = distance to the
-// second-closest; after the centres move by delta[c], ub grows by delta[assigned] and lb shrinks by the largest movement
-// of any other centre.  Documents with ub + slack >= lb - slack are appended to `active` and re-evaluated against all
-// centres.  slack covers the fp32 cancellation error of |b|^2 + |c|^2 - 2 b.c under the square root.
+// prove that its closest centre cannot have changed).  ub >= distance to the assigned centre, lb <= distance to the
+// second-closest (both already widened by the fp32 error of the distance evaluation, see hamerly.h); after the centres
+// move by delta[c], ub grows by delta[assigned] and lb shrinks by the largest movement of any other centre.  Documents
+// whose bounds overlap are appended to `active` and re-evaluated against all centres.
 __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restrict__ order, uint32_t D, const uint32_t* __restrict__ assign,
                                                          float* __restrict__ ub, float* __restrict__ lb, const float* __restrict__ delta,
                                                          uint32_t amax, float d1, float d2, const float* __restrict__ dn, float cn_max,
@@ -518,12 +521,12 @@ __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restri
   if (i >= D) return;
   const uint32_t d = order ? order[i] : i;
   const uint32_t a = assign[d];
-  const float u = ub[d] + delta[a];
-  const float l = lb[d] - (a == amax ? d2 : d1);
+  const float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of these two updates
+  float l = lb[d] - (a == amax ? d2 : d1) * 1.000001f;
+  l = l > 0.f ? l * 0.999999f : l;
   ub[d] = u;
   lb[d] = l;
-  const float slack = 2e-3f * sqrtf(dn[d] + cn_max) + 1e-6f;
-  if (u + slack >= l - slack) active[atomicAdd(nactive, 1u)] = d;
+  if (u >= l) active[atomicAdd(nactive, 1u)] = d;
 }
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
                      float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive, int fam) {
