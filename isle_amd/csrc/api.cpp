@@ -169,15 +169,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
-  c->vals.release(); c->rows.release(); c->offs.release();
-  c->bcol.release(); c->bval.release(); c->seg_off.release(); c->Zpart.release();
-  c->Xrm.release(); c->Yrm.release(); c->Zrm.release(); c->Xcm.release(); c->Zcm.release();
-  c->basis.release(); c->Fbuf.release(); c->Tmp.release(); c->part.release(); c->coef.release();
-  c->gram.release(); c->small.release(); c->jacW.release(); c->jacV.release(); c->jacS.release(); c->Wf.release();
-  c->Ucm.release(); c->Urm.release(); c->P.release(); c->Pt.release(); c->pnorm.release(); c->min_dist.release();
-  c->cum.release(); c->scan_blk.release(); c->Cdev.release(); c->cnorm.release(); c->Csum.release();
-  c->assign.release(); c->assign_prev.release(); c->counts.release(); c->flags.release(); c->members.release(); c->moff.release();
-  c->centers_rm.release(); c->centers_cm.release(); c->dnorm.release(); c->hub.release(); c->hlb.release(); c->active.release(); c->centers_old.release(); c->Pa.release(); c->pna.release(); c->Cold.release();
+  (void)hipStreamSynchronize(c->stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1339,15 +1331,23 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   HIPCHK(c, c->assign.reserve(D ? D : 1));
   c->assign_valid = false;
   ISLECHK(k_doc_norms(c, c->dnorm.p));  // :1680-1687
-  // Hamerly bounds: an exact acceleration of the assignment step (documents whose bounds prove "unchanged" are skipped)
-  const bool hamerly = !getenv("ISLE_NO_HAMERLY");
+  // Distance bounds: exact accelerations of the assignment step (documents whose bounds prove "unchanged" are skipped).
+  // Default: Yinyang group bounds (groups of 8 centres); ISLE_KMEANS_BOUNDS=hamerly|none selects the others.
+  const char* bmode = getenv("ISLE_KMEANS_BOUNDS");
+  const bool nobounds = getenv("ISLE_NO_HAMERLY") || (bmode && !strcmp(bmode, "none"));
+  const bool hamerly = !nobounds;                                   // any bound-based mode
+  const bool yinyang = hamerly && !(bmode && !strcmp(bmode, "hamerly"));
+  const int G = (k + 7) / 8;
+  if (yinyang) HIPCHK(c, c->yglb.reserve((size_t)(D ? D : 1) * G + 64));
+  float* gmax_dev = nullptr;
   HIPCHK(c, c->hub.reserve(D ? D : 1));
   HIPCHK(c, c->hlb.reserve(D ? D : 1));
   HIPCHK(c, c->active.reserve(D + 1));
   HIPCHK(c, c->centers_old.reserve((size_t)V * ld));
-  HIPCHK(c, c->Csum.reserve((size_t)2 * k + 16));
+  HIPCHK(c, c->Csum.reserve((size_t)2 * k + 16 + G));
   float* delta_dev = c->Csum.p;  // k floats
-  std::vector<float> delta(k, 0.f), cnh(k);
+  gmax_dev = c->Csum.p + 2 * k + 16;  // G floats
+  std::vector<float> delta(k, 0.f), cnh(k), gmax(G, 0.f);
   uint32_t amax = 0;
   float d1 = 0.f, d2 = 0.f;
   StopRule stop(c, k);
@@ -1360,7 +1360,21 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     if (it == 0 || !hamerly) {
       // documents are visited grouped by their previous centre (cache locality of the centre rows); results are order-independent
       ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p,
-                                 c->members_valid ? c->members.p : nullptr, nullptr, c->hub.p, c->hlb.p));  // :1606
+                                 c->members_valid ? c->members.p : nullptr, nullptr, c->hub.p, yinyang ? c->yglb.p : c->hlb.p,
+                                 yinyang ? G : 0));  // :1606
+    } else if (yinyang) {
+      HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      float cn_max = 0.f;
+      for (int i = 0; i < k; ++i) cn_max = std::max(cn_max, cnh[i]);
+      uint32_t* nact = c->active.p + D;
+      ISLECHK(k_yy_filter(c, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
+      ISLECHK(k_yy_scan(c, c->centers_rm.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p));
+      if (getenv("ISLE_DEBUG_HAMERLY")) {
+        uint32_t na = 0;
+        HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[yinyang] iter %d active %u of %llu  d1 %.4f\n", it, na, (unsigned long long)D, d1);
+      }
     } else {
       HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1405,6 +1419,14 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
         }
       }
       HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      if (yinyang) {
+        for (int g = 0; g < G; ++g) {
+          float m = 0.f;
+          for (int i = 8 * g; i < std::min(k, 8 * g + 8); ++i) m = std::max(m, delta[i]);
+          gmax[g] = m;
+        }
+        HIPCHK(c, hipMemcpyAsync(gmax_dev, gmax.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      }
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     bool conv = false;

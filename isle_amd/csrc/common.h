@@ -36,6 +36,10 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }  // every buffer of a context dies with it
 };
 
 struct isle_ctx {
@@ -150,6 +154,7 @@ struct isle_ctx {
   int centers_k = 0;
   DevBuf<float> dnorm;     // D   |b_d|^2
   DevBuf<float> hub, hlb;  // D   Hamerly bounds (sparse Lloyd)
+  DevBuf<float> yglb;      // D x G Yinyang group bounds (sparse Lloyd)
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<float> centers_old;  // V x ldk
   DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
@@ -200,7 +205,11 @@ int k_frobenius(isle_ctx* c, double* out_host);
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms);
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
                        const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
-                       float* ub = nullptr, float* lb = nullptr);
+                       float* ub = nullptr, float* lb = nullptr, int G = 0 /*> 0: lb holds G Yinyang group bounds per document*/);
+int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev, uint32_t* active,
+                uint32_t* nactive);
+int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, float cn_max, const uint32_t* active,
+              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb);
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
                      float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive,
                      int fam = ISLE_T_SPARSE_ASSIGN);

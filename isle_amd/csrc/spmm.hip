@@ -316,6 +316,7 @@ int k_frobenius(isle_ctx* c, double* out_host) {
 // ------------------------------------------------------------------------------------------
 enum { WIDE_PROJECT = 0, WIDE_ASSIGN = 1 };
 #include "hamerly.h"
+constexpr int YY_GROUP = 8;  // centres per Yinyang group: two float4 of a centre row, never straddling a 64-byte line
 
 template <int NIT, int MODE>
 __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
                                                     const float* __restrict__ cn, const float* __restrict__ dn,
                                                     uint32_t* __restrict__ assign, const uint32_t* __restrict__ perm,
                                                     const uint32_t* __restrict__ nslots /*nullable: device-side slot count*/,
-                                                    float* __restrict__ ub, float* __restrict__ lb /*nullable: Hamerly bounds out*/) {
+                                                    float* __restrict__ ub, float* __restrict__ lb /*nullable: Hamerly bounds out*/,
+                                                    int G /*0: lb = one bound per document; > 0: lb = G group bounds per document*/) {
   const int lane = threadIdx.x & 63;
   if (nslots) D = min(D, *nslots);
   // XCD-contiguous slots: workgroups of one XCD (blockIdx % 8) walk one contiguous eighth of the slot list, so that
@@ -413,9 +415,37 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
     }
+    if (ub && G > 0) {
+      // Yinyang group bounds: for every group of YY_GROUP consecutive centres the distance to its closest member other than
+      // the assigned centre.  A lane holds 4 consecutive centres, lane ^ 1 the other half of the group.
+      const float E = 1e-4f * (dnd + cmax), sE = sqrtf(E);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int cidx = lane + 64 * it;
+        float m = 3.4e38f;
+        if (cidx < nq) {
+          const float a[4] = {acc[it].x, acc[it].y, acc[it].z, acc[it].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cc = 4 * cidx + j;
+            if (cc < k && (uint32_t)cc != bidx) m = fminf(m, fabsf((-2.0f * a[j] + cn[cc]) + dnd));
+          }
+        }
+        m = fminf(m, __shfl_xor(m, 1));
+        const int g = cidx >> 1;
+        if (!(lane & 1) && g < G) {
+          const float l = sqrtf(m);
+          lb[(size_t)d * G + g] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+        }
+      }
+      if (lane == 0) {
+        const float u = sqrtf(best);
+        ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+      }
+    }
     if (lane == 0) {
       assign[d] = bidx;
-      if (ub) hamerly_store_bounds(best, second, dnd + cmax, &ub[d], &lb[d]);
+      if (ub && G == 0) hamerly_store_bounds(best, second, dnd + cmax, &ub[d], &lb[d]);
     }
   }
 }
@@ -423,7 +453,7 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
 template <int MODE>
 static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms, const float* cn, const float* dn,
                        uint32_t* assign, const uint32_t* perm, const uint32_t* nslots = nullptr, float* ub = nullptr,
-                       float* lb = nullptr) {
+                       float* lb = nullptr, int G = 0) {
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
   const int nq = ldk / 4;
@@ -431,7 +461,7 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
   dim3 g(8 * cdiv(cdiv(D, 4), 8)), b(256);  // multiple of 8 so that the XCD slot map is a bijection
 #define LW(N)                                                                                                              \
   hipLaunchKernelGGL((spmm_wide_k<N, MODE>), g, b, 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Mrm, nq, k, D, \
-                     (float4*)P, norms, cn, dn, assign, perm, nslots, ub, lb)
+                     (float4*)P, norms, cn, dn, assign, perm, nslots, ub, lb, G)
   if (nit <= 1) LW(1);
   else if (nit <= 2) LW(2);
   else if (nit <= 4) LW(4);
@@ -446,9 +476,9 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
   return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr, nullptr);
 }
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
-                       const uint32_t* perm, const uint32_t* nslots, float* ub, float* lb) {
+                       const uint32_t* perm, const uint32_t* nslots, float* ub, float* lb, int G) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
-  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm, nslots, ub, lb);
+  return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm, nslots, ub, lb, G);
 }
 
 // |b_d|^2  (compute_docs_l2sq  src/sparseMatrix.cpp:1680-1687)
@@ -536,6 +566,171 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
   if (D == 0) return 0;
   hipLaunchKernelGGL(hamerly_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, lb, delta_dev, amax, d1, d2, dn,
                      cn_max, active, nactive);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Yinyang bounds for Lloyd on the sparse matrix (Ding et al., ICML 2015) — like Hamerly's an EXACT acceleration, with one
+// lower bound per GROUP of YY_GROUP centres instead of one per document: after an update a group's bound only shrinks by
+// the largest movement inside that group, and a document that cannot be skipped re-examines only the groups whose bound
+// overlaps its upper bound.  A group is 32 bytes of a centre row, so a group scan gathers one 32-byte piece per nonzero
+// of the document instead of the whole k-wide row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb, int G,
+                                                    const float* __restrict__ delta, const float* __restrict__ gmax, uint32_t* __restrict__ active,
+                                                    uint32_t* __restrict__ nactive) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float u = (ub[d] + delta[assign[d]]) * 1.000001f;
+  float* gl = glb + (size_t)d * G;
+  float lmin = 3.4e38f;
+  for (int g = 0; g < G; ++g) {
+    float l = gl[g] - gmax[g] * 1.000001f;
+    l = l > 0.f ? l * 0.999999f : l;
+    gl[g] = l;
+    lmin = fminf(lmin, l);
+  }
+  ub[d] = u;
+  if (u >= lmin) active[atomicAdd(nactive, 1u)] = d;
+}
+
+// top-2 of a group from the 4 distances of this lane and the 4 of lane ^ 1
+struct YyTop2 {
+  float m1, m2;
+  uint32_t i1;
+};
+__device__ inline YyTop2 yy_group_top2(const float dist[4], int c0, int k) {
+  YyTop2 t{3.4e38f, 3.4e38f, 0xffffffffu};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cc = c0 + j;
+    if (cc < k) {
+      if (dist[j] < t.m1) {
+        t.m2 = t.m1;
+        t.m1 = dist[j];
+        t.i1 = (uint32_t)cc;
+      } else {
+        t.m2 = fminf(t.m2, dist[j]);
+      }
+    }
+  }
+  const float om1 = __shfl_xor(t.m1, 1), om2 = __shfl_xor(t.m2, 1);
+  const uint32_t oi1 = __shfl_xor(t.i1, 1);
+  if (om1 < t.m1 || (om1 == t.m1 && oi1 < t.i1)) {
+    t.m2 = fminf(t.m1, om2);
+    t.m1 = om1;
+    t.i1 = oi1;
+  } else {
+    t.m2 = fminf(t.m2, om1);
+  }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                  const float* __restrict__ C /*V x ld row-major*/, int ld, int k, int G, const float* __restrict__ cn,
+                                                  const float* __restrict__ dn, float cn_max, const uint32_t* __restrict__ active,
+                                                  const uint32_t* __restrict__ nactive, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                  float* __restrict__ glb) {
+  const int lane = threadIdx.x & 63;
+  uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (slot >= *nactive) return;
+  const uint32_t d = __builtin_amdgcn_readfirstlane(active[slot]);
+  const int64_t beg = offs[d], end = offs[d + 1];
+  const float dnd = dn[d];
+  const uint32_t a = assign[d];
+  const int ga = (int)(a / YY_GROUP);
+  const float E = 1e-4f * (dnd + cn_max), sE = sqrtf(E);
+  const int q = lane & 1, e = lane >> 1;
+  float* gl = glb + (size_t)d * G;
+
+  // distances of the document to the YY_GROUP centres of group g; lane parity q holds centres 8g+4q .. 8g+4q+3
+  auto scan_group = [&](int g, float dist[4]) {
+    const int col = YY_GROUP * g + 4 * q;
+    const float live = (col < ld) ? 1.f : 0.f;
+    const float4* base = reinterpret_cast<const float4*>(C + min(col, ld - 4));
+    const size_t rstride = (size_t)ld / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t b0 = beg; b0 < end; b0 += 64) {
+      const int cnt = (int)min((int64_t)64, end - b0);
+      const uint32_t myrow = (lane < cnt) ? rows[b0 + lane] : 0u;
+      const float myval = (lane < cnt) ? vals[b0 + lane] : 0.f;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        if (st * 32 < cnt) {  // wave-uniform
+          const uint32_t r = __shfl(myrow, st * 32 + e);
+          const float v = __shfl(myval, st * 32 + e) * live;  // 0 beyond the document's end
+          acc = f4_fma(v, base[(size_t)r * rstride], acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 2; m < 64; m <<= 1) {
+      acc.x += __shfl_xor(acc.x, m);
+      acc.y += __shfl_xor(acc.y, m);
+      acc.z += __shfl_xor(acc.z, m);
+      acc.w += __shfl_xor(acc.w, m);
+    }
+    const float aa[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = min(col + j, k - 1);
+      dist[j] = fabsf((-2.0f * aa[j] + cn[cc]) + dnd);
+    }
+  };
+
+  float best = 3.4e38f, best_group_second = 3.4e38f;
+  uint32_t bidx = 0xffffffffu;
+  auto absorb = [&](int g, const YyTop2& t) {
+    // provisional bound of the group: its closest centre; the group of the final assignment is fixed up at the end
+    const float l = sqrtf(t.m1);
+    if (lane == 0) gl[g] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+    if (t.m1 < best || (t.m1 == best && t.i1 < bidx)) {
+      best = t.m1;
+      bidx = t.i1;
+      best_group_second = t.m2;
+    }
+  };
+  float dist[4];
+  scan_group(ga, dist);                                   // tighten: exact distance to the assigned centre (and its group)
+  absorb(ga, yy_group_top2(dist, YY_GROUP * ga + 4 * q, k));
+  for (int g = 0; g < G; ++g) {
+    if (g == ga) continue;
+    const float u = sqrtf(best);
+    const float uhi = u + fminf(sE, E / fmaxf(u, 1e-30f));
+    const float lg = gl[g];                               // already lowered by this update's movement (yy_filter_k)
+    if (lg <= uhi) {                                      // wave-uniform
+      scan_group(g, dist);
+      absorb(g, yy_group_top2(dist, YY_GROUP * g + 4 * q, k));
+    }
+  }
+  if (lane == 0) {
+    const float u = sqrtf(best);
+    ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+    assign[d] = bidx;
+    const float l = sqrtf(best_group_second);             // the assigned centre does not bound its own group
+    gl[bidx / YY_GROUP] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+  }
+}
+
+int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev, uint32_t* active,
+                uint32_t* nactive) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  const uint32_t D = (uint32_t)c->D;
+  HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(yy_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, D, assign, ub, glb, G, delta_dev, gmax_dev, active, nactive);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, float cn_max, const uint32_t* active,
+              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  const uint32_t D = (uint32_t)c->D;
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(yy_scan_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, Crm, ld, k, G, cn, dn, cn_max, active,
+                     nactive, assign, ub, glb);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

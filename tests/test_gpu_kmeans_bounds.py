@@ -1,0 +1,52 @@
+"""The distance-bound accelerations of the sparse Lloyd loop (Yinyang group bounds by default, Hamerly, none) are EXACT:
+every mode must return the same partition, iteration count and centres on the same input (src/sparseMatrix.cpp:1587-1746)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import corpus
+from isle_amd import HotPath
+out = {}
+for (V, D, k, seed) in [(5000, 30000, 20, 3), (3000, 20000, 30, 4), (2000, 6000, 5, 5)]:
+    B = corpus(V, D, k, seed)
+    hp = HotPath(0)
+    hp.upload_csc(B["V"], B["vals"], B["rows"], B["offs"])
+    hp.compute_block_ks(k, seed=1)
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=2)
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    ls = hp.run_lloyds(k)
+    out["%%d_%%d_%%d" %% (V, D, k)] = dict(iters=ls["iters"], assign=hashlib.sha1(ls["assign"].tobytes()).hexdigest(),
+                                         sizes=np.bincount(ls["assign"], minlength=k).tolist(), cen=float(np.abs(ls["centers"]).sum()))
+print("RESULT " + json.dumps(out))
+''' % (ROOT, ROOT)
+
+
+def run(mode):
+    env = dict(os.environ)
+    env.pop("ISLE_NO_HAMERLY", None)
+    env["ISLE_KMEANS_BOUNDS"] = mode
+    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_bound_modes_agree():
+    base = run("none")
+    for mode in ("hamerly", "yinyang"):
+        got = run(mode)
+        for key in base:
+            assert got[key]["iters"] == base[key]["iters"], (mode, key)
+            assert got[key]["assign"] == base[key]["assign"], (mode, key, got[key]["sizes"], base[key]["sizes"])
+            assert abs(got[key]["cen"] - base[key]["cen"]) <= 1e-5 * base[key]["cen"], (mode, key)
