@@ -125,6 +125,13 @@ int isle_hip_frobenius(isle_ctx* ctx, float* out);
  * Z (V x b, col-major) = B * (B^T * X), X V x b col-major, 1 <= b <= 32. */
 int isle_hip_gram_apply(isle_ctx* ctx, const float* X_colmajor, int b, float* Z_colmajor);
 
+/* Which form of the operator the last build chose for the current B (the operator is built by the first
+ * isle_hip_gram_apply / isle_hip_block_ks after an upload, like the MKL_SpSpTrProd constructor
+ * include/matUtils.h:52-273): *form = 1 LDS-banded form (every row of B holds one value, as threshold_and_copy
+ * src/sparseMatrix.cpp:1285-1321 produces), 0 gather form (any CSC matrix), -1 not built yet.
+ * Environment ISLE_GRAM_LDS=0 forces the gather form. */
+int isle_hip_operator_form(isle_ctx* ctx, int* form);
+
 /* FPSparseMatrix::compute_block_ks  src/sparseMatrix.cpp:1195-1220  driving
  * BlockKs<ProdOp>(op, nev, ncv, maxit, blk, tol) init()+compute()
  * block-ks/restarted_block_ks.h:190-321.  The reference passes

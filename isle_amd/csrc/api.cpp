@@ -666,6 +666,22 @@ static int panel_width(int b) { return 4 * ((b + 3) / 4); }  // BP in {4, 8, ...
 // Zcm (V x b col-major) = B (B^T Xcm) on device pointers, 1 <= b <= 32, one pass over both copies of B per call.
 static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
   if (b < 1 || b > 32) return isle_fail(c, ISLE_E_ARG, "gram_apply: b = %d not in [1, 32]", b);
+  ISLECHK(k_band_build(c));  // first application of a solve: operator build (and the choice of the form)
+  if (c->gl_mode == 1) {
+    // LDS-banded form (gram_lds.hip), panels of at most 12 columns; column groups of a col-major block are contiguous
+    for (int j0 = 0; j0 < b; j0 += 12) {
+      const int bg = std::min(12, b - j0);
+      const int BPg = panel_width(bg);
+      HIPCHK(c, c->Xrm.reserve((size_t)c->V * BPg));
+      HIPCHK(c, c->Zrm.reserve((size_t)c->V * BPg));
+      HIPCHK(c, c->Yrm.reserve((size_t)c->D * BPg));
+      ISLECHK(k_pack_rm(c, Xcm + (size_t)j0 * c->V, c->V, bg, BPg, c->Xrm.p));
+      ISLECHK(k_gl_apply(c, BPg));
+      ISLECHK(allreduce_sum<float>(c, c->Zrm.p, (size_t)c->V * BPg));
+      ISLECHK(k_unpack_cm(c, c->Zrm.p, c->V, bg, BPg, Zcm + (size_t)j0 * c->V));
+    }
+    return 0;
+  }
   const int BP = panel_width(b);
   HIPCHK(c, c->Xrm.reserve((size_t)c->V * BP));
   HIPCHK(c, c->Zrm.reserve((size_t)c->V * BP));
@@ -689,6 +705,12 @@ extern "C" int isle_hip_gram_apply(isle_ctx* c, const float* X, int b, float* Z)
   ISLECHK(gram_apply_dev(c, c->Xcm.p, b, c->Zcm.p));
   HIPCHK(c, hipMemcpyAsync(Z, c->Zcm.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int isle_hip_operator_form(isle_ctx* c, int* form) {
+  if (!c || !form) return ISLE_E_ARG;
+  *form = c->band_ready ? c->gl_mode : -1;
   return 0;
 }
 

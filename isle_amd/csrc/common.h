@@ -42,6 +42,20 @@ struct DevBuf {
   ~DevBuf() { release(); }  // every buffer of a context dies with it
 };
 
+// One side of the LDS-banded Gram apply (gram_lds.hip): a sliced-ELL stream of band-local u16 source ids.
+struct GlDesc {  // one workgroup: 16 waves wave0 + i*wstride (i < nw), source bands [b0, b1), output slab
+  uint32_t wave0, wstride, nw, b0, b1, slab, pos_base, pad;
+};
+struct GlSide {
+  uint32_t n_out = 0, n_src = 0, NB = 0, nslice = 0, nwv = 0, ndesc = 0;
+  DevBuf<uint32_t> slice_of;  // nwv x 4: slice (64 consecutive output positions) of (wave, group), 0xffffffff = none
+  DevBuf<int64_t> roff;       // nwv x NB + 1: first super-round of (wave, band)
+  DevBuf<uint16_t> cnt;       // nwv x NB x 4: super-rounds (4 nonzeros per lane) of (wave, band, group)
+  DevBuf<uint2> ids;          // super-rounds x 64 lanes: four u16 band-local source ids per lane (+ prefetch slack)
+  DevBuf<GlDesc> desc;
+  int64_t total_sr = 0;
+};
+
 struct isle_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -106,6 +120,25 @@ struct isle_ctx {
   DevBuf<float> bval;      // nnz
   DevBuf<int64_t> seg_off; // nchunks*V + 1
   DevBuf<float> Zpart;     // nchunks x V x BP partial rows
+
+  // --- LDS-banded Gram apply (gram_lds.hip): used when every row of B holds a single value (B = diag(s) * pattern, which is
+  // what threshold_and_copy produces, src/sparseMatrix.cpp:1285-1321); otherwise the gather kernels of spmm.hip run.
+  int gl_mode = -1;          // -1 not decided for the current B, 0 gather path, 1 LDS path
+  bool cells_rowmajor = false;  // bcol / bval / seg_off hold row-major (word, document band) cells instead of chunk-major ones
+  GlSide gl1, gl2;           // pass 1 (outputs = documents, sources = words), pass 2 (outputs = words, sources = documents)
+  DevBuf<float> rowval;      // V: the value of row w
+  DevBuf<int> gl_flag;
+  DevBuf<uint32_t> dperm, dpos, wperm;  // document position -> document, document -> position, word position -> word
+  DevBuf<uint64_t> gl_key_a, gl_key_b;
+  DevBuf<uint32_t> gl_val_a, gl_val_b;
+  DevBuf<uint32_t> gl_bst;   // D x (NB1 + 1): first entry of each word band inside a document's column
+  DevBuf<uint32_t> gl_cellcnt, gl_srsum;
+  DevBuf<int64_t> gl_scan;
+  DevBuf<unsigned long long> gl_blocktot;
+  DevBuf<uint32_t> gl_slab0, gl_nch;  // per word block: first partial slab, number of slabs
+  DevBuf<float> gl_Xs, gl_part;       // scaled panel diag(s) X; partial rows of Z per (word block, band chunk)
+  DevBuf<uint32_t> rs_hist;           // radix sort scratch (ingest.hip: k_sort_pairs_u64)
+  DevBuf<int64_t> rs_hist_off, rs_scratch;
 
   // --- gram-apply workspaces
   DevBuf<float> Xrm, Yrm, Zrm;   // V*BP, D*BP, V*BP
@@ -201,6 +234,13 @@ int k_unpack_cm(isle_ctx* c, const float* Zrm, uint64_t V, int b, int BP, float*
 int k_gram_pass1(isle_ctx* c, int BP);   // Yrm = B^T Xrm
 int k_gram_pass2(isle_ctx* c, int BP);   // Zrm = B Yrm
 int k_band_build(isle_ctx* c);
+int k_band_build_chunked(isle_ctx* c);   // chunk-major cells for the gather path (spmm.hip)
+// gram_lds.hip
+int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B
+int k_gl_build(isle_ctx* c);
+int k_gl_apply(isle_ctx* c, int BP);     // Zrm = B (B^T Xrm), BP in {4, 8, 12}
+// ingest.hip
+int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);
 int k_frobenius(isle_ctx* c, double* out_host);
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms);
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,

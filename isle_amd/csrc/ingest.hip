@@ -12,6 +12,8 @@
 // leak into the next line (the reference keeps its was_whitespace flag across '\n'), blank lines are skipped, a bad
 // character or a line with more than three fields is an error instead of a debug assert.  The reference's
 // std::sort + std::unique keeps an unspecified one of several equal (doc, word) lines; here it is the first in the file.
+#include <utility>
+
 #include "common.h"
 #include "scan.h"
 
@@ -216,6 +218,31 @@ __global__ __launch_bounds__(IT) void ing_offsets_k(const uint32_t* __restrict__
 
 #define LAUNCH_CHECK(c) HIPCHK(c, hipGetLastError())
 
+// Stable LSD radix sort of n (key, payload) pairs on the low key_bits bits of the keys, ping-ponging between the caller's
+// two buffer pairs; *in_a tells which pair holds the sorted sequence.  Also used by gram_lds.hip to order documents and
+// words by their number of nonzeros.
+int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a) {
+  *in_a = true;
+  if (n < 2) return 0;
+  const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  HIPCHK(c, c->rs_hist.reserve((size_t)256 * nblocks));
+  HIPCHK(c, c->rs_hist_off.reserve((size_t)256 * nblocks + 1));
+  HIPCHK(c, c->rs_scratch.reserve(isle_scan_scratch((uint64_t)256 * nblocks) + 8));
+  uint64_t *ka = key_a, *kb = key_b;
+  uint32_t *va = val_a, *vb = val_b;
+  for (int shift = 0; shift < key_bits; shift += 8) {
+    hipLaunchKernelGGL(rs_hist_k, dim3(nblocks), dim3(IT), 0, c->stream, ka, n, shift, nblocks, c->rs_hist.p);
+    LAUNCH_CHECK(c);
+    HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, c->rs_hist.p, (uint64_t)256 * nblocks, c->rs_hist_off.p, c->rs_scratch.p)));
+    hipLaunchKernelGGL(rs_scatter_k, dim3(nblocks), dim3(IT), 0, c->stream, ka, va, n, shift, nblocks, c->rs_hist_off.p, kb, vb);
+    LAUNCH_CHECK(c);
+    std::swap(ka, kb);
+    std::swap(va, vb);
+    *in_a = !*in_a;
+  }
+  return 0;
+}
+
 // text_dev: n bytes on the device.  On success the context's count matrix is set (a_cnt / a_rows / a_offs, a_nnz).
 int k_ingest_tdf(isle_ctx* c, const unsigned char* text_dev, uint64_t n, uint64_t V, uint64_t D, uint64_t* entries_read, uint64_t* err_out /*2*/) {
   TimeScope ts(c, ISLE_T_INGEST);
@@ -237,11 +264,11 @@ int k_ingest_tdf(isle_ctx* c, const unsigned char* text_dev, uint64_t n, uint64_
   };
 #define ING(call)            \
   do {                       \
-    hipError_t e__ = (call); \
-    if (e__ != hipSuccess) { \
-      cleanup();             \
-      HIPCHK(c, e__);        \
-    }                        \
+    hipError_t ing_e = (call); \
+    if (ing_e != hipSuccess) { \
+      cleanup();               \
+      HIPCHK(c, ing_e);        \
+    }                          \
   } while (0)
   ING(tile_cnt.reserve(ntiles ? ntiles : 1));
   ING(tile_off.reserve(ntiles + 1));

@@ -191,6 +191,12 @@ class HotPath:
         self._chk(self._lib.isle_hip_gram_apply(self._h, _p(X), X.shape[1], _p(Z)))
         return Z
 
+    def operator_form(self):
+        """1 = LDS-banded Gram apply (row-constant B), 0 = gather form, -1 = operator not built yet."""
+        f = C.c_int()
+        self._chk(self._lib.isle_hip_operator_form(self._h, C.byref(f)))
+        return f.value
+
     def compute_block_ks(self, num_topics, blk=BLOCK_KS_BLOCK_SIZE, ncv=None, maxit=BLOCK_KS_MAX_ITERS,
                          tol=BLOCK_KS_TOLERANCE, seed=1, allow_noconv=False):
         """FPSparseMatrix::compute_block_ks(num_topics, evalues) — src/sparseMatrix.cpp:1195-1220."""

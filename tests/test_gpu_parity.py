@@ -67,6 +67,61 @@ def test_gram_apply_ragged_and_empty_columns(hp):
     assert relerr(hp.gram_apply(X), o.gram_apply(X)) <= 1e-5
 
 
+def _ragged(V, D, seed, row_constant):
+    rng = np.random.default_rng(seed)
+    cols = []
+    for d in range(D):
+        n = [0, 1, 7, 64, 65, 700][d % 6]
+        if d == 17:
+            n = V
+        cols.append(np.sort(rng.choice(V, size=min(n, V), replace=False)).astype(np.uint32))
+    offs = np.zeros(D + 1, np.int64)
+    offs[1:] = np.cumsum([len(c) for c in cols])
+    rows = np.concatenate(cols)
+    if row_constant:
+        vals = rng.uniform(0.5, 3.0, size=V).astype(np.float32)[rows]
+    else:
+        vals = rng.uniform(0.5, 3.0, size=rows.shape[0]).astype(np.float32)
+    return vals, rows, offs
+
+
+@pytest.mark.parametrize("V,D", [(4500, 300), (3412, 64), (3413, 65), (7000, 9000), (100, 5)])
+@pytest.mark.parametrize("b", [1, 5, 10, 12, 13, 25])
+def test_gram_apply_lds_form_ragged(hp, V, D, b):
+    # B = diag(s) * pattern (what threshold_and_copy builds): the LDS-banded form must be chosen and agree with the oracle;
+    # sizes straddle the band size (3412 rows), slices of 64 and workgroup blocks of 4096; empty / dense columns included
+    from oracle.oracle import OracleCsc
+    vals, rows, offs = _ragged(V, D, 11, True)
+    o = OracleCsc(V, D, vals, rows, offs)
+    hp.upload_csc(V, vals, rows, offs)
+    X = np.random.default_rng(b).standard_normal((V, b)).astype(np.float32)
+    Z = hp.gram_apply(X)
+    assert hp.operator_form() == 1
+    assert relerr(Z, o.gram_apply(X)) <= 1e-5
+
+
+def test_gram_apply_forms_agree(hp, small50):
+    # the two forms of the operator on the same thresholded matrix; a perturbed value switches to the gather form
+    B = small50
+    upload(hp, B)
+    X = np.random.default_rng(5).standard_normal((B["V"], 10)).astype(np.float32)
+    Z1 = hp.gram_apply(X)
+    assert hp.operator_form() == 1
+    vals = B["vals"].copy()
+    vals[len(vals) // 2] *= 1.5
+    hp.upload_csc(B["V"], vals, B["rows"], B["offs"])
+    Z0 = hp.gram_apply(X)
+    assert hp.operator_form() == 0
+    vals[len(vals) // 2] = B["vals"][len(vals) // 2]
+    assert relerr(Z1, B["oracle"].gram_apply(X)) <= 1e-5
+    # Z0 is the product with the perturbed matrix: only the rows / columns touched by that entry differ
+    from oracle.oracle import OracleCsc
+    vals2 = B["vals"].copy()
+    vals2[len(vals2) // 2] *= 1.5
+    o2 = OracleCsc(B["V"], B["D"], vals2, B["rows"], B["offs"])
+    assert relerr(Z0, o2.gram_apply(X)) <= 1e-5
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 30, 57, 200])
 def test_eig_sym_matches_lapack(hp, n):
     rng = np.random.default_rng(n)
@@ -175,6 +230,31 @@ def test_lift_and_sparse_lloyds_match_oracle(hp, small50):
     # host-provided centres take the same path
     sg2 = hp.run_lloyds(k, centers=cen_o)
     assert (sg2["assign"] == so["assign"]).mean() >= 0.99
+
+
+def test_gather_form_forced_by_env(hp, small50, monkeypatch):
+    """ISLE_GRAM_LDS=0 keeps the gather kernels (and the chunk-major cells the centroid update then walks) covered on a
+    thresholded matrix: same sigma, same sparse-Lloyd partition as the LDS-banded form."""
+    from oracle.oracle import lift
+    B, k = small50, 50
+    res = {}
+    for form in (1, 0):
+        monkeypatch.setenv("ISLE_GRAM_LDS", str(form))
+        upload(hp, B)
+        r = hp.compute_block_ks(k)
+        assert hp.operator_form() == form
+        U = B["oracle"].block_ks(k)["U"] if "U_or" not in res else res["U_or"]
+        res["U_or"] = U
+        hp.set_U(U)
+        ko = B["oracle"].kmeanspp(U, k, seed=5)
+        lo = B["oracle"].lloyds_projected(U, ko["C_lowd"])
+        hp.left_multiply_by_U(lo["C_lowd"], fetch=False)
+        sg = hp.run_lloyds(k)
+        res[form] = (np.sqrt(r["evals"]), sg["assign"], sg["centers"])
+    monkeypatch.delenv("ISLE_GRAM_LDS")
+    assert np.max(np.abs(res[1][0] - res[0][0]) / res[0][0]) <= 1e-5
+    assert (res[1][1] == res[0][1]).mean() >= 0.999
+    assert relerr(res[1][2], res[0][2]) <= 1e-4
 
 
 def test_full_hot_path_end_to_end(hp, small50):
