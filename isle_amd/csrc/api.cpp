@@ -246,6 +246,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   }
   HIPCHK(c, hipMemcpy(c->offs.p, offs, (D + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   c->band_ready = false;
+  c->gl_mode = -1;
   c->P_ready = false;
   c->Pt_ready = false;
   c->members_valid = false;
@@ -484,6 +485,7 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   ISLECHK(k_th_emit(c, c->a_doc_offset));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->band_ready = false;
+  c->gl_mode = -1;
   c->P_ready = false;
   c->Pt_ready = false;
   c->members_valid = false;
@@ -1413,7 +1415,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       }
     }
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
-    if (it + 1 < max_reps) {
+    {  // documents grouped by centre: visiting order of the next assignment, and what the counting centroid update walks
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_member_lists(c, c->assign.p, D, k, c->counts.p, nullptr));
     }

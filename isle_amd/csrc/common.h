@@ -124,15 +124,16 @@ struct isle_ctx {
   // --- LDS-banded Gram apply (gram_lds.hip): used when every row of B holds a single value (B = diag(s) * pattern, which is
   // what threshold_and_copy produces, src/sparseMatrix.cpp:1285-1321); otherwise the gather kernels of spmm.hip run.
   int gl_mode = -1;          // -1 not decided for the current B, 0 gather path, 1 LDS path
-  bool cells_rowmajor = false;  // bcol / bval / seg_off hold row-major (word, document band) cells instead of chunk-major ones
   GlSide gl1, gl2;           // pass 1 (outputs = documents, sources = words), pass 2 (outputs = words, sources = documents)
   DevBuf<float> rowval;      // V: the value of row w
   DevBuf<int> gl_flag;
-  DevBuf<uint32_t> dperm, dpos, wperm;  // document position -> document, document -> position, word position -> word
+  DevBuf<uint32_t> dperm, dpos, wperm, wpos;  // position -> document, document -> position, position -> word, word -> position
   DevBuf<uint64_t> gl_key_a, gl_key_b;
   DevBuf<uint32_t> gl_val_a, gl_val_b;
   DevBuf<uint32_t> gl_bst;   // D x (NB1 + 1): first entry of each word band inside a document's column
-  DevBuf<uint32_t> gl_cellcnt, gl_srsum;
+  DevBuf<uint16_t> gl_cellcnt;   // V x NB2: entries of (word, document band)
+  DevBuf<uint32_t> gl_srsum, gl_sbase;
+  DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)
   DevBuf<int64_t> gl_scan;
   DevBuf<unsigned long long> gl_blocktot;
   DevBuf<uint32_t> gl_slab0, gl_nch;  // per word block: first partial slab, number of slabs
@@ -236,7 +237,8 @@ int k_gram_pass2(isle_ctx* c, int BP);   // Zrm = B Yrm
 int k_band_build(isle_ctx* c);
 int k_band_build_chunked(isle_ctx* c);   // chunk-major cells for the gather path (spmm.hip)
 // gram_lds.hip
-int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B
+int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
+int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);  // needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
 int k_gl_apply(isle_ctx* c, int BP);     // Zrm = B (B^T Xrm), BP in {4, 8, 12}
 // ingest.hip

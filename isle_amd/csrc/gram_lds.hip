@@ -20,9 +20,16 @@
 // Pass 2: a word block (64 consecutive slices) is split over document-band chunks in proportion to its work; chunk
 // partials go to slabs that gl_reduce_k sums in fixed order (and scales by s_w).
 //
-// The summation order inside a (word, document band) cell follows the placement atomics of the build (as in the
-// chunked-CSR copy of spmm.hip), so Z may differ between runs by fp32 rounding only.
+// The build never materialises a transposed copy of B: per document band one workgroup histograms the band's entries by
+// word in LDS (two u16 counters per dword) — first to count the (word, band) cells, then again as placement cursors
+// that drop every entry's band-local document id straight into its slot of the pass-2 stream.  The summation order
+// inside a (word, document band) cell therefore follows those LDS atomics, so Z may differ between runs by fp32 rounding
+// only (as with the chunked-CSR copy of spmm.hip).
+//
+// The same row-constant structure turns the centroid update of Lloyd on B (lloyds_iter, src/sparseMatrix.cpp:1631-1646)
+// into integer counting: centre_c[w] = s_w * #{members of c that contain w} / |c|  (cc_hist_k below).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -38,6 +45,9 @@ constexpr uint32_t GL_RB = 3412;  // source rows per band: (3412 + 1 zero row) *
 constexpr uint32_t GL_LDS = (GL_RB + 1) * 48;
 constexpr int GL_PF = 4;  // super-rounds in flight per wave (4 x 512 B)
 constexpr uint32_t GL_NONE = 0xffffffffu;
+constexpr uint32_t GL_VP = 81920;  // words per vocabulary part of the LDS histograms (two u16 counters per dword: 160 KiB)
+constexpr uint32_t GL_HLDS = GL_VP / 2 * 4;
+constexpr double GL_BAND_COST = 64.0;  // cost of staging one band, in super-rounds (workgroup sizing of pass 2)
 constexpr uint32_t GL_BLOCK_SLICES = GL_WAVES * GL_G;       // 64 slices
 constexpr uint32_t GL_BLOCK_ITEMS = GL_BLOCK_SLICES * 64;   // 4096 output items per workgroup
 
@@ -102,10 +112,10 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 
 // cnt[(wv * NB + band) * 4 + g] = super-rounds of (wave, band, group); srsum[wv * NB + band] = their sum.
 // One workgroup of 4 waves per wave wv (wave g of the workgroup = group g).  PASS 1: lane count = bst differences;
-// PASS 2: lane count = size of cell (word wperm[q], band) of the row-major cells.
+// PASS 2: lane count = size of cell (word wperm[q], band).
 template <int PASS>
 __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ slice_of, uint32_t n_out, uint32_t NB,
-                                                 const uint32_t* __restrict__ bst, const int64_t* __restrict__ seg_off,
+                                                 const uint32_t* __restrict__ bst, const uint16_t* __restrict__ cellcnt,
                                                  const uint32_t* __restrict__ wperm, uint16_t* __restrict__ cnt, uint32_t* __restrict__ srsum,
                                                  int* __restrict__ overflow) {
   __shared__ uint32_t sh[4];
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ sli
   if (live) base = PASS == 1 ? (size_t)pos * (NB + 1) : (size_t)wperm[pos] * NB;
   for (uint32_t band = 0; band < NB; ++band) {
     uint32_t n = 0;
-    if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)(seg_off[base + band + 1] - seg_off[base + band]);
+    if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[base + band];
     const uint32_t sr = (wave_max_u32(n) + 3) >> 2;
     if (lane == 0) {
       if (sr > 0xffffu) *overflow = 1;
@@ -170,69 +180,86 @@ __global__ __launch_bounds__(256) void gl_fill1_k(const uint32_t* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 2 build: row-major (word, document band) cells of B, band = position of the document / GL_RB.
-// Stands in for the CSR copy of the reference's operator constructor (mkl_scsrcsc, include/matUtils.h:103-106); the
-// cells of one word are contiguous, so centers_from_rows_k (spmm.hip) walks them as one CSR row.
+// pass 2 build: (word, document band) cell sizes and the id stream, by LDS histograms over the band's entries.
+// band = position of the document / GL_RB; grid = (bands, vocabulary parts of GL_VP words).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gl_cell_count_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
-                                                        const uint32_t* __restrict__ dpos, uint32_t D, uint32_t NB,
-                                                        uint32_t* __restrict__ cellcnt) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= D) return;
-  const uint32_t band = dpos[d] / GL_RB;
-  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) atomicAdd(&cellcnt[(size_t)rows[i] * NB + band], 1u);
-}
-__global__ __launch_bounds__(256) void gl_cell_fill_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
-                                                       const int64_t* __restrict__ offs, const uint32_t* __restrict__ dpos, uint32_t D,
-                                                       uint32_t NB, const int64_t* __restrict__ seg_off, uint32_t* __restrict__ cursor,
-                                                       uint32_t* __restrict__ ccol, float* __restrict__ cval) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= D) return;
-  const uint32_t band = dpos[d] / GL_RB;
-  for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
-    const size_t cell = (size_t)rows[i] * NB + band;
-    const int64_t at = seg_off[cell] + atomicAdd(&cursor[cell], 1u);
-    ccol[at] = d;
-    cval[at] = vals[i];
+__global__ __launch_bounds__(GL_THREADS) void gl_hist_count_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                               const uint32_t* __restrict__ dperm, uint32_t D, uint32_t V, uint32_t NB,
+                                                               uint16_t* __restrict__ cellcnt /* V x NB */) {
+  extern __shared__ uint32_t hist[];  // GL_VP / 2 dwords, two u16 counters each (a cell holds <= GL_RB entries)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t band = blockIdx.x;
+  const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
+  for (uint32_t j = threadIdx.x; j < GL_VP / 2; j += GL_THREADS) hist[j] = 0;
+  __syncthreads();
+  const uint32_t p0 = band * GL_RB, p1 = min(D, p0 + GL_RB);
+  for (uint32_t p = p0 + wave; p < p1; p += GL_WAVES) {
+    const uint32_t d = dperm[p];
+    for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+      const uint32_t w = rows[i];
+      if (w >= w0 && w < w1) atomicAdd(&hist[(w - w0) >> 1], ((w - w0) & 1u) ? 0x10000u : 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < (w1 - w0 + 1) / 2; j += GL_THREADS) {
+    const uint32_t v = hist[j];
+    const uint32_t w = w0 + 2 * j;
+    cellcnt[(size_t)w * NB + band] = (uint16_t)(v & 0xffffu);
+    if (w + 1 < w1) cellcnt[(size_t)(w + 1) * NB + band] = (uint16_t)(v >> 16);
   }
 }
 
-__global__ __launch_bounds__(256) void gl_fill2_k(const uint32_t* __restrict__ slice_of, uint32_t V, uint32_t NB,
-                                                   const int64_t* __restrict__ seg_off, const uint32_t* __restrict__ wperm,
-                                                   const uint32_t* __restrict__ ccol, const uint32_t* __restrict__ dpos, uint64_t nnz,
-                                                   const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const size_t wb = blockIdx.x;
+// sort key of a word: its row length = sum of its cells
+__global__ __launch_bounds__(256) void gl_rowlen_key_k(const uint16_t* __restrict__ cellcnt, uint32_t V, uint32_t NB, uint64_t maxkey,
+                                                        uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= V) return;
+  uint64_t len = 0;
+  for (uint32_t b = 0; b < NB; ++b) len += cellcnt[(size_t)w * NB + b];
+  key[w] = maxkey - (len < maxkey ? len : maxkey);
+  val[w] = w;
+}
+
+// sbase[slice * NB + band] = first super-round of (slice, band) in the stream
+__global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ slice_of, const uint16_t* __restrict__ cnt,
+                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase) {
+  const size_t wb = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (wb >= nwb) return;
   const size_t wv = wb / NB;
   const uint32_t band = (uint32_t)(wb - wv * NB);
-  const uint16_t* cc = cnt + wb * 4;
-  const uint32_t n = cc[g];
-  if (n == 0) return;
-  int64_t sr0 = roff[wb];
-  for (int j = 0; j < g; ++j) sr0 += cc[j];
-  const uint32_t sl = slice_of[wv * 4 + g];
-  const uint64_t pos = (uint64_t)sl * 64 + lane;
-  int64_t base = 0;
-  uint32_t len = 0;
-  if (sl != GL_NONE && pos < V) {
-    const size_t cell = (size_t)wperm[pos] * NB + band;
-    base = seg_off[cell];
-    len = (uint32_t)(seg_off[cell + 1] - base);
+  uint32_t base = (uint32_t)roff[wb];
+  for (int g = 0; g < GL_G; ++g) {
+    const uint32_t sl = slice_of[wv * 4 + g];
+    if (sl != GL_NONE) sbase[(size_t)sl * NB + band] = base;
+    base += cnt[wb * 4 + g];
   }
-  const uint32_t r0 = band * GL_RB;
-  for (uint32_t r = 0; r < n; ++r) {
-    uint32_t id[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t j = 4 * r + t;
-      int64_t at = base + j;
-      if (at > (int64_t)nnz - 1) at = (int64_t)nnz - 1;
-      const uint32_t p = dpos[ccol[at]];
-      id[t] = j < len ? p - r0 : GL_RB;
+}
+
+// every entry (w, d) of the band: slot = cursor of cell (w, band) (LDS, returning atomic) -> ids of pass 2
+__global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                              const uint32_t* __restrict__ dperm, uint32_t D, uint32_t V, uint32_t NB,
+                                                              const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ sbase,
+                                                              uint16_t* __restrict__ ids16) {
+  extern __shared__ uint32_t hist[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t band = blockIdx.x;
+  const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
+  for (uint32_t j = threadIdx.x; j < GL_VP / 2; j += GL_THREADS) hist[j] = 0;
+  __syncthreads();
+  const uint32_t p0 = band * GL_RB, p1 = min(D, p0 + GL_RB);
+  for (uint32_t p = p0 + wave; p < p1; p += GL_WAVES) {
+    const uint32_t d = dperm[p];
+    for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+      const uint32_t w = rows[i];
+      if (w >= w0 && w < w1) {
+        const uint32_t odd = (w - w0) & 1u;
+        const uint32_t cur = atomicAdd(&hist[(w - w0) >> 1], odd ? 0x10000u : 1u);
+        const uint32_t j = odd ? (cur >> 16) : (cur & 0xffffu);
+        const uint32_t q = wpos[w];
+        const size_t sr = (size_t)sbase[(size_t)(q >> 6) * NB + band] + (j >> 2);
+        ids16[(sr * 64 + (q & 63u)) * 4 + (j & 3u)] = (uint16_t)(p - p0);
+      }
     }
-    ids[(size_t)(sr0 + r) * 64 + lane] = make_uint2(id[0] | (id[1] << 16), id[2] | (id[3] << 16));
   }
 }
 
@@ -378,20 +405,71 @@ __global__ __launch_bounds__(256) void gl_reduce_k(const float4* __restrict__ pa
   Z[(size_t)w * LPE + l] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// centroid update of Lloyd on B for row-constant B (lloyds_iter, src/sparseMatrix.cpp:1613-1646):
+//   sum over the members d of centre c of B[w, d]  =  s_w * #{members of c that contain w}
+// One workgroup per CC_CH consecutive entries of the member list (documents grouped by centre) and vocabulary part:
+// word histogram in LDS (ds_add_u32, two u16 counters per dword), flushed with one global integer atomic per word
+// present, once per centre the range touches.  No float atomics, no transposed copy of B; the counts are exact.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t CC_CH = 2048;
+__global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                         const uint32_t* __restrict__ members, const int* __restrict__ moff,
+                                                         const uint32_t* __restrict__ assign, uint32_t D, uint32_t V, int ld,
+                                                         uint32_t* __restrict__ cnt /* V x ld */) {
+  extern __shared__ uint32_t hist[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
+  const uint32_t nh = (w1 - w0 + 1) / 2;
+  for (uint32_t j = threadIdx.x; j < nh; j += GL_THREADS) hist[j] = 0;
+  __syncthreads();
+  const uint32_t m0 = blockIdx.x * CC_CH, m1 = min(D, m0 + CC_CH);
+  uint32_t m = m0;
+  while (m < m1) {  // uniform over the workgroup
+    const uint32_t cc = assign[members[m]];
+    const uint32_t mend = min(m1, (uint32_t)moff[cc + 1]);  // centre cc owns members [moff[cc], moff[cc + 1])
+    for (uint32_t idx = m + wave; idx < mend; idx += GL_WAVES) {
+      const uint32_t d = members[idx];
+      for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+        const uint32_t w = rows[i];
+        if (w >= w0 && w < w1) atomicAdd(&hist[(w - w0) >> 1], ((w - w0) & 1u) ? 0x10000u : 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nh; j += GL_THREADS) {
+      const uint32_t v = hist[j];
+      if (v) {
+        const size_t w = (size_t)w0 + 2 * j;
+        if (v & 0xffffu) atomicAdd(&cnt[w * ld + cc], v & 0xffffu);
+        if (v >> 16) atomicAdd(&cnt[(w + 1) * ld + cc], v >> 16);
+        hist[j] = 0;
+      }
+    }
+    __syncthreads();
+    m = mend;
+  }
+}
+__global__ __launch_bounds__(256) void cc_centers_k(const uint32_t* __restrict__ cnt, const float* __restrict__ rowval, size_t n, int ld,
+                                                     float* __restrict__ Crm) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) Crm[i] = rowval[i / ld] * (float)cnt[i];
+}
+
 int bits_for(uint64_t n) {
   int b = 1;
   while ((1ull << b) <= n) ++b;
   return b;
 }
 
-// order n items by decreasing length (len_i = off[(i+1)*stride] - off[i*stride]); perm[p] = item at position p
-int order_by_length(isle_ctx* c, const int64_t* off, uint64_t n, uint64_t stride, uint64_t maxlen, uint32_t* perm) {
+int reserve_sort(isle_ctx* c, uint64_t n) {
   HIPCHK(c, c->gl_key_a.reserve(n));
   HIPCHK(c, c->gl_key_b.reserve(n));
   HIPCHK(c, c->gl_val_a.reserve(n));
   HIPCHK(c, c->gl_val_b.reserve(n));
-  hipLaunchKernelGGL(gl_len_key_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, off, n, stride, maxlen, c->gl_key_a.p, c->gl_val_a.p);
-  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+// keys (maxlen - length) in gl_key_a, items in gl_val_a  ->  perm[p] = item at position p, longest first (stable)
+int sort_by_key(isle_ctx* c, uint64_t n, uint64_t maxlen, uint32_t* perm) {
   bool in_a = true;
   ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, n, bits_for(maxlen), &in_a));
   HIPCHK(c, hipMemcpyAsync(perm, in_a ? c->gl_val_a.p : c->gl_val_b.p, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -410,7 +488,7 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(nwb) + 8));
   HIPCHK(c, c->gl_flag.reserve(4));
   HIPCHK(c, hipMemsetAsync(c->gl_flag.p, 0, sizeof(int), c->stream));
-  hipLaunchKernelGGL((gl_cnt_k<PASS>), dim3(s.nwv), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->seg_off.p,
+  hipLaunchKernelGGL((gl_cnt_k<PASS>), dim3(s.nwv), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->gl_cellcnt.p,
                      c->wperm.p, s.cnt.p, c->gl_srsum.p, c->gl_flag.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, c->gl_srsum.p, nwb, s.roff.p, c->gl_scan.p)));
@@ -419,16 +497,26 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   HIPCHK(c, hipMemcpyAsync(&s.total_sr, s.roff.p + nwb, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (overflow) return isle_fail(c, ISLE_E_NUMERIC, "operator build: more than 65535 super-rounds in one (wave, band) cell");
+  if (s.total_sr >= 0xfffffff0ll) return isle_fail(c, ISLE_E_ARG, "operator build: id stream too long (%lld super-rounds)", (long long)s.total_sr);
   HIPCHK(c, s.ids.reserve(((size_t)s.total_sr + 2 * GL_PF) * 64));
-  // the prefetch ring reads up to GL_PF super-rounds past the end: keep that slack defined
-  HIPCHK(c, hipMemsetAsync(s.ids.p + (size_t)s.total_sr * 64, 0, (size_t)2 * GL_PF * 64 * sizeof(uint2), c->stream));
-  if (nwb) {
-    if (PASS == 1)
-      hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
-                         c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
-    else
-      hipLaunchKernelGGL(gl_fill2_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->seg_off.p, c->wperm.p,
-                         c->bcol.p, c->dpos.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
+  // the prefetch ring reads up to GL_PF super-rounds past the end: that slack, and in pass 2 every slot no entry lands in,
+  // holds the padding id (the zero row behind the band)
+  const size_t n16_all = ((size_t)s.total_sr + 2 * GL_PF) * 64 * 4, n16_body = (size_t)s.total_sr * 64 * 4;
+  uint16_t* ids16 = reinterpret_cast<uint16_t*>(s.ids.p);
+  if (PASS == 1) {
+    HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)GL_RB, n16_all - n16_body, c->stream));
+    if (nwb) hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
+                                c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
+    HIPCHK(c, c->gl_sbase.reserve((size_t)s.nslice * s.NB));
+    if (nwb) hipLaunchKernelGGL(gl_sbase_k, dim3(cdiv((long)nwb, 256)), dim3(256), 0, c->stream, s.slice_of.p, s.cnt.p, s.roff.p, nwb, s.NB,
+                                c->gl_sbase.p);
+    HIPCHK(c, hipGetLastError());
+    const uint32_t nvp = (s.n_out + GL_VP - 1) / GL_VP;
+    hipLaunchKernelGGL(gl_hist_fill_k, dim3(s.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, s.n_out,
+                       s.NB, c->wpos.p, c->gl_sbase.p, ids16);
     HIPCHK(c, hipGetLastError());
   }
   return 0;
@@ -453,6 +541,7 @@ int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, si
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 int k_gl_detect(isle_ctx* c) {
+  if (c->gl_mode >= 0) return 0;  // decided for this B (reset by every upload / thresholding)
   c->gl_mode = 0;
   const char* e = getenv("ISLE_GRAM_LDS");
   if (e && atoi(e) == 0) return 0;
@@ -478,10 +567,20 @@ int k_gl_build(isle_ctx* c) {
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
   GlSide& s1 = c->gl1;
   GlSide& s2 = c->gl2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)gl_hist_count_k, hipFuncAttributeMaxDynamicSharedMemorySize, GL_HLDS));
+    HIPCHK(c, hipFuncSetAttribute((const void*)gl_hist_fill_k, hipFuncAttributeMaxDynamicSharedMemorySize, GL_HLDS));
+    attr_set = true;
+  }
   // ---- documents by decreasing length
   HIPCHK(c, c->dperm.reserve(D));
   HIPCHK(c, c->dpos.reserve(D));
-  ISLECHK(order_by_length(c, c->offs.p, D, 1, V, c->dperm.p));
+  ISLECHK(reserve_sort(c, std::max(D, V)));
+  hipLaunchKernelGGL(gl_len_key_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->offs.p, (uint64_t)D, (uint64_t)1, (uint64_t)V, c->gl_key_a.p,
+                     c->gl_val_a.p);
+  HIPCHK(c, hipGetLastError());
+  ISLECHK(sort_by_key(c, D, V, c->dperm.p));
   hipLaunchKernelGGL(gl_invert_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dperm.p, (uint64_t)D, c->dpos.p);
   HIPCHK(c, hipGetLastError());
 
@@ -519,31 +618,26 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));  // ds / so are stack-owned
   }
 
-  // ---- row-major (word, document band) cells
+  // ---- (word, document band) cell sizes: one LDS histogram per band and vocabulary part
   s2.n_out = V;
   s2.n_src = D;
   s2.NB = (D + GL_RB - 1) / GL_RB;
   const size_t ncell = (size_t)V * s2.NB;
+  const uint32_t nvp = (V + GL_VP - 1) / GL_VP;
   HIPCHK(c, c->gl_cellcnt.reserve(ncell));
-  HIPCHK(c, c->seg_off.reserve(ncell + 1));
-  HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(ncell) + 8));
-  HIPCHK(c, c->bcol.reserve(c->nnz));
-  HIPCHK(c, c->bval.reserve(c->nnz));
-  HIPCHK(c, hipMemsetAsync(c->gl_cellcnt.p, 0, ncell * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(gl_cell_count_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->rows.p, c->offs.p, c->dpos.p, D, s2.NB, c->gl_cellcnt.p);
+  hipLaunchKernelGGL(gl_hist_count_k, dim3(s2.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, D, V, s2.NB,
+                     c->gl_cellcnt.p);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, c->gl_cellcnt.p, ncell, c->seg_off.p, c->gl_scan.p)));
-  HIPCHK(c, hipMemsetAsync(c->gl_cellcnt.p, 0, ncell * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(gl_cell_fill_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, c->dpos.p, D, s2.NB,
-                     c->seg_off.p, c->gl_cellcnt.p, c->bcol.p, c->bval.p);
-  HIPCHK(c, hipGetLastError());
-  c->nbands = s2.NB;
-  c->chunk_cols = GL_RB;
-  c->cells_rowmajor = true;
 
   // ---- words by decreasing row length
   HIPCHK(c, c->wperm.reserve(V));
-  ISLECHK(order_by_length(c, c->seg_off.p, V, s2.NB, D, c->wperm.p));
+  HIPCHK(c, c->wpos.reserve(V));
+  hipLaunchKernelGGL(gl_rowlen_key_k, dim3(cdiv(V, 256)), dim3(256), 0, c->stream, c->gl_cellcnt.p, V, s2.NB, (uint64_t)D, c->gl_key_a.p,
+                     c->gl_val_a.p);
+  HIPCHK(c, hipGetLastError());
+  ISLECHK(sort_by_key(c, V, D, c->wperm.p));
+  hipLaunchKernelGGL(gl_invert_k, dim3(cdiv(V, 256)), dim3(256), 0, c->stream, c->wperm.p, (uint64_t)V, c->wpos.p);
+  HIPCHK(c, hipGetLastError());
 
   // ---- pass 2: outputs = words (position order), sources = documents (position order)
   s2.nslice = (V + 63) / 64;
@@ -567,15 +661,18 @@ int k_gl_build(isle_ctx* c) {
     std::vector<unsigned long long> tot(nblk);
     HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // band chunks per word block in proportion to its super-rounds; about two workgroups per CU in total
-    unsigned long long all = 0;
-    for (auto t : tot) all += t;
-    const double target = std::max(1.0, (double)all / (2.0 * c->num_cus));
+    // band chunks per word block in proportion to its cost; about two workgroups per CU in total.  Cost of a block = its
+    // super-rounds (LDS-bound: ~50 ns of CU time each) + one 160 KB band load per band (~3 us, GL_BAND_COST super-rounds);
+    // without the second term a block of rare words would walk every band in a single workgroup
+    const double band_cost = GL_BAND_COST * (double)s2.NB;
+    double all = 0;
+    for (auto t : tot) all += (double)t + band_cost;
+    const double target = std::max(1.0, all / (2.0 * c->num_cus));
     std::vector<uint32_t> slab0(nblk), nch(nblk);
     std::vector<GlDesc> ds;
     uint32_t nslab = 0;
     for (uint32_t ob = 0; ob < nblk; ++ob) {
-      uint32_t n = (uint32_t)std::min<double>((double)s2.NB, std::max(1.0, std::ceil((double)tot[ob] / target)));
+      uint32_t n = (uint32_t)std::min<double>((double)s2.NB, std::max(1.0, std::ceil(((double)tot[ob] + band_cost) / target)));
       slab0[ob] = nslab;
       nch[ob] = n;
       for (uint32_t ch = 0; ch < n; ++ch) {
@@ -593,6 +690,12 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->gl_nch.p, nch.data(), nblk * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->gl_part.reserve((size_t)nslab * GL_BLOCK_ITEMS * 12));  // sized for the widest panel (BP = 12)
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("ISLE_GL_VERBOSE"))
+      fprintf(stderr,
+              "[gram_lds] V=%u D=%u nnz=%llu | pass1: bands=%u waves=%u wgs=%u padded=%.2fx | pass2: bands=%u blocks=%u wgs=%u slabs=%u "
+              "padded=%.2fx\n",
+              V, D, (unsigned long long)c->nnz, s1.NB, s1.nwv, s1.ndesc, (double)s1.total_sr * 256.0 / (double)c->nnz, s2.NB, nblk, s2.ndesc,
+              nslab, (double)s2.total_sr * 256.0 / (double)c->nnz);
   }
   return 0;
 }
@@ -627,5 +730,30 @@ int k_gl_apply(isle_ctx* c, int BP) {
                        c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, (float4*)c->Zrm.p);
     HIPCHK(c, hipGetLastError());
   }
+  return 0;
+}
+
+// Crm (V x ld row-major) = per-centre sums of the member columns (not yet divided by the cluster sizes).
+// c->members / c->moff must hold the documents grouped by `assign` (k_member_lists).
+int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* Crm) {
+  TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
+  (void)k;
+  const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)cc_hist_k, hipFuncAttributeMaxDynamicSharedMemorySize, GL_HLDS));
+    attr_set = true;
+  }
+  const size_t n = (size_t)V * ld;
+  HIPCHK(c, c->ccount.reserve(n));
+  HIPCHK(c, hipMemsetAsync(c->ccount.p, 0, n * sizeof(uint32_t), c->stream));
+  if (D) {
+    const uint32_t nvp = (V + GL_VP - 1) / GL_VP;
+    hipLaunchKernelGGL(cc_hist_k, dim3(cdiv(D, CC_CH), nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->members.p, c->moff.p,
+                       assign, D, V, ld, c->ccount.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(cc_centers_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, c->ccount.p, c->rowval.p, n, ld, Crm);
+  HIPCHK(c, hipGetLastError());
   return 0;
 }

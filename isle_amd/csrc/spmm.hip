@@ -205,7 +205,6 @@ int k_band_build(isle_ctx* c) {
 
 int k_band_build_chunked(isle_ctx* c) {
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
-  c->cells_rowmajor = false;
   // chunk size: a chunk's slice of Y (Cc x 16 floats) should sit comfortably in a 4 MiB XCD L2
   uint32_t Cc = c->band_rows ? c->band_rows : 32768;
   uint32_t nch = (uint32_t)((D + Cc - 1) / Cc);
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_k(const float4* __restrict_
 
 int k_gram_pass2(isle_ctx* c, int BP) {
   ISLECHK(k_band_build(c));
-  if (c->cells_rowmajor) return isle_fail(c, ISLE_E_ARG, "gather pass 2 needs the chunk-major cells");
+  if (c->gl_mode == 1) return isle_fail(c, ISLE_E_ARG, "gather pass 2 called on the LDS-banded form");
   TimeScope ts(c, ISLE_T_GRAM_PASS2);
   const uint32_t V = (uint32_t)c->V;
   const uint32_t nch = c->nbands;
@@ -516,7 +515,7 @@ int k_doc_norms(isle_ctx* c, float* dn) {
 // One wave per vocabulary row w walks the row's cells of the chunked-CSR copy and keeps a k-bin histogram in LDS
 // (one ds_add_f32 per nonzero); the finished row of sums is written once, coalesced.
 __global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restrict__ cval, const uint32_t* __restrict__ ccol,
-                                                            const int64_t* __restrict__ seg_off, uint32_t V, uint32_t nch, int rowmajor,
+                                                            const int64_t* __restrict__ seg_off, uint32_t V, uint32_t nch,
                                                             const uint32_t* __restrict__ assign, int ldk, float* __restrict__ Crm) {
   extern __shared__ float bins_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -524,12 +523,9 @@ __global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restri
   const uint32_t w = blockIdx.x * 4 + wave;
   if (w >= V) return;
   for (int j = lane; j < ldk; j += 64) bins[j] = 0.f;
-  // chunk-major cells: one segment per chunk; row-major cells (gram_lds.hip): the row's cells are one contiguous segment
-  const uint32_t nseg = rowmajor ? 1u : nch;
-  for (uint32_t ch = 0; ch < nseg; ++ch) {
+  for (uint32_t ch = 0; ch < nch; ++ch) {
     const size_t seg = (size_t)ch * V + w;
-    const int64_t beg = rowmajor ? seg_off[(size_t)w * nch] : seg_off[seg];
-    const int64_t end = rowmajor ? seg_off[(size_t)(w + 1) * nch] : seg_off[seg + 1];
+    const int64_t beg = seg_off[seg], end = seg_off[seg + 1];
     for (int64_t i = beg + lane; i < end; i += 64) {
       const uint32_t d = __builtin_nontemporal_load(&ccol[i]);
       const float v = __builtin_nontemporal_load(&cval[i]);
@@ -542,12 +538,14 @@ __global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restri
 }
 
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm) {
+  ISLECHK(k_gl_detect(c));
+  if (c->gl_mode == 1) return k_centers_counts(c, assign, k, ldk, Crm);  // row-constant B: integer counting, no transposed copy
   ISLECHK(k_band_build(c));
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
   const uint32_t V = (uint32_t)c->V;
   const size_t lds = 4 * (size_t)ldk * sizeof(float);
   hipLaunchKernelGGL(centers_from_rows_k, dim3(cdiv(V, 4)), dim3(256), lds, c->stream, c->bval.p, c->bcol.p, c->seg_off.p, V, c->nbands,
-                     c->cells_rowmajor ? 1 : 0, assign, ldk, Crm);
+                     assign, ldk, Crm);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
