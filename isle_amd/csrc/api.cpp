@@ -678,7 +678,7 @@ static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
       HIPCHK(c, c->Zrm.reserve((size_t)c->V * BPg));
       HIPCHK(c, c->Yrm.reserve((size_t)c->D * BPg));
       ISLECHK(k_pack_rm(c, Xcm + (size_t)j0 * c->V, c->V, bg, BPg, c->Xrm.p));
-      ISLECHK(k_gl_apply(c, BPg));
+      ISLECHK(k_gl_apply(c, bg, BPg));
       ISLECHK(allreduce_sum<float>(c, c->Zrm.p, (size_t)c->V * BPg));
       ISLECHK(k_unpack_cm(c, c->Zrm.p, c->V, bg, BPg, Zcm + (size_t)j0 * c->V));
     }

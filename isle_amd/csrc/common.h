@@ -240,7 +240,7 @@ int k_band_build_chunked(isle_ctx* c);   // chunk-major cells for the gather pat
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);  // needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
-int k_gl_apply(isle_ctx* c, int BP);     // Zrm = B (B^T Xrm), BP in {4, 8, 12}
+int k_gl_apply(isle_ctx* c, int b, int BP);  // Zrm = B (B^T Xrm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip
 int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);
 int k_frobenius(isle_ctx* c, double* out_host);

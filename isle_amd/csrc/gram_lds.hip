@@ -42,11 +42,12 @@ constexpr int GL_WAVES = 16;
 constexpr int GL_THREADS = GL_WAVES * 64;
 constexpr int GL_G = 4;
 constexpr uint32_t GL_RB = 3412;  // source rows per band: (3412 + 1 zero row) * 48 B = 163 824 B <= 160 KiB
-constexpr uint32_t GL_LDS = (GL_RB + 1) * 48;
+constexpr uint32_t GL_LDS = 163840;  // all of it: the last 1-KiB DMA piece of a band ends 16 bytes behind the padding row
 constexpr int GL_PF = 4;  // super-rounds in flight per wave (4 x 512 B)
 constexpr uint32_t GL_NONE = 0xffffffffu;
 constexpr uint32_t GL_VP = 81920;  // words per vocabulary part of the LDS histograms (two u16 counters per dword: 160 KiB)
 constexpr uint32_t GL_HLDS = GL_VP / 2 * 4;
+constexpr int GL_SUB = 8;  // lanes per document in the histogram kernels
 constexpr double GL_BAND_COST = 64.0;  // cost of staging one band, in super-rounds (workgroup sizing of pass 2)
 constexpr uint32_t GL_BLOCK_SLICES = GL_WAVES * GL_G;       // 64 slices
 constexpr uint32_t GL_BLOCK_ITEMS = GL_BLOCK_SLICES * 64;   // 4096 output items per workgroup
@@ -187,15 +188,16 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_count_k(const uint32_t* __
                                                                const uint32_t* __restrict__ dperm, uint32_t D, uint32_t V, uint32_t NB,
                                                                uint16_t* __restrict__ cellcnt /* V x NB */) {
   extern __shared__ uint32_t hist[];  // GL_VP / 2 dwords, two u16 counters each (a cell holds <= GL_RB entries)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t band = blockIdx.x;
   const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
   for (uint32_t j = threadIdx.x; j < GL_VP / 2; j += GL_THREADS) hist[j] = 0;
   __syncthreads();
   const uint32_t p0 = band * GL_RB, p1 = min(D, p0 + GL_RB);
-  for (uint32_t p = p0 + wave; p < p1; p += GL_WAVES) {
+  // GL_SUB lanes per document: 64 / GL_SUB independent load -> atomic chains per wave (the loop is latency-bound)
+  for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
     const uint32_t d = dperm[p];
-    for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+    for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
       const uint32_t w = rows[i];
       if (w >= w0 && w < w1) atomicAdd(&hist[(w - w0) >> 1], ((w - w0) & 1u) ? 0x10000u : 1u);
     }
@@ -241,15 +243,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
                                                               const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ sbase,
                                                               uint16_t* __restrict__ ids16) {
   extern __shared__ uint32_t hist[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t band = blockIdx.x;
   const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
   for (uint32_t j = threadIdx.x; j < GL_VP / 2; j += GL_THREADS) hist[j] = 0;
   __syncthreads();
   const uint32_t p0 = band * GL_RB, p1 = min(D, p0 + GL_RB);
-  for (uint32_t p = p0 + wave; p < p1; p += GL_WAVES) {
+  for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
     const uint32_t d = dperm[p];
-    for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+    for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
       const uint32_t w = rows[i];
       if (w >= w0 && w < w1) {
         const uint32_t odd = (w - w0) & 1u;
@@ -290,21 +292,27 @@ __device__ inline void add4(float4& a, const float4 b) {
   a.w += b.w;
 }
 
-template <int LPE>
+// LPE float4 per panel row; HALF: the panel's last two columns are padding (b = 4 LPE - 2 or 4 LPE - 3), so only the low
+// half of the last float4 is read and accumulated (b = 10: 40 of 48 bytes per gathered row).
+template <int LPE, bool HALF>
 __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restrict__ In, uint32_t n_src, const uint2* __restrict__ ids,
                                                           const int64_t* __restrict__ roff, const uint16_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ slice_of, const GlDesc* __restrict__ desc, uint32_t NB,
                                                           float4* __restrict__ Out, size_t slab_stride, uint32_t n_out) {
   extern __shared__ float4 xs[];  // (GL_RB + 1) rows of LPE float4
+  constexpr int NF = HALF ? LPE - 1 : LPE;  // whole float4 per row
   const GlDesc ds = desc[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool wvalid = (uint32_t)w < ds.nw;  // wave-uniform
   const size_t wv = wvalid ? (size_t)ds.wave0 + (size_t)w * ds.wstride : (size_t)ds.wave0;
-  float4 acc[GL_G][LPE];
+  float4 acc[GL_G][NF > 0 ? NF : 1];
+  float2 acch[GL_G];
 #pragma unroll
-  for (int g = 0; g < GL_G; ++g)
+  for (int g = 0; g < GL_G; ++g) {
 #pragma unroll
-    for (int l = 0; l < LPE; ++l) acc[g][l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < NF; ++l) acc[g][l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    acch[g] = make_float2(0.f, 0.f);
+  }
   // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
   uint2 q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
@@ -312,22 +320,22 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
     __syncthreads();  // every wave is done with the previous band
     {
+      // stage the band: ten 1-KiB LDS-DMA pieces per wave (global_load_lds_dwordx4: no VGPR round trip, all in flight at once)
       const uint32_t r0 = band * GL_RB;
       const uint32_t nrow = min(GL_RB, n_src - r0);
       const float4* src = In + (size_t)r0 * LPE;
       const uint32_t n4 = nrow * LPE;  // <= 10 * 1024
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float4 tmp[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) tmp[j] = src[min(threadIdx.x + (h * 5 + j) * (uint32_t)GL_THREADS, n4 - 1)];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const uint32_t i = threadIdx.x + (h * 5 + j) * (uint32_t)GL_THREADS;
-          if (i < n4) xs[i] = tmp[j];
+      for (int j = 0; j < 10; ++j) {
+        const uint32_t i0 = (uint32_t)(j * GL_WAVES + w) * 64;  // wave-uniform LDS base, lane l lands at i0 + l
+        if (i0 + lane < n4) {  // lanes past the band's end stay masked: they must not land on the padding row
+          const float4* gp = src + i0 + lane;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)(xs + i0),
+                                           16, 0, 0);
         }
       }
-      if (threadIdx.x < LPE) xs[GL_RB * LPE + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
+      if (threadIdx.x < LPE) xs[GL_RB * LPE + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding row
     }
     __syncthreads();
     const uint2 cc = *reinterpret_cast<const uint2*>(cnt + (wv * NB + band) * 4);
@@ -343,15 +351,17 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
         q2 = q3;
         q3 = *p;
         p += 64;
-        const uint32_t a0 = (u.x & 0xffffu) * LPE, a1 = (u.x >> 16) * LPE, a2 = (u.y & 0xffffu) * LPE, a3 = (u.y >> 16) * LPE;
+        const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
 #pragma unroll
-        for (int l = 0; l < LPE; ++l) add4(acc[g][l], xs[a0 + l]);
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int l = 0; l < LPE; ++l) add4(acc[g][l], xs[a1 + l]);
-#pragma unroll
-        for (int l = 0; l < LPE; ++l) add4(acc[g][l], xs[a2 + l]);
-#pragma unroll
-        for (int l = 0; l < LPE; ++l) add4(acc[g][l], xs[a3 + l]);
+          for (int l = 0; l < NF; ++l) add4(acc[g][l], xs[a[t] + l]);
+          if (HALF) {
+            const float2 h = *reinterpret_cast<const float2*>(&xs[a[t] + NF]);
+            acch[g].x += h.x;
+            acch[g].y += h.y;
+          }
+        }
       }
     }
   }
@@ -363,7 +373,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     const uint64_t pos = (uint64_t)sl * 64 + lane;
     if (sl != GL_NONE && pos < n_out) {
 #pragma unroll
-      for (int l = 0; l < LPE; ++l) out[(pos - ds.pos_base) * LPE + l] = acc[g][l];
+      for (int l = 0; l < NF; ++l) out[(pos - ds.pos_base) * LPE + l] = acc[g][l];
+      if (HALF) out[(pos - ds.pos_base) * LPE + NF] = make_float4(acch[g].x, acch[g].y, 0.f, 0.f);
     }
   }
 }
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restri
                                                          const uint32_t* __restrict__ assign, uint32_t D, uint32_t V, int ld,
                                                          uint32_t* __restrict__ cnt /* V x ld */) {
   extern __shared__ uint32_t hist[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
   const uint32_t nh = (w1 - w0 + 1) / 2;
   for (uint32_t j = threadIdx.x; j < nh; j += GL_THREADS) hist[j] = 0;
@@ -428,9 +439,9 @@ __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restri
   while (m < m1) {  // uniform over the workgroup
     const uint32_t cc = assign[members[m]];
     const uint32_t mend = min(m1, (uint32_t)moff[cc + 1]);  // centre cc owns members [moff[cc], moff[cc + 1])
-    for (uint32_t idx = m + wave; idx < mend; idx += GL_WAVES) {
+    for (uint32_t idx = m + wave * (64 / GL_SUB) + sub; idx < mend; idx += GL_WAVES * (64 / GL_SUB)) {
       const uint32_t d = members[idx];
-      for (int64_t i = offs[d] + lane; i < offs[d + 1]; i += 64) {
+      for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
         const uint32_t w = rows[i];
         if (w >= w0 && w < w1) atomicAdd(&hist[(w - w0) >> 1], ((w - w0) & 1u) ? 0x10000u : 1u);
       }
@@ -522,17 +533,22 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   return 0;
 }
 
-template <int LPE>
+template <int LPE, bool HALF>
 int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)gl_apply_k<LPE>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS));
+    HIPCHK(c, hipFuncSetAttribute((const void*)gl_apply_k<LPE, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gl_apply_k<LPE>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
+  hipLaunchKernelGGL((gl_apply_k<LPE, HALF>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
                      s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+int launch_apply_any(isle_ctx* c, int LPE, bool half, const GlSide& s, const float4* In, float4* Out, size_t slab_stride) {
+  if (LPE == 1) return half ? launch_apply<1, true>(c, s, In, Out, slab_stride) : launch_apply<1, false>(c, s, In, Out, slab_stride);
+  if (LPE == 2) return half ? launch_apply<2, true>(c, s, In, Out, slab_stride) : launch_apply<2, false>(c, s, In, Out, slab_stride);
+  return half ? launch_apply<3, true>(c, s, In, Out, slab_stride) : launch_apply<3, false>(c, s, In, Out, slab_stride);
 }
 
 }  // namespace
@@ -700,10 +716,11 @@ int k_gl_build(isle_ctx* c) {
   return 0;
 }
 
-// Zrm (V x BP) = B (B^T Xrm); Xrm / Yrm / Zrm of the context, BP in {4, 8, 12}
-int k_gl_apply(isle_ctx* c, int BP) {
+// Zrm (V x BP) = B (B^T Xrm); Xrm / Yrm / Zrm of the context; b columns in a panel of BP = 4, 8 or 12
+int k_gl_apply(isle_ctx* c, int b, int BP) {
   const int LPE = BP / 4;
-  if (LPE < 1 || LPE > 3) return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: panel width %d not in {4, 8, 12}", BP);
+  if (LPE < 1 || LPE > 3 || b > BP || b <= BP - 4) return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: b = %d in a panel of %d", b, BP);
+  const bool half = b <= BP - 2;
   const uint32_t V = (uint32_t)c->V;
   const size_t nx4 = (size_t)V * LPE;
   HIPCHK(c, c->gl_Xs.reserve((size_t)V * BP));
@@ -712,20 +729,11 @@ int k_gl_apply(isle_ctx* c, int BP) {
     hipLaunchKernelGGL(gl_scale_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->Xrm.p, c->rowval.p, nx4, LPE,
                        (float4*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
-    const float4* X = (const float4*)c->gl_Xs.p;
-    float4* Y = (float4*)c->Yrm.p;
-    if (LPE == 1) ISLECHK(launch_apply<1>(c, c->gl1, X, Y, 0));
-    if (LPE == 2) ISLECHK(launch_apply<2>(c, c->gl1, X, Y, 0));
-    if (LPE == 3) ISLECHK(launch_apply<3>(c, c->gl1, X, Y, 0));
+    ISLECHK(launch_apply_any(c, LPE, half, c->gl1, (const float4*)c->gl_Xs.p, (float4*)c->Yrm.p, 0));
   }
   {
     TimeScope ts(c, ISLE_T_GRAM_PASS2);
-    const float4* Y = (const float4*)c->Yrm.p;
-    float4* P = (float4*)c->gl_part.p;
-    const size_t stride = (size_t)GL_BLOCK_ITEMS * LPE;
-    if (LPE == 1) ISLECHK(launch_apply<1>(c, c->gl2, Y, P, stride));
-    if (LPE == 2) ISLECHK(launch_apply<2>(c, c->gl2, Y, P, stride));
-    if (LPE == 3) ISLECHK(launch_apply<3>(c, c->gl2, Y, P, stride));
+    ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)GL_BLOCK_ITEMS * LPE));
     hipLaunchKernelGGL(gl_reduce_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->gl_part.p, c->gl_slab0.p,
                        c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, (float4*)c->Zrm.p);
     HIPCHK(c, hipGetLastError());
