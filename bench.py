@@ -186,6 +186,11 @@ def main():
     except Exception:
         pass
     device_ms = {f: round(v[0] / steps, 3) for f, v in tm.items() if v[1]}
+    form = hp.operator_form()
+    form_kernels = ("LDS-banded form: gl_scale_k + gl_apply_k<3,true> (pass 1) + gl_apply_k<3,true> + gl_reduce_k (pass 2)" if form == 1
+                    else "gather form: seg_gather_k<3,false> (pass 1) + seg_gather_k<3,true> + reduce_chunks_k (pass 2)")
+    if form != 1:
+        traffic = None  # profiles/pmc_traffic.json holds the LDS-banded form's counters
 
     # ---------------- CPU baseline: the oracle ("port") on a bounded sample of the same work --------------
     cpu = None
@@ -311,7 +316,7 @@ def main():
         },
         "accuracy": {"sigma_rel_err_bound": float(np.max(resid) / 2.0), "checked_pairs": int(kk),
                      "note": "|sigma-sigma_true|/sigma <= ||A u - lambda u|| / (2 lambda), residual computed with the HIP Gram apply"},
-        "roofline": {"bound": "hbm", "kernel": "gram_apply = gram_pass1_k + gram_pass2_k (Z = B(B^T X), b=%d)" % b,
+        "roofline": {"bound": "hbm", "kernel": "gram_apply (Z = B(B^T X), b=%d) = %s" % (b, form_kernels),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},

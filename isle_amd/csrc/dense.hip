@@ -613,8 +613,12 @@ __global__ __launch_bounds__(256) void bj_gram_k(const double* __restrict__ W, i
 }
 
 // (2) one cyclic sweep of two-sided rotations on G in LDS, Q accumulated; grid = pairs
+// cross_only: rotate only the 16 x 16 pairs (column of block A, column of block B), 16 rounds instead of the 31 of the full
+// tournament.  The host asks for the full tournament in round 0 of every sweep (each block is in exactly one pair there),
+// so every column pair of the matrix is rotated exactly once per sweep — the classical cyclic Jacobi in a block ordering —
+// instead of the intra-block pairs being revisited in every round.
 __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, double tol, double abs_tol, const double* __restrict__ gpart,
-                                                   int nrowch, double* __restrict__ scr, unsigned int* __restrict__ rotated) {
+                                                   int nrowch, double* __restrict__ scr, unsigned int* __restrict__ rotated, int cross_only) {
   __shared__ double G[BJ_P][BJ_P + 1];
   __shared__ double Q[BJ_P][BJ_P + 1];
   __shared__ unsigned int nrot;
@@ -634,15 +638,39 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
   }
   if (t == 0) nrot = 0;
   __syncthreads();
+  {
+    // Already diagonal to tolerance (every pair in the late sweeps, all of them in the last one)?  Then no rotation below
+    // would fire: leave without the 31 rounds.  Same test as the rotation rule, applied to the whole block at once.
+    int live = 0;
+    for (int idx = t; idx < BJ_P * BJ_P; idx += 256) {
+      const int i = idx / BJ_P, j = idx % BJ_P;
+      if (i < j && (!cross_only || (i < BJ_W && j >= BJ_W))) {
+        const double a = G[i][i], b = G[j][j], g = G[i][j];
+        live |= (a > 0.0 && b > 0.0 && g * g > tol * tol * a * b && fabs(g) > abs_tol) ? 1 : 0;
+      }
+    }
+    if (!__syncthreads_or(live)) {
+      if (t == 0) S[BJ_P * BJ_P] = 0.0;
+      return;
+    }
+  }
   // Thread (bi, bj) owns the 2x2 block G[{p_i,q_i}][{p_j,q_j}] of rotation pairs i and j, and two rows of Q's column
   // pair i.  Every thread derives the two rotations it needs from G's diagonal blocks itself (redundant arithmetic, but
   // no separate parameter phase): a round is read -> barrier -> write -> barrier.
   const int bi = t >> 4, bj = t & 15;
   unsigned int my_rot = 0;
-  for (int ir = 0; ir < BJ_P - 1; ++ir) {
+  const int nrounds = cross_only ? BJ_W : BJ_P - 1;
+  for (int ir = 0; ir < nrounds; ++ir) {
     int pi, qi, pj, qj;
-    rr_pair(BJ_P, ir, bi, &pi, &qi);
-    rr_pair(BJ_P, ir, bj, &pj, &qj);
+    if (cross_only) {
+      pi = bi;
+      qi = BJ_W + ((bi + ir) & (BJ_W - 1));
+      pj = bj;
+      qj = BJ_W + ((bj + ir) & (BJ_W - 1));
+    } else {
+      rr_pair(BJ_P, ir, bi, &pi, &qi);
+      rr_pair(BJ_P, ir, bj, &pj, &qj);
+    }
     if (pi > qi) {
       const int x = pi;
       pi = qi;
@@ -707,7 +735,7 @@ __global__ __launch_bounds__(256) void bj_inner_k(int n, int nblk2, int round, d
 
 // (3) [Ma Mb] <- [Ma Mb] Q for M = W and V, one thread per row; grid = (pairs, row chunks)
 __global__ __launch_bounds__(256) void bj_apply_k(double* __restrict__ W, double* __restrict__ Vv, int n, int nblk2, int round,
-                                                   const double* __restrict__ scr) {
+                                                   const double* __restrict__ scr, int nmat) {
   __shared__ double Q[BJ_P][BJ_P + 1];
   int A, Bk;
   bj_blocks(nblk2, round, blockIdx.x, &A, &Bk);
@@ -722,8 +750,7 @@ __global__ __launch_bounds__(256) void bj_apply_k(double* __restrict__ W, double
   // made hipcc branch around every load, wait for each separately and spill: 33 us per launch).
   const int r = blockIdx.y * BJ_ROWS + (t & 63);
   const int c0 = (t >> 6) * 8;
-#pragma unroll
-  for (int mat = 0; mat < 2; ++mat) {
+  for (int mat = 0; mat < nmat; ++mat) {
     double* M = mat ? Vv : W;
     double x[BJ_P];
 #pragma unroll
@@ -823,8 +850,10 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
     HIPCHK(c, hipMemsetAsync(rot, 0, sizeof(unsigned int), c->stream));
     for (int round = 0; round < nblk - 1; ++round) {
       hipLaunchKernelGGL(bj_gram_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, np, nblk, round, gpart);
-      hipLaunchKernelGGL(bj_inner_k, dim3(npairs), dim3(256), 0, c->stream, np, nblk, round, tol, abs_tol, gpart, nrowch, c->jacS.p, rot);
-      hipLaunchKernelGGL(bj_apply_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, np, nblk, round, c->jacS.p);
+      hipLaunchKernelGGL(bj_inner_k, dim3(npairs), dim3(256), 0, c->stream, np, nblk, round, tol, abs_tol, gpart, nrowch, c->jacS.p, rot,
+                         (round > 0 && !getenv("ISLE_EVD_FULL_TOURNAMENT")) ? 1 : 0);
+      hipLaunchKernelGGL(bj_apply_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, np, nblk, round, c->jacS.p,
+                         2);
     }
     HIPCHK(c, hipGetLastError());
     unsigned int nrot = 0;
