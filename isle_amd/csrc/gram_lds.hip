@@ -48,7 +48,7 @@ constexpr uint32_t GL_NONE = 0xffffffffu;
 constexpr uint32_t GL_VP = 81920;  // words per vocabulary part of the LDS histograms (two u16 counters per dword: 160 KiB)
 constexpr uint32_t GL_HLDS = GL_VP / 2 * 4;
 constexpr int GL_SUB = 8;  // lanes per document in the histogram kernels
-constexpr double GL_BAND_COST = 64.0;  // cost of staging one band, in super-rounds (workgroup sizing of pass 2)
+constexpr double GL_BAND_COST = 256.0;  // cost of staging one 160 KB band from HBM in pass 2, in super-rounds (measured by sweep at C2)
 constexpr uint32_t GL_BLOCK_SLICES = GL_WAVES * GL_G;       // 64 slices
 constexpr uint32_t GL_BLOCK_ITEMS = GL_BLOCK_SLICES * 64;   // 4096 output items per workgroup
 
@@ -265,21 +265,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
   }
 }
 
-// total super-rounds of every word block (16 waves x all bands): the weight used to size its band chunks
-__global__ __launch_bounds__(256) void gl_blocktot_k(const uint32_t* __restrict__ srsum, uint32_t nwv, uint32_t NB,
+// total super-rounds of every (word block, band zone): the weights used to size the band chunks.  grid = (blocks, zones)
+__global__ __launch_bounds__(256) void gl_blocktot_k(const uint32_t* __restrict__ srsum, uint32_t nwv, uint32_t NB, uint32_t nzones,
                                                       unsigned long long* __restrict__ tot) {
   __shared__ unsigned long long sh[256];
   const size_t w0 = (size_t)blockIdx.x * GL_WAVES;
   const size_t w1 = (w0 + GL_WAVES < (size_t)nwv) ? w0 + GL_WAVES : (size_t)nwv;
+  const uint32_t z = blockIdx.y;
+  const uint32_t zb0 = (uint32_t)((uint64_t)z * NB / nzones), zb1 = (uint32_t)((uint64_t)(z + 1) * NB / nzones);
+  const uint32_t nzb = zb1 - zb0;
   unsigned long long s = 0;
-  for (size_t i = w0 * NB + threadIdx.x; i < w1 * NB; i += 256) s += srsum[i];
+  for (size_t i = threadIdx.x; i < (w1 - w0) * nzb; i += 256) {
+    const size_t w = w0 + i / nzb;
+    s += srsum[w * NB + zb0 + (uint32_t)(i % nzb)];
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int m = 128; m >= 1; m >>= 1) {
     if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
     __syncthreads();
   }
-  if (threadIdx.x == 0) tot[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) tot[(size_t)blockIdx.x * nzones + z] = sh[0];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -560,18 +566,28 @@ int k_gl_detect(isle_ctx* c) {
   if (c->gl_mode >= 0) return 0;  // decided for this B (reset by every upload / thresholding)
   c->gl_mode = 0;
   const char* e = getenv("ISLE_GRAM_LDS");
-  if (e && atoi(e) == 0) return 0;
-  if (c->nnz == 0 || c->D == 0 || c->V == 0) return 0;
-  if (c->D >= 0xfffffff0ull || c->V >= 0xfffffff0ull) return 0;
-  HIPCHK(c, c->rowval.reserve(c->V));
+  // every rank takes part in the agreement below, whatever its own shard looks like
+  bool eligible = !(e && atoi(e) == 0) && c->nnz > 0 && c->D > 0 && c->V > 0 && c->D < 0xfffffff0ull && c->V < 0xfffffff0ull;
   HIPCHK(c, c->gl_flag.reserve(4));
-  HIPCHK(c, hipMemsetAsync(c->rowval.p, 0, c->V * sizeof(float), c->stream));
   HIPCHK(c, hipMemsetAsync(c->gl_flag.p, 0, sizeof(int), c->stream));
-  const dim3 g(cdiv((long)c->nnz, 256)), b(256);
-  hipLaunchKernelGGL(gl_rowval_set_k, g, b, 0, c->stream, c->vals.p, c->rows.p, c->nnz, c->rowval.p);
-  HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(gl_rowval_chk_k, g, b, 0, c->stream, c->vals.p, c->rows.p, c->nnz, c->rowval.p, c->gl_flag.p);
-  HIPCHK(c, hipGetLastError());
+  if (eligible) {
+    HIPCHK(c, c->rowval.reserve(c->V));
+    HIPCHK(c, hipMemsetAsync(c->rowval.p, 0, c->V * sizeof(float), c->stream));
+    const dim3 g(cdiv((long)c->nnz, 256)), b(256);
+    hipLaunchKernelGGL(gl_rowval_set_k, g, b, 0, c->stream, c->vals.p, c->rows.p, c->nnz, c->rowval.p);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(gl_rowval_chk_k, g, b, 0, c->stream, c->vals.p, c->rows.p, c->nnz, c->rowval.p, c->gl_flag.p);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    const int one = 1;
+    HIPCHK(c, hipMemcpyAsync(c->gl_flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (c->comm) {  // one form on all ranks (the collectives per application must match)
+    TimeScope ts(c, ISLE_T_COMM);
+    const ncclResult_t r = ncclAllReduce(c->gl_flag.p, c->gl_flag.p, 1, ncclInt, ncclMax, c->comm, c->stream);
+    if (r != ncclSuccess) return isle_fail(c, ISLE_E_COMM, "operator form agreement: %s", ncclGetErrorString(r));
+  }
   int flag = 0;
   HIPCHK(c, hipMemcpyAsync(&flag, c->gl_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -671,32 +687,58 @@ int k_gl_build(isle_ctx* c) {
         }
       }
     ISLECHK(build_side<2>(c, s2, so));
-    HIPCHK(c, c->gl_blocktot.reserve(nblk));
-    hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, s2.NB, c->gl_blocktot.p);
+    // Band zones (experiment, off by default: ISLE_GL_ZONES=8): workgroup i runs on XCD i % 8, so descriptor i is taken from
+    // zone i % 8 of the document bands, hoping that the word blocks walking one zone share its L2 (every one of the 13 word
+    // blocks at C2 stages every band of Y: 0.62 GB per application).  Measured slower at C2 (0.36 vs 0.30 ms): the zones'
+    // workgroups do not stay in step and the load balance over XCDs gets worse.
+    const char* e_nz = getenv("ISLE_GL_ZONES");
+    const uint32_t NZ = (e_nz && atoi(e_nz) == 8 && s2.NB >= 64) ? 8u : 1u;
+    HIPCHK(c, c->gl_blocktot.reserve((size_t)nblk * NZ));
+    hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, NZ), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, s2.NB, NZ, c->gl_blocktot.p);
     HIPCHK(c, hipGetLastError());
-    std::vector<unsigned long long> tot(nblk);
-    HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> tot((size_t)nblk * NZ);
+    HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // band chunks per word block in proportion to its cost; about two workgroups per CU in total.  Cost of a block = its
-    // super-rounds (LDS-bound: ~50 ns of CU time each) + one 160 KB band load per band (~3 us, GL_BAND_COST super-rounds);
-    // without the second term a block of rare words would walk every band in a single workgroup
-    const double band_cost = GL_BAND_COST * (double)s2.NB;
+    // band chunks per (word block, zone) in proportion to cost; about two workgroups per CU in total.  Cost = super-rounds
+    // (LDS-bound, ~50 ns of CU time each) + GL_BAND_COST per band staged; without the second term a block of rare words
+    // would walk a whole zone in a single workgroup
+    const char* e_bc = getenv("ISLE_GL_BAND_COST");   // tuning knobs (defaults measured at C2)
+    const char* e_wg = getenv("ISLE_GL_WGS_PER_CU");
+    const double bc = e_bc ? atof(e_bc) : GL_BAND_COST;
     double all = 0;
-    for (auto t : tot) all += (double)t + band_cost;
-    const double target = std::max(1.0, all / (2.0 * c->num_cus));
-    std::vector<uint32_t> slab0(nblk), nch(nblk);
-    std::vector<GlDesc> ds;
+    for (auto t : tot) all += (double)t;
+    all += bc * (double)s2.NB * nblk;
+    const double target = std::max(1.0, all / ((e_wg ? atof(e_wg) : 2.0) * c->num_cus));
+    std::vector<uint32_t> slab0(nblk), nch(nblk, 0);
+    std::vector<std::vector<GlDesc>> zone(NZ);
     uint32_t nslab = 0;
     for (uint32_t ob = 0; ob < nblk; ++ob) {
-      uint32_t n = (uint32_t)std::min<double>((double)s2.NB, std::max(1.0, std::ceil(((double)tot[ob] + band_cost) / target)));
       slab0[ob] = nslab;
-      nch[ob] = n;
-      for (uint32_t ch = 0; ch < n; ++ch) {
-        const uint32_t b0 = (uint32_t)((uint64_t)ch * s2.NB / n), b1 = (uint32_t)((uint64_t)(ch + 1) * s2.NB / n);
-        ds.push_back(GlDesc{ob * GL_WAVES, 1u, (uint32_t)GL_WAVES, b0, b1, nslab + ch, ob * GL_BLOCK_ITEMS, 0u});
+      for (uint32_t z = 0; z < NZ; ++z) {
+        const uint32_t zb0 = (uint32_t)((uint64_t)z * s2.NB / NZ), zb1 = (uint32_t)((uint64_t)(z + 1) * s2.NB / NZ);
+        const uint32_t nzb = zb1 - zb0;
+        if (nzb == 0) continue;
+        const double cost = (double)tot[(size_t)ob * NZ + z] + bc * nzb;
+        const uint32_t n = (uint32_t)std::min<double>((double)nzb, std::max(1.0, std::ceil(cost / target)));
+        for (uint32_t ch = 0; ch < n; ++ch) {
+          const uint32_t b0 = zb0 + (uint32_t)((uint64_t)ch * nzb / n), b1 = zb0 + (uint32_t)((uint64_t)(ch + 1) * nzb / n);
+          zone[z].push_back(GlDesc{ob * GL_WAVES, 1u, (uint32_t)GL_WAVES, b0, b1, nslab, ob * GL_BLOCK_ITEMS, 0u});
+          ++nslab;
+          ++nch[ob];
+        }
       }
-      nslab += n;
     }
+    size_t zmax = 0;
+    for (auto& zl : zone) {
+      // inside a zone: by first band, so that the workgroups in flight on that XCD stage neighbouring bands
+      if (getenv("ISLE_GL_SORT")) std::stable_sort(zl.begin(), zl.end(), [](const GlDesc& a, const GlDesc& b) { return a.b0 < b.b0; });
+      zmax = std::max(zmax, zl.size());
+    }
+    std::vector<GlDesc> ds;
+    ds.reserve(zmax * NZ);
+    for (size_t j = 0; j < zmax; ++j)
+      for (uint32_t z = 0; z < NZ; ++z)
+        ds.push_back(j < zone[z].size() ? zone[z][j] : GlDesc{0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u});  // empty: no wave is valid
     s2.ndesc = (uint32_t)ds.size();
     HIPCHK(c, s2.desc.reserve(ds.size()));
     HIPCHK(c, c->gl_slab0.reserve(nblk));

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Timing probe for the Gram apply at C2 size: device ms of pass 1 / pass 2 / operator build for a list of environment
+settings (each setting re-uploads B, which rebuilds the operator).  usage: gram_probe.py ['ENV=VAL,ENV=VAL' ...]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from isle_amd import HotPath  # noqa: E402
+from tools.synth import Corpus  # noqa: E402
+
+V, D, k, seed = 50_000, 1_000_000, 200, 2024
+B = Corpus(V, D, k, seed).threshold(k, free_A=True)
+hp = HotPath(0)
+X = np.random.default_rng(0).standard_normal((V, 10)).astype(np.float32)
+ref = None
+for setting in (sys.argv[1:] or [""]):
+    kv = [s.split("=") for s in setting.split(",") if s]
+    for a, b in kv:
+        os.environ[a] = b
+    hp.upload_csc(V, B["vals"], B["rows"], B["offs"])
+    Z = hp.gram_apply(X)
+    if ref is None:
+        ref = Z
+    hp.timing_enable(True)
+    hp.timing_reset()
+    for _ in range(20):
+        hp.gram_apply(X)
+    t = hp.timing_get()
+    err = float(np.linalg.norm(Z - ref) / np.linalg.norm(ref))
+    print("%-40s form=%d pass1 %.4f ms  pass2 %.4f ms  (relerr vs first %.1e)" % (setting or "(default)", hp.operator_form(),
+          t["gram_pass1"][0] / 20, t["gram_pass2"][0] / 20, err), flush=True)
+    for a, b in kv:
+        del os.environ[a]
