@@ -883,18 +883,27 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
 // ------------------------------------------------------------------------------------------
 // column sums of squares of a row-major matrix (centre norms, src/sparseMatrix.cpp:1575-1584)
 // ------------------------------------------------------------------------------------------
-constexpr int CN_ROWS = 512;
+constexpr int CN_ROWS = 128;
+// 256 threads = 4 row groups x 64 column lanes: coalesced 256-B row segments, 32 rows per thread, fp64 partial sums
 __global__ __launch_bounds__(256) void colnorm_partial_k(const float* __restrict__ Mrm, const float* __restrict__ Sub /*nullable*/,
                                                           uint64_t rows, int k, int ldk, double* __restrict__ part) {
+  __shared__ double sh[4][64];
   const uint64_t r0 = (uint64_t)blockIdx.x * CN_ROWS;
   const uint64_t r1 = min(rows, r0 + CN_ROWS);
-  for (int cc = threadIdx.x; cc < k; cc += 256) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < k; c0 += 64) {
+    const int cc = c0 + cl;
     double s = 0.0;
-    for (uint64_t r = r0; r < r1; ++r) {
-      const double x = (double)Mrm[r * ldk + cc] - (Sub ? (double)Sub[r * ldk + cc] : 0.0);
-      s = fma(x, x, s);
+    if (cc < k) {
+      for (uint64_t r = r0 + rg; r < r1; r += 4) {
+        const double x = (double)Mrm[r * ldk + cc] - (Sub ? (double)Sub[r * ldk + cc] : 0.0);
+        s = fma(x, x, s);
+      }
     }
-    part[(size_t)blockIdx.x * k + cc] = s;
+    sh[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && cc < k) part[(size_t)blockIdx.x * k + cc] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    __syncthreads();
   }
 }
 __global__ void colnorm_reduce_k(const double* __restrict__ part, int nchunks, int k, float* __restrict__ out) {
