@@ -1420,7 +1420,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       ISLECHK(k_member_lists(c, c->assign.p, D, k, c->counts.p, nullptr));
     }
     if (hamerly) HIPCHK(c, hipMemcpyAsync(c->centers_old.p, c->centers_rm.p, (size_t)V * ld * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p));                          // :1613-1638
+    ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p, it == 0));                 // :1613-1638
     ISLECHK(allreduce_sum<float>(c, c->centers_rm.p, (size_t)V * ld));
     std::vector<long long> sizes;
     ISLECHK(fetch_sizes(c, k, sizes));

@@ -134,6 +134,7 @@ struct isle_ctx {
   DevBuf<uint16_t> gl_cellcnt;   // V x NB2: entries of (word, document band)
   DevBuf<uint32_t> gl_srsum, gl_sbase;
   DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)
+  DevBuf<uint32_t> ccounted;     // D: the centre under which document d is counted in ccount
   DevBuf<int64_t> gl_scan;
   DevBuf<unsigned long long> gl_blocktot;
   DevBuf<uint32_t> gl_slab0, gl_nch;  // per word block: first partial slab, number of slabs
@@ -238,8 +239,9 @@ int k_band_build(isle_ctx* c);
 int k_band_build_chunked(isle_ctx* c);   // chunk-major cells for the gather path (spmm.hip)
 // gram_lds.hip
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
-int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);  // needs c->members grouped by `assign`
+int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out);  // Out (D x ld) = B^T M, LDS-banded form only
 int k_gl_apply(isle_ctx* c, int b, int BP);  // Zrm = B (B^T Xrm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip
 int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);
@@ -257,7 +259,7 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
                      int fam = ISLE_T_SPARSE_ASSIGN);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
 int k_doc_norms(isle_ctx* c, float* dn);
-int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm);
+int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool first_of_run = true);
 
 // threshold.hip
 int k_th_stats(isle_ctx* c, uint64_t* tokens_nz_dev);

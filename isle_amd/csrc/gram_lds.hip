@@ -304,7 +304,9 @@ template <int LPE, bool HALF>
 __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restrict__ In, uint32_t n_src, const uint2* __restrict__ ids,
                                                           const int64_t* __restrict__ roff, const uint16_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ slice_of, const GlDesc* __restrict__ desc, uint32_t NB,
-                                                          float4* __restrict__ Out, size_t slab_stride, uint32_t n_out) {
+                                                          float4* __restrict__ Out, size_t slab_stride, uint32_t n_out,
+                                                          const uint32_t* __restrict__ rowmap /*nullable: position -> output row*/,
+                                                          uint32_t out_ld4 /*output row stride in float4*/) {
   extern __shared__ float4 xs[];  // (GL_RB + 1) rows of LPE float4
   constexpr int NF = HALF ? LPE - 1 : LPE;  // whole float4 per row
   const GlDesc ds = desc[blockIdx.x];
@@ -378,11 +380,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     const uint32_t sl = slice_of[wv * 4 + g];
     const uint64_t pos = (uint64_t)sl * 64 + lane;
     if (sl != GL_NONE && pos < n_out) {
+      const size_t row = rowmap ? (size_t)rowmap[pos] : (size_t)(pos - ds.pos_base);
 #pragma unroll
-      for (int l = 0; l < NF; ++l) out[(pos - ds.pos_base) * LPE + l] = acc[g][l];
-      if (HALF) out[(pos - ds.pos_base) * LPE + NF] = make_float4(acch[g].x, acch[g].y, 0.f, 0.f);
+      for (int l = 0; l < NF; ++l) out[row * out_ld4 + l] = acc[g][l];
+      if (HALF) out[row * out_ld4 + NF] = make_float4(acch[g].x, acch[g].y, 0.f, 0.f);
     }
   }
+}
+
+// Xs[w, 0:4 LPE) = s_w * M[w, j0 : j0 + ncol)  (zero padded), M row-major with leading dimension ld: one panel of a wide operand
+__global__ __launch_bounds__(256) void gl_pack_panel_k(const float* __restrict__ M, int ld, int j0, int ncol, int LPE, const float* __restrict__ rowval,
+                                                        size_t n4, float4* __restrict__ Xs) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const size_t w = i / LPE;
+  const int l = (int)(i - w * LPE);
+  const float s = rowval[w];
+  const float* src = M + w * (size_t)ld + j0 + 4 * l;
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = (4 * l + t < ncol) ? s * src[t] : 0.f;
+  Xs[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // Xs[w, :] = s_w * X[w, :]
@@ -466,6 +484,23 @@ __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restri
     m = mend;
   }
 }
+// Incremental form for the later Lloyd iterations: only documents whose centre changed touch the counts (integer counts are
+// exact, so add / subtract leaves precisely what a fresh count would give).  GL_SUB lanes per document.
+__global__ __launch_bounds__(256) void cc_moved_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                   const uint32_t* __restrict__ assign, uint32_t* __restrict__ counted /*D: centre the counts hold*/,
+                                                   uint32_t D, int ld, uint32_t* __restrict__ cnt) {
+  const int sub = (threadIdx.x & 63) / GL_SUB, sl = threadIdx.x % GL_SUB;
+  const uint32_t d = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / GL_SUB) + sub;
+  if (d >= D) return;
+  const uint32_t a = assign[d], o = counted[d];
+  if (a == o) return;
+  for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
+    const size_t w = rows[i];
+    atomicAdd(&cnt[w * ld + a], 1u);
+    atomicSub(&cnt[w * ld + o], 1u);
+  }
+  if (sl == 0) counted[d] = a;
+}
 __global__ __launch_bounds__(256) void cc_centers_k(const uint32_t* __restrict__ cnt, const float* __restrict__ rowval, size_t n, int ld,
                                                      float* __restrict__ Crm) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -540,14 +575,15 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
 }
 
 template <int LPE, bool HALF>
-int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride) {
+int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap = nullptr,
+                 uint32_t out_ld4 = 0) {
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(c, hipFuncSetAttribute((const void*)gl_apply_k<LPE, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS));
     attr_set = true;
   }
   hipLaunchKernelGGL((gl_apply_k<LPE, HALF>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
-                     s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out);
+                     s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -784,8 +820,9 @@ int k_gl_apply(isle_ctx* c, int b, int BP) {
 }
 
 // Crm (V x ld row-major) = per-centre sums of the member columns (not yet divided by the cluster sizes).
-// c->members / c->moff must hold the documents grouped by `assign` (k_member_lists).
-int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* Crm) {
+// fresh: count from scratch — c->members / c->moff must hold the documents grouped by `assign` (k_member_lists);
+// otherwise the counts of the previous call (same k, ld, B) are updated by the documents that changed centre.
+int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* Crm, bool fresh) {
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
   (void)k;
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
@@ -796,14 +833,48 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
   }
   const size_t n = (size_t)V * ld;
   HIPCHK(c, c->ccount.reserve(n));
-  HIPCHK(c, hipMemsetAsync(c->ccount.p, 0, n * sizeof(uint32_t), c->stream));
-  if (D) {
-    const uint32_t nvp = (V + GL_VP - 1) / GL_VP;
-    hipLaunchKernelGGL(cc_hist_k, dim3(cdiv(D, CC_CH), nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->members.p, c->moff.p,
-                       assign, D, V, ld, c->ccount.p);
+  HIPCHK(c, c->ccounted.reserve(D ? D : 1));
+  if (fresh) {
+    HIPCHK(c, hipMemsetAsync(c->ccount.p, 0, n * sizeof(uint32_t), c->stream));
+    if (D) {
+      const uint32_t nvp = (V + GL_VP - 1) / GL_VP;
+      hipLaunchKernelGGL(cc_hist_k, dim3(cdiv(D, CC_CH), nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->members.p, c->moff.p,
+                         assign, D, V, ld, c->ccount.p);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->ccounted.p, assign, (size_t)D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+  } else if (D) {
+    hipLaunchKernelGGL(cc_moved_k, dim3(cdiv(D, 4 * (64 / GL_SUB))), dim3(256), 0, c->stream, c->rows.p, c->offs.p, assign, c->ccounted.p, D, ld,
+                       c->ccount.p);
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(cc_centers_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, c->ccount.p, c->rowval.p, n, ld, Crm);
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// Out (D x ld row-major, natural document order) = B^T M for a wide row-major operand M (V x ld, k <= ld columns): the k-wide SpMM
+// of FPSparseMatrix::multiply_with (src/sparseMatrix.cpp:1749-1782) as ceil(k / 12) passes of the pass-1 stream, twelve
+// columns of diag(s) M staged per pass.  Per gathered nonzero the operand comes from LDS instead of the L2 / Infinity Cache
+// row gather of spmm_wide_k (~2x faster at C2).
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
+  ISLECHK(k_band_build(c));
+  if (c->gl_mode != 1) return isle_fail(c, ISLE_E_ARG, "k_gl_wide needs the LDS-banded form");
+  if (ld % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: leading dimension %d not a multiple of 4", ld);
+  const uint32_t V = (uint32_t)c->V;
+  HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
+  for (int j0 = 0; j0 < k; j0 += 12) {
+    const int ncol = std::min(12, k - j0);
+    const int LPE = (ncol + 3) / 4;
+    const size_t n4 = (size_t)V * LPE;
+    hipLaunchKernelGGL(gl_pack_panel_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Mrm, ld, j0, ncol, LPE, c->rowval.p, n4,
+                       (float4*)c->gl_Xs.p);
+    HIPCHK(c, hipGetLastError());
+    float4* out = (float4*)(Out + j0);  // 48-byte steps: 16-byte aligned
+    const uint32_t ld4 = (uint32_t)(ld / 4);
+    if (LPE == 1) ISLECHK((launch_apply<1, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+    if (LPE == 2) ISLECHK((launch_apply<2, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+    if (LPE == 3) ISLECHK((launch_apply<3, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+  }
   return 0;
 }

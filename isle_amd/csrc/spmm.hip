@@ -328,6 +328,90 @@ enum { WIDE_PROJECT = 0, WIDE_ASSIGN = 1 };
 #include "hamerly.h"
 constexpr int YY_GROUP = 8;  // centres per Yinyang group: two float4 of a centre row, never straddling a 64-byte line
 
+// The assignment epilogue shared by the fused k-wide SpMM (spmm_wide_k) and the dots-from-memory variant (dots_assign_k):
+// lane `lane` holds the dot products of document d with centres 4 (lane + 64 it) .. + 3.
+// argmin_c | |b_d|^2 + |C_c|^2 - 2 b_d^T C_c |  with cblas_isamin semantics (first index of the minimum), plus the Hamerly /
+// Yinyang bounds of the chosen centre (src/sparseMatrix.cpp:1494-1572).
+template <int NIT>
+__device__ inline void wide_assign_epilogue(const float4 (&acc)[NIT], int lane, uint32_t d, int nq, int k, const float* __restrict__ cn,
+                                            const float* __restrict__ dn, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                            float* __restrict__ lb, int G) {
+  const float dnd = dn[d];
+  float best = 3.4e38f, second = 3.4e38f, cmax = 0.f;
+  uint32_t bidx = 0xffffffffu;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int cidx = lane + 64 * it;
+    if (cidx < nq) {
+      const float a[4] = {acc[it].x, acc[it].y, acc[it].z, acc[it].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = 4 * cidx + j;
+        if (cc < k) {
+          cmax = fmaxf(cmax, cn[cc]);
+          const float dist = fabsf((-2.0f * a[j] + cn[cc]) + dnd);
+          if (dist < best) {  // ascending cc per lane -> first index wins ties
+            second = best;
+            best = dist;
+            bidx = (uint32_t)cc;
+          } else {
+            second = fminf(second, dist);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const float os = __shfl_xor(second, off);
+    const uint32_t oi = __shfl_xor(bidx, off);
+    if (ob < best || (ob == best && oi < bidx)) {
+      second = fminf(best, os);
+      best = ob;
+      bidx = oi;
+    } else {
+      second = fminf(second, ob);
+    }
+  }
+  if (ub) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+  }
+  if (ub && G > 0) {
+    // Yinyang group bounds: for every group of YY_GROUP consecutive centres the distance to its closest member other than
+    // the assigned centre.  A lane holds 4 consecutive centres, lane ^ 1 the other half of the group.
+    const float E = 1e-4f * (dnd + cmax), sE = sqrtf(E);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int cidx = lane + 64 * it;
+      float m = 3.4e38f;
+      if (cidx < nq) {
+        const float a[4] = {acc[it].x, acc[it].y, acc[it].z, acc[it].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = 4 * cidx + j;
+          if (cc < k && (uint32_t)cc != bidx) m = fminf(m, fabsf((-2.0f * a[j] + cn[cc]) + dnd));
+        }
+      }
+      m = fminf(m, __shfl_xor(m, 1));
+      const int g = cidx >> 1;
+      if (!(lane & 1) && g < G) {
+        const float l = sqrtf(m);
+        lb[(size_t)d * G + g] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+      }
+    }
+    if (lane == 0) {
+      const float u = sqrtf(best);
+      ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+    }
+  }
+  if (lane == 0) {
+    assign[d] = bidx;
+    if (ub && G == 0) hamerly_store_bounds(best, second, dnd + cmax, &ub[d], &lb[d]);
+  }
+}
+
 template <int NIT, int MODE>
 __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows,
                                                     const int64_t* __restrict__ offs, const float4* __restrict__ M, int nq,
@@ -383,80 +467,7 @@ __global__ __launch_bounds__(256) void spmm_wide_k(const float* __restrict__ val
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) norms[d] = s;
   } else {
-    const float dnd = dn[d];
-    float best = 3.4e38f, second = 3.4e38f, cmax = 0.f;
-    uint32_t bidx = 0xffffffffu;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int cidx = lane + 64 * it;
-      if (cidx < nq) {
-        const float a[4] = {acc[it].x, acc[it].y, acc[it].z, acc[it].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cc = 4 * cidx + j;
-          if (cc < k) {
-            cmax = fmaxf(cmax, cn[cc]);
-            const float dist = fabsf((-2.0f * a[j] + cn[cc]) + dnd);
-            if (dist < best) {  // ascending cc per lane -> first index wins ties
-              second = best;
-              best = dist;
-              bidx = (uint32_t)cc;
-            } else {
-              second = fminf(second, dist);
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ob = __shfl_xor(best, off);
-      const float os = __shfl_xor(second, off);
-      const uint32_t oi = __shfl_xor(bidx, off);
-      if (ob < best || (ob == best && oi < bidx)) {
-        second = fminf(best, os);
-        best = ob;
-        bidx = oi;
-      } else {
-        second = fminf(second, ob);
-      }
-    }
-    if (ub) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off));
-    }
-    if (ub && G > 0) {
-      // Yinyang group bounds: for every group of YY_GROUP consecutive centres the distance to its closest member other than
-      // the assigned centre.  A lane holds 4 consecutive centres, lane ^ 1 the other half of the group.
-      const float E = 1e-4f * (dnd + cmax), sE = sqrtf(E);
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int cidx = lane + 64 * it;
-        float m = 3.4e38f;
-        if (cidx < nq) {
-          const float a[4] = {acc[it].x, acc[it].y, acc[it].z, acc[it].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int cc = 4 * cidx + j;
-            if (cc < k && (uint32_t)cc != bidx) m = fminf(m, fabsf((-2.0f * a[j] + cn[cc]) + dnd));
-          }
-        }
-        m = fminf(m, __shfl_xor(m, 1));
-        const int g = cidx >> 1;
-        if (!(lane & 1) && g < G) {
-          const float l = sqrtf(m);
-          lb[(size_t)d * G + g] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
-        }
-      }
-      if (lane == 0) {
-        const float u = sqrtf(best);
-        ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
-      }
-    }
-    if (lane == 0) {
-      assign[d] = bidx;
-      if (ub && G == 0) hamerly_store_bounds(best, second, dnd + cmax, &ub[d], &lb[d]);
-    }
+    wide_assign_epilogue<NIT>(acc, lane, d, nq, k, cn, dn, assign, ub, lb, G);
   }
 }
 
@@ -481,13 +492,56 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// Assignment from stored dot products (dots = B^T C computed by the LDS-banded wide SpMM, gram_lds.hip): one wave per document.
+template <int NIT>
+__global__ __launch_bounds__(256) void dots_assign_k(const float4* __restrict__ dots, int nq, int k, uint32_t D, const float* __restrict__ cn,
+                                                      const float* __restrict__ dn, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                      float* __restrict__ lb, int G) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= D) return;
+  float4 acc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int cidx = lane + 64 * it;
+    acc[it] = cidx < nq ? dots[(size_t)d * nq + cidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  wide_assign_epilogue<NIT>(acc, lane, d, nq, k, cn, dn, assign, ub, lb, G);
+}
+
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms) {
   TimeScope ts(c, ISLE_T_PROJECT);
+  ISLECHK(k_gl_detect(c));
+  if (c->gl_mode == 1 && !getenv("ISLE_WIDE_GATHER")) {  // row-constant B: panels of M through LDS (gram_lds.hip)
+    ISLECHK(k_gl_wide(c, Mrm, k, ldk, P));
+    return k_rownorms(c, P, (int)c->D, k, ldk, norms);
+  }
   return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr, nullptr);
 }
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
                        const uint32_t* perm, const uint32_t* nslots, float* ub, float* lb, int G) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  ISLECHK(k_gl_detect(c));
+  if (c->gl_mode == 1 && !nslots && c->D && !getenv("ISLE_WIDE_GATHER")) {
+    // full assignment on a row-constant B: dots = B^T C by the LDS-banded wide SpMM into the projection buffer (P is
+    // recomputed if it is needed again), then the same epilogue from memory.  `perm` is only a visiting order: ignored.
+    const uint32_t D = (uint32_t)c->D;
+    HIPCHK(c, c->P.reserve((size_t)D * ldk));
+    c->P_ready = false;
+    c->Pt_ready = false;
+    ISLECHK(k_gl_wide(c, Mrm, k, ldk, c->P.p));
+    const int nq = ldk / 4, nit = cdiv(nq, 64);
+    const dim3 g(cdiv(D, 4)), b(256);
+#define DA(N) hipLaunchKernelGGL((dots_assign_k<N>), g, b, 0, c->stream, (const float4*)c->P.p, nq, k, D, cn, dn, assign, ub, lb, G)
+    if (nit <= 1) DA(1);
+    else if (nit <= 2) DA(2);
+    else if (nit <= 4) DA(4);
+    else if (nit <= 8) DA(8);
+    else return isle_fail(c, ISLE_E_ARG, "assignment: k = %d too large (max 2048)", k);
+#undef DA
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm, nslots, ub, lb, G);
 }
 
@@ -537,9 +591,12 @@ __global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restri
   for (int j = lane; j < ldk; j += 64) Crm[(size_t)w * ldk + j] = bins[j];
 }
 
-int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm) {
+// first_of_run: first centroid update of a Lloyd run (the counting form then counts from scratch, later calls only move the
+// documents that changed centre)
+int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool first_of_run) {
   ISLECHK(k_gl_detect(c));
-  if (c->gl_mode == 1) return k_centers_counts(c, assign, k, ldk, Crm);  // row-constant B: integer counting, no transposed copy
+  if (c->gl_mode == 1)  // row-constant B: integer counting, no transposed copy
+    return k_centers_counts(c, assign, k, ldk, Crm, first_of_run || getenv("ISLE_CENTERS_FRESH") != nullptr);
   ISLECHK(k_band_build(c));
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
   const uint32_t V = (uint32_t)c->V;

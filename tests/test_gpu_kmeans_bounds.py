@@ -32,10 +32,11 @@ print("RESULT " + json.dumps(out))
 ''' % (ROOT, ROOT)
 
 
-def run(mode):
+def run(mode, extra_env=None):
     env = dict(os.environ)
     env.pop("ISLE_NO_HAMERLY", None)
     env["ISLE_KMEANS_BOUNDS"] = mode
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
@@ -50,3 +51,18 @@ def test_bound_modes_agree():
             assert got[key]["iters"] == base[key]["iters"], (mode, key)
             assert got[key]["assign"] == base[key]["assign"], (mode, key, got[key]["sizes"], base[key]["sizes"])
             assert abs(got[key]["cen"] - base[key]["cen"]) <= 1e-5 * base[key]["cen"], (mode, key)
+
+
+def test_incremental_centroid_counts_are_exact():
+    """Row-constant B: the centroid update keeps integer (word, centre) counts and from the second iteration on only moves
+    the documents that changed centre; counting from scratch every iteration (ISLE_CENTERS_FRESH=1) must give bit-identical
+    partitions and centres, and so must the float-histogram update of the gather form (ISLE_GRAM_LDS=0) up to rounding."""
+    inc = run("yinyang")
+    fresh = run("yinyang", {"ISLE_CENTERS_FRESH": "1"})
+    gather = run("yinyang", {"ISLE_GRAM_LDS": "0"})
+    for key in inc:
+        assert inc[key]["iters"] == fresh[key]["iters"]
+        assert inc[key]["assign"] == fresh[key]["assign"]
+        assert inc[key]["cen"] == fresh[key]["cen"]
+        assert inc[key]["sizes"] == gather[key]["sizes"] or sum(abs(a - b) for a, b in zip(inc[key]["sizes"], gather[key]["sizes"])) <= 0.002 * sum(inc[key]["sizes"])
+        assert abs(inc[key]["cen"] - gather[key]["cen"]) <= 1e-4 * gather[key]["cen"]
