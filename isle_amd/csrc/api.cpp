@@ -848,9 +848,9 @@ struct Ks {
     HMat subH = hsub(H, nconv, nconv, H.c - 1, H.c - 1);
     std::vector<float> eH(n), vH(n * n);
     HIPCHK(c, c->Wf.reserve(n * n));
-    ISLECHK(k_jacobi_eig(c, subH.a.data(), (int)n, eH.data(), c->Wf.p));
-    HIPCHK(c, hipMemcpyAsync(vH.data(), c->Wf.p, n * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    const size_t keep = nev - nconv;
+    const size_t keep = nev - nconv;  // only the leading `keep` eigenvectors are used below
+    ISLECHK(k_eig_small(c, subH.a.data(), (int)n, eH.data(), c->Wf.p, (int)keep));
+    HIPCHK(c, hipMemcpyAsync(vH.data(), c->Wf.p, n * keep * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     // V = [ V(:, :nconv) | V(:, nconv : ncols-blk) * vH(:, :keep) | V(:, tail blk) ]
     ISLECHK(k_gemm_nn(c, col(nconv), dim, (int)n, c->Wf.p, (int)n, (int)keep, c->Tmp.p));
     HIPCHK(c, hipMemcpyAsync(c->Fbuf.p, col(vcols - blk), blk * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -1003,7 +1003,7 @@ extern "C" int isle_hip_eig_sym(isle_ctx* c, const float* S, int n, float* evals
   if (!c || !S || !evals || !vecs || n < 1) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->Wf.reserve((size_t)n * n));
-  ISLECHK(k_jacobi_eig(c, S, n, evals, c->Wf.p));
+  ISLECHK(k_eig_small(c, S, n, evals, c->Wf.p, n));
   HIPCHK(c, hipMemcpy(vecs, c->Wf.p, (size_t)n * n * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }

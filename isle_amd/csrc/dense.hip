@@ -906,19 +906,24 @@ __global__ __launch_bounds__(256) void colnorm_partial_k(const float* __restrict
     __syncthreads();
   }
 }
-__global__ void colnorm_reduce_k(const double* __restrict__ part, int nchunks, int k, float* __restrict__ out) {
-  const int cc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cc >= k) return;
+// out[cc] = sum over chunks, fixed order: 4 chunk groups x 64 columns per workgroup
+__global__ __launch_bounds__(256) void colnorm_reduce_k(const double* __restrict__ part, int nchunks, int k, float* __restrict__ out) {
+  __shared__ double sh[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int cc = blockIdx.x * 64 + cl;
   double s = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) s += part[(size_t)ch * k + cc];
-  out[cc] = (float)s;
+  if (cc < k)
+    for (int ch = rg; ch < nchunks; ch += 4) s += part[(size_t)ch * k + cc];
+  sh[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && cc < k) out[cc] = (float)((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]));
 }
 // out[c] = sum_r (M[r][c] - Sub[r][c])^2   (Sub nullable: plain column norms)
 int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out, const float* Sub) {
   const int nchunks = cdiv(rows, CN_ROWS);
   HIPCHK(c, c->part.reserve((size_t)nchunks * k));
   hipLaunchKernelGGL(colnorm_partial_k, dim3(nchunks), dim3(256), 0, c->stream, Mrm, Sub, rows, k, ldk, c->part.p);
-  hipLaunchKernelGGL(colnorm_reduce_k, dim3(cdiv(k, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, k, out);
+  hipLaunchKernelGGL(colnorm_reduce_k, dim3(cdiv(k, 64)), dim3(256), 0, c->stream, c->part.p, nchunks, k, out);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -939,4 +944,20 @@ int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, cons
   hipLaunchKernelGGL(scale_centers_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, Crm, rows, k, ldk, counts);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+// arma::eig_sym stand-in: eigenvalues (all n, descending) on the host, the nvec leading eigenvectors on the device
+// (n x nvec col-major).  Tridiagonalisation + bisection + twisted factorisation (evd_tridiag.hip) first; the block Jacobi
+// solver above is the fallback for sizes it does not take and for spectra whose eigenvectors fail its orthogonality check
+// (clusters far tighter than Ritz matrices show).  ISLE_EVD_JACOBI=1 forces the Jacobi solver.
+int k_eig_small(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec) {
+  if (n >= 16 && !getenv("ISLE_EVD_JACOBI")) {
+    int rc;
+    {
+      TimeScope ts(c, ISLE_T_EVD);
+      rc = k_tridiag_eig(c, S_host, n, evals_host, vecs_dev, nvec);
+    }
+    if (rc <= 0) return rc;
+  }
+  return k_jacobi_eig(c, S_host, n, evals_host, vecs_dev);
 }

@@ -1,0 +1,402 @@
+// isle_amd/csrc/evd_tridiag.hip — small symmetric eigensolver by tridiagonalisation, for arma::eig_sym (-> ssyevd) in
+// BlockKs::truncate (block-ks/restarted_block_ks.h:138-187).
+//
+// The block Jacobi solver of dense.hip needs 11-13 sweeps on Ritz matrices (clustered spectrum: eight or nine sweeps in which
+// every column pair still rotates), each sweep a chain of n/16 dependent rounds.  Here, in fp64 throughout:
+//   1. Householder tridiagonalisation S = Q T Q^T, one column per step.  Two launches per column: td_step_k (one workgroup:
+//      finish p = tau A v from the partial products, w = p - tau/2 (p.v) v, then the next column of the updated matrix and its
+//      reflector) and td_update_symv_k (all workgroups: A -= v w^T + w v^T fused with the partial products A v_next of the
+//      next step, per column block, summed later in fixed order — no atomics, bitwise reproducible).
+//   2. td_bisect_k: eigenvalue i by bisection on the Sturm count, one thread per eigenvalue (ordered for free).
+//   3. td_vectors_k: eigenvector of T by twisted factorisation (the core of dlar1v / MRRR: forward L D L^T, backward U D U^T,
+//      twist at the smallest |gamma|, one substitution sweep each way), one thread per eigenvector, only the leading nvec.
+//   4. td_back_k: Z = Q Z_T, eight eigenvector columns per workgroup held in LDS, reflectors applied in reverse order.
+//   5. td_check_k: every vector against its four neighbours in eigenvalue order and its own norm; if orthogonality is worse than
+//      1e-6 (clusters tighter than ~1e-9 relative, exact multiplicities) the caller falls back to the Jacobi solver.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TD_T = 1024;
+constexpr int TD_MAXPT = 4;        // values per thread in td_step_k: n <= 4096
+constexpr int TD_ROWS = 256;       // rows per workgroup of td_update_symv_k
+constexpr int TD_NMAX_BACK = 2048; // td_back_k keeps n x 8 doubles in LDS (128 KB)
+
+__device__ inline double td_block_sum(double v, double* sh /* >= 16 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int nw = (int)(blockDim.x >> 6);
+  for (int w = 0; w < nw; ++w) s += sh[w];  // fixed order
+  return s;
+}
+
+// One workgroup.  first: set up column 0 only.  Otherwise, for step j:
+//   p = tau_j * sum_cb part[cb][:]  (rows j+1..n-1),  w = p - tau_j/2 (p.v_j) v_j        (v_j = A[j+1:, j], v_j[j+1] = 1)
+//   column cj = j+1 of A - v w^T - w v^T  ->  d[cj], reflector v_cj into A[cj+1:, cj], e[cj], tau[cj]
+__global__ __launch_bounds__(TD_T) void td_step_k(double* __restrict__ A, int n, int j, int first, int ncb, const double* __restrict__ part,
+                                                   double* __restrict__ w, double* __restrict__ d, double* __restrict__ e,
+                                                   double* __restrict__ tau) {
+  __shared__ double sh[16];
+  __shared__ double bc[2];
+  __shared__ double bw;
+  const int t = threadIdx.x;
+  double wv[TD_MAXPT], vv[TD_MAXPT];
+  double w_cj = 0.0;
+  const int cj = first ? 0 : j + 1;
+  if (!first) {
+    const double tj = tau[j];
+    const int r0 = j + 1;
+    double dot = 0.0;
+#pragma unroll
+    for (int s = 0; s < TD_MAXPT; ++s) {
+      const int i = r0 + t + s * TD_T;
+      wv[s] = 0.0;
+      vv[s] = 0.0;
+      if (i < n) {
+        double p = 0.0;
+        for (int cb = 0; cb < ncb; ++cb) p += part[(size_t)cb * n + i];  // fixed order
+        p *= tj;
+        const double v = A[(size_t)j * n + i];
+        wv[s] = p;
+        vv[s] = v;
+        dot = fma(p, v, dot);
+      }
+    }
+    dot = td_block_sum(dot, sh);
+    const double a2 = -0.5 * tj * dot;
+#pragma unroll
+    for (int s = 0; s < TD_MAXPT; ++s) {
+      const int i = r0 + t + s * TD_T;
+      if (i < n) {
+        wv[s] = fma(a2, vv[s], wv[s]);
+        w[i] = wv[s];
+        if (i == cj) bw = wv[s];
+      }
+    }
+    __syncthreads();
+    w_cj = bw;  // w at row j+1 (v_j there is 1)
+  }
+  // column cj of the updated matrix, rows cj..n-1 (thread-local rows: i = cj + t + s*TD_T; note cj = r0 when !first)
+  double cv[TD_MAXPT];
+  double nrm2 = 0.0;
+#pragma unroll
+  for (int s = 0; s < TD_MAXPT; ++s) {
+    const int i = cj + t + s * TD_T;
+    cv[s] = 0.0;
+    if (i < n) {
+      double a = A[(size_t)cj * n + i];
+      if (!first) a -= vv[s] * w_cj + wv[s];  // v_j[cj] = 1
+      cv[s] = a;
+      if (i == cj) bc[0] = a;
+      if (i == cj + 1) bc[1] = a;
+      if (i > cj + 1) nrm2 = fma(a, a, nrm2);
+    }
+  }
+  nrm2 = td_block_sum(nrm2, sh);
+  __syncthreads();
+  if (t == 0) d[cj] = bc[0];
+  if (cj == n - 1) return;
+  const double alpha = bc[1];
+  double beta = alpha, tv = 0.0, scale = 0.0;
+  if (nrm2 > 0.0) {
+    beta = -copysign(sqrt(fma(alpha, alpha, nrm2)), alpha);
+    tv = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  if (t == 0) {
+    e[cj] = beta;
+    tau[cj] = tv;
+  }
+#pragma unroll
+  for (int s = 0; s < TD_MAXPT; ++s) {
+    const int i = cj + t + s * TD_T;
+    if (i < n && i > cj) A[(size_t)cj * n + i] = (i == cj + 1) ? 1.0 : cv[s] * scale;
+  }
+}
+
+// All workgroups: the block B = rows/cols r0..n-1 of A, r0 = j + 2 (j = -1: no update, r0 = 1).
+//   update:  B -= v_j w_j^T + w_j v_j^T     (v_j = A[:, j], w_j = w)
+//   part[cb][i] = sum over this column block of B[i][k] * vn[k]     (vn = v_{j+1} = A[:, j+1])
+// grid = (row blocks of TD_ROWS, column blocks of CB)
+__global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__ A, int n, int j, int update, int CB, const double* __restrict__ w,
+                                                             double* __restrict__ part) {
+  extern __shared__ double cs[];  // 3 x CB: v_j[k], w[k], vn[k]
+  const int r0 = j + 2;
+  const int k0 = r0 + blockIdx.y * CB;
+  const int k1 = min(n, k0 + CB);
+  const int i = r0 + blockIdx.x * TD_ROWS + threadIdx.x;
+  for (int kk = threadIdx.x; kk < k1 - k0; kk += TD_ROWS) {
+    const int k = k0 + kk;
+    cs[kk] = update ? A[(size_t)j * n + k] : 0.0;
+    cs[CB + kk] = update ? w[k] : 0.0;
+    cs[2 * CB + kk] = A[(size_t)(j + 1) * n + k];
+  }
+  __syncthreads();
+  if (i >= n) return;
+  const double vi = update ? A[(size_t)j * n + i] : 0.0;
+  const double wi = update ? w[i] : 0.0;
+  double acc = 0.0;
+  for (int k = k0; k < k1; ++k) {
+    double a = A[(size_t)k * n + i];
+    if (update) {
+      a -= vi * cs[CB + (k - k0)] + wi * cs[k - k0];
+      A[(size_t)k * n + i] = a;
+    }
+    acc = fma(a, cs[2 * CB + (k - k0)], acc);
+  }
+  part[(size_t)blockIdx.y * n + i] = acc;
+}
+
+// Eigenvalue number idx (ascending) of the tridiagonal (d, e) by bisection on the Sturm count; out descending.
+__global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d, const double* __restrict__ e, int n, double* __restrict__ lam_desc) {
+  extern __shared__ double sm[];  // d[n], e2[n]
+  double* sd = sm;
+  double* se2 = sm + n;
+  double lo = 1e300, hi = -1e300, emax = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double di = d[i];
+    const double el = i > 0 ? fabs(e[i - 1]) : 0.0, er = i < n - 1 ? fabs(e[i]) : 0.0;
+    sd[i] = di;
+    se2[i] = i < n - 1 ? e[i] * e[i] : 0.0;
+    lo = fmin(lo, di - el - er);
+    hi = fmax(hi, di + el + er);
+    emax = fmax(emax, er * er);
+  }
+  // block min / max
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, off));
+    hi = fmax(hi, __shfl_xor(hi, off));
+    emax = fmax(emax, __shfl_xor(emax, off));
+  }
+  __shared__ double s_lo[4], s_hi[4], s_em[4];
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+    s_em[threadIdx.x >> 6] = emax;
+  }
+  __syncthreads();
+  lo = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
+  hi = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
+  emax = fmax(fmax(s_em[0], s_em[1]), fmax(s_em[2], s_em[3]));
+  const double span = fmax(fabs(lo), fabs(hi));
+  lo -= 2.0 * 2.3e-16 * span * n + 1e-300;
+  hi += 2.0 * 2.3e-16 * span * n + 1e-300;
+  const double pivmin = fmax(2.3e-308 * fmax(1.0, emax), 1e-300);
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    double a = lo, b = hi;
+    for (int it = 0; it < 80; ++it) {
+      const double x = 0.5 * (a + b);
+      if (x <= a || x >= b) break;
+      int cnt = 0;
+      double q = sd[0] - x;
+      if (fabs(q) < pivmin) q = -pivmin;
+      cnt += q < 0.0;
+      for (int k = 1; k < n; ++k) {
+        q = (sd[k] - x) - se2[k - 1] / q;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += q < 0.0;
+      }
+      if (cnt > idx) b = x;  // more than idx eigenvalues below x: eigenvalue idx (0-based, ascending) is below x
+      else a = x;
+    }
+    lam_desc[n - 1 - idx] = 0.5 * (a + b);
+  }
+}
+
+// Eigenvector of T for lam_desc[v], v < nvec: twisted factorisation.  One thread per vector; per-thread work arrays
+// interleaved over vectors ([i * nvec + v]: coalesced).  Z row-major n x nvec, unit 2-norm.
+__global__ __launch_bounds__(64) void td_vectors_k(const double* __restrict__ d, const double* __restrict__ e, int n, const double* __restrict__ lam_desc,
+                                                    int nvec, double* __restrict__ Dp /*n x nvec*/, double* __restrict__ Lf /*n x nvec*/,
+                                                    double* __restrict__ Z /*n x nvec; also holds U factors during the backward sweep*/) {
+  const int v = blockIdx.x * 64 + threadIdx.x;
+  if (v >= nvec) return;
+  const double lam = lam_desc[v];
+  double tnorm = 0.0;
+  for (int i = 0; i < n; ++i) tnorm = fmax(tnorm, fabs(d[i]) + (i < n - 1 ? fabs(e[i]) : 0.0) + (i > 0 ? fabs(e[i - 1]) : 0.0));
+  const double piv = fmax(2.3e-16 * tnorm, 1e-300);
+  auto IDX = [&](int i) { return (size_t)i * nvec + v; };
+  // forward: T - lam I = L D L^T
+  double D = d[0] - lam;
+  if (fabs(D) < piv) D = -piv;
+  Dp[IDX(0)] = D;
+  for (int i = 0; i < n - 1; ++i) {
+    const double ei = e[i];
+    const double l = ei / D;
+    Lf[IDX(i)] = l;
+    D = (d[i + 1] - lam) - l * ei;
+    if (fabs(D) < piv) D = -piv;
+    Dp[IDX(i + 1)] = D;
+  }
+  // backward: T - lam I = U Dm U^T; gamma_i = Dp_i + Dm_i - (d_i - lam)
+  double Dm = d[n - 1] - lam;
+  if (fabs(Dm) < piv) Dm = -piv;
+  double gbest = fabs(Dp[IDX(n - 1)] + Dm - (d[n - 1] - lam));
+  int r = n - 1;
+  for (int i = n - 2; i >= 0; --i) {
+    const double ei = e[i];
+    const double u = ei / Dm;
+    Z[IDX(i)] = u;  // U factor of row i (used for z_{i+1} = -u_i z_i)
+    Dm = (d[i] - lam) - u * ei;
+    if (fabs(Dm) < piv) Dm = -piv;
+    const double g = fabs(Dp[IDX(i)] + Dm - (d[i] - lam));
+    if (g < gbest) {
+      gbest = g;
+      r = i;
+    }
+  }
+  // substitution from the twist
+  double nrm = 1.0;
+  double z = 1.0;
+  for (int i = r - 1; i >= 0; --i) {
+    z = -Lf[IDX(i)] * z;
+    Dp[IDX(i)] = z;  // Dp is free below the twist: park z there
+    nrm = fma(z, z, nrm);
+  }
+  z = 1.0;
+  for (int i = r; i < n - 1; ++i) {
+    z = -Z[IDX(i)] * z;  // reads u_i, then row i+1 of Z is written below (u_{i+1} is read in the next iteration first)
+    Lf[IDX(i + 1)] = z;  // park in Lf (free above the twist)
+    nrm = fma(z, z, nrm);
+  }
+  const double s = 1.0 / sqrt(nrm);
+  for (int i = 0; i < r; ++i) Z[IDX(i)] = Dp[IDX(i)] * s;
+  Z[IDX(r)] = s;
+  for (int i = r + 1; i < n; ++i) Z[IDX(i)] = Lf[IDX(i)] * s;
+}
+
+// Z (n x nvec row-major, fp64) <- Q Z, Q = H_0 ... H_{n-3} (reflector j: v = A[j+1:, j], tau[j]); result as fp32 col-major n x nvec.
+// One workgroup per 8 eigenvectors, tile in LDS.
+__global__ __launch_bounds__(256) void td_back_k(const double* __restrict__ A, const double* __restrict__ tau, int n, const double* __restrict__ Z, int nvec,
+                                                  float* __restrict__ out) {
+  extern __shared__ double zs[];  // n x 8
+  __shared__ double red[32][9];
+  const int c0 = blockIdx.x * 8;
+  const int t = threadIdx.x, c = t & 7, rl = t >> 3;  // 32 row lanes x 8 columns
+  const bool live = c0 + c < nvec;
+  for (int i = rl; i < n; i += 32) zs[i * 8 + c] = live ? Z[(size_t)i * nvec + c0 + c] : 0.0;
+  __syncthreads();
+  for (int j = n - 3; j >= 0; --j) {
+    const double tj = tau[j];
+    if (tj == 0.0) continue;  // uniform
+    const double* vj = A + (size_t)j * n;
+    double s = 0.0;
+    for (int i = j + 1 + rl; i < n; i += 32) s = fma(vj[i], zs[i * 8 + c], s);
+    red[rl][c] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) tot += red[q][c];  // fixed order
+    tot *= tj;
+    for (int i = j + 1 + rl; i < n; i += 32) zs[i * 8 + c] = fma(-tot, vj[i], zs[i * 8 + c]);
+    __syncthreads();
+  }
+  if (live)
+    for (int i = rl; i < n; i += 32) out[(size_t)(c0 + c) * n + i] = (float)zs[i * 8 + c];
+}
+
+// max over vectors of | <z_c, z_{c+q}> | (q = 1..4) and | |z_c|^2 - 1 |, as the bits of a non-negative float
+__global__ __launch_bounds__(256) void td_check_k(const float* __restrict__ Zc, int n, int nvec, unsigned int* __restrict__ worst) {
+  __shared__ double sh[16];
+  const int c = blockIdx.x;
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double a = Zc[(size_t)c * n + i];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (c + q < nvec) acc[q] = fma(a, (double)Zc[(size_t)(c + q) * n + i], acc[q]);
+  }
+  double dev = 0.0;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const double s = td_block_sum(acc[q], sh);
+    if (c + q < nvec) dev = fmax(dev, fabs(q == 0 ? s - 1.0 : s));
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(worst, __float_as_uint((float)dev));
+}
+
+}  // namespace
+
+// evals_host: all n eigenvalues, descending; vecs_dev: the nvec leading eigenvectors (n x nvec col-major fp32).
+// Returns 1 (no error) if the result failed the orthogonality check and the caller should use another solver.
+int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec) {
+  if (n < 3 || n > TD_NMAX_BACK || n > TD_T * TD_MAXPT) return 1;
+  nvec = std::max(1, std::min(nvec, n));
+  const size_t nn = (size_t)n * n;
+  std::vector<double> Ah(nn);
+  // LAPACK 'U' semantics: the upper triangle defines the matrix
+  for (int jj = 0; jj < n; ++jj)
+    for (int i = 0; i < n; ++i) Ah[(size_t)jj * n + i] = (i <= jj) ? (double)S_host[(size_t)jj * n + i] : (double)S_host[(size_t)i * n + jj];
+  int CB = 16;
+  while (CB < 64 && (n + CB - 1) / CB > 32) CB *= 2;
+  const int ncb_max = (n + CB - 1) / CB;
+  // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
+  const size_t need = nn + (size_t)ncb_max * n + 5 * (size_t)n + 3 * (size_t)n * nvec + 8;
+  HIPCHK(c, c->jacW.reserve(need));
+  double* A = c->jacW.p;
+  double* part = A + nn;
+  double* w = part + (size_t)ncb_max * n;
+  double* d = w + n;
+  double* e = d + n;
+  double* tau = e + n;
+  double* lam = tau + n;
+  double* Dp = lam + n;
+  double* Lf = Dp + (size_t)n * nvec;
+  double* Z = Lf + (size_t)n * nvec;
+  unsigned int* worst = reinterpret_cast<unsigned int*>(Z + (size_t)n * nvec);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)td_back_k, hipFuncAttributeMaxDynamicSharedMemorySize, TD_NMAX_BACK * 8 * (int)sizeof(double)));
+    attr_set = true;
+  }
+  HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(e, 0, (size_t)n * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(worst, 0, sizeof(unsigned int), c->stream));
+  // ---- 1. tridiagonalisation
+  hipLaunchKernelGGL(td_step_k, dim3(1), dim3(TD_T), 0, c->stream, A, n, -1, 1, 0, part, w, d, e, tau);
+  int ncb = 0;
+  for (int j = -1; j <= n - 2; ++j) {
+    if (j >= 0) hipLaunchKernelGGL(td_step_k, dim3(1), dim3(TD_T), 0, c->stream, A, n, j, 0, ncb, part, w, d, e, tau);
+    const int r0 = j + 2;  // block of the next step
+    if (r0 <= n - 1 && j + 1 <= n - 2) {
+      const int m = n - r0;
+      ncb = (m + CB - 1) / CB;
+      hipLaunchKernelGGL(td_update_symv_k, dim3((m + TD_ROWS - 1) / TD_ROWS, ncb), dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j,
+                         j >= 0 ? 1 : 0, CB, w, part);
+    } else {
+      ncb = 0;
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
+  hipLaunchKernelGGL(td_bisect_k, dim3((n + 255) / 256), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
+  hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
+  hipLaunchKernelGGL(td_back_k, dim3((nvec + 7) / 8), dim3(256), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
+  hipLaunchKernelGGL(td_check_k, dim3(nvec), dim3(256), 0, c->stream, vecs_dev, n, nvec, worst);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> ev(n);
+  unsigned int wbits = 0;
+  HIPCHK(c, hipMemcpyAsync(ev.data(), lam, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&wbits, worst, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float dev;
+  static_assert(sizeof(dev) == sizeof(wbits), "");
+  memcpy(&dev, &wbits, sizeof dev);
+  if (getenv("ISLE_DEBUG_EVD")) fprintf(stderr, "[evd n=%d] tridiagonal solver: nvec %d, worst orthogonality defect %.3g\n", n, nvec, (double)dev);
+  if (!(dev <= 1e-6f)) return 1;
+  for (int i = 0; i < n; ++i) evals_host[i] = (float)ev[i];
+  return 0;
+}
