@@ -24,8 +24,6 @@
 
 namespace {
 
-constexpr int TD_T = 1024;
-constexpr int TD_MAXPT = 4;        // values per thread in td_step_k: n <= 4096
 constexpr int TD_ROWS = 256;       // rows per workgroup of td_update_symv_k
 constexpr int TD_NMAX_BACK = 2048; // td_back_k keeps n x 8 doubles in LDS (128 KB)
 
@@ -45,9 +43,10 @@ __device__ inline double td_block_sum(double v, double* sh /* >= 16 */) {
 // One workgroup.  first: set up column 0 only.  Otherwise, for step j:
 //   p = tau_j * sum_cb part[cb][:]  (rows j+1..n-1),  w = p - tau_j/2 (p.v_j) v_j        (v_j = A[j+1:, j], v_j[j+1] = 1)
 //   column cj = j+1 of A - v w^T - w v^T  ->  d[cj], reflector v_cj into A[cj+1:, cj], e[cj], tau[cj]
-__global__ __launch_bounds__(TD_T) void td_step_k(double* __restrict__ A, int n, int j, int first, int ncb, const double* __restrict__ part,
-                                                   double* __restrict__ w, double* __restrict__ d, double* __restrict__ e,
-                                                   double* __restrict__ tau) {
+template <int TD_MAXPT>  // values per thread: 256 threads x 4 for n <= 1024, x 16 for n <= 4096
+__device__ inline void td_step_dev(double* __restrict__ A, int n, int j, int first, int ncb, const double* __restrict__ part,
+                                   double* __restrict__ w, double* __restrict__ d, double* __restrict__ e, double* __restrict__ tau) {
+  constexpr int TD_T = TD_ROWS;
   __shared__ double sh[16];
   __shared__ double bc[2];
   __shared__ double bw;
@@ -126,13 +125,24 @@ __global__ __launch_bounds__(TD_T) void td_step_k(double* __restrict__ A, int n,
   }
 }
 
+template <int PT>
+__global__ __launch_bounds__(TD_ROWS) void td_first_k(double* __restrict__ A, int n, double* __restrict__ w, double* __restrict__ d,
+                                                       double* __restrict__ e, double* __restrict__ tau) {
+  td_step_dev<PT>(A, n, -1, 1, 0, nullptr, w, d, e, tau);
+}
+
 // All workgroups: the block B = rows/cols r0..n-1 of A, r0 = j + 2 (j = -1: no update, r0 = 1).
 //   update:  B -= v_j w_j^T + w_j v_j^T     (v_j = A[:, j], w_j = w)
 //   part[cb][i] = sum over this column block of B[i][k] * vn[k]     (vn = v_{j+1} = A[:, j+1])
 // grid = (row blocks of TD_ROWS, column blocks of CB)
-__global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__ A, int n, int j, int update, int CB, const double* __restrict__ w,
-                                                             double* __restrict__ part) {
+// The workgroup that finishes last (ticket counter, release / acquire fences at agent scope) then runs step j + 1 in place:
+// one launch per column.
+template <int PT>
+__global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__ A, int n, int j, int update, int CB, double* __restrict__ w,
+                                                             double* __restrict__ part, double* __restrict__ d, double* __restrict__ e,
+                                                             double* __restrict__ tau, unsigned int* __restrict__ tickets) {
   extern __shared__ double cs[];  // 3 x CB: v_j[k], w[k], vn[k]
+  __shared__ unsigned int ticket;
   const int r0 = j + 2;
   const int k0 = r0 + blockIdx.y * CB;
   const int k1 = min(n, k0 + CB);
@@ -144,22 +154,33 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
     cs[2 * CB + kk] = A[(size_t)(j + 1) * n + k];
   }
   __syncthreads();
-  if (i >= n) return;
-  const double vi = update ? A[(size_t)j * n + i] : 0.0;
-  const double wi = update ? w[i] : 0.0;
-  double acc = 0.0;
-  for (int k = k0; k < k1; ++k) {
-    double a = A[(size_t)k * n + i];
-    if (update) {
-      a -= vi * cs[CB + (k - k0)] + wi * cs[k - k0];
-      A[(size_t)k * n + i] = a;
+  if (i < n) {
+    const double vi = update ? A[(size_t)j * n + i] : 0.0;
+    const double wi = update ? w[i] : 0.0;
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) {
+      double a = A[(size_t)k * n + i];
+      if (update) {
+        a -= vi * cs[CB + (k - k0)] + wi * cs[k - k0];
+        A[(size_t)k * n + i] = a;
+      }
+      acc = fma(a, cs[2 * CB + (k - k0)], acc);
     }
-    acc = fma(a, cs[2 * CB + (k - k0)], acc);
+    part[(size_t)blockIdx.y * n + i] = acc;
   }
-  part[(size_t)blockIdx.y * n + i] = acc;
+  // last workgroup done?
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&tickets[j + 1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != gridDim.x * gridDim.y - 1) return;  // uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold lines other workgroups have rewritten
+  td_step_dev<PT>(A, n, j + 1, 0, (int)gridDim.y, part, w, d, e, tau);
 }
 
-// Eigenvalue number idx (ascending) of the tridiagonal (d, e) by bisection on the Sturm count; out descending.
+// Eigenvalue number idx (ascending) of the tridiagonal (d, e) by multisection on the Sturm count: one wave per eigenvalue, the
+// 64 lanes count at 64 interior points of the current interval, which shrinks 65-fold per pass (ten passes instead of
+// fifty-odd dependent bisection steps of n divisions each).  Output descending.
 __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d, const double* __restrict__ e, int n, double* __restrict__ lam_desc) {
   extern __shared__ double sm[];  // d[n], e2[n]
   double* sd = sm;
@@ -174,7 +195,6 @@ __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d,
     hi = fmax(hi, di + el + er);
     emax = fmax(emax, er * er);
   }
-  // block min / max
   for (int off = 32; off > 0; off >>= 1) {
     lo = fmin(lo, __shfl_xor(lo, off));
     hi = fmax(hi, __shfl_xor(hi, off));
@@ -194,11 +214,12 @@ __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d,
   lo -= 2.0 * 2.3e-16 * span * n + 1e-300;
   hi += 2.0 * 2.3e-16 * span * n + 1e-300;
   const double pivmin = fmax(2.3e-308 * fmax(1.0, emax), 1e-300);
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-    double a = lo, b = hi;
-    for (int it = 0; it < 80; ++it) {
-      const double x = 0.5 * (a + b);
-      if (x <= a || x >= b) break;
+  const int lane = threadIdx.x & 63;
+  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {  // wave-uniform
+    double a = lo, b = hi;  // invariant: count(a) <= idx < count(b)
+    for (int it = 0; it < 16; ++it) {
+      const double h = (b - a) * (1.0 / 65.0);
+      const double x = a + h * (double)(lane + 1);
       int cnt = 0;
       double q = sd[0] - x;
       if (fabs(q) < pivmin) q = -pivmin;
@@ -208,10 +229,17 @@ __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d,
         if (fabs(q) < pivmin) q = -pivmin;
         cnt += q < 0.0;
       }
-      if (cnt > idx) b = x;  // more than idx eigenvalues below x: eigenvalue idx (0-based, ascending) is below x
-      else a = x;
+      // first lane whose point has more than idx eigenvalues below it (counts are monotone in x up to rounding)
+      const unsigned long long above = __ballot(cnt > idx);
+      const int f = above ? __ffsll((long long)above) - 1 : 64;
+      const double na = f == 0 ? a : a + h * (double)f;          // point of lane f - 1
+      const double nb = f == 64 ? b : a + h * (double)(f + 1);   // point of lane f
+      const bool stop = !(nb - na < b - a) || (nb - na) <= 4.0 * 2.3e-16 * fmax(fabs(na), fabs(nb));
+      a = na;
+      b = nb;
+      if (stop) break;
     }
-    lam_desc[n - 1 - idx] = 0.5 * (a + b);
+    if (lane == 0) lam_desc[n - 1 - idx] = 0.5 * (a + b);
   }
 }
 
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(256) void td_check_k(const float* __restrict__ Zc, 
 // evals_host: all n eigenvalues, descending; vecs_dev: the nvec leading eigenvectors (n x nvec col-major fp32).
 // Returns 1 (no error) if the result failed the orthogonality check and the caller should use another solver.
 int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec) {
-  if (n < 3 || n > TD_NMAX_BACK || n > TD_T * TD_MAXPT) return 1;
+  if (n < 3 || n > TD_NMAX_BACK || n > TD_ROWS * 16) return 1;
   nvec = std::max(1, std::min(nvec, n));
   const size_t nn = (size_t)n * n;
   std::vector<double> Ah(nn);
@@ -343,7 +371,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   while (CB < 64 && (n + CB - 1) / CB > 32) CB *= 2;
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
-  const size_t need = nn + (size_t)ncb_max * n + 5 * (size_t)n + 3 * (size_t)n * nvec + 8;
+  const size_t need = nn + (size_t)ncb_max * n + 6 * (size_t)n + 3 * (size_t)n * nvec + 16;
   HIPCHK(c, c->jacW.reserve(need));
   double* A = c->jacW.p;
   double* part = A + nn;
@@ -356,6 +384,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   double* Lf = Dp + (size_t)n * nvec;
   double* Z = Lf + (size_t)n * nvec;
   unsigned int* worst = reinterpret_cast<unsigned int*>(Z + (size_t)n * nvec);
+  unsigned int* tickets = worst + 2;  // n + 1 counters
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(c, hipFuncSetAttribute((const void*)td_back_k, hipFuncAttributeMaxDynamicSharedMemorySize, TD_NMAX_BACK * 8 * (int)sizeof(double)));
@@ -364,25 +393,26 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
   HIPCHK(c, hipMemsetAsync(e, 0, (size_t)n * sizeof(double), c->stream));
-  HIPCHK(c, hipMemsetAsync(worst, 0, sizeof(unsigned int), c->stream));
+  HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4) * sizeof(unsigned int), c->stream));
   // ---- 1. tridiagonalisation
-  hipLaunchKernelGGL(td_step_k, dim3(1), dim3(TD_T), 0, c->stream, A, n, -1, 1, 0, part, w, d, e, tau);
-  int ncb = 0;
-  for (int j = -1; j <= n - 2; ++j) {
-    if (j >= 0) hipLaunchKernelGGL(td_step_k, dim3(1), dim3(TD_T), 0, c->stream, A, n, j, 0, ncb, part, w, d, e, tau);
-    const int r0 = j + 2;  // block of the next step
-    if (r0 <= n - 1 && j + 1 <= n - 2) {
-      const int m = n - r0;
-      ncb = (m + CB - 1) / CB;
-      hipLaunchKernelGGL(td_update_symv_k, dim3((m + TD_ROWS - 1) / TD_ROWS, ncb), dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j,
-                         j >= 0 ? 1 : 0, CB, w, part);
-    } else {
-      ncb = 0;
-    }
+  const bool small = n <= TD_ROWS * 4;
+  if (small) hipLaunchKernelGGL((td_first_k<4>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
+  else hipLaunchKernelGGL((td_first_k<16>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
+  // F_j = update of step j fused with the products of step j + 1 and, in its last workgroup, step j + 1 itself
+  for (int j = -1; j <= n - 3; ++j) {
+    const int m = n - (j + 2);
+    const int ncb = (m + CB - 1) / CB;
+    const dim3 g((m + TD_ROWS - 1) / TD_ROWS, ncb);
+    if (small)
+      hipLaunchKernelGGL((td_update_symv_k<4>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, d, e, tau,
+                         tickets);
+    else
+      hipLaunchKernelGGL((td_update_symv_k<16>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, d, e, tau,
+                         tickets);
   }
   HIPCHK(c, hipGetLastError());
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
-  hipLaunchKernelGGL(td_bisect_k, dim3((n + 255) / 256), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
+  hipLaunchKernelGGL(td_bisect_k, dim3((n + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
   hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
   hipLaunchKernelGGL(td_back_k, dim3((nvec + 7) / 8), dim3(256), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
   hipLaunchKernelGGL(td_check_k, dim3(nvec), dim3(256), 0, c->stream, vecs_dev, n, nvec, worst);
