@@ -138,6 +138,7 @@ struct isle_ctx {
   DevBuf<int64_t> gl_scan;
   DevBuf<unsigned long long> gl_blocktot;
   DevBuf<uint32_t> gl_slab0, gl_nch;  // per word block: first partial slab, number of slabs
+  uint32_t gl_block_items = 4096;     // words per word block of pass 2 (256 per wave of the block)
   DevBuf<float> gl_Xs, gl_part;       // scaled panel diag(s) X; partial rows of Z per (word block, band chunk)
   DevBuf<uint32_t> rs_hist;           // radix sort scratch (ingest.hip: k_sort_pairs_u64)
   DevBuf<int64_t> rs_hist_off, rs_scratch;

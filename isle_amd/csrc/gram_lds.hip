@@ -49,8 +49,6 @@ constexpr uint32_t GL_VP = 81920;  // words per vocabulary part of the LDS histo
 constexpr uint32_t GL_HLDS = GL_VP / 2 * 4;
 constexpr int GL_SUB = 8;  // lanes per document in the histogram kernels
 constexpr double GL_BAND_COST = 256.0;  // cost of staging one 160 KB band from HBM in pass 2, in super-rounds (measured by sweep at C2)
-constexpr uint32_t GL_BLOCK_SLICES = GL_WAVES * GL_G;       // 64 slices
-constexpr uint32_t GL_BLOCK_ITEMS = GL_BLOCK_SLICES * 64;   // 4096 output items per workgroup
 
 // ---------------------------------------------------------------------------------------------------------------
 // does every row hold a single value?
@@ -266,11 +264,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
 }
 
 // total super-rounds of every (word block, band zone): the weights used to size the band chunks.  grid = (blocks, zones)
-__global__ __launch_bounds__(256) void gl_blocktot_k(const uint32_t* __restrict__ srsum, uint32_t nwv, uint32_t NB, uint32_t nzones,
+__global__ __launch_bounds__(256) void gl_blocktot_k(const uint32_t* __restrict__ srsum, uint32_t nwv, uint32_t wpb, uint32_t NB, uint32_t nzones,
                                                       unsigned long long* __restrict__ tot) {
   __shared__ unsigned long long sh[256];
-  const size_t w0 = (size_t)blockIdx.x * GL_WAVES;
-  const size_t w1 = (w0 + GL_WAVES < (size_t)nwv) ? w0 + GL_WAVES : (size_t)nwv;
+  const size_t w0 = (size_t)blockIdx.x * wpb;
+  const size_t w1 = (w0 + wpb < (size_t)nwv) ? w0 + wpb : (size_t)nwv;
   const uint32_t z = blockIdx.y;
   const uint32_t zb0 = (uint32_t)((uint64_t)z * NB / nzones), zb1 = (uint32_t)((uint64_t)(z + 1) * NB / nzones);
   const uint32_t nzb = zb1 - zb0;
@@ -420,14 +418,15 @@ __global__ __launch_bounds__(256) void gl_scale_k(const float4* __restrict__ X, 
 // Z[wperm[q], :] = s_w * sum over the slabs of q's word block (fixed order)
 __global__ __launch_bounds__(256) void gl_reduce_k(const float4* __restrict__ part, const uint32_t* __restrict__ slab0,
                                                     const uint32_t* __restrict__ nch, const uint32_t* __restrict__ wperm,
-                                                    const float* __restrict__ rowval, uint32_t V, int LPE, float4* __restrict__ Z) {
+                                                    const float* __restrict__ rowval, uint32_t V, int LPE, uint32_t bitems,
+                                                    float4* __restrict__ Z) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)V * LPE) return;
   const uint32_t q = (uint32_t)(i / LPE);
   const int l = (int)(i - (size_t)q * LPE);
-  const uint32_t ob = q / GL_BLOCK_ITEMS;
-  const size_t stride = (size_t)GL_BLOCK_ITEMS * LPE;
-  const float4* src = part + (size_t)slab0[ob] * stride + (size_t)(q - ob * GL_BLOCK_ITEMS) * LPE + l;
+  const uint32_t ob = q / bitems;
+  const size_t stride = (size_t)bitems * LPE;
+  const float4* src = part + (size_t)slab0[ob] * stride + (size_t)(q - ob * bitems) * LPE + l;
   float4 s = src[0];
   const uint32_t n = nch[ob];
   for (uint32_t ch = 1; ch < n; ++ch) add4(s, src[(size_t)ch * stride]);
@@ -673,11 +672,28 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipGetLastError());
     ISLECHK(build_side<1>(c, s1, so));
     // workgroup j = waves j, j + nwg, j + 2 nwg, ... : equal totals, one slab (Y itself)
-    const uint32_t nwg = (s1.nwv + GL_WAVES - 1) / GL_WAVES;
+    // small matrices: fewer (valid) waves per workgroup, so that there is still about one workgroup per CU
+    // waves per workgroup: the makespan model  rounds x (waves x LDS time of a wave + staging of all bands)  over 1..16 waves
+    // (small matrices: fewer valid waves per workgroup keep all CUs busy; large ones: avoid a nearly empty last round)
+    uint32_t wpw = GL_WAVES;
+    {
+      const double t_wave = 0.05 * (double)s1.total_sr / std::max<uint32_t>(1u, s1.nwv);  // us: ~50 ns of LDS time per super-round
+      const double t_stage = 2.0 * s1.NB;                                                  // us: ~2 us per band from L2
+      double best = 1e300;
+      for (uint32_t cand = GL_WAVES; cand >= 1; --cand) {
+        const uint32_t wgs = (s1.nwv + cand - 1) / cand;
+        const double cost = (double)((wgs + c->num_cus - 1) / c->num_cus) * (cand * t_wave + t_stage);
+        if (cost < best * 0.97) {  // prefer more waves per workgroup unless clearly worse
+          best = cost;
+          wpw = cand;
+        }
+      }
+    }
+    const uint32_t nwg = (s1.nwv + wpw - 1) / wpw;
     std::vector<GlDesc> ds(nwg);
     for (uint32_t j = 0; j < nwg; ++j) {
       uint32_t nw = 0;
-      while (nw < GL_WAVES && (uint64_t)j + (uint64_t)nw * nwg < s1.nwv) ++nw;
+      while (nw < wpw && (uint64_t)j + (uint64_t)nw * nwg < s1.nwv) ++nw;
       ds[j] = GlDesc{j, nwg, nw, 0u, s1.NB, 0u, 0u, 0u};
     }
     s1.ndesc = nwg;
@@ -709,17 +725,23 @@ int k_gl_build(isle_ctx* c) {
 
   // ---- pass 2: outputs = words (position order), sources = documents (position order)
   s2.nslice = (V + 63) / 64;
-  const uint32_t nblk = (s2.nslice + GL_BLOCK_SLICES - 1) / GL_BLOCK_SLICES;
-  s2.nwv = nblk * GL_WAVES;
+  // a word block = wpb waves = 4 wpb consecutive slices; 16 waves unless the vocabulary is so small that blocks x bands would
+  // leave CUs idle
+  uint32_t wpb = GL_WAVES;
+  while (wpb > 1 && (uint64_t)((s2.nslice + 4 * wpb - 1) / (4 * wpb)) * s2.NB < 2ull * c->num_cus) wpb /= 2;
+  const uint32_t bslices = 4 * wpb, bitems = 64 * bslices;
+  const uint32_t nblk = (s2.nslice + bslices - 1) / bslices;
+  s2.nwv = nblk * wpb;
+  c->gl_block_items = bitems;
   {
-    // a word block = 64 consecutive slices; serpentine inside the block keeps its 16 waves level
+    // serpentine inside the block keeps its waves level
     std::vector<uint32_t> so((size_t)s2.nwv * 4);
     for (uint32_t ob = 0; ob < nblk; ++ob)
-      for (uint32_t w = 0; w < GL_WAVES; ++w) {
-        const uint32_t cand[4] = {w, 31 - w, 32 + w, 63 - w};
+      for (uint32_t w = 0; w < wpb; ++w) {
+        const uint32_t cand[4] = {w, 2 * wpb - 1 - w, 2 * wpb + w, 4 * wpb - 1 - w};
         for (int g = 0; g < 4; ++g) {
-          const uint64_t sl = (uint64_t)ob * GL_BLOCK_SLICES + cand[g];
-          so[((size_t)ob * GL_WAVES + w) * 4 + g] = sl < s2.nslice ? (uint32_t)sl : GL_NONE;
+          const uint64_t sl = (uint64_t)ob * bslices + cand[g];
+          so[((size_t)ob * wpb + w) * 4 + g] = sl < s2.nslice ? (uint32_t)sl : GL_NONE;
         }
       }
     ISLECHK(build_side<2>(c, s2, so));
@@ -730,7 +752,7 @@ int k_gl_build(isle_ctx* c) {
     const char* e_nz = getenv("ISLE_GL_ZONES");
     const uint32_t NZ = (e_nz && atoi(e_nz) == 8 && s2.NB >= 64) ? 8u : 1u;
     HIPCHK(c, c->gl_blocktot.reserve((size_t)nblk * NZ));
-    hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, NZ), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, s2.NB, NZ, c->gl_blocktot.p);
+    hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, NZ), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, wpb, s2.NB, NZ, c->gl_blocktot.p);
     HIPCHK(c, hipGetLastError());
     std::vector<unsigned long long> tot((size_t)nblk * NZ);
     HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -758,7 +780,7 @@ int k_gl_build(isle_ctx* c) {
         const uint32_t n = (uint32_t)std::min<double>((double)nzb, std::max(1.0, std::ceil(cost / target)));
         for (uint32_t ch = 0; ch < n; ++ch) {
           const uint32_t b0 = zb0 + (uint32_t)((uint64_t)ch * nzb / n), b1 = zb0 + (uint32_t)((uint64_t)(ch + 1) * nzb / n);
-          zone[z].push_back(GlDesc{ob * GL_WAVES, 1u, (uint32_t)GL_WAVES, b0, b1, nslab, ob * GL_BLOCK_ITEMS, 0u});
+          zone[z].push_back(GlDesc{ob * wpb, 1u, wpb, b0, b1, nslab, ob * bitems, 0u});
           ++nslab;
           ++nch[ob];
         }
@@ -782,7 +804,7 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(s2.desc.p, ds.data(), ds.size() * sizeof(GlDesc), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->gl_slab0.p, slab0.data(), nblk * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->gl_nch.p, nch.data(), nblk * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, c->gl_part.reserve((size_t)nslab * GL_BLOCK_ITEMS * 12));  // sized for the widest panel (BP = 12)
+    HIPCHK(c, c->gl_part.reserve((size_t)nslab * bitems * 12));  // sized for the widest panel (BP = 12)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (getenv("ISLE_GL_VERBOSE"))
       fprintf(stderr,
@@ -811,9 +833,9 @@ int k_gl_apply(isle_ctx* c, int b, int BP) {
   }
   {
     TimeScope ts(c, ISLE_T_GRAM_PASS2);
-    ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)GL_BLOCK_ITEMS * LPE));
+    ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)c->gl_block_items * LPE));
     hipLaunchKernelGGL(gl_reduce_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->gl_part.p, c->gl_slab0.p,
-                       c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, (float4*)c->Zrm.p);
+                       c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, c->gl_block_items, (float4*)c->Zrm.p);
     HIPCHK(c, hipGetLastError());
   }
   return 0;

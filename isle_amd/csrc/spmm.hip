@@ -492,6 +492,15 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// The k-wide products as ceil(k / 12) passes of the LDS-banded pass-1 stream pay one staging of every word band per pass: a
+// win while the vocabulary spans few bands (C2: 15 bands, 5.8 vs 7.0 ms), a loss at 30 bands (C3 shard: 68 vs 52 ms).
+// ISLE_WIDE_GATHER=1 / ISLE_WIDE_LDS=1 force either form.
+static bool wide_through_lds(const isle_ctx* c) {
+  if (getenv("ISLE_WIDE_GATHER")) return false;
+  if (getenv("ISLE_WIDE_LDS")) return true;
+  return c->V <= 20 * 3412;
+}
+
 // Assignment from stored dot products (dots = B^T C computed by the LDS-banded wide SpMM, gram_lds.hip): one wave per document.
 template <int NIT>
 __global__ __launch_bounds__(256) void dots_assign_k(const float4* __restrict__ dots, int nq, int k, uint32_t D, const float* __restrict__ cn,
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(256) void dots_assign_k(const float4* __restrict__ 
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms) {
   TimeScope ts(c, ISLE_T_PROJECT);
   ISLECHK(k_gl_detect(c));
-  if (c->gl_mode == 1 && !getenv("ISLE_WIDE_GATHER")) {  // row-constant B: panels of M through LDS (gram_lds.hip)
+  if (c->gl_mode == 1 && wide_through_lds(c)) {  // row-constant B: panels of M through LDS (gram_lds.hip)
     ISLECHK(k_gl_wide(c, Mrm, k, ldk, P));
     return k_rownorms(c, P, (int)c->D, k, ldk, norms);
   }
@@ -522,7 +531,7 @@ int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const floa
                        const uint32_t* perm, const uint32_t* nslots, float* ub, float* lb, int G) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   ISLECHK(k_gl_detect(c));
-  if (c->gl_mode == 1 && !nslots && c->D && !getenv("ISLE_WIDE_GATHER")) {
+  if (c->gl_mode == 1 && !nslots && c->D && wide_through_lds(c)) {
     // full assignment on a row-constant B: dots = B^T C by the LDS-banded wide SpMM into the projection buffer (P is
     // recomputed if it is needed again), then the same epilogue from memory.  `perm` is only a visiting order: ignored.
     const uint32_t D = (uint32_t)c->D;
