@@ -811,34 +811,48 @@ struct Ks {
   }
 
   int expand() {  // :62-136
-    while (H.r < ncv) {
-      const size_t m = H.r;
+    // H grows by blk rows and columns per step; it is kept in a work matrix of the final size while the loop runs (copying
+    // the whole of H at every step cost ~10 ms of host time per solve at ncv = 410, with the GPU idle behind the QR's sync)
+    const size_t cap_r = std::max<size_t>(ncv, H.r) + blk, cap_c = H.c + (cap_r - H.r);
+    HMat W(cap_r, cap_c);
+    for (size_t j = 0; j < H.c; ++j)
+      for (size_t i = 0; i < H.r; ++i) W(i, j) = H(i, j);
+    size_t hr = H.r, hcn = H.c;
+    auto shrink = [&]() {  // H = W[:hr, :hcn]
+      HMat Hn(hr, hcn);
+      for (size_t j = 0; j < hcn; ++j)
+        for (size_t i = 0; i < hr; ++i) Hn(i, j) = W(i, j);
+      H = Hn;
+    };
+    while (hr < ncv) {
+      const size_t m = hr;
       float* F = c->Fbuf.p;
-      ISLECHK(apply(col(H.c), F));
+      ISLECHK(apply(col(hcn), F));
       ISLECHK(ortho(F, (int)blk, m, 3));  // CGS + 2 DGKS passes (:83-91)
       std::vector<float> hc(3 * m * blk);
       HIPCHK(c, hipMemcpyAsync(hc.data(), c->coef.p, hc.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
       std::vector<float> R;
       int rk = 0;
-      ISLECHK(dev_qr(c, F, dim, (int)blk, col(H.c + blk), R, &rk));  // synchronises
-      HMat Hn(m + blk, H.c + blk);
-      for (size_t j = 0; j < H.c; ++j)
-        for (size_t i = 0; i < m; ++i) Hn(i, j) = H(i, j);
+      ISLECHK(dev_qr(c, F, dim, (int)blk, col(hcn + blk), R, &rk));  // synchronises
+      if (m + blk > cap_r || hcn + blk > cap_c) return isle_fail(c, ISLE_E_NUMERIC, "expand: projected matrix outgrew its work space");
       for (size_t j = 0; j < blk; ++j)
         for (size_t i = 0; i < m; ++i) {
           float h = hc[j * m + i];
           h = h + hc[m * blk + j * m + i];
           h = h + hc[2 * m * blk + j * m + i];
-          Hn(i, H.c + j) = h;
+          W(i, hcn + j) = h;
         }
       for (size_t j = 0; j < blk; ++j)
-        for (int i = 0; i < rk; ++i) Hn(m + i, H.c + j) = R[j * rk + i];
-      H = Hn;
+        for (int i = 0; i < rk; ++i) W(m + i, hcn + j) = R[j * rk + i];
+      hr = m + blk;
+      hcn += blk;
       if ((size_t)rk < blk) {
+        shrink();  // repair() reads H.r / H.c
         size_t nvecs = H.c + rk;
         ISLECHK(repair(nvecs, H.r, blk - rk));
       }
     }
+    shrink();
     vcols = H.r;
     return 0;
   }
