@@ -116,14 +116,17 @@ __global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, 
   }
 }
 
+// coef[j][i] = sum over chunks (fixed order) of part[chunk][i][j]; thread = one (i, j) of the slab, chunk slabs are read coalesced
 template <class Tout>
-__global__ void vtf_reduce_k(const double* __restrict__ part, int nchunks, int m, int BT, int b, Tout* __restrict__ coef) {
+__global__ __launch_bounds__(256) void vtf_reduce_k(const double* __restrict__ part, int nchunks, int m, int BT, int b, Tout* __restrict__ coef) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= m * b) return;
-  const int j = idx / m, i = idx - j * m;
+  const int slab = m * BT;
+  if (idx >= slab) return;
   double s = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) s += part[((size_t)ch * m + i) * BT + j];
-  coef[(size_t)j * m + i] = (Tout)s;
+#pragma unroll 8
+  for (int ch = 0; ch < nchunks; ++ch) s += part[(size_t)ch * slab + idx];
+  const int i = idx / BT, j = idx - i * BT;
+  if (j < b) coef[(size_t)j * m + i] = (Tout)s;
 }
 
 static int bt_of(int b) { return b <= 4 ? 4 : b <= 8 ? 8 : b <= 12 ? 12 : b <= 16 ? 16 : 32; }
@@ -143,7 +146,7 @@ static int vtf_impl(isle_ctx* c, const float* Vb, uint64_t n, int m, const float
     default: hipLaunchKernelGGL(vtf_partial_k<32>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
   }
   HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(vtf_reduce_k<Tout>, dim3(cdiv((long)m * b, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, m, BT, b, out_dev);
+  hipLaunchKernelGGL(vtf_reduce_k<Tout>, dim3(cdiv((long)m * BT, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, m, BT, b, out_dev);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -156,7 +159,7 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
     HIPCHK(c, c->part.reserve((size_t)nch * m * BT));
     hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 64)), dim3(256), 0, c->stream, Vb, n, m, F, b, BT, c->part.p);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(vtf_reduce_k<float>, dim3(cdiv((long)m * b, 256)), dim3(256), 0, c->stream, c->part.p, nch, m, BT, b, coef);
+    hipLaunchKernelGGL(vtf_reduce_k<float>, dim3(cdiv((long)m * BT, 256)), dim3(256), 0, c->stream, c->part.p, nch, m, BT, b, coef);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
@@ -166,12 +169,17 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
 // ------------------------------------------------------------------------------------------
 // F[r, :] -= sum_i Vb[r, i] * coef[i, :]        one thread per row, coef tiles staged in LDS
 // ------------------------------------------------------------------------------------------
+// Workgroup = 64 rows x 4 waves; wave q takes the basis columns i = q (mod 4) blocks of UPD_TILE / 4, so a 50k-row panel
+// spreads over ~3000 waves instead of ~800 (the loop is a chain of dependent-address loads: latency-bound at low occupancy).
+// The four partial sums of a row are added in fixed order.
 constexpr int UPD_TILE = 128;
 template <int BT>
 __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t n, int b, const float* __restrict__ Vb, int m,
                                                  const float* __restrict__ coef /*m x b col-major*/) {
   __shared__ float Cs[UPD_TILE][BT];
-  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[3][64][BT + 1];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const uint64_t r = (uint64_t)blockIdx.x * 64 + lane;
   const bool live = r < n;
   float acc[BT];
 #pragma unroll
@@ -185,26 +193,32 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
     }
     __syncthreads();
     if (live) {
+      const int ib = q * (UPD_TILE / 4), ie = min(cnt, ib + UPD_TILE / 4);
       const float* v = Vb + (uint64_t)i0 * n + r;
 #pragma unroll 8
-      for (int ii = 0; ii < cnt; ++ii) {
+      for (int ii = ib; ii < ie; ++ii) {
         const float x = v[(uint64_t)ii * n];
 #pragma unroll
         for (int j = 0; j < BT; ++j) acc[j] = fmaf(x, Cs[ii][j], acc[j]);
       }
     }
   }
-  if (live) {
+  if (q > 0) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j) red[q - 1][lane][j] = acc[j];
+  }
+  __syncthreads();
+  if (q == 0 && live) {
 #pragma unroll
     for (int j = 0; j < BT; ++j)
-      if (j < b) F[(uint64_t)j * n + r] -= acc[j];
+      if (j < b) F[(uint64_t)j * n + r] -= ((acc[j] + red[0][lane][j]) + red[1][lane][j]) + red[2][lane][j];
   }
 }
 
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef) {
   TimeScope ts(c, ISLE_T_ORTHO);
   const int BT = bt_of(b);
-  dim3 g(cdiv(n, 256)), blk(256);
+  dim3 g(cdiv(n, 64)), blk(256);
   switch (BT) {
     case 4: hipLaunchKernelGGL(update_k<4>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
     case 8: hipLaunchKernelGGL(update_k<8>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
