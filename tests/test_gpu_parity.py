@@ -136,6 +136,44 @@ def test_eig_sym_matches_lapack(hp, n):
     assert np.abs(S.astype(np.float64) @ v - v * e).max() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("case", ["identity", "zero", "rank1", "pairs", "cluster", "graded", "n3", "n17"])
+def test_eig_sym_hard_spectra(hp, case):
+    """The tridiagonal solver (bisection + twisted factorisation) needs separated eigenvalues for orthogonal vectors; exact
+    multiplicities must be caught by its orthogonality check and handed to the Jacobi solver.  Either way the result has to be
+    an orthonormal eigenbasis with LAPACK's eigenvalues."""
+    rng = np.random.default_rng(7)
+    n = 64
+    if case == "identity":
+        S = np.eye(n)
+    elif case == "zero":
+        S = np.zeros((n, n))
+    elif case == "rank1":
+        x = rng.standard_normal(n)
+        S = np.outer(x, x)
+    else:
+        if case == "n3":
+            n = 3
+        if case == "n17":
+            n = 17
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        if case == "pairs":
+            lam = np.repeat(np.arange(n // 2, 0, -1.0), 2)          # every eigenvalue twice
+        elif case == "cluster":
+            lam = np.concatenate([[1e3], 10 * (1 + 1e-5 * np.arange(n - 1))])  # relative gaps 1e-5
+        elif case == "graded":
+            lam = 10.0 ** (-np.arange(n) / 8.0)
+        else:
+            lam = np.arange(n, 0, -1.0)
+        S = (Q * lam) @ Q.T
+    S = S.astype(np.float32)
+    e, v = hp.eig_sym(S)
+    er = np.linalg.eigvalsh(S.astype(np.float64))[::-1]
+    scale = max(np.abs(er).max(), 1e-30)
+    assert np.abs(e - er).max() <= 2e-6 * scale
+    assert np.abs(v.astype(np.float64).T @ v - np.eye(n)).max() <= 1e-5
+    assert np.abs(S.astype(np.float64) @ v - v * e).max() <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("which", ["tiny10", "tiny20"])
 def test_block_ks_sigma(hp, which, request):
     B = request.getfixturevalue(which)
