@@ -169,6 +169,8 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  for (auto& e : c->ks_ev)
+    if (e) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -824,17 +826,40 @@ struct Ks {
         for (size_t i = 0; i < hr; ++i) Hn(i, j) = W(i, j);
       H = Hn;
     };
+    // Pipelined: after the QR of step i is enqueued, the operator application and orthogonalisation of step i + 1 are
+    // enqueued too (they only need Q on the device, assuming full rank), and the host then waits for the QR's event alone to
+    // fold R and the coefficients into H.  The GPU never idles behind the per-step round trip.  A rank-deficient panel
+    // (never seen on thresholded matrices) discards the speculative work and repairs, as the synchronous form does.
+    const bool pipelined = !getenv("ISLE_KS_SYNC");
+    for (int i = 0; i < 2; ++i)
+      if (!c->ks_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ks_ev[i], hipEventDisableTiming));
+    std::vector<float> hcbuf[2], Rbuf[2];
+    int metabuf[2][2] = {{0, 0}, {0, 0}};
+    bool spec = false;  // apply + ortho of the current step already enqueued
+    int slot = 0;
     while (hr < ncv) {
       const size_t m = hr;
       float* F = c->Fbuf.p;
-      ISLECHK(apply(col(hcn), F));
-      ISLECHK(ortho(F, (int)blk, m, 3));  // CGS + 2 DGKS passes (:83-91)
-      std::vector<float> hc(3 * m * blk);
+      if (!spec) {
+        ISLECHK(apply(col(hcn), F));
+        ISLECHK(ortho(F, (int)blk, m, 3));  // CGS + 2 DGKS passes (:83-91)
+      }
+      spec = false;
+      std::vector<float>& hc = hcbuf[slot];
+      std::vector<float>& Rfull = Rbuf[slot];
+      hc.resize(3 * m * blk);
+      Rfull.assign(blk * blk, 0.f);
       HIPCHK(c, hipMemcpyAsync(hc.data(), c->coef.p, hc.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      std::vector<float> R;
-      int rk = 0;
-      ISLECHK(dev_qr(c, F, dim, (int)blk, col(hcn + blk), R, &rk));  // synchronises
+      ISLECHK(k_panel_qr_enqueue(c, F, dim, (int)blk, col(hcn + blk), Rfull.data(), metabuf[slot], c->ks_ev[slot]));
       if (m + blk > cap_r || hcn + blk > cap_c) return isle_fail(c, ISLE_E_NUMERIC, "expand: projected matrix outgrew its work space");
+      const bool more = m + blk < ncv;
+      if (pipelined && more) {  // speculate: full rank -> next step works on the blk new columns with m + blk basis vectors
+        ISLECHK(apply(col(hcn + blk), F));
+        ISLECHK(ortho(F, (int)blk, m + blk, 3));
+        spec = true;
+      }
+      int rk = 0;
+      ISLECHK(k_panel_qr_finish(c, c->ks_ev[slot], metabuf[slot], &rk));
       for (size_t j = 0; j < blk; ++j)
         for (size_t i = 0; i < m; ++i) {
           float h = hc[j * m + i];
@@ -843,15 +868,22 @@ struct Ks {
           W(i, hcn + j) = h;
         }
       for (size_t j = 0; j < blk; ++j)
-        for (int i = 0; i < rk; ++i) W(m + i, hcn + j) = R[j * rk + i];
+        for (int i = 0; i < rk; ++i) W(m + i, hcn + j) = Rfull[j * rk + i];
       hr = m + blk;
       hcn += blk;
       if ((size_t)rk < blk) {
+        if (spec) {  // the speculative step used columns that are about to be replaced
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          spec = false;
+          napplies--;
+        }
         shrink();  // repair() reads H.r / H.c
         size_t nvecs = H.c + rk;
         ISLECHK(repair(nvecs, H.r, blk - rk));
       }
+      slot ^= 1;
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     shrink();
     vcols = H.r;
     return 0;
@@ -1091,13 +1123,11 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     ISLECHK(k_scan_f2d(c, c->min_dist.p, D, c->cum.p));  // :2170-2172 (double, parallel; the reference's is fp32 sequential)
     // totals (per rank) -> offsets
     double my[2] = {0.0, 0.0};
+    float lm = 0.f;
     HIPCHK(c, hipMemcpyAsync(&my[0], c->cum.p + D, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (D > 0) {
-      float lm = 0.f;
-      HIPCHK(c, hipMemcpy(&lm, c->min_dist.p + (D - 1), sizeof(float), hipMemcpyDeviceToHost));
-      my[1] = lm;
-    }
+    if (D > 0) HIPCHK(c, hipMemcpyAsync(&lm, c->min_dist.p + (D - 1), sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // one round trip for both scalars
+    my[1] = lm;
     std::vector<double> tot(2 * c->world, 0.0);
     if (multi) {
       double* dv = c->gram.p;
@@ -1134,7 +1164,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
       }
       double* dd = c->gram.p + 64;
       uint64_t* od = (uint64_t*)(c->gram.p + 128);
-      HIPCHK(c, hipMemcpy(dd, local.data(), ndraw * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpyAsync(dd, local.data(), ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
       ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
       HIPCHK(c, hipMemcpyAsync(drawn.data(), od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));

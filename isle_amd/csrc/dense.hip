@@ -413,7 +413,9 @@ __global__ __launch_bounds__(256) void pqr_apply_k(const float* F, uint64_t n, i
 }
 
 // F: n x w (device, destroyed).  Q: n x rank at Qdst.  R_host: room for w*w floats, rank x w as [j*rank + r].
-int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* rank_out) {
+// Enqueue only: the kernels, then the copies of {rank, status} and R into the caller's host buffers (which must stay alive),
+// then `done` is recorded.  k_panel_qr_finish waits for that event alone, so work enqueued behind the QR keeps the GPU busy.
+int k_panel_qr_enqueue(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* meta_host /*2*/, hipEvent_t done) {
   TimeScope ts(c, ISLE_T_QR);
   if (w < 1 || w > PQ_W) return isle_fail(c, ISLE_E_ARG, "panel QR: width %d not in [1, %d]", w, PQ_W);
   const int nparts = cdiv((long)n, PQ_ROWS * PQ_SUB);
@@ -430,13 +432,22 @@ int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_h
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, c->pq_meta.p, c->pq_T.p, Rout);
   hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, c->pq_meta.p, Qdst);
   HIPCHK(c, hipGetLastError());
-  int meta[2];
-  HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(meta_host, c->pq_meta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
-  *rank_out = meta[0];
+  if (done) HIPCHK(c, hipEventRecord(done, c->stream));
   return 0;
+}
+int k_panel_qr_finish(isle_ctx* c, hipEvent_t done, const int* meta_host, int* rank_out) {
+  if (done) HIPCHK(c, hipEventSynchronize(done));
+  else HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (meta_host[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
+  *rank_out = meta_host[0];
+  return 0;
+}
+int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* rank_out) {
+  int meta[2] = {0, 0};
+  ISLECHK(k_panel_qr_enqueue(c, F, n, w, Qdst, R_host, meta, nullptr));
+  return k_panel_qr_finish(c, nullptr, meta, rank_out);
 }
 
 // uniform [0,1) fill (arma::randu stand-in, block-ks/restarted_block_ks.h:212)
