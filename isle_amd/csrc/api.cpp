@@ -753,10 +753,11 @@ struct Ks {
   int randu(float* F, size_t cols) { return k_randu(c, F, dim * cols, seed + 0x1000 * (++draws)); }
 
   // orthogonalise F (dim x w) against the first m basis columns, `passes` times; coefficient blocks kept on device
-  int ortho(float* F, int w, size_t m, int passes) {
+  int ortho(float* F, int w, size_t m, int passes, float* coef_dev = nullptr) {
     HIPCHK(c, c->coef.reserve(3 * (c->basis.cap / dim) * 32));
+    float* base = coef_dev ? coef_dev : c->coef.p;
     for (int p = 0; p < passes; ++p) {
-      float* cf = c->coef.p + (size_t)p * m * w;
+      float* cf = base + (size_t)p * m * w;
       ISLECHK(k_vtf(c, Vb(), dim, (int)m, F, w, cf));
       ISLECHK(k_update(c, F, dim, w, Vb(), (int)m, cf));
     }
@@ -827,14 +828,21 @@ struct Ks {
       H = Hn;
     };
     // Pipelined: after the QR of step i is enqueued, the operator application and orthogonalisation of step i + 1 are
-    // enqueued too (they only need Q on the device, assuming full rank), and the host then waits for the QR's event alone to
-    // fold R and the coefficients into H.  The GPU never idles behind the per-step round trip.  A rank-deficient panel
-    // (never seen on thresholded matrices) discards the speculative work and repairs, as the synchronous form does.
+    // enqueued too (they only need Q on the device, assuming full rank), and the host then waits for an event recorded
+    // behind the QR to fold R and the coefficients into H.  Everything the host needs from a step — rank and status of the QR,
+    // R, the three coefficient blocks — is written into one device mailbox and comes back as ONE copy (every small copy
+    // costs ~20 us of queue time).  A rank-deficient panel (never seen on thresholded matrices) discards the speculative
+    // work and repairs, as the synchronous form (ISLE_KS_SYNC=1) does.
     const bool pipelined = !getenv("ISLE_KS_SYNC");
+    constexpr size_t MB_R = 64, MB_COEF = 64 + 32 * 32;  // mailbox offsets (floats): [meta ints | R | coefficients]
+    const size_t mb_floats = MB_COEF + 3 * cap_r * blk;
+    HIPCHK(c, c->ks_mail.reserve(mb_floats));
     for (int i = 0; i < 2; ++i)
       if (!c->ks_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ks_ev[i], hipEventDisableTiming));
-    std::vector<float> hcbuf[2], Rbuf[2];
-    int metabuf[2][2] = {{0, 0}, {0, 0}};
+    std::vector<float> host_mail[2];
+    host_mail[0].resize(mb_floats);
+    host_mail[1].resize(mb_floats);
+    float* mail = c->ks_mail.p;
     bool spec = false;  // apply + ortho of the current step already enqueued
     int slot = 0;
     while (hr < ncv) {
@@ -842,24 +850,26 @@ struct Ks {
       float* F = c->Fbuf.p;
       if (!spec) {
         ISLECHK(apply(col(hcn), F));
-        ISLECHK(ortho(F, (int)blk, m, 3));  // CGS + 2 DGKS passes (:83-91)
+        ISLECHK(ortho(F, (int)blk, m, 3, mail + MB_COEF));  // CGS + 2 DGKS passes (:83-91)
       }
       spec = false;
-      std::vector<float>& hc = hcbuf[slot];
-      std::vector<float>& Rfull = Rbuf[slot];
-      hc.resize(3 * m * blk);
-      Rfull.assign(blk * blk, 0.f);
-      HIPCHK(c, hipMemcpyAsync(hc.data(), c->coef.p, hc.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      ISLECHK(k_panel_qr_enqueue(c, F, dim, (int)blk, col(hcn + blk), Rfull.data(), metabuf[slot], c->ks_ev[slot]));
       if (m + blk > cap_r || hcn + blk > cap_c) return isle_fail(c, ISLE_E_NUMERIC, "expand: projected matrix outgrew its work space");
+      ISLECHK(k_panel_qr_kernels(c, F, dim, (int)blk, col(hcn + blk), reinterpret_cast<int*>(mail), mail + MB_R));
+      float* hm = host_mail[slot].data();
+      HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + 3 * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->ks_ev[slot], c->stream));
       const bool more = m + blk < ncv;
       if (pipelined && more) {  // speculate: full rank -> next step works on the blk new columns with m + blk basis vectors
         ISLECHK(apply(col(hcn + blk), F));
-        ISLECHK(ortho(F, (int)blk, m + blk, 3));
+        ISLECHK(ortho(F, (int)blk, m + blk, 3, mail + MB_COEF));  // behind the copy on the same stream: no hazard
         spec = true;
       }
-      int rk = 0;
-      ISLECHK(k_panel_qr_finish(c, c->ks_ev[slot], metabuf[slot], &rk));
+      HIPCHK(c, hipEventSynchronize(c->ks_ev[slot]));
+      const int* meta = reinterpret_cast<const int*>(hm);
+      if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
+      const int rk = meta[0];
+      const float* hc = hm + MB_COEF;
+      const float* Rfull = hm + MB_R;
       for (size_t j = 0; j < blk; ++j)
         for (size_t i = 0; i < m; ++i) {
           float h = hc[j * m + i];

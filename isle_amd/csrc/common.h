@@ -195,7 +195,10 @@ struct isle_ctx {
   DevBuf<float> centers_old;  // V x ldk
   DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
 
-  hipEvent_t ks_ev[2] = {nullptr, nullptr};  // block Krylov-Schur: QR-done events of the pipelined expand loop
+  // block Krylov-Schur, pipelined expand loop: device mailbox [rank, status, pivots | R | coefficients] of a step, fetched by
+  // one copy; the events that mark its arrival
+  hipEvent_t ks_ev[2] = {nullptr, nullptr};
+  DevBuf<float> ks_mail;
 
   // --- timing
   bool timing = false;
@@ -291,8 +294,7 @@ int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, 
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef);
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
-int k_panel_qr_enqueue(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* meta_host /*2*/, hipEvent_t done);
-int k_panel_qr_finish(isle_ctx* c, hipEvent_t done, const int* meta_host, int* rank_out);
+int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, int* meta_dev /*2 + 32*/, float* Rout_dev /*w*w*/);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C);  // col-major, lda = ldc = M
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl

@@ -413,41 +413,38 @@ __global__ __launch_bounds__(256) void pqr_apply_k(const float* F, uint64_t n, i
 }
 
 // F: n x w (device, destroyed).  Q: n x rank at Qdst.  R_host: room for w*w floats, rank x w as [j*rank + r].
-// Enqueue only: the kernels, then the copies of {rank, status} and R into the caller's host buffers (which must stay alive),
-// then `done` is recorded.  k_panel_qr_finish waits for that event alone, so work enqueued behind the QR keeps the GPU busy.
-int k_panel_qr_enqueue(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* meta_host /*2*/, hipEvent_t done) {
+// Kernels only.  meta_dev (2 + PQ_W ints: rank, status, pivots) and Rout_dev (rank x w, leading dimension rank) are device
+// buffers of the caller's choice, so that a pipelined caller can fetch them, together with whatever else it needs from the
+// step, in ONE copy (every small copy costs ~20 us of queue time).
+int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, int* meta_dev, float* Rout_dev) {
   TimeScope ts(c, ISLE_T_QR);
   if (w < 1 || w > PQ_W) return isle_fail(c, ISLE_E_ARG, "panel QR: width %d not in [1, %d]", w, PQ_W);
   const int nparts = cdiv((long)n, PQ_ROWS * PQ_SUB);
   HIPCHK(c, c->pq_part.reserve((size_t)nparts * PQ_W * PQ_W));
   HIPCHK(c, c->pq_R1.reserve(PQ_W * PQ_W));
   HIPCHK(c, c->pq_T.reserve(2 * PQ_W * PQ_W));
-  HIPCHK(c, c->pq_meta.reserve(2 + PQ_W));
-  float* Rout = c->pq_T.p + PQ_W * PQ_W;
   const dim3 rows(cdiv((long)n, 256));
   hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, F, n, w, (const int*)nullptr, c->pq_part.p);
-  hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 1, c->pq_R1.p, c->pq_meta.p, c->pq_T.p, Rout);
-  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, F, n, w, 1, c->pq_T.p, c->pq_meta.p, Qdst);
-  hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, Qdst, n, w, c->pq_meta.p, c->pq_part.p);
-  hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, c->pq_meta.p, c->pq_T.p, Rout);
-  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, c->pq_meta.p, Qdst);
+  hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 1, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
+  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, F, n, w, 1, c->pq_T.p, meta_dev, Qdst);
+  hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, Qdst, n, w, meta_dev, c->pq_part.p);
+  hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
+  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, meta_dev, Qdst);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(meta_host, c->pq_meta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  if (done) HIPCHK(c, hipEventRecord(done, c->stream));
-  return 0;
-}
-int k_panel_qr_finish(isle_ctx* c, hipEvent_t done, const int* meta_host, int* rank_out) {
-  if (done) HIPCHK(c, hipEventSynchronize(done));
-  else HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (meta_host[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
-  *rank_out = meta_host[0];
   return 0;
 }
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* rank_out) {
+  HIPCHK(c, c->pq_T.reserve(2 * PQ_W * PQ_W));
+  HIPCHK(c, c->pq_meta.reserve(2 + PQ_W));
+  float* Rout = c->pq_T.p + PQ_W * PQ_W;
+  ISLECHK(k_panel_qr_kernels(c, F, n, w, Qdst, c->pq_meta.p, Rout));
   int meta[2] = {0, 0};
-  ISLECHK(k_panel_qr_enqueue(c, F, n, w, Qdst, R_host, meta, nullptr));
-  return k_panel_qr_finish(c, nullptr, meta, rank_out);
+  HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
+  *rank_out = meta[0];
+  return 0;
 }
 
 // uniform [0,1) fill (arma::randu stand-in, block-ks/restarted_block_ks.h:212)
