@@ -219,6 +219,24 @@ int isle_hip_get_doc_topic_sums(isle_ctx* ctx, int64_t* doc_offsets, uint32_t* t
  * (1 - primary_ratio) * Model[:, pairs[2e+1]]; edge is vocab x n column-major. */
 int isle_hip_edge_topics(isle_ctx* ctx, const int64_t* pairs, int n, float primary_ratio, float* edge);
 
+/* ---- inference ---------------------------------------------------- */
+/* ISLEInfer over a batch of documents: drivers/ISLEInfer.cpp:60-112 (normalize_docs(true, true),
+ * infer_doc_in_file per document, heaviest topics) with ISLEInfer::mwu / grad / calculate_llh
+ * src/infer.cpp:361-492.  model_by_word: vocab x num_topics ROW-major (element (word, topic) at
+ * word * num_topics + topic), what load_model_from_sparse_file src/infer.cpp:32-70 builds from
+ * M_hat_catch_sparse.  The documents are a count matrix in CSC (word ids ascending per document).
+ * iters / Lf_guess: INFER_ITERS_DEFAULT 15 / INFER_LF_DEAFULT 10.0 (include/hyperparams.h:81-82).
+ * avg_doc_sz: SparseMatrix::avg_doc_sz of the documents (src/sparseMatrix.cpp:98).
+ * Outputs (host, each nullable): weights docs x num_topics row-major (1 / num_topics where inference did
+ * not converge, as the dense writer prints them); top_topic / top_weight docs x 5, topics with weight >
+ * 1 / num_topics in decreasing weight, -1 / 0 where there are fewer; llh docs x 2 (first = sum * avg_doc_sz,
+ * second = sum * words in the document; 0, 0 when not converged); nconverged = documents with llh.first != 0.
+ * Independent of the matrices held by the context. */
+int isle_hip_infer(isle_ctx* ctx, uint64_t vocab_size, int num_topics, const float* model_by_word,
+                   uint64_t num_docs, uint64_t nnz, const float* counts, const uint32_t* rows,
+                   const int64_t* offsets, int iters, float Lf_guess, float avg_doc_sz, float* weights,
+                   int32_t* top_topic, float* top_weight, float* llh, uint64_t* nconverged);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* Per-kernel-family device time accumulated with HIP events on the context's stream since the
  * last reset (only while enabled; enabling adds event records around each launch).
@@ -240,7 +258,8 @@ enum {
   ISLE_T_THRESHOLD = 13,   /* A -> B thresholding (upstream stage) */
   ISLE_T_POST = 14,        /* catchwords / topic model / edge topics (downstream stage) */
   ISLE_T_INGEST = 15,      /* tdf text -> count matrix */
-  ISLE_T_COUNT = 16
+  ISLE_T_INFER = 16,       /* ISLEInfer: multiplicative-weights inference */
+  ISLE_T_COUNT = 17
 };
 int isle_hip_timing_enable(isle_ctx* ctx, int on);
 int isle_hip_timing_reset(isle_ctx* ctx);

@@ -646,6 +646,16 @@ extern "C" int isle_hip_edge_topics(isle_ctx* c, const int64_t* pairs, int n, fl
   return 0;
 }
 
+extern "C" int isle_hip_infer(isle_ctx* c, uint64_t V, int k, const float* model_by_word, uint64_t D, uint64_t nnz, const float* counts,
+                              const uint32_t* rows, const int64_t* offs, int iters, float Lf, float avg_doc_sz, float* weights,
+                              int32_t* top_topic, float* top_weight, float* llh, uint64_t* nconverged) {
+  if (!c || !model_by_word || !offs || (nnz && (!counts || !rows))) return ISLE_E_ARG;
+  if (iters < 1 || !(Lf > 0.f)) return isle_fail(c, ISLE_E_ARG, "infer: iters = %d, Lf = %g", iters, (double)Lf);
+  if (offs[0] != 0 || (uint64_t)offs[D] != nnz) return isle_fail(c, ISLE_E_ARG, "infer: offsets do not span the %llu entries", (unsigned long long)nnz);
+  HIPCHK(c, hipSetDevice(c->device));
+  return k_infer(c, V, k, model_by_word, D, nnz, counts, rows, offs, iters, Lf, avg_doc_sz, weights, top_topic, top_weight, llh, nconverged);
+}
+
 extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
   if (!c || !out) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));

@@ -279,6 +279,11 @@ int k_th_emit(isle_ctx* c, uint64_t doc_base);
 // ingest.hip
 int k_ingest_tdf(isle_ctx* c, const unsigned char* text_dev, uint64_t n, uint64_t V, uint64_t D, uint64_t* entries_read, uint64_t* err_out);
 
+// infer.hip
+int k_infer(isle_ctx* c, uint64_t V, int k, const float* model_by_word, uint64_t D, uint64_t nnz, const float* counts, const uint32_t* rows,
+            const int64_t* offs, int iters, float Lfguess, float avg_doc_sz, float* weights, int32_t* top_topic, float* top_weight, float* llh,
+            uint64_t* nconverged);
+
 // post.hip
 int k_post_normalize(isle_ctx* c, float avg);
 int k_post_cluster_of(isle_ctx* c, const uint32_t* assign_dev, bool identity);

@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import IsleHipError, load_library
 
 TIMING_FAMILIES = ["gram_pass1", "gram_pass2", "ortho", "qr", "evd", "rotate", "project", "kmpp", "lloyd_proj",
-                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post", "ingest"]
+                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post", "ingest", "infer"]
 
 BLOCK_KS_MAX_ITERS = 100      # include/hyperparams.h:38
 BLOCK_KS_BLOCK_SIZE = 10      # include/hyperparams.h:39
@@ -264,6 +264,28 @@ class HotPath:
         return dict(centers=cout, assign=assign, iters=it.value)
 
     # ---- measurement ------------------------------------------------------------------------
+    # ---- inference -------------------------------------------------------
+    def infer(self, model_by_word, offs, rows, counts, iters=15, Lf=10.0, avg_doc_sz=None, want_weights=True):
+        """ISLEInfer over a count matrix in CSC (drivers/ISLEInfer.cpp:60-112, src/infer.cpp:361-492).
+        model_by_word: V x k row-major.  Returns weights (D x k), top_topic / top_weight (D x 5), llh (D x 2), nconverged."""
+        M = np.ascontiguousarray(model_by_word, np.float32)
+        V, k = M.shape
+        offs = np.ascontiguousarray(offs, np.int64)
+        rows = np.ascontiguousarray(rows, np.uint32)
+        counts = np.ascontiguousarray(counts, np.float32)
+        D = offs.shape[0] - 1
+        if avg_doc_sz is None:  # populate_CSC, src/sparseMatrix.cpp:87-98
+            nz = int((np.diff(offs) > 0).sum())
+            avg_doc_sz = float(int(counts.astype(np.float64).sum()) // max(nz, 1))
+        W = np.empty((D, k), np.float32) if want_weights else None
+        tt = np.empty((D, 5), np.int32)
+        tw = np.empty((D, 5), np.float32)
+        llh = np.empty((D, 2), np.float32)
+        nc = C.c_uint64()
+        self._chk(self._lib.isle_hip_infer(self._h, V, k, _p(M), D, rows.shape[0], _p(counts), _p(rows), _p(offs), int(iters), float(Lf),
+                                           float(avg_doc_sz), _p(W) if want_weights else None, _p(tt), _p(tw), _p(llh), C.byref(nc)))
+        return dict(weights=W, top_topic=tt, top_weight=tw, llh=llh, nconverged=int(nc.value), avg_doc_sz=avg_doc_sz)
+
     def timing_enable(self, on=True):
         self._chk(self._lib.isle_hip_timing_enable(self._h, 1 if on else 0))
 

@@ -274,3 +274,30 @@ def post_edge_topics(model, top1, top2, max_edge_topics, want_edge=True):
     n = int(L.orc_post_edge_topics(V, t1.shape[0], _p(t1), _p(t2), ncap, EDGE_TOPIC_MIN_DOCS, _p(model),
                                    EDGE_TOPIC_PRIMARY_RATIO, _p(pairs), _p(edge)))
     return pairs[:n], (edge[:, :n] if want_edge else None)
+
+
+# ---- inference: isle_infer_oracle.cpp ----------------------------------------------------------
+INFER_ITERS_DEFAULT = 15   # include/hyperparams.h:81
+INFER_LF_DEFAULT = 10.0    # include/hyperparams.h:82
+
+
+def infer(model_by_word, offs, rows, counts, iters=INFER_ITERS_DEFAULT, Lf=INFER_LF_DEFAULT, avg_doc_sz=None):
+    """ISLEInfer over a count matrix (CSC) — drivers/ISLEInfer.cpp:60-100, src/infer.cpp:361-492.
+    model_by_word: V x k row-major.  Returns weights (D x k), llh (D x 2), number of converged documents."""
+    M = np.ascontiguousarray(model_by_word, np.float32)
+    V, k = M.shape
+    offs = np.ascontiguousarray(offs, np.int64)
+    rows = np.ascontiguousarray(rows, np.uint32)
+    counts = np.ascontiguousarray(counts, np.float32)
+    D = offs.shape[0] - 1
+    if avg_doc_sz is None:  # populate_CSC, src/sparseMatrix.cpp:87-98: integer division of the token total by the non-empty documents
+        nz = int((np.diff(offs) > 0).sum())
+        avg_doc_sz = float(int(counts.astype(np.float64).sum()) // max(nz, 1))
+    W = np.empty((D, k), np.float32)
+    llh = np.empty((D, 2), np.float32)
+    L = lib()
+    L.orc_infer.restype = C.c_uint64
+    L.orc_infer.argtypes = [C.c_uint64, C.c_int] + [C.c_void_p] + [C.c_uint64] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_float,
+                                                                                                   C.c_void_p, C.c_void_p]
+    n = int(L.orc_infer(V, k, _p(M), D, _p(offs), _p(rows), _p(counts), int(iters), float(Lf), float(avg_doc_sz), _p(W), _p(llh)))
+    return dict(weights=W, llh=llh, nconverged=n, avg_doc_sz=avg_doc_sz)
