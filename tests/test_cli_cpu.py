@@ -43,6 +43,14 @@ def test_usage_message_and_exit_code():
     assert "Incorrect usage of ISLETrain" in r.stdout and "<max_edge_topics>" in r.stdout
 
 
+def test_isleinfer_usage_message_and_exit_code():
+    # drivers/ISLEInfer.cpp:11-20: anything but 11 arguments prints the usage text and exits with -1
+    exe = os.path.join(ROOT, "isle_amd", "host", "ISLEInfer")
+    r = subprocess.run([exe, "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 255
+    assert "Incorrect usage of ISLEInfer" in r.stdout
+
+
 def test_prestage_matches_input_tool(tmp_path):
     V, D, k = 400, 1500, 6
     c = Corpus(V, D, k, seed=8, L0=50.0)

@@ -76,3 +76,47 @@ def test_infer_lipschitz_guess_doubles(hp):
     o = oracle.infer(M, offs, rows, counts, Lf=1e-3)
     g = hp.infer(M, offs, rows, counts, Lf=1e-3)
     check(g, o, 30)
+
+
+def test_isleinfer_cli(hp, tmp_path):
+    """drivers/ISLEInfer.cpp end to end: sparse model file + tdf documents in, top_topics file and summary lines out."""
+    import os
+    import subprocess
+    from oracle import oracle
+    from test_cli_cpu import write_tdf
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    V, k, D = 700, 25, 300
+    M, offs, rows, counts = make_case(V, k, D, 9)
+    # the model as ISLETrain writes it: "<topic>\t<word>\t<weight>", 1-based, six decimals (truncated), entries <= 1e-8 dropped
+    Mq = np.floor(M.astype(np.float64) * 1e6) / 1e6
+    lines = ["%d\t%d\t%.6f" % (t + 1, w + 1, Mq[w, t]) for t in range(k) for w in range(V) if Mq[w, t] > 1e-8]
+    model_file = str(tmp_path / "M_hat_catch_sparse")
+    open(model_file, "w").write("\n".join(lines) + "\n")
+    tdf = str(tmp_path / "docs.tdf")
+    n = write_tdf(tdf, counts, rows, offs)
+    out = str(tmp_path / "out")
+    os.mkdir(out)
+    # documents 1..D; the reference takes num_docs = max_id - min_id, so the range end is D + 1
+    args = [os.path.join(ROOT, "isle_amd", "host", "ISLEInfer"), model_file, tdf, out, str(k), str(V), "1", str(D + 1), str(n), str(len(lines)), "0", "0"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Number of docs for which inference converged: " in r.stdout and "Avg LLH per word: " in r.stdout
+    name = os.path.join(out, "top_topics_iters_15_Lf_10.000000_doc_1_to_%d" % (D + 1))
+    assert os.path.isfile(name), os.listdir(out)
+    o = oracle.infer(Mq.astype(np.float32), offs, rows, counts)
+    nconv = int(r.stdout.split("Number of docs for which inference converged: ")[1].split()[0])
+    assert nconv == o["nconverged"]
+    got = {}
+    for ln in open(name).read().splitlines():
+        d, t, w = ln.split("\t")
+        got.setdefault(int(d) - 1, []).append((int(t) - 1, float(w)))
+    for d in range(D):
+        w = o["weights"][d]
+        conv = o["llh"][d, 0] != 0
+        cand = np.flatnonzero(w > 1.0 / k) if conv else np.zeros(0, int)
+        cand = cand[np.argsort(-w[cand], kind="stable")][:5]
+        g = got.get(d, [])
+        assert len(g) == len(cand)
+        for (t, wt), tc in zip(g, cand):
+            assert t == tc or abs(w[t] - w[tc]) <= 2e-4 * w.max()
+            assert abs(wt - w[t]) <= 2e-4 * w.max() + 1e-6  # six truncated decimals
