@@ -287,8 +287,30 @@ def main():
                 "catchwords_wall_ms": round(t_cw * 1e3, 3), "topic_model_wall_ms": round(t_tm * 1e3, 3),
                 "device_ms": round(tm3["post"][0], 3), "num_catchwords": cw["num_catchwords"],
                 "doc_topic_sums": tmo["num_sums"], "model_columns_sum_to_one": bool(np.allclose(np.abs(tmo["model"]).sum(0), 1.0, rtol=1e-3))}
+        # inference (next-4): ISLEInfer of all documents of A under the model just built; the CPU restatement on a sample
+        from oracle import oracle as orc
+        model_by_word = np.ascontiguousarray(np.nan_to_num(tmo["model"]), np.float32)  # V x k, element (word, topic): row-major
+        hp.timing_enable(True)
+        hp.timing_reset()
+        t1 = time.perf_counter()
+        inf = hp.infer(model_by_word, offsA, rowsA, cntA, want_weights=False)
+        t_inf = time.perf_counter() - t1
+        tm4 = hp.timing_get()
+        hp.timing_enable(False)
+        ns = min(D_per, 20000)  # bounded CPU sample: the first ns documents
+        t1 = time.perf_counter()
+        oi = orc.infer(model_by_word, offsA[:ns + 1], rowsA[:offsA[ns]], cntA[:offsA[ns]], avg_doc_sz=inf["avg_doc_sz"])
+        t_inf_cpu = time.perf_counter() - t1
+        conv = oi["llh"][:, 0] != 0
+        llh_ok = bool(np.allclose(inf["llh"][:ns], oi["llh"], rtol=2e-4, atol=1e-4))
+        top_ok = float(np.mean(inf["top_topic"][:ns][conv, 0] == np.argmax(oi["weights"][conv], axis=1))) if conv.any() else 1.0
+        infer_stage = {"stage": "ISLEInfer on the device (drivers/ISLEInfer.cpp, src/infer.cpp:361-492): all documents of A, 15 iterations",
+                       "docs": int(D_per), "wall_ms_incl_transfers": round(t_inf * 1e3, 1), "device_ms": round(tm4["infer"][0], 3),
+                       "docs_per_sec_device": round(D_per / max(tm4["infer"][0], 1e-9) * 1e3, 1), "converged": inf["nconverged"],
+                       "cpu_port_docs_per_sec": round(ns / t_inf_cpu, 1), "cpu_cores": effective_cpus(), "cpu_sample_docs": int(ns),
+                       "llh_matches_cpu_on_sample": llh_ok, "heaviest_topic_agreement_on_sample": round(top_ok, 5)}
         up = {"note": "stages either side of the hot path, run OUTSIDE the timed region at the same size, each checked at full size",
-              "ingest": ingest, "threshold": up, "downstream": down}
+              "ingest": ingest, "threshold": up, "downstream": down, "inference": infer_stage}
         del A_host
 
     out = {

@@ -8,15 +8,16 @@
 //   ISLEInfer::calculate_llh       src/infer.cpp:467-492   sum_d a_d log (M w)_d, scaled by avg_doc_sz / by the word count
 //   drivers/ISLEInfer.cpp:92-112                           top topics: weight > 1 / k, heaviest five
 //
-// One workgroup (4 waves) per document.  The document's slice of the model (its words' rows, k floats each) is staged in LDS
-// once and re-read from there in every iteration (15 by default); documents whose slice does not fit (> ~195 rows at k = 200)
-// read the rows from global memory instead.  Lanes own topics (one float4 per 64 topics), waves split the rows: per row one
+// One workgroup (4 waves) per document.  The document's slice of the model (its words' rows, k floats each) is re-read from
+// L2 / Infinity Cache in every iteration (15 by default); optionally (ISLE_INFER_CAP_ROWS) slices of up to that many rows are
+// staged in LDS once — slower in practice, see k_infer.  Lanes own topics (one float4 per 64 topics), waves split the rows: per row one
 // wave-wide dot product (z_d), then its contribution a_d / z_d * row to the gradient; the four partial gradients are added in
 // fixed order.  Every wave keeps its own, identical copy of w.  Arithmetic as the reference: fp32 products and sums, eta and
 // the exponential in double.  (Sums inside a row and over topics are tree reductions, the reference's are sequential or
 // MKL's: results agree to fp32 rounding, not bit for bit.)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -64,10 +65,22 @@ __global__ __launch_bounds__(256) void inf_prep_k(const float* __restrict__ coun
   if (lane == 0) nkeep[d] = n;
 }
 
-__device__ inline float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// Sum over the 16 lanes of a DPP row, result in every lane of the row: four data-parallel-primitive moves (quad swaps, half-row
+// mirror, row mirror) instead of four ds_bpermute round trips (__shfl_xor goes through the LDS crossbar: ~100 clk each, and
+// the row dot products are one dependent chain of them).
+__device__ inline float dpp_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
   return v;
+}
+__device__ inline float wave_sum_f(float v) {  // all 64 lanes, result uniform
+  v = dpp_sum16(v);
+  const int b = __builtin_bit_cast(int, v);
+  return ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+          __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32))) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
 }
 __device__ inline double wave_sum_d(double v) {
 #pragma unroll
@@ -76,146 +89,82 @@ __device__ inline double wave_sum_d(double v) {
 }
 __device__ inline float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
-template <int NIT>
-__global__ __launch_bounds__(INF_T) void inf_docs_k(const float4* __restrict__ M, int k, int nq, const int64_t* __restrict__ offs,
-                                                     const uint32_t* __restrict__ fw, const float* __restrict__ fa,
-                                                     const uint32_t* __restrict__ nkeep, uint64_t D, int iters, float Lfguess, float avg_doc_sz,
-                                                     uint32_t cap_rows, float* __restrict__ weights /*nullable D x k*/,
-                                                     int32_t* __restrict__ top_topic, float* __restrict__ top_weight, float* __restrict__ llh,
-                                                     unsigned int* __restrict__ nconverged) {
-  extern __shared__ float4 sm[];          // [cap_rows x nq] model rows | [4 x nq] partial gradients | [cap_rows] a
-  __shared__ float sred[4];
-  const uint64_t d = blockIdx.x;
-  if (d >= D) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t n = nkeep[d];
-  const int64_t beg = offs[d];
-  const uint32_t words_in_doc = (uint32_t)(offs[d + 1] - beg);
-  float4* rowbuf = sm;
-  float4* gbuf = sm + (size_t)cap_rows * nq;
-  float* as = reinterpret_cast<float*>(gbuf + 4 * (size_t)nq);
-  const bool in_lds = n <= cap_rows;
-  const float unif = 1.0f / (float)k;
-  // validity mask of this lane's topics
-  float4 mask[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int q = lane + 64 * it, t0 = 4 * q;
-    mask[it] = make_float4(q < nq && t0 < k ? 1.f : 0.f, q < nq && t0 + 1 < k ? 1.f : 0.f, q < nq && t0 + 2 < k ? 1.f : 0.f,
-                           q < nq && t0 + 3 < k ? 1.f : 0.f);
-  }
-  if (in_lds) {
-    for (uint32_t r = wave; r < n; r += 4) {
-      const float4* src = M + (size_t)fw[beg + r] * nq;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int q = lane + 64 * it;
-        if (q < nq) rowbuf[(size_t)r * nq + q] = src[q];
-      }
-    }
-    for (uint32_t r = threadIdx.x; r < n; r += INF_T) as[r] = fa[beg + r];
-  }
-  __syncthreads();
-  auto load_row = [&](uint32_t r, float4 (&rv)[NIT]) {
-    const float4* src = in_lds ? rowbuf + (size_t)r * nq : M + (size_t)fw[beg + r] * nq;
+// One pass over the rows of this wave (r = wave, wave + 4, ...): z_r = row_r . w (wave-wide), then either the gradient
+// contribution a_r / z_r * row_r (LLH = false) or the log-likelihood term a_r log z_r (LLH = true).  IN_LDS picks the address
+// space at compile time (a run-time choice of pointer makes the compiler emit flat loads).
+template <int NIT, bool IN_LDS, bool LLH>
+__device__ inline float inf_rows_pass(const float4* __restrict__ M, int nq, const float4* rowbuf, const float* as, const uint32_t* __restrict__ fwd,
+                                      const float* __restrict__ fad, uint32_t n, int lane, int wave, const float4 (&w)[NIT], float4 (&g)[NIT]) {
+  float llh = 0.f;
+  auto load = [&](uint32_t r, float4 (&rv)[NIT]) {
+    const float4* src = IN_LDS ? rowbuf + (size_t)r * nq : M + (size_t)fwd[r] * nq;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int q = lane + 64 * it;
       rv[it] = q < nq ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto a_of = [&](uint32_t r) { return in_lds ? as[r] : fa[beg + r]; };
+  auto aof = [&](uint32_t r) { return IN_LDS ? as[r] : fad[r]; };
+  uint32_t r = wave;
+  for (; r + 4 < n; r += 8) {  // two rows per pass: independent chains overlap
+    float4 ra[NIT], rb[NIT];
+    load(r, ra);
+    load(r + 4, rb);
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      pa += dot4(ra[it], w[it]);
+      pb += dot4(rb[it], w[it]);
+    }
+    pa = wave_sum_f(pa);
+    pb = wave_sum_f(pb);
+    if (LLH) {
+      llh += aof(r) * logf(pa);
+      llh += aof(r + 4) * logf(pb);
+    } else {
+      const float qa = aof(r) / pa, qb = aof(r + 4) / pb;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        g[it].x = fmaf(ra[it].x, qa, g[it].x);
+        g[it].y = fmaf(ra[it].y, qa, g[it].y);
+        g[it].z = fmaf(ra[it].z, qa, g[it].z);
+        g[it].w = fmaf(ra[it].w, qa, g[it].w);
+        g[it].x = fmaf(rb[it].x, qb, g[it].x);
+        g[it].y = fmaf(rb[it].y, qb, g[it].y);
+        g[it].z = fmaf(rb[it].z, qb, g[it].z);
+        g[it].w = fmaf(rb[it].w, qb, g[it].w);
+      }
+    }
+  }
+  for (; r < n; r += 4) {
+    float4 rv[NIT];
+    load(r, rv);
+    float p = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) p += dot4(rv[it], w[it]);
+    const float z = wave_sum_f(p);
+    if (LLH) {
+      llh += aof(r) * logf(z);
+    } else {
+      const float rr = aof(r) / z;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        g[it].x = fmaf(rv[it].x, rr, g[it].x);
+        g[it].y = fmaf(rv[it].y, rr, g[it].y);
+        g[it].z = fmaf(rv[it].z, rr, g[it].z);
+        g[it].w = fmaf(rv[it].w, rr, g[it].w);
+      }
+    }
+  }
+  return llh;
+}
 
-  float4 w[NIT];
-  bool converged = false;
-  float Lf = Lfguess;
-  if (n > 0) {
-    for (int guess = 0; guess < 10; ++guess) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) w[it] = make_float4(unif * mask[it].x, unif * mask[it].y, unif * mask[it].z, unif * mask[it].w);
-      for (int iter = 0; iter < iters; ++iter) {
-        float4 g[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t r = wave; r < n; r += 4) {  // grad :443-465
-          float4 rv[NIT];
-          load_row(r, rv);
-          float p = 0.f;
-#pragma unroll
-          for (int it = 0; it < NIT; ++it) p += dot4(rv[it], w[it]);
-          const float z = wave_sum_f(p);
-          const float rr = a_of(r) / z;
-#pragma unroll
-          for (int it = 0; it < NIT; ++it) {
-            g[it].x = fmaf(rv[it].x, rr, g[it].x);
-            g[it].y = fmaf(rv[it].y, rr, g[it].y);
-            g[it].z = fmaf(rv[it].z, rr, g[it].z);
-            g[it].w = fmaf(rv[it].w, rr, g[it].w);
-          }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int q = lane + 64 * it;
-          if (q < nq) gbuf[(size_t)wave * nq + q] = g[it];
-        }
-        __syncthreads();
-        const double eta = sqrt(2.0 * (double)logf((float)k) / (double)(float)(iter + 1)) / (double)Lf;  // :415
-        float part = 0.f;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int q = lane + 64 * it;
-          if (q < nq) {
-            const float4 g0 = gbuf[q], g1 = gbuf[(size_t)nq + q], g2 = gbuf[2 * (size_t)nq + q], g3 = gbuf[3 * (size_t)nq + q];
-            const float gx = ((g0.x + g1.x) + g2.x) + g3.x, gy = ((g0.y + g1.y) + g2.y) + g3.y;
-            const float gz = ((g0.z + g1.z) + g2.z) + g3.z, gw = ((g0.w + g1.w) + g2.w) + g3.w;
-            w[it].x = (float)((double)w[it].x * exp(eta * (double)gx));  // :418
-            w[it].y = (float)((double)w[it].y * exp(eta * (double)gy));
-            w[it].z = (float)((double)w[it].z * exp(eta * (double)gz));
-            w[it].w = (float)((double)w[it].w * exp(eta * (double)gw));
-            part += (w[it].x + w[it].y) + (w[it].z + w[it].w);
-          }
-        }
-        const float normalizer = wave_sum_f(part);  // :420
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          w[it].x /= normalizer;
-          w[it].y /= normalizer;
-          w[it].z /= normalizer;
-          w[it].w /= normalizer;
-        }
-        __syncthreads();  // gbuf is rewritten in the next iteration
-      }
-      double ps = 0.0;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) ps += ((double)w[it].x + (double)w[it].y) + ((double)w[it].z + (double)w[it].w);
-      const double sumw = wave_sum_d(ps);  // :425
-      const bool normal = isfinite(sumw) && fabs(sumw) >= 2.2250738585072014e-308;  // std::isnormal
-      if (normal) {
-        converged = !(fabs(1.0 - sumw) > 0.01);
-        break;  // :427-432: a finite sum far from 1 is retried with the same Lf in the reference — same outcome every time
-      }
-      Lf *= 2.0f;
-    }
-  }
-  // calculate_llh :467-492
-  float first = 0.f, second = 0.f;
-  if (converged) {
-    float s = 0.f;
-    for (uint32_t r = wave; r < n; r += 4) {
-      float4 rv[NIT];
-      load_row(r, rv);
-      float p = 0.f;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) p += dot4(rv[it], w[it]);
-      const float z = wave_sum_f(p);
-      s += a_of(r) * logf(z);
-    }
-    if (lane == 0) sred[wave] = s;
-    __syncthreads();
-    s = ((sred[0] + sred[1]) + sred[2]) + sred[3];
-    second = s * (float)words_in_doc;
-    first = s * avg_doc_sz;
-  }
+// llh, the weights (uniform where inference failed) and the heaviest five topics of one document; called by wave 0 with the
+// weights in the lane layout q = lane + 64 it.
+template <int NIT>
+__device__ inline void inf_emit(const float4 (&w)[NIT], int lane, int wave, uint64_t d, int k, int nq, float unif, float first, float second,
+                                float* __restrict__ weights, int32_t* __restrict__ top_topic, float* __restrict__ top_weight,
+                                float* __restrict__ llh, unsigned int* __restrict__ nconverged) {
   const bool good = first != 0.0f;  // drivers/ISLEInfer.cpp:93
   if (wave == 0) {
     if (lane == 0) {
@@ -282,6 +231,322 @@ __global__ __launch_bounds__(INF_T) void inf_docs_k(const float4* __restrict__ M
   }
 }
 
+template <int NIT>
+__global__ __launch_bounds__(INF_T) void inf_docs_k(const float4* __restrict__ M, int k, int nq, const int64_t* __restrict__ offs,
+                                                     const uint32_t* __restrict__ fw, const float* __restrict__ fa,
+                                                     const uint32_t* __restrict__ nkeep, uint64_t D, int iters, float Lfguess, float avg_doc_sz,
+                                                     uint32_t cap_rows, float* __restrict__ weights /*nullable D x k*/,
+                                                     int32_t* __restrict__ top_topic, float* __restrict__ top_weight, float* __restrict__ llh,
+                                                     unsigned int* __restrict__ nconverged) {
+  extern __shared__ float4 sm[];          // [cap_rows x nq] model rows | [4 x nq] partial gradients | [nq] weights | [cap_rows] a
+  __shared__ float sred[4];
+  const uint64_t d = blockIdx.x;
+  if (d >= D) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n = nkeep[d];
+  const int64_t beg = offs[d];
+  const uint32_t words_in_doc = (uint32_t)(offs[d + 1] - beg);
+  float4* rowbuf = sm;
+  float4* gbuf = sm + (size_t)cap_rows * nq;
+  float4* wbuf4 = gbuf + 4 * (size_t)nq;
+  float* wflat = reinterpret_cast<float*>(wbuf4);
+  float* as = reinterpret_cast<float*>(wbuf4 + nq);
+  const bool in_lds = n <= cap_rows;
+  const float unif = 1.0f / (float)k;
+  // validity mask of this lane's topics
+  float4 mask[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = lane + 64 * it, t0 = 4 * q;
+    mask[it] = make_float4(q < nq && t0 < k ? 1.f : 0.f, q < nq && t0 + 1 < k ? 1.f : 0.f, q < nq && t0 + 2 < k ? 1.f : 0.f,
+                           q < nq && t0 + 3 < k ? 1.f : 0.f);
+  }
+  if (in_lds) {
+    // stage the slice: wave `wave` takes rows wave, wave + 4, ...  The word ids of 64 of its rows are fetched by one coalesced-ish
+    // load and handed out by shuffles, and four row loads are in flight at a time (a plain loop is a chain of two dependent
+    // global loads per row: ~75 us per 100-word document)
+    for (uint32_t base = 0; base < n; base += 256) {
+      const uint32_t myr = base + wave + 4 * lane;
+      const uint32_t myw = myr < n ? fw[beg + myr] : 0u;
+      const uint32_t left = n > base + wave ? (n - base - wave + 3) / 4 : 0u;
+      const uint32_t cnt = min(64u, left);
+      for (uint32_t j = 0; j < cnt; j += 4) {
+        float4 v[4][NIT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t wj = (uint32_t)__shfl((int)myw, (int)min(j + u, cnt - 1));
+          const float4* src = M + (size_t)wj * nq;
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int q = lane + 64 * it;
+            v[u][it] = q < nq ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + u < cnt) {
+            const uint32_t r = base + wave + 4 * (j + u);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+              const int q = lane + 64 * it;
+              if (q < nq) rowbuf[(size_t)r * nq + q] = v[u][it];
+            }
+          }
+        }
+      }
+    }
+    for (uint32_t r = threadIdx.x; r < n; r += INF_T) as[r] = fa[beg + r];
+  }
+  __syncthreads();
+  float4 w[NIT];
+  bool converged = false;
+  float Lf = Lfguess;
+  float* gflat = reinterpret_cast<float*>(gbuf);  // 4 x ld floats
+  const int ld = 4 * nq;
+  if (n > 0) {
+    for (int guess = 0; guess < 10; ++guess) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) w[it] = make_float4(unif * mask[it].x, unif * mask[it].y, unif * mask[it].z, unif * mask[it].w);
+      for (int iter = 0; iter < iters; ++iter) {
+        float4 g[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // grad :443-465
+        if (in_lds) (void)inf_rows_pass<NIT, true, false>(M, nq, rowbuf, as, fw + beg, fa + beg, n, lane, wave, w, g);
+        else (void)inf_rows_pass<NIT, false, false>(M, nq, rowbuf, as, fw + beg, fa + beg, n, lane, wave, w, g);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int q = lane + 64 * it;
+          if (q < nq) gbuf[(size_t)wave * nq + q] = g[it];
+        }
+        if (wave == 0) {  // the weights of this iteration, for the per-topic update below
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int q = lane + 64 * it;
+            if (q < nq) wbuf4[q] = w[it];
+          }
+        }
+        __syncthreads();
+        // one thread per topic: w <- w * exp(eta * grad) (:418, double), then the normaliser (:420) over the workgroup
+        const double eta = sqrt(2.0 * (double)logf((float)k) / (double)(float)(iter + 1)) / (double)Lf;  // :415
+        float part = 0.f;
+        for (int t = threadIdx.x; t < k; t += INF_T) {
+          const float gt = ((gflat[t] + gflat[ld + t]) + gflat[2 * ld + t]) + gflat[3 * ld + t];
+          const float wn = (float)((double)wflat[t] * exp(eta * (double)gt));
+          wflat[t] = wn;
+          part += wn;
+        }
+        part = wave_sum_f(part);
+        if (lane == 0) sred[wave] = part;
+        __syncthreads();
+        const float normalizer = ((sred[0] + sred[1]) + sred[2]) + sred[3];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int q = lane + 64 * it;
+          if (q < nq) {
+            const float4 u = wbuf4[q];
+            w[it] = make_float4(u.x / normalizer * mask[it].x, u.y / normalizer * mask[it].y, u.z / normalizer * mask[it].z,
+                                u.w / normalizer * mask[it].w);
+          }
+        }
+        __syncthreads();  // gbuf / wbuf / sred are rewritten in the next iteration
+      }
+      double ps = 0.0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) ps += ((double)w[it].x + (double)w[it].y) + ((double)w[it].z + (double)w[it].w);
+      const double sumw = wave_sum_d(ps);  // :425
+      const bool normal = isfinite(sumw) && fabs(sumw) >= 2.2250738585072014e-308;  // std::isnormal
+      if (normal) {
+        converged = !(fabs(1.0 - sumw) > 0.01);
+        break;  // :427-432: a finite sum far from 1 is retried with the same Lf in the reference — same outcome every time
+      }
+      Lf *= 2.0f;
+    }
+  }
+  // calculate_llh :467-492
+  float first = 0.f, second = 0.f;
+  if (converged) {
+    float4 gdummy[NIT];
+    float s = in_lds ? inf_rows_pass<NIT, true, true>(M, nq, rowbuf, as, fw + beg, fa + beg, n, lane, wave, w, gdummy)
+                     : inf_rows_pass<NIT, false, true>(M, nq, rowbuf, as, fw + beg, fa + beg, n, lane, wave, w, gdummy);
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    s = ((sred[0] + sred[1]) + sred[2]) + sred[3];
+    second = s * (float)words_in_doc;
+    first = s * avg_doc_sz;
+  }
+  if (wave == 0) inf_emit<NIT>(w, lane, wave, d, k, nq, unif, first, second, weights, top_topic, top_weight, llh, nconverged);
+}
+
+// k <= 256: sixteen lanes per row.  A wave works on four rows at a time (sub-group sub = lane / 16 takes rows
+// 4 wave + sub, + 16, ...), lane s of a sub-group holds the float4 chunks q = s + 16 f of w, of the row and of its partial
+// gradient.  The row dot products reduce over 16 lanes (four xor steps) instead of 64, sixteen rows are in flight per
+// workgroup instead of eight, and the sixteen partial gradients are added in fixed order by the per-topic update.
+template <int NF>
+__global__ __launch_bounds__(INF_T) void inf_docs16_k(const float4* __restrict__ M, int k, int nq, const int64_t* __restrict__ offs,
+                                                       const uint32_t* __restrict__ fw, const float* __restrict__ fa,
+                                                       const uint32_t* __restrict__ nkeep, uint64_t D, int iters, float Lfguess, float avg_doc_sz,
+                                                       uint32_t cap_rows, float* __restrict__ weights, int32_t* __restrict__ top_topic,
+                                                       float* __restrict__ top_weight, float* __restrict__ llh,
+                                                       unsigned int* __restrict__ nconverged) {
+  extern __shared__ float4 sm[];  // [cap_rows x nq] model rows | [16 x nq] partial gradients | [nq] weights | [cap_rows] a
+  __shared__ float sred[16];
+  const uint64_t d = blockIdx.x;
+  if (d >= D) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, sl = lane & 15, grp = wave * 4 + sub;
+  const uint32_t n = nkeep[d];
+  const int64_t beg = offs[d];
+  const uint32_t words_in_doc = (uint32_t)(offs[d + 1] - beg);
+  float4* rowbuf = sm;
+  float4* gbuf = sm + (size_t)cap_rows * nq;
+  float4* wbuf4 = gbuf + 16 * (size_t)nq;
+  float* wflat = reinterpret_cast<float*>(wbuf4);
+  float* gflat = reinterpret_cast<float*>(gbuf);
+  float* as = reinterpret_cast<float*>(wbuf4 + nq);
+  const int ld = 4 * nq;
+  const bool in_lds = n <= cap_rows;
+  const float unif = 1.0f / (float)k;
+  const uint32_t* fwd = fw + beg;
+  const float* fad = fa + beg;
+  if (in_lds) {  // stage the slice (same scheme as inf_docs_k: ids by one load + shuffles, four row loads in flight)
+    for (uint32_t base = 0; base < n; base += 256) {
+      const uint32_t myr = base + wave + 4 * lane;
+      const uint32_t myw = myr < n ? fwd[myr] : 0u;
+      const uint32_t left = n > base + wave ? (n - base - wave + 3) / 4 : 0u;
+      const uint32_t cnt = min(64u, left);
+      for (uint32_t j = 0; j < cnt; j += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t wj = (uint32_t)__shfl((int)myw, (int)min(j + u, cnt - 1));
+          v[u] = lane < nq ? M[(size_t)wj * nq + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j + u < cnt && lane < nq) rowbuf[(size_t)(base + wave + 4 * (j + u)) * nq + lane] = v[u];
+      }
+    }
+    for (uint32_t r = threadIdx.x; r < n; r += INF_T) as[r] = fad[r];
+  }
+  auto sub_sum = [](float v) { return dpp_sum16(v); };
+  // one pass over this sub-group's rows; LLH = false: gradient contributions into g, true: returns sum a_r log z_r
+  auto rows_pass = [&](const float4 (&wl)[NF], float4 (&g)[NF], bool want_llh) {
+    float acc = 0.f;
+    for (uint32_t r = grp; r < n; r += 16) {
+      float4 rv[NF];
+      const float4* src = in_lds ? nullptr : M + (size_t)fwd[r] * nq;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int q = sl + 16 * f;
+        rv[f] = q < nq ? (in_lds ? rowbuf[(size_t)r * nq + q] : src[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float p = 0.f;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) p += dot4(rv[f], wl[f]);
+      const float z = sub_sum(p);
+      const float ar = in_lds ? as[r] : fad[r];
+      if (want_llh) {
+        acc += ar * logf(z);
+      } else {
+        const float rr = ar / z;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          g[f].x = fmaf(rv[f].x, rr, g[f].x);
+          g[f].y = fmaf(rv[f].y, rr, g[f].y);
+          g[f].z = fmaf(rv[f].z, rr, g[f].z);
+          g[f].w = fmaf(rv[f].w, rr, g[f].w);
+        }
+      }
+    }
+    return acc;
+  };
+
+  float4 wl[NF];
+  bool converged = false;
+  float Lf = Lfguess;
+  float normalizer = 1.f;
+  if (n > 0) {
+    for (int guess = 0; guess < 10; ++guess) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < ld; t += INF_T) wflat[t] = t < k ? unif : 0.f;
+      normalizer = 1.f;
+      __syncthreads();
+      for (int iter = 0; iter < iters; ++iter) {
+        float4 g[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int q = sl + 16 * f;
+          g[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 u = q < nq ? wbuf4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          wl[f] = make_float4(u.x / normalizer, u.y / normalizer, u.z / normalizer, u.w / normalizer);  // :421
+        }
+        __syncthreads();  // every wave has read the weights before they are updated
+        (void)rows_pass(wl, g, false);  // grad :443-465
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int q = sl + 16 * f;
+          if (q < nq) gbuf[(size_t)grp * nq + q] = g[f];
+        }
+        __syncthreads();
+        const double eta = sqrt(2.0 * (double)logf((float)k) / (double)(float)(iter + 1)) / (double)Lf;  // :415
+        float part = 0.f;
+        for (int t = threadIdx.x; t < k; t += INF_T) {
+          float gt = gflat[t];
+#pragma unroll
+          for (int pp = 1; pp < 16; ++pp) gt += gflat[pp * ld + t];  // fixed order
+          const float wn = (float)((double)(wflat[t] / normalizer) * exp(eta * (double)gt));  // :418
+          wflat[t] = wn;
+          part += wn;
+        }
+        part = wave_sum_f(part);
+        if (lane == 0) sred[wave] = part;
+        __syncthreads();
+        normalizer = ((sred[0] + sred[1]) + sred[2]) + sred[3];  // :420
+      }
+      // sum of the final weights (:425), by every sub-group on its own copy
+      double ps = 0.0;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int q = sl + 16 * f;
+        const float4 u = q < nq ? wbuf4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        wl[f] = make_float4(u.x / normalizer, u.y / normalizer, u.z / normalizer, u.w / normalizer);
+        ps += ((double)wl[f].x + (double)wl[f].y) + ((double)wl[f].z + (double)wl[f].w);
+      }
+      ps += __shfl_xor(ps, 1);
+      ps += __shfl_xor(ps, 2);
+      ps += __shfl_xor(ps, 4);
+      ps += __shfl_xor(ps, 8);
+      const double sumw = ps;
+      const bool normal = isfinite(sumw) && fabs(sumw) >= 2.2250738585072014e-308;  // std::isnormal
+      if (normal) {
+        converged = !(fabs(1.0 - sumw) > 0.01);
+        break;
+      }
+      Lf *= 2.0f;
+    }
+  }
+  float first = 0.f, second = 0.f;
+  if (converged) {  // calculate_llh :467-492
+    float4 gd[NF];
+    float sacc = rows_pass(wl, gd, true);
+    __syncthreads();
+    if (sl == 0) sred[grp] = sacc;
+    __syncthreads();
+    float tot = sred[0];
+#pragma unroll
+    for (int pp = 1; pp < 16; ++pp) tot += sred[pp];
+    second = tot * (float)words_in_doc;
+    first = tot * avg_doc_sz;
+  }
+  if (wave == 0) {
+    float4 w1[1];
+    const float4 u = lane < nq ? wbuf4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    w1[0] = make_float4(u.x / normalizer, u.y / normalizer, u.z / normalizer, u.w / normalizer);
+    inf_emit<1>(w1, lane, wave, d, k, nq, unif, first, second, weights, top_topic, top_weight, llh, nconverged);
+  }
+}
+
 }  // namespace
 
 // Host pointers in and out; the model and the documents are uploaded for the call (inference is independent of the
@@ -325,20 +590,34 @@ int k_infer(isle_ctx* c, uint64_t V, int k, const float* model_by_word, uint64_t
     hipLaunchKernelGGL(inf_rowok_k, dim3(cdiv((long)V, 256)), dim3(256), 0, c->stream, dM.p, V, k, ld, dok.p);
     if (D) hipLaunchKernelGGL(inf_prep_k, dim3(cdiv((long)D, 4)), dim3(256), 0, c->stream, dcounts.p, drows.p, doffs.p, D, dok.p, dfw.p, dfa.p, dnk.p);
     HIPCHK(c, hipGetLastError());
-    // LDS: cap_rows model rows + 4 partial gradients + cap_rows values of a
-    const size_t fixed = 4 * (size_t)ld * sizeof(float);
-    const uint32_t cap_rows = (uint32_t)((INF_LDS - fixed) / ((size_t)ld * sizeof(float) + sizeof(float)));
+    // LDS: cap_rows model rows + 4 partial gradients + the weights + cap_rows values of a
+    const bool lanes16 = nq <= 64 && !getenv("ISLE_INFER_WAVE_ROWS");  // k <= 256: sixteen lanes per row
+    const size_t fixed = (lanes16 ? 17 : 5) * (size_t)ld * sizeof(float);
+    uint32_t cap_rows = (uint32_t)((INF_LDS - fixed) / ((size_t)ld * sizeof(float) + sizeof(float)));
+    // Measured at C2 size (50k x 200 model, ~108 kept words per document): staging a document's slice in LDS (one workgroup per
+    // CU at 160 KB) runs 3.1 M docs/s, re-reading the rows from L2 / Infinity Cache in every iteration with ~10 workgroups per
+    // CU 5.3 M docs/s (6.9 TB/s of row gathers) — occupancy beats locality, so no rows are staged unless
+    // ISLE_INFER_CAP_ROWS asks for it.
+    {
+      const char* e = getenv("ISLE_INFER_CAP_ROWS");
+      cap_rows = std::min<uint32_t>(cap_rows, e ? (uint32_t)atoi(e) : 0u);
+    }
     const size_t lds = (size_t)cap_rows * ld * sizeof(float) + fixed + (size_t)cap_rows * sizeof(float);
     if (D) {
-#define INF(N)                                                                                                                          \
+#define INF(KERNEL)                                                                                                                     \
   do {                                                                                                                                  \
-    HIPCHK(c, hipFuncSetAttribute((const void*)inf_docs_k<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INF_LDS));              \
-    hipLaunchKernelGGL((inf_docs_k<N>), dim3((unsigned)D), dim3(INF_T), lds, c->stream, (const float4*)dM.p, k, nq, doffs.p, dfw.p, dfa.p, \
-                       dnk.p, D, iters, Lfguess, avg_doc_sz, cap_rows, weights ? dW.p : nullptr, dtt.p, dtw.p, dllh.p, dnc.p);          \
+    HIPCHK(c, hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INF_LDS));                      \
+    hipLaunchKernelGGL(KERNEL, dim3((unsigned)D), dim3(INF_T), lds, c->stream, (const float4*)dM.p, k, nq, doffs.p, dfw.p, dfa.p, dnk.p, \
+                       D, iters, Lfguess, avg_doc_sz, cap_rows, weights ? dW.p : nullptr, dtt.p, dtw.p, dllh.p, dnc.p);                 \
   } while (0)
-      if (nit <= 1) INF(1);
-      else if (nit <= 2) INF(2);
-      else INF(4);
+      if (lanes16) {
+        const int nf = (nq + 15) / 16;
+        if (nf <= 1) INF((inf_docs16_k<1>));
+        else if (nf <= 2) INF((inf_docs16_k<2>));
+        else INF((inf_docs16_k<4>));
+      } else if (nit <= 1) INF((inf_docs_k<1>));
+      else if (nit <= 2) INF((inf_docs_k<2>));
+      else INF((inf_docs_k<4>));
 #undef INF
       HIPCHK(c, hipGetLastError());
     }

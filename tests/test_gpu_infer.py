@@ -60,8 +60,12 @@ def test_infer_matches_oracle(hp, V, k, D, seed):
     check(g, o, k)
 
 
-def test_infer_long_documents_take_the_global_path(hp):
-    # documents whose slice of the model does not fit LDS (> ~195 rows at k = 200) re-read the rows from memory
+@pytest.mark.parametrize("cap", [None, "1000", "50"])
+def test_infer_lds_staging_variants(hp, cap, monkeypatch):
+    # default: rows re-read from cache every iteration; ISLE_INFER_CAP_ROWS stages slices of up to that many rows in LDS
+    # (documents beyond the capacity keep the global path)
+    if cap is not None:
+        monkeypatch.setenv("ISLE_INFER_CAP_ROWS", cap)
     from oracle import oracle
     M, offs, rows, counts = make_case(4000, 200, 40, 6, maxlen=900, zero_rows=0)
     o = oracle.infer(M, offs, rows, counts, iters=5)
