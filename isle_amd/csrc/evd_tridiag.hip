@@ -54,6 +54,13 @@ __device__ inline void td_step_dev(double* __restrict__ A, int n, int j, int fir
   double wv[TD_MAXPT], vv[TD_MAXPT];
   double w_cj = 0.0;
   const int cj = first ? 0 : j + 1;
+  // the next column is needed only after two block-wide sums: fetch it now, its latency hides behind the partial sums
+  double a0[TD_MAXPT];
+#pragma unroll
+  for (int s = 0; s < TD_MAXPT; ++s) {
+    const int i = cj + t + s * TD_T;
+    a0[s] = i < n ? A[(size_t)cj * n + i] : 0.0;
+  }
   if (!first) {
     const double tj = tau[j];
     const int r0 = j + 1;
@@ -95,7 +102,7 @@ __device__ inline void td_step_dev(double* __restrict__ A, int n, int j, int fir
     const int i = cj + t + s * TD_T;
     cv[s] = 0.0;
     if (i < n) {
-      double a = A[(size_t)cj * n + i];
+      double a = a0[s];
       if (!first) a -= vv[s] * w_cj + wv[s];  // v_j[cj] = 1
       cv[s] = a;
       if (i == cj) bc[0] = a;

@@ -634,7 +634,15 @@ __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restri
   l = l > 0.f ? l * 0.999999f : l;
   ub[d] = u;
   lb[d] = l;
-  if (u >= l) active[atomicAdd(nactive, 1u)] = d;
+  const bool act = u >= l;  // one atomic per wave
+  const unsigned long long m = __ballot(act);
+  if (m) {
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(nactive, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, first);
+    if (act) active[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
+  }
 }
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
                      float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive, int fam) {
@@ -670,7 +678,16 @@ __global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* _
     lmin = fminf(lmin, l);
   }
   ub[d] = u;
-  if (u >= lmin) active[atomicAdd(nactive, 1u)] = d;
+  // append with one atomic per wave (a third of the documents stay active: one atomic each serialises on a single address)
+  const bool act = u >= lmin;
+  const unsigned long long m = __ballot(act);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(nactive, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+    if (act) active[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
+  }
 }
 
 // top-2 of a group from the 4 distances of this lane and the 4 of lane ^ 1
