@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void member_fill_k(const uint32_t* __restrict_
 // Csum[c][:] += sum of P rows of the members [j*MC, (j+1)*MC) of centre c.  grid = (chunks, k).
 // Each wave sums whole rows (coalesced 4*k-byte reads), waves are combined in LDS, one atomicAdd per (block, coordinate).
 constexpr int SEG_MC = 256;
-template <int NIT>
+template <int NIT>  // float4 chunks per lane: ldk / 4 <= 64 NIT
 __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P, int k, int ldk, const int* __restrict__ off,
                                                       const uint32_t* __restrict__ members, float* __restrict__ Csum) {
   extern __shared__ float red[];  // 4 x ldk
@@ -449,21 +449,42 @@ __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P
   const int end = min(off[cc + 1], beg + SEG_MC);
   if (beg >= end) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc[NIT];
+  const int nq = ldk / 4;
+  float4 acc[NIT];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) acc[it] = 0.f;
-  for (int m = beg + wave; m < end; m += 4) {
-    const float* row = P + (size_t)members[m] * ldk;
+  for (int it = 0; it < NIT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // this wave's members: beg + wave, + 4, ... (at most 64): ids by one load and shuffles, four 16-byte row loads in flight
+  const int myi = beg + wave + 4 * lane;
+  const uint32_t mym = myi < end ? members[myi] : 0u;
+  const int cnt = end > beg + wave ? min(64, (end - beg - wave + 3) / 4) : 0;
+  for (int j = 0; j < cnt; j += 4) {
+    float4 v[4][NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int j = lane + 64 * it;
-      if (j < k) acc[it] += row[j];
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t mj = (uint32_t)__shfl((int)mym, min(j + u, cnt - 1));
+      const float4* row = reinterpret_cast<const float4*>(P + (size_t)mj * ldk);
+      const float live = j + u < cnt ? 1.f : 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int q = lane + 64 * it;
+        const float4 x = q < nq ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u][it] = make_float4(x.x * live, x.y * live, x.z * live, x.w * live);
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        acc[it].x += v[u][it].x;
+        acc[it].y += v[u][it].y;
+        acc[it].z += v[u][it].z;
+        acc[it].w += v[u][it].w;
+      }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int j = lane + 64 * it;
-    if (j < k) red[wave * ldk + j] = acc[it];
+    const int q = lane + 64 * it;
+    if (q < nq) reinterpret_cast<float4*>(red + (size_t)wave * ldk)[q] = acc[it];
   }
   __syncthreads();
   for (int j = threadIdx.x; j < k; j += 256) {
@@ -508,14 +529,12 @@ int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, c
   if (mx == 0) return 0;
   dim3 g(cdiv(mx, SEG_MC), k), b(256);
   const size_t lds = 4 * (size_t)ldk * sizeof(float);
-  const int nit = cdiv(k, 64);
+  const int nit = cdiv(ldk / 4, 64);  // float4 chunks per lane
 #define LS(N) hipLaunchKernelGGL(proj_segsum_k<N>, g, b, lds, c->stream, P, k, ldk, offd, c->members.p, Csum)
   if (nit <= 1) LS(1);
   else if (nit <= 2) LS(2);
   else if (nit <= 4) LS(4);
   else if (nit <= 8) LS(8);
-  else if (nit <= 16) LS(16);
-  else if (nit <= 32) LS(32);
   else return isle_fail(c, ISLE_E_ARG, "k too large");
 #undef LS
   HIPCHK(c, hipGetLastError());
