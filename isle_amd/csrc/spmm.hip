@@ -722,6 +722,15 @@ __device__ inline YyTop2 yy_group_top2(const float dist[4], int c0, int k) {
   return t;
 }
 
+__device__ inline float yy_parity_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                   const float* __restrict__ C /*V x ld row-major*/, int ld, int k, int G, const float* __restrict__ cn,
                                                   const float* __restrict__ dn, float cn_max, const uint32_t* __restrict__ active,
@@ -760,13 +769,12 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
         }
       }
     }
-#pragma unroll
-    for (int m = 2; m < 64; m <<= 1) {
-      acc.x += __shfl_xor(acc.x, m);
-      acc.y += __shfl_xor(acc.y, m);
-      acc.z += __shfl_xor(acc.z, m);
-      acc.w += __shfl_xor(acc.w, m);
-    }
+    // sum over the 32 lanes of equal parity: inside a DPP row by data-parallel moves that keep the parity (swap quad halves,
+    // rotate by 4, rotate by 8), across the four rows by two ds_bpermute steps (five of those per value before)
+    acc.x = yy_parity_sum(acc.x);
+    acc.y = yy_parity_sum(acc.y);
+    acc.z = yy_parity_sum(acc.z);
+    acc.w = yy_parity_sum(acc.w);
     const float aa[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
