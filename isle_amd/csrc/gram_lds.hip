@@ -249,15 +249,32 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
   const uint32_t p0 = band * GL_RB, p1 = min(D, p0 + GL_RB);
   for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
     const uint32_t d = dperm[p];
-    for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
-      const uint32_t w = rows[i];
-      if (w >= w0 && w < w1) {
-        const uint32_t odd = (w - w0) & 1u;
-        const uint32_t cur = atomicAdd(&hist[(w - w0) >> 1], odd ? 0x10000u : 1u);
-        const uint32_t j = odd ? (cur >> 16) : (cur & 0xffffu);
-        const uint32_t q = wpos[w];
-        const size_t sr = (size_t)sbase[(size_t)(q >> 6) * NB + band] + (j >> 2);
-        ids16[(sr * 64 + (q & 63u)) * 4 + (j & 3u)] = (uint16_t)(p - p0);
+    const int64_t iend = offs[d + 1];
+    // four entries per lane and pass: the chain row id -> cursor -> word position -> slice base -> store is five dependent
+    // round trips, so independent entries are kept in flight together
+    for (int64_t i = offs[d] + sl; i < iend; i += 4 * GL_SUB) {
+      uint32_t w[4], q[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t iu = i + (int64_t)u * GL_SUB;
+        const bool live = iu < iend;
+        w[u] = rows[live ? iu : iend - 1];
+        in[u] = live && w[u] >= w0 && w[u] < w1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = in[u] ? wpos[w[u]] : 0u;
+      uint32_t sb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sb[u] = in[u] ? sbase[(size_t)(q[u] >> 6) * NB + band] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (in[u]) {
+          const uint32_t odd = (w[u] - w0) & 1u;
+          const uint32_t cur = atomicAdd(&hist[(w[u] - w0) >> 1], odd ? 0x10000u : 1u);
+          const uint32_t j = odd ? (cur >> 16) : (cur & 0xffffu);
+          ids16[((size_t)(sb[u] + (j >> 2)) * 64 + (q[u] & 63u)) * 4 + (j & 3u)] = (uint16_t)(p - p0);
+        }
       }
     }
   }
