@@ -58,6 +58,53 @@ __global__ __launch_bounds__(256) void kmpp_update_k(const float* __restrict__ P
   if (lane == 0) min_dist[d] = best;
 }
 
+// The same update on the coordinate-major copy Pt (Pt[j * D + d]): one lane per document, the loop over the coordinates reads
+// 256 contiguous bytes per wave and step, the (at most 16) new centres sit in LDS as [coordinate][centre] and are read as
+// broadcast float4 — no cross-lane reduction at all.  A k-means++ round is then one streaming pass over Pt
+// (4 k D bytes, the figure of SURVEY 8d) instead of a pass through the MFMA distance kernel built for hundreds of centres.
+template <int NQ>  // float4 of centres per coordinate: nc <= 4 NQ
+__global__ __launch_bounds__(256) void kmpp_min_pt_k(const float* __restrict__ Pt, const float* __restrict__ pn, uint32_t D, int k, int ldk,
+                                                      const float* __restrict__ newC, const float* __restrict__ cn, int nc,
+                                                      float* __restrict__ min_dist) {
+  extern __shared__ float4 Cq[];  // k x NQ float4: Cq[j * NQ + q] = centres 4q..4q+3 at coordinate j (0 beyond nc)
+  for (int idx = threadIdx.x; idx < k * NQ * 4; idx += 256) {
+    const int j = idx / (NQ * 4), cc = idx - j * (NQ * 4);
+    reinterpret_cast<float*>(Cq)[idx] = cc < nc ? newC[(size_t)cc * ldk + j] : 0.f;
+  }
+  __syncthreads();
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t dd = d < D ? d : D - 1;  // clamped: loads stay unconditional
+  float4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* col = Pt + dd;
+#pragma unroll 8
+  for (int j = 0; j < k; ++j) {
+    const float x = col[(size_t)j * D];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 cv = Cq[j * NQ + q];
+      acc[q].x = fmaf(x, cv.x, acc[q].x);
+      acc[q].y = fmaf(x, cv.y, acc[q].y);
+      acc[q].z = fmaf(x, cv.z, acc[q].z);
+      acc[q].w = fmaf(x, cv.w, acc[q].w);
+    }
+  }
+  if (d >= D) return;
+  const float nd = pn[d];
+  float best = min_dist[d];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float a[4] = {acc[q].x, acc[q].y, acc[q].z, acc[q].w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cc = 4 * q + u;
+      if (cc < nc) best = fminf(best, fmaxf((-2.0f * a[u] + cn[cc]) + nd, 0.0f));  // :1838-1846 order, clamp :2117
+    }
+  }
+  min_dist[d] = best;
+}
+
 // out[r] = sum_j M[r*ldk + j]^2 over j < k   (compute_projected_centers_l2sq :1874-1884)
 __global__ __launch_bounds__(256) void rownorms_k(const float* __restrict__ M, int rows, int k, int ldk, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -103,6 +150,19 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   if (D == 0 || nc == 0) return 0;
   HIPCHK(c, c->cnorm.reserve((size_t)std::max(k, nc)));
   ISLECHK(k_rownorms(c, newC, nc, k, ldk, c->cnorm.p));
+  if (nc <= 16 && c->Pt_ready && !getenv("ISLE_KMPP_MFMA")) {  // streaming pass over the coordinate-major copy
+    const int nq = (nc + 3) / 4;
+    const dim3 g(cdiv(D, 256)), b(256);
+    const size_t lds = (size_t)k * nq * sizeof(float4);
+#define LP(N) hipLaunchKernelGGL(kmpp_min_pt_k<N>, g, b, lds, c->stream, c->Pt.p, pn, (uint32_t)D, k, ldk, newC, c->cnorm.p, nc, min_dist)
+    if (nq == 1) LP(1);
+    else if (nq == 2) LP(2);
+    else if (nq == 3) LP(3);
+    else LP(4);
+#undef LP
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   if (nc <= 32) {  // distance tile on the matrix cores: the nc newest centres are one 32-row MFMA tile
     bool done = false;
     ISLECHK(launch_proj_reg<PR_MINDIST>(c, D, nc, ldk, newC, c->cnorm.p, pn, nullptr, min_dist, &done));
