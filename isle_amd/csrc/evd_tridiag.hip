@@ -376,6 +376,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     for (int i = 0; i < n; ++i) Ah[(size_t)jj * n + i] = (i <= jj) ? (double)S_host[(size_t)jj * n + i] : (double)S_host[(size_t)i * n + jj];
   int CB = 16;
   while (CB < 64 && (n + CB - 1) / CB > 32) CB *= 2;
+  if (const char* e = getenv("ISLE_TD_CB")) CB = std::max(8, std::min(128, atoi(e)));  // tuning knob
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
   const size_t need = nn + (size_t)ncb_max * n + 6 * (size_t)n + 3 * (size_t)n * nvec + 16;

@@ -150,7 +150,8 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   if (D == 0 || nc == 0) return 0;
   HIPCHK(c, c->cnorm.reserve((size_t)std::max(k, nc)));
   ISLECHK(k_rownorms(c, newC, nc, k, ldk, c->cnorm.p));
-  if (nc <= 16 && c->Pt_ready && !getenv("ISLE_KMPP_MFMA")) {  // streaming pass over the coordinate-major copy
+  if (nc <= 16 && c->Pt_ready && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024 && !getenv("ISLE_KMPP_MFMA")) {
+    // streaming pass over the coordinate-major copy (the centres fit the default 64 KB of dynamic LDS)
     const int nq = (nc + 3) / 4;
     const dim3 g(cdiv(D, 256)), b(256);
     const size_t lds = (size_t)k * nq * sizeof(float4);
