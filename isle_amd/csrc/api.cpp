@@ -1098,15 +1098,14 @@ static int ensure_P(isle_ctx* c, int k) {
 static int fetch_rows(isle_ctx* c, const uint64_t* ids, int n, float* dst) {
   if (n == 0) return 0;
   const bool multi = c->comm != nullptr;
-  if (multi) HIPCHK(c, hipMemsetAsync(dst, 0, (size_t)n * c->ldk * sizeof(float), c->stream));
+  std::vector<uint64_t> local(n);
   for (int i = 0; i < n; ++i) {
     const uint64_t g = ids[i];
-    if (g >= c->doc_offset && g < c->doc_offset + c->D)
-      HIPCHK(c, hipMemcpyAsync(dst + (size_t)i * c->ldk, c->P.p + (size_t)(g - c->doc_offset) * c->ldk, (size_t)c->ldk * sizeof(float),
-                               hipMemcpyDeviceToDevice, c->stream));
-    else if (!multi)
-      return isle_fail(c, ISLE_E_ARG, "seed doc id %llu out of range", (unsigned long long)g);
+    if (g >= c->doc_offset && g < c->doc_offset + c->D) local[i] = g - c->doc_offset;
+    else if (multi) local[i] = ~0ull;  // another rank's document: zeros here, the all-reduce brings the row
+    else return isle_fail(c, ISLE_E_ARG, "seed doc id %llu out of range", (unsigned long long)g);
   }
+  ISLECHK(k_fetch_rows(c, c->P.p, c->ldk, local.data(), n, dst));  // one kernel (the ids travel as arguments), not one copy per row
   if (multi) ISLECHK(allreduce_sum<float>(c, dst, (size_t)n * c->ldk));
   return 0;
 }
@@ -1143,11 +1142,9 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     ISLECHK(k_scan_f2d(c, c->min_dist.p, D, c->cum.p));  // :2170-2172 (double, parallel; the reference's is fp32 sequential)
     // totals (per rank) -> offsets
     double my[2] = {0.0, 0.0};
-    float lm = 0.f;
-    HIPCHK(c, hipMemcpyAsync(&my[0], c->cum.p + D, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (D > 0) HIPCHK(c, hipMemcpyAsync(&lm, c->min_dist.p + (D - 1), sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // one round trip for both scalars
-    my[1] = lm;
+    ISLECHK(k_pack2(c, c->cum.p + D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, c->gram.p + 200));
+    HIPCHK(c, hipMemcpyAsync(my, c->gram.p + 200, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // one copy, one round trip for both scalars
     std::vector<double> tot(2 * c->world, 0.0);
     if (multi) {
       double* dv = c->gram.p;
@@ -1184,8 +1181,12 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
       }
       double* dd = c->gram.p + 64;
       uint64_t* od = (uint64_t*)(c->gram.p + 128);
-      HIPCHK(c, hipMemcpyAsync(dd, local.data(), ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
-      ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
+      if (ndraw <= 16) {
+        ISLECHK(k_search_args(c, c->cum.p, D, local.data(), ndraw, od));  // dice as kernel arguments
+      } else {
+        HIPCHK(c, hipMemcpyAsync(dd, local.data(), ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
+        ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
+      }
       HIPCHK(c, hipMemcpyAsync(drawn.data(), od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       for (int i = 0; i < ndraw; ++i) {

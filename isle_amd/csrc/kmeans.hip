@@ -184,6 +184,61 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   return 0;
 }
 
+// Small-count variants for the k-means++ rounds: every hipMemcpy of a few bytes costs ~20 us of queue time, so the dice travel
+// as kernel arguments and the seeds' rows are gathered by one kernel instead of one copy each.
+struct KmDice {
+  double x[16];
+};
+__global__ void search_args_k(const double* __restrict__ cum, uint64_t n, KmDice dice, int nd, uint64_t* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nd) return;
+  const double x = dice.x[t];
+  uint64_t lo = 0, hi = n + 1;  // first index with cum[idx] > x
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (cum[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  out[t] = lo - 1;
+}
+int k_search_args(isle_ctx* c, const double* cum, uint64_t n, const double* dice_host, int nd, uint64_t* out_dev) {
+  if (nd == 0) return 0;
+  if (nd > 16) return isle_fail(c, ISLE_E_ARG, "k_search_args: %d > 16 dice", nd);
+  KmDice dd;
+  for (int i = 0; i < 16; ++i) dd.x[i] = i < nd ? dice_host[i] : 0.0;
+  hipLaunchKernelGGL(search_args_k, dim3(1), dim3(64), 0, c->stream, cum, n, dd, nd, out_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+struct KmIds {
+  uint64_t id[16];  // local row, or ~0 for "not on this rank" (destination row zeroed)
+};
+__global__ __launch_bounds__(256) void fetch_rows_k(const float* __restrict__ P, int ldk, KmIds ids, int n, float* __restrict__ dst) {
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  const uint64_t id = ids.id[r];
+  for (int j = threadIdx.x; j < ldk; j += 256) dst[(size_t)r * ldk + j] = id == ~0ull ? 0.f : P[(size_t)id * ldk + j];
+}
+int k_fetch_rows(isle_ctx* c, const float* P, int ldk, const uint64_t* local_ids /*~0: absent*/, int n, float* dst) {
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    KmIds ids;
+    const int m = std::min(16, n - i0);
+    for (int i = 0; i < 16; ++i) ids.id[i] = i < m ? local_ids[i0 + i] : ~0ull;
+    hipLaunchKernelGGL(fetch_rows_k, dim3(m), dim3(256), 0, c->stream, P, ldk, ids, m, dst + (size_t)i0 * ldk);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+// {cum[n], last[0]} -> out2 (doubles): the two scalars a k-means++ round needs on the host, one copy instead of two
+__global__ void pack2_k(const double* __restrict__ a, const float* __restrict__ b, double* __restrict__ out2) {
+  out2[0] = a[0];
+  out2[1] = b ? (double)b[0] : 0.0;
+}
+int k_pack2(isle_ctx* c, const double* a, const float* b, double* out2) {
+  hipLaunchKernelGGL(pack2_k, dim3(1), dim3(1), 0, c->stream, a, b, out2);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int k_scan_f2d(isle_ctx* c, const float* in, uint64_t n, double* cum) {
   TimeScope ts(c, ISLE_T_KMPP);
   HIPCHK(c, c->scan_blk.reserve(isle_scan::scan_scratch_elems(n)));
