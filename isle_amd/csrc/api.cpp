@@ -1436,7 +1436,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   HIPCHK(c, c->Csum.reserve((size_t)2 * k + 16 + G));
   float* delta_dev = c->Csum.p;  // k floats
   gmax_dev = c->Csum.p + 2 * k + 16;  // G floats
-  std::vector<float> delta(k, 0.f), cnh(k), gmax(G, 0.f);
+  std::vector<float> delta(k, 0.f), cnh(k);
   uint32_t amax = 0;
   float d1 = 0.f, d2 = 0.f;
   StopRule stop(c, k);
@@ -1452,13 +1452,16 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
                                  c->members_valid ? c->members.p : nullptr, nullptr, c->hub.p, yinyang ? c->yglb.p : c->hlb.p,
                                  yinyang ? G : 0));  // :1606
     } else if (yinyang) {
-      HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      float cn_max = 0.f;
-      for (int i = 0; i < k; ++i) cn_max = std::max(cn_max, cnh[i]);
+      // all bookkeeping of the Yinyang iteration stays on the device (largest centre norm, movements, group maxima, member
+      // offsets): the only host round trip of an iteration is the one the stop rule needs
+      float* cn_max_dev = c->Csum.p + 2 * k + 8;
+      {
+        TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+        ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
+      }
       uint32_t* nact = c->active.p + D;
       ISLECHK(k_yy_filter(c, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
-      ISLECHK(k_yy_scan(c, c->centers_rm.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p));
+      ISLECHK(k_yy_scan(c, c->centers_rm.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p));
       if (getenv("ISLE_DEBUG_HAMERLY")) {
         uint32_t na = 0;
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
@@ -1482,7 +1485,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
     {  // documents grouped by centre: visiting order of the next assignment, and what the counting centroid update walks
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
-      ISLECHK(k_member_lists(c, c->assign.p, D, k, c->counts.p, nullptr));
+      ISLECHK(k_member_lists_dev(c, c->assign.p, D, k, c->counts.p));
     }
     if (hamerly) HIPCHK(c, hipMemcpyAsync(c->centers_old.p, c->centers_rm.p, (size_t)V * ld * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p, it == 0));                 // :1613-1638
@@ -1493,30 +1496,26 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     if (hamerly && it + 1 < max_reps) {  // centre movements for the next filter
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, delta_dev, c->centers_old.p));
-      HIPCHK(c, hipMemcpyAsync(delta.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      amax = 0;
-      d1 = d2 = 0.f;
-      for (int i = 0; i < k; ++i) {
-        delta[i] = std::sqrt(std::max(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
-        if (delta[i] > d1) {
-          d2 = d1;
-          d1 = delta[i];
-          amax = (uint32_t)i;
-        } else if (delta[i] > d2) {
-          d2 = delta[i];
-        }
-      }
-      HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
       if (yinyang) {
-        for (int g = 0; g < G; ++g) {
-          float m = 0.f;
-          for (int i = 8 * g; i < std::min(k, 8 * g + 8); ++i) m = std::max(m, delta[i]);
-          gmax[g] = m;
+        ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
+      } else {
+        HIPCHK(c, hipMemcpyAsync(delta.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        amax = 0;
+        d1 = d2 = 0.f;
+        for (int i = 0; i < k; ++i) {
+          delta[i] = std::sqrt(std::max(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
+          if (delta[i] > d1) {
+            d2 = d1;
+            d1 = delta[i];
+            amax = (uint32_t)i;
+          } else if (delta[i] > d2) {
+            d2 = delta[i];
+          }
         }
-        HIPCHK(c, hipMemcpyAsync(gmax_dev, gmax.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
       }
-      HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));

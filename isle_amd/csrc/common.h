@@ -258,12 +258,15 @@ int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const floa
                        float* ub = nullptr, float* lb = nullptr, int G = 0 /*> 0: lb holds G Yinyang group bounds per document*/);
 int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev, uint32_t* active,
                 uint32_t* nactive);
-int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, float cn_max, const uint32_t* active,
+int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
               const uint32_t* nactive, uint32_t* assign, float* ub, float* glb);
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
                      float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive,
                      int fam = ISLE_T_SPARSE_ASSIGN);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
+int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev);  // no host round trip
+int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev);
+int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev);
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool first_of_run = true);
 

@@ -609,6 +609,75 @@ __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P
   }
 }
 
+// Device-only variant: offsets by a one-workgroup scan of the counts, no host round trip (the sparse Lloyd loop calls it every
+// iteration and needs nothing of it on the host).
+__global__ __launch_bounds__(256) void member_offsets_k(const int* __restrict__ counts, int k, int* __restrict__ off /*k+1*/, int* __restrict__ cursor /*k*/) {
+  __shared__ int sh[256];
+  int carry = 0;
+  for (int base = 0; base < k; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < k ? counts[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < k) {
+      off[i] = carry + sh[threadIdx.x] - v;
+      cursor[i] = 0;
+    }
+    carry += sh[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[k] = carry;
+}
+int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev) {
+  HIPCHK(c, c->members.reserve(D ? D : 1));
+  HIPCHK(c, c->moff.reserve(2 * (size_t)k + 2));
+  int* offd = c->moff.p;
+  int* cur = c->moff.p + k + 1;
+  hipLaunchKernelGGL(member_offsets_k, dim3(1), dim3(256), 0, c->stream, counts_dev, k, offd, cur);
+  if (D)
+    hipLaunchKernelGGL(member_fill_k, dim3(cdiv(D, 256 * CS_ITEMS)), dim3(256), 2 * (size_t)k * sizeof(int), c->stream, assign, (uint32_t)D, k,
+                       offd, cur, c->members.p);
+  HIPCHK(c, hipGetLastError());
+  c->members_valid = true;
+  return 0;
+}
+
+// Yinyang bookkeeping on the device: delta[i] <- rounded-up movement of centre i, gmax[g] <- largest movement in group g
+__global__ void yy_delta_k(float* __restrict__ delta, int k, int G, int group, float* __restrict__ gmax) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  float m = 0.f;
+  for (int i = group * g; i < min(k, group * g + group); ++i) {
+    const float dv = sqrtf(fmaxf(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
+    delta[i] = dv;
+    m = fmaxf(m, dv);
+  }
+  gmax[g] = m;
+}
+int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev) {
+  hipLaunchKernelGGL(yy_delta_k, dim3(cdiv(G, 64)), dim3(64), 0, c->stream, delta_dev, k, G, group, gmax_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+__global__ void max_f32_k(const float* __restrict__ v, int n, float* __restrict__ out) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, v[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) *out = m;
+}
+int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev) {
+  hipLaunchKernelGGL(max_f32_k, dim3(1), dim3(64), 0, c->stream, v, n, out_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // members = local documents grouped by centre (counts_dev = LOCAL cluster sizes from k_count_sizes).
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out) {
   std::vector<int> h(k), off(k + 1, 0);

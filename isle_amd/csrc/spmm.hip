@@ -748,7 +748,7 @@ __device__ inline float yy_parity_sum(float v) {
 
 __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                   const float* __restrict__ C /*V x ld row-major*/, int ld, int k, int G, const float* __restrict__ cn,
-                                                  const float* __restrict__ dn, float cn_max, const uint32_t* __restrict__ active,
+                                                  const float* __restrict__ dn, const float* __restrict__ cn_max_p, const uint32_t* __restrict__ active,
                                                   const uint32_t* __restrict__ nactive, uint32_t* __restrict__ assign, float* __restrict__ ub,
                                                   float* __restrict__ glb) {
   const int lane = threadIdx.x & 63;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
   const float dnd = dn[d];
   const uint32_t a = assign[d];
   const int ga = (int)(a / YY_GROUP);
-  const float E = 1e-4f * (dnd + cn_max), sE = sqrtf(E);
+  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
   const int q = lane & 1, e = lane >> 1;
   float* gl = glb + (size_t)d * G;
 
@@ -845,7 +845,7 @@ int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int 
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, float cn_max, const uint32_t* active,
+int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
               const uint32_t* nactive, uint32_t* assign, float* ub, float* glb) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D;
