@@ -50,7 +50,7 @@ def check(g, o, k):
         assert np.allclose(g["weights"][d], 1.0 / k)
 
 
-@pytest.mark.parametrize("V,k,D,seed", [(500, 20, 300, 1), (3000, 50, 500, 2), (2000, 200, 200, 3), (1000, 7, 100, 4), (800, 300, 60, 5)])
+@pytest.mark.parametrize("V,k,D,seed", [(500, 20, 300, 1), (3000, 50, 500, 2), (2000, 200, 200, 3), (1000, 7, 100, 4), (800, 300, 60, 5), (600, 700, 40, 8)])
 def test_infer_matches_oracle(hp, V, k, D, seed):
     from oracle import oracle
     M, offs, rows, counts = make_case(V, k, D, seed)

@@ -296,6 +296,37 @@ def test_gather_form_forced_by_env(hp, small50, monkeypatch):
     assert relerr(res[1][2], res[0][2]) <= 1e-4
 
 
+def test_sparse_lloyd_wide_vocabulary(hp, monkeypatch):
+    """Vocabulary beyond one 81920-word part of the LDS histograms (two parts in the operator build and in the counting centroid
+    update): Lloyd on B from given centres, LDS-banded / counting forms against the gather / float-histogram forms."""
+    V, D, k = 90_000, 3_000, 12
+    rng = np.random.default_rng(21)
+    cols = [np.sort(rng.choice(V, size=int(n), replace=False)).astype(np.uint32) for n in rng.integers(20, 120, size=D)]
+    offs = np.zeros(D + 1, np.int64)
+    offs[1:] = np.cumsum([len(c) for c in cols])
+    rows = np.concatenate(cols)
+    vals = rng.uniform(0.5, 2.0, size=V).astype(np.float32)[rows]
+    seeds = rng.choice(D, size=k, replace=False)
+    cen = np.zeros((V, k), np.float32, order="F")
+    for j, d in enumerate(seeds):
+        cen[rows[offs[d]:offs[d + 1]], j] = vals[offs[d]:offs[d + 1]]
+    res = {}
+    for form in (1, 0):
+        monkeypatch.setenv("ISLE_GRAM_LDS", str(form))
+        hp.upload_csc(V, vals, rows, offs)
+        X = rng.standard_normal((V, 10)).astype(np.float32) if form == 1 else res["X"]
+        res["X"] = X
+        Z = hp.gram_apply(X)
+        assert hp.operator_form() == form
+        sg = hp.run_lloyds(k, centers=cen)
+        res[form] = (Z, sg["assign"], sg["centers"], sg["iters"])
+    monkeypatch.delenv("ISLE_GRAM_LDS")
+    assert relerr(res[1][0], res[0][0]) <= 1e-5
+    assert res[1][3] == res[0][3]
+    assert (res[1][1] == res[0][1]).mean() >= 0.999
+    assert relerr(res[1][2], res[0][2]) <= 1e-4
+
+
 def test_full_hot_path_end_to_end(hp, small50):
     """src/trainer.cpp:490-571 call sequence on the GPU, checked against planted topics and the oracle's ranges."""
     B, k = small50, 50
