@@ -1305,12 +1305,10 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
     HIPCHK(c, c->active.reserve(D + 1));
     HIPCHK(c, c->Pa.reserve((size_t)(D ? D : 1) * ldk));
     HIPCHK(c, c->pna.reserve(D ? D : 1));
-    HIPCHK(c, c->Cold.reserve((size_t)k * ldk + k));
+    HIPCHK(c, c->Cold.reserve((size_t)k * ldk + k + 8));
   }
   float* delta_dev = hamerly ? c->Cold.p + (size_t)k * ldk : nullptr;
-  std::vector<float> delta(k, 0.f), cnh(k);
-  uint32_t amax = 0;
-  float d1 = 0.f, d2 = 0.f;
+  HamTop* top_dev = hamerly ? reinterpret_cast<HamTop*>(c->Cold.p + (size_t)k * ldk + ((k + 3) & ~3)) : nullptr;
   StopRule stop(c, k);
   int it = 0;
   for (; it < max_reps; ++it) {
@@ -1319,13 +1317,8 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
       ISLECHK(k_proj_assign(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p,
                             hamerly ? c->hub.p : nullptr, hamerly ? c->hlb.p : nullptr));                // :1947
     } else {
-      HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      float cn_max = 0.f;
-      for (int i = 0; i < k; ++i) cn_max = std::max(cn_max, cnh[i]);
       uint32_t* nact = c->active.p + D;
-      ISLECHK(k_hamerly_filter(c, nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, amax, d1, d2, c->pnorm.p, cn_max, c->active.p, nact,
-                               ISLE_T_LLOYD_PROJ));
+      ISLECHK(k_hamerly_filter(c, nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, top_dev, c->active.p, nact, ISLE_T_LLOYD_PROJ));
       uint32_t na = 0;
       HIPCHK(c, hipMemcpyAsync(&na, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1341,22 +1334,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
     ISLECHK(k_proj_finalize(c, c->Csum.p, c->counts.p, k, ldk, c->Cdev.p));                             // :1988-1992
     if (hamerly && it + 1 < max_reps) {
       ISLECHK(k_rownorms_diff(c, c->Cdev.p, c->Cold.p, k, k, ldk, delta_dev));
-      HIPCHK(c, hipMemcpyAsync(delta.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      amax = 0;
-      d1 = d2 = 0.f;
-      for (int i = 0; i < k; ++i) {
-        delta[i] = std::sqrt(std::max(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;
-        if (delta[i] > d1) {
-          d2 = d1;
-          d1 = delta[i];
-          amax = (uint32_t)i;
-        } else if (delta[i] > d2) {
-          d2 = delta[i];
-        }
-      }
-      HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));  // rounded-up movements and their top two, on the device
     }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));
@@ -1436,9 +1414,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   HIPCHK(c, c->Csum.reserve((size_t)2 * k + 16 + G));
   float* delta_dev = c->Csum.p;  // k floats
   gmax_dev = c->Csum.p + 2 * k + 16;  // G floats
-  std::vector<float> delta(k, 0.f), cnh(k);
-  uint32_t amax = 0;
-  float d1 = 0.f, d2 = 0.f;
+  HamTop* top_dev = reinterpret_cast<HamTop*>(c->Csum.p + 2 * k + 12);
   StopRule stop(c, k);
   int it = 0;
   for (; it < max_reps; ++it) {
@@ -1465,21 +1441,17 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       if (getenv("ISLE_DEBUG_HAMERLY")) {
         uint32_t na = 0;
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[yinyang] iter %d active %u of %llu  d1 %.4f\n", it, na, (unsigned long long)D, d1);
+        fprintf(stderr, "[yinyang] iter %d active %u of %llu\n", it, na, (unsigned long long)D);
       }
     } else {
-      HIPCHK(c, hipMemcpyAsync(cnh.data(), c->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      float cn_max = 0.f;
-      for (int i = 0; i < k; ++i) cn_max = std::max(cn_max, cnh[i]);
       uint32_t* nact = c->active.p + D;
-      ISLECHK(k_hamerly_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, amax, d1, d2,
-                               c->dnorm.p, cn_max, c->active.p, nact));
+      ISLECHK(k_hamerly_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, top_dev, c->active.p,
+                               nact));
       ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->active.p, nact, c->hub.p, c->hlb.p));
       if (getenv("ISLE_DEBUG_HAMERLY")) {
         uint32_t na = 0;
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[hamerly] iter %d active %u of %llu  d1 %.4f d2 %.4f\n", it, na, (unsigned long long)D, d1, d2);
+        fprintf(stderr, "[hamerly] iter %d active %u of %llu\n", it, na, (unsigned long long)D);
       }
     }
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
@@ -1496,26 +1468,8 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     if (hamerly && it + 1 < max_reps) {  // centre movements for the next filter
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, delta_dev, c->centers_old.p));
-      if (yinyang) {
-        ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
-      } else {
-        HIPCHK(c, hipMemcpyAsync(delta.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        amax = 0;
-        d1 = d2 = 0.f;
-        for (int i = 0; i < k; ++i) {
-          delta[i] = std::sqrt(std::max(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
-          if (delta[i] > d1) {
-            d2 = d1;
-            d1 = delta[i];
-            amax = (uint32_t)i;
-          } else if (delta[i] > d2) {
-            d2 = delta[i];
-          }
-        }
-        HIPCHK(c, hipMemcpyAsync(delta_dev, delta.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-      }
+      if (yinyang) ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
+      else ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));
     }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));

@@ -260,9 +260,13 @@ int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int 
                 uint32_t* nactive);
 int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
               const uint32_t* nactive, uint32_t* assign, float* ub, float* glb);
-int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
-                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive,
-                     int fam = ISLE_T_SPARSE_ASSIGN);
+struct HamTop {  // largest and second largest centre movement of an iteration (Hamerly's bound update), device resident
+  uint32_t amax;
+  float d1, d2, pad;
+};
+int k_ham_delta(isle_ctx* c, float* delta_dev /*in: squared movements, out: rounded-up movements*/, int k, HamTop* top_dev);
+int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, const HamTop* top_dev,
+                     uint32_t* active, uint32_t* nactive, int fam = ISLE_T_SPARSE_ASSIGN);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
 int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev);  // no host round trip
 int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev);

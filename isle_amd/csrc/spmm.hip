@@ -623,10 +623,12 @@ int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, flo
 // whose bounds overlap are appended to `active` and re-evaluated against all centres.
 __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restrict__ order, uint32_t D, const uint32_t* __restrict__ assign,
                                                          float* __restrict__ ub, float* __restrict__ lb, const float* __restrict__ delta,
-                                                         uint32_t amax, float d1, float d2, const float* __restrict__ dn, float cn_max,
-                                                         uint32_t* __restrict__ active, uint32_t* __restrict__ nactive) {
+                                                         const HamTop* __restrict__ top, uint32_t* __restrict__ active,
+                                                         uint32_t* __restrict__ nactive) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= D) return;
+  const uint32_t amax = top->amax;
+  const float d1 = top->d1, d2 = top->d2;
   const uint32_t d = order ? order[i] : i;
   const uint32_t a = assign[d];
   const float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of these two updates
@@ -644,14 +646,59 @@ __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restri
     if (act) active[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
   }
 }
-int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, uint32_t amax,
-                     float d1, float d2, const float* dn, float cn_max, uint32_t* active, uint32_t* nactive, int fam) {
+// delta[i] <- rounded-up movement of centre i (from its squared movement); top <- {index of the largest, largest, second largest}.
+// One workgroup; replaces a device -> host -> device round trip per Lloyd iteration.
+__global__ __launch_bounds__(256) void ham_delta_k(float* __restrict__ delta, int k, HamTop* __restrict__ top) {
+  __shared__ float s1[256], s2[256];
+  __shared__ uint32_t si[256];
+  float d1 = 0.f, d2 = 0.f;
+  uint32_t a = 0;
+  for (int i = threadIdx.x; i < k; i += 256) {
+    const float dv = sqrtf(fmaxf(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
+    delta[i] = dv;
+    if (dv > d1) {
+      d2 = d1;
+      d1 = dv;
+      a = (uint32_t)i;
+    } else if (dv > d2) {
+      d2 = dv;
+    }
+  }
+  s1[threadIdx.x] = d1;
+  s2[threadIdx.x] = d2;
+  si[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float b1 = 0.f, b2 = 0.f;
+    uint32_t bi = 0;
+    for (int t = 0; t < 256; ++t) {  // merge in thread order: the same (largest, first index) the host loop found
+      if (s1[t] > b1 || (s1[t] == b1 && s1[t] > 0.f && si[t] < bi)) {
+        b2 = fmaxf(b1, s2[t]);
+        b1 = s1[t];
+        bi = si[t];
+      } else {
+        b2 = fmaxf(b2, s1[t]);
+      }
+    }
+    top->amax = bi;
+    top->d1 = b1;
+    top->d2 = b2;
+  }
+}
+int k_ham_delta(isle_ctx* c, float* delta_dev, int k, HamTop* top_dev) {
+  hipLaunchKernelGGL(ham_delta_k, dim3(1), dim3(256), 0, c->stream, delta_dev, k, top_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, const HamTop* top_dev,
+                     uint32_t* active, uint32_t* nactive, int fam) {
   TimeScope ts(c, fam);
   const uint32_t D = (uint32_t)c->D;
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
-  hipLaunchKernelGGL(hamerly_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, lb, delta_dev, amax, d1, d2, dn,
-                     cn_max, active, nactive);
+  hipLaunchKernelGGL(hamerly_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, lb, delta_dev, top_dev, active,
+                     nactive);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
