@@ -26,6 +26,7 @@ namespace {
 
 constexpr int TD_ROWS = 256;       // rows per workgroup of td_update_symv_k
 constexpr int TD_NMAX_BACK = 2048; // td_back_k keeps n x 8 doubles in LDS (128 KB)
+constexpr int TD_NRB = TD_NMAX_BACK / TD_ROWS;  // row blocks of td_update_symv_k at the largest n (stride of its row-block tickets)
 
 __device__ inline double td_block_sum(double v, double* sh /* >= 16 */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -142,12 +143,13 @@ __global__ __launch_bounds__(TD_ROWS) void td_first_k(double* __restrict__ A, in
 //   update:  B -= v_j w_j^T + w_j v_j^T     (v_j = A[:, j], w_j = w)
 //   part[cb][i] = sum over this column block of B[i][k] * vn[k]     (vn = v_{j+1} = A[:, j+1])
 // grid = (row blocks of TD_ROWS, column blocks of CB)
-// The workgroup that finishes last (ticket counter, release / acquire fences at agent scope) then runs step j + 1 in place:
-// one launch per column.
+// The workgroups that finish last (ticket counters, see the end of the kernel) reduce the partial products and run step j + 1
+// in place: one launch per column.
 template <int PT>
 __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__ A, int n, int j, int update, int CB, double* __restrict__ w,
-                                                             double* __restrict__ part, double* __restrict__ d, double* __restrict__ e,
-                                                             double* __restrict__ tau, unsigned int* __restrict__ tickets) {
+                                                             double* __restrict__ part, double* __restrict__ psum, double* __restrict__ d,
+                                                             double* __restrict__ e, double* __restrict__ tau, unsigned int* __restrict__ tickets,
+                                                             unsigned int* __restrict__ tickets_rb) {
   extern __shared__ double cs[];  // 3 x CB: v_j[k], w[k], vn[k]
   __shared__ unsigned int ticket;
   const int r0 = j + 2;
@@ -175,14 +177,28 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
     }
     part[(size_t)blockIdx.y * n + i] = acc;
   }
-  // last workgroup done?
+  // Two ticket levels (release / acquire fences at agent scope around each).  The last column block of a ROW block sums that row
+  // block's partial products in column-block order into psum — in parallel over the row blocks, instead of one workgroup
+  // walking all n x ncb partials; the last row block to finish that then runs the step on the single summed vector.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    ticket = __hip_atomic_fetch_add(&tickets_rb[(size_t)(j + 1) * TD_NRB + blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != gridDim.y - 1) return;  // uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold lines other workgroups have rewritten
+  if (i < n) {
+    double s = 0.0;
+    for (unsigned int cb = 0; cb < gridDim.y; ++cb) s += part[(size_t)cb * n + i];  // fixed order
+    psum[i] = s;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&tickets[j + 1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (ticket != gridDim.x * gridDim.y - 1) return;  // uniform
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 may hold lines other workgroups have rewritten
-  td_step_dev<PT>(A, n, j + 1, 0, (int)gridDim.y, part, w, d, e, tau);
+  if (ticket != gridDim.x - 1) return;  // uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  td_step_dev<PT>(A, n, j + 1, 0, 1, psum, w, d, e, tau);
 }
 
 // Eigenvalue number idx (ascending) of the tridiagonal (d, e) by multisection on the Sturm count: one wave per eigenvalue, the
@@ -379,11 +395,13 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   if (const char* e = getenv("ISLE_TD_CB")) CB = std::max(8, std::min(128, atoi(e)));  // tuning knob
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
-  const size_t need = nn + (size_t)ncb_max * n + 6 * (size_t)n + 3 * (size_t)n * nvec + 16;
+  const int nrb_max = TD_NRB;
+  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8;
   HIPCHK(c, c->jacW.reserve(need));
   double* A = c->jacW.p;
   double* part = A + nn;
-  double* w = part + (size_t)ncb_max * n;
+  double* psum = part + (size_t)ncb_max * n;
+  double* w = psum + n;
   double* d = w + n;
   double* e = d + n;
   double* tau = e + n;
@@ -392,7 +410,8 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   double* Lf = Dp + (size_t)n * nvec;
   double* Z = Lf + (size_t)n * nvec;
   unsigned int* worst = reinterpret_cast<unsigned int*>(Z + (size_t)n * nvec);
-  unsigned int* tickets = worst + 2;  // n + 1 counters
+  unsigned int* tickets = worst + 2;  // n + 1 counters, then n x nrb_max row-block counters
+  unsigned int* tickets_rb = tickets + n + 2;
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(c, hipFuncSetAttribute((const void*)td_back_k, hipFuncAttributeMaxDynamicSharedMemorySize, TD_NMAX_BACK * 8 * (int)sizeof(double)));
@@ -401,7 +420,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
   HIPCHK(c, hipMemsetAsync(e, 0, (size_t)n * sizeof(double), c->stream));
-  HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4) * sizeof(unsigned int), c->stream));
+  HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4 + (size_t)n * nrb_max + 4) * sizeof(unsigned int), c->stream));
   // ---- 1. tridiagonalisation
   const bool small = n <= TD_ROWS * 4;
   if (small) hipLaunchKernelGGL((td_first_k<4>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
@@ -412,11 +431,11 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     const int ncb = (m + CB - 1) / CB;
     const dim3 g((m + TD_ROWS - 1) / TD_ROWS, ncb);
     if (small)
-      hipLaunchKernelGGL((td_update_symv_k<4>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, d, e, tau,
-                         tickets);
+      hipLaunchKernelGGL((td_update_symv_k<4>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, psum, d, e, tau,
+                         tickets, tickets_rb);
     else
-      hipLaunchKernelGGL((td_update_symv_k<16>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, d, e, tau,
-                         tickets);
+      hipLaunchKernelGGL((td_update_symv_k<16>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, psum, d, e, tau,
+                         tickets, tickets_rb);
   }
   HIPCHK(c, hipGetLastError());
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
