@@ -823,6 +823,15 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->gl_nch.p, nch.data(), nblk * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->gl_part.reserve((size_t)nslab * bitems * 12));  // sized for the widest panel (BP = 12)
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("ISLE_GL_VERBOSE")) {
+      fprintf(stderr, "[gram_lds] pass-2 word blocks (super-rounds, chunks):");
+      for (uint32_t ob = 0; ob < nblk; ++ob) {
+        unsigned long long t = 0;
+        for (uint32_t z = 0; z < NZ; ++z) t += tot[(size_t)ob * NZ + z];
+        fprintf(stderr, " %llu/%u", t, nch[ob]);
+      }
+      fprintf(stderr, "\n");
+    }
     if (getenv("ISLE_GL_VERBOSE"))
       fprintf(stderr,
               "[gram_lds] V=%u D=%u nnz=%llu | pass1: bands=%u waves=%u wgs=%u padded=%.2fx | pass2: bands=%u blocks=%u wgs=%u slabs=%u "
