@@ -85,7 +85,7 @@ def _ragged(V, D, seed, row_constant):
     return vals, rows, offs
 
 
-@pytest.mark.parametrize("V,D", [(4500, 300), (3412, 64), (3413, 65), (7000, 9000), (100, 5), (90000, 300)])
+@pytest.mark.parametrize("V,D", [(4500, 300), (3412, 64), (3413, 65), (6825, 3411), (7000, 9000), (100, 5), (90000, 300)])
 @pytest.mark.parametrize("b", [1, 5, 10, 12, 13, 25])
 def test_gram_apply_lds_form_ragged(hp, V, D, b):
     # B = diag(s) * pattern (what threshold_and_copy builds): the LDS-banded form must be chosen and agree with the oracle;
@@ -294,6 +294,35 @@ def test_gather_form_forced_by_env(hp, small50, monkeypatch):
     assert np.max(np.abs(res[1][0] - res[0][0]) / res[0][0]) <= 1e-5
     assert (res[1][1] == res[0][1]).mean() >= 0.999
     assert relerr(res[1][2], res[0][2]) <= 1e-4
+
+
+@pytest.mark.parametrize("k", [7, 13, 25, 30, 37])
+def test_wide_products_odd_topic_counts(hp, small50, monkeypatch, k):
+    """k-wide products (projection, first full assignment) with topic counts that are not multiples of the twelve-column
+    panel or of the padded row (ldk = 4 ceil(k/4)): the LDS-banded form, the row-gather form and the oracle agree."""
+    from oracle.oracle import lift
+    B = small50
+    rng = np.random.default_rng(k)
+    U = B["oracle"].block_ks(k)["U"]
+    seeds = rng.choice(B["D"], size=k, replace=False).astype(np.uint64)
+    res = {}
+    for form in ("ISLE_WIDE_LDS", "ISLE_WIDE_GATHER"):
+        monkeypatch.setenv(form, "1")
+        upload(hp, B)
+        hp.set_U(U)
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=seeds)
+        lg = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lg["C_lowd"], fetch=False)
+        sg = hp.run_lloyds(k)
+        res[form] = (g["C_lowd"], hp.get_min_dist(), lg["assign"], sg["assign"], sg["centers"])
+        monkeypatch.delenv(form)
+    a, b = res["ISLE_WIDE_LDS"], res["ISLE_WIDE_GATHER"]
+    assert relerr(a[0], b[0]) <= 1e-5 and np.abs(a[1] - b[1]).max() <= 1e-4 * b[1].max()
+    assert (a[2] == b[2]).mean() >= 0.995 and (a[3] == b[3]).mean() >= 0.995
+    lo = B["oracle"].lloyds_projected(U, a[0])
+    assert (a[2] == lo["assign"]).mean() >= 0.99
+    so = B["oracle"].lloyds_sparse(lift(U, lo["C_lowd"]))
+    assert (a[3] == so["assign"]).mean() >= 0.99
 
 
 def test_sparse_lloyd_wide_vocabulary(hp, monkeypatch):
