@@ -51,6 +51,16 @@ const char* isle_hip_last_error(isle_ctx* ctx);
 int isle_hip_comm_unique_id(void* out128);
 int isle_hip_comm_init(isle_ctx* ctx, int world_size, int rank, const void* unique_id128);
 
+/* Rehearsal transport for tests: RCCL refuses two ranks on one device, so to run the sharded path with several
+ * ranks on ONE GPU (tests/test_gpu_multirank.py) every collective is staged through host memory and handed to
+ * `fn` (the tests pass a torch.distributed/gloo exchange).  kind: ISLE_XCHG_*; dtype: 0 f32, 1 f64, 2 i32, 3 u32,
+ * 4 u64.  All-reduce: `buf` holds `count` elements, reduced in place.  All-gather: `buf` holds world * count
+ * elements with this rank's part already at rank * count; fill the rest.  Return 0 on success.  Collectives then
+ * cost two PCIe copies and two stream synchronisations each: never use it for measurements (bench.py does not). */
+enum { ISLE_XCHG_ALLREDUCE_SUM = 0, ISLE_XCHG_ALLREDUCE_MAX = 1, ISLE_XCHG_ALLGATHER = 2 };
+typedef int (*isle_host_exchange_fn)(void* user, int kind, void* buf, uint64_t count, int dtype);
+int isle_hip_comm_init_host(isle_ctx* ctx, int world_size, int rank, isle_host_exchange_fn fn, void* user);
+
 /* Contiguous, nnz-balanced document ranges for `parts` shards (pure host function, no GPU):
  * bounds[p] .. bounds[p+1] are the columns of shard p; bounds has parts+1 entries. */
 int isle_hip_plan_shards(uint64_t num_docs, const int64_t* offsets_CSC, int parts, uint64_t* bounds);

@@ -13,6 +13,7 @@ SYMBOLS = {
     "isle_hip_last_error": (C.c_char_p, [_P]),
     "isle_hip_comm_unique_id": (_I, [_P]),
     "isle_hip_comm_init": (_I, [_P, _I, _I, _P]),
+    "isle_hip_comm_init_host": (_I, [_P, _I, _I, _P, _P]),
     "isle_hip_plan_shards": (_I, [_U64, _P, _I, _P]),
     "isle_hip_upload_csc_u64": (_I, [_P, _U64, _U64, _U64, _P, _P, _P, _U64, _U64]),
     "isle_hip_upload_csc_u32": (_I, [_P, _U64, _U64, _U64, _P, _P, _P, _U64, _U64]),

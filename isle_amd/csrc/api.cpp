@@ -67,25 +67,59 @@ static int drain_events(isle_ctx* c) {
       return isle_fail((ctx), ISLE_E_COMM, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r__)); \
   } while (0)
 
+static const ncclDataType_t kNcclType[5] = {ncclFloat, ncclDouble, ncclInt, ncclUint32, ncclUint64};
+static const size_t kDtSize[5] = {4, 8, 4, 4, 8};
+
+// host-staged exchange: device -> host, the caller's function (gloo in tests/), host -> device
+static int host_exchange(isle_ctx* c, int kind, void* dev, size_t count_per_rank, int dtype) {
+  const size_t total = (kind == ISLE_XCHG_ALLGATHER ? (size_t)c->world : 1) * count_per_rank * kDtSize[dtype];
+  std::vector<char> h(total);
+  HIPCHK(c, hipMemcpyAsync(h.data(), dev, total, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int rc = c->host_xchg(c->host_xchg_user, kind, h.data(), (uint64_t)count_per_rank, dtype);
+  if (rc != 0) return isle_fail(c, ISLE_E_COMM, "host exchange function returned %d", rc);
+  HIPCHK(c, hipMemcpyAsync(dev, h.data(), total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int isle_allreduce(isle_ctx* c, void* buf, size_t count, int dtype, bool max_op) {
+  if (!c->multi() || !count) return 0;
+  if (c->host_xchg) return host_exchange(c, max_op ? ISLE_XCHG_ALLREDUCE_MAX : ISLE_XCHG_ALLREDUCE_SUM, buf, count, dtype);
+  NCCLCHK(c, ncclAllReduce(buf, buf, count, kNcclType[dtype], max_op ? ncclMax : ncclSum, c->comm, c->stream));
+  return 0;
+}
+
+int isle_allgather(isle_ctx* c, const void* send, void* recv, size_t count_per_rank, int dtype) {
+  if (!c->multi() || !count_per_rank) return 0;
+  if (c->host_xchg) {
+    const size_t bytes = count_per_rank * kDtSize[dtype];
+    char* mine = (char*)recv + (size_t)c->rank * bytes;
+    if ((const void*)mine != send) HIPCHK(c, hipMemcpyAsync(mine, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return host_exchange(c, ISLE_XCHG_ALLGATHER, recv, count_per_rank, dtype);
+  }
+  NCCLCHK(c, ncclAllGather(send, recv, count_per_rank, kNcclType[dtype], c->comm, c->stream));
+  return 0;
+}
+
 template <class T>
-static ncclDataType_t nccl_type();
+struct DtOf;
 template <>
-ncclDataType_t nccl_type<float>() { return ncclFloat; }
+struct DtOf<float> { static constexpr int v = ISLE_DT_F32; };
 template <>
-ncclDataType_t nccl_type<double>() { return ncclDouble; }
+struct DtOf<double> { static constexpr int v = ISLE_DT_F64; };
 template <>
-ncclDataType_t nccl_type<int>() { return ncclInt; }
+struct DtOf<int> { static constexpr int v = ISLE_DT_I32; };
 template <>
-ncclDataType_t nccl_type<uint64_t>() { return ncclUint64; }
+struct DtOf<uint32_t> { static constexpr int v = ISLE_DT_U32; };
 template <>
-ncclDataType_t nccl_type<uint32_t>() { return ncclUint32; }
+struct DtOf<uint64_t> { static constexpr int v = ISLE_DT_U64; };
 
 template <class T>
 static int allreduce_sum(isle_ctx* c, T* buf, size_t count) {
-  if (!c->comm) return 0;
+  if (!c->multi()) return 0;
   TimeScope ts(c, ISLE_T_COMM);
-  NCCLCHK(c, ncclAllReduce(buf, buf, count, nccl_type<T>(), ncclSum, c->comm, c->stream));
-  return 0;
+  return isle_allreduce(c, buf, count, DtOf<T>::v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -197,6 +231,16 @@ extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* 
   ncclUniqueId id;
   memcpy(&id, uid, sizeof id);
   NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
+  return 0;
+}
+
+extern "C" int isle_hip_comm_init_host(isle_ctx* c, int world, int rank, isle_host_exchange_fn fn, void* user) {
+  if (!c || world < 1 || rank < 0 || rank >= world || !fn) return isle_fail(c, ISLE_E_ARG, "bad world/rank/function");
+  if (c->comm) return isle_fail(c, ISLE_E_ARG, "the context already has an RCCL communicator");
+  c->world = world;
+  c->rank = rank;
+  c->host_xchg = fn;
+  c->host_xchg_user = user;
   return 0;
 }
 
@@ -410,7 +454,7 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (entries_above) {
     uint64_t g = (uint64_t)above_local;
-    if (c->comm) {
+    if (c->multi()) {
       HIPCHK(c, hipMemcpyAsync(st_dev, &g, sizeof(g), hipMemcpyHostToDevice, c->stream));
       ISLECHK(allreduce_sum<uint64_t>(c, st_dev, 1));
       HIPCHK(c, hipMemcpyAsync(&g, st_dev, sizeof(g), hipMemcpyDeviceToHost, c->stream));
@@ -455,13 +499,13 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
 
   // placement of this shard in B's global column numbering
   uint64_t b_off = 0, b_glob = Db;
-  if (c->comm) {
+  if (c->multi()) {
     DevBuf<uint64_t> all;
     HIPCHK(c, all.reserve((size_t)c->world + 1));
     HIPCHK(c, hipMemcpyAsync(all.p + c->world, &Db, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     {
       TimeScope ts(c, ISLE_T_COMM);
-      NCCLCHK(c, ncclAllGather(all.p + c->world, all.p, 1, ncclUint64, c->comm, c->stream));
+      ISLECHK(isle_allgather(c, all.p + c->world, all.p, 1, ISLE_DT_U64));
     }
     std::vector<uint64_t> h(c->world);
     HIPCHK(c, hipMemcpyAsync(h.data(), all.p, c->world * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -661,7 +705,7 @@ extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
   HIPCHK(c, hipSetDevice(c->device));
   double s = 0.0;
   ISLECHK(k_frobenius(c, &s));
-  if (c->comm) {
+  if (c->multi()) {
     HIPCHK(c, c->gram.reserve(1024));
     HIPCHK(c, hipMemcpyAsync(c->gram.p, &s, sizeof(double), hipMemcpyHostToDevice, c->stream));
     ISLECHK(allreduce_sum<double>(c, c->gram.p, 1));
@@ -1097,7 +1141,7 @@ static int ensure_P(isle_ctx* c, int k) {
 // dst (n x ldk, device) <- P rows of the given GLOBAL doc ids (owner contributes, others zero, then all-reduce)
 static int fetch_rows(isle_ctx* c, const uint64_t* ids, int n, float* dst) {
   if (n == 0) return 0;
-  const bool multi = c->comm != nullptr;
+  const bool multi = c->multi();
   std::vector<uint64_t> local(n);
   for (int i = 0; i < n; ++i) {
     const uint64_t g = ids[i];
@@ -1118,7 +1162,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2144
   const uint64_t D = c->D, Dg = c->D_global;
   const int ldk = c->ldk;
-  const bool multi = c->comm != nullptr;
+  const bool multi = c->multi();
   HIPCHK(c, c->min_dist.reserve(D ? D : 1));
   HIPCHK(c, c->cum.reserve(D + 1));
   HIPCHK(c, c->Cdev.reserve((size_t)k * ldk));
@@ -1151,7 +1195,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
       HIPCHK(c, hipMemcpyAsync(dv + 2 * c->world, my, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
       {
         TimeScope ts(c, ISLE_T_COMM);
-        NCCLCHK(c, ncclAllGather(dv + 2 * c->world, dv, 2, ncclDouble, c->comm, c->stream));
+        ISLECHK(isle_allgather(c, dv + 2 * c->world, dv, 2, ISLE_DT_F64));
       }
       HIPCHK(c, hipMemcpyAsync(tot.data(), dv, 2 * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -65,6 +65,11 @@ struct isle_ctx {
   // --- communicator (null for single GPU)
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+  // rehearsal transport (isle_hip_comm_init_host): collectives staged through host memory and a caller-provided exchange
+  // function, so that several ranks can share one GPU in tests (RCCL refuses two ranks on one device)
+  isle_host_exchange_fn host_xchg = nullptr;
+  void* host_xchg_user = nullptr;
+  bool multi() const { return comm != nullptr || host_xchg != nullptr; }
 
   // --- B (this rank's column shard), CSC
   uint64_t V = 0, D = 0, nnz = 0, doc_offset = 0, D_global = 0;
@@ -244,6 +249,10 @@ int k_gram_pass2(isle_ctx* c, int BP);   // Zrm = B Yrm
 int k_band_build(isle_ctx* c);
 int k_band_build_chunked(isle_ctx* c);   // chunk-major cells for the gather path (spmm.hip)
 // gram_lds.hip
+// collectives on c->stream (api.cpp): RCCL, or the host-staged rehearsal transport; no-ops without a communicator
+enum { ISLE_DT_F32 = 0, ISLE_DT_F64 = 1, ISLE_DT_I32 = 2, ISLE_DT_U32 = 3, ISLE_DT_U64 = 4 };
+int isle_allreduce(isle_ctx* c, void* buf, size_t count, int dtype, bool max_op = false);  // in place
+int isle_allgather(isle_ctx* c, const void* send, void* recv, size_t count_per_rank, int dtype);  // recv: world * count_per_rank
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);

@@ -635,10 +635,9 @@ int k_gl_detect(isle_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->gl_flag.p, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  if (c->comm) {  // one form on all ranks (the collectives per application must match)
+  if (c->multi()) {  // one form on all ranks (the collectives per application must match)
     TimeScope ts(c, ISLE_T_COMM);
-    const ncclResult_t r = ncclAllReduce(c->gl_flag.p, c->gl_flag.p, 1, ncclInt, ncclMax, c->comm, c->stream);
-    if (r != ncclSuccess) return isle_fail(c, ISLE_E_COMM, "operator form agreement: %s", ncclGetErrorString(r));
+    ISLECHK(isle_allreduce(c, c->gl_flag.p, 1, ISLE_DT_I32, true));
   }
   int flag = 0;
   HIPCHK(c, hipMemcpyAsync(&flag, c->gl_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -62,6 +62,46 @@ class HotPath:
         uid = np.ascontiguousarray(uid, np.uint8)
         self._chk(self._lib.isle_hip_comm_init(self._h, world, rank, _p(uid)))
 
+    def comm_init_host(self, world, rank, exchange):
+        """Rehearsal transport (tests only; include/isle_hip.h): every collective is staged through host memory and
+        handed to exchange(kind, array, count) -> None, which must complete it in place.  kind: 0 all-reduce sum,
+        1 all-reduce max, 2 all-gather (array has world * count elements, this rank's part filled in)."""
+        dts = [np.float32, np.float64, np.int32, np.uint32, np.uint64]
+
+        def tramp(user, kind, buf, count, dtype):
+            try:
+                n = count * (world if kind == 2 else 1)
+                dt = np.dtype(dts[dtype])
+                a = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(buf), dtype=dt)
+                exchange(kind, a, count)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._xchg_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int)(tramp)
+        self._chk(self._lib.isle_hip_comm_init_host(self._h, world, rank, C.cast(self._xchg_cb, C.c_void_p), None))
+
+    @staticmethod
+    def gloo_exchange(dist, world, rank):
+        """exchange function for comm_init_host over an initialised torch.distributed (gloo) process group."""
+        import torch
+
+        def exchange(kind, a, count):
+            if kind == 2:
+                # all-gather: a.view(world, count), own row filled; gloo has no unsigned types -> move the bytes
+                t = torch.from_numpy(a.view(np.uint8).reshape(world, -1))
+                parts = [torch.empty_like(t[0]) for _ in range(world)]
+                dist.all_gather(parts, t[rank].clone())
+                for r in range(world):
+                    t[r].copy_(parts[r])
+                return
+            signed = {np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64}.get(a.dtype)
+            t = torch.from_numpy(a.view(signed) if signed else a)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if kind == 1 else dist.ReduceOp.SUM)
+        return exchange
+
     @staticmethod
     def plan_shards(offs, parts):
         offs = np.ascontiguousarray(offs, np.int64)

@@ -1,0 +1,166 @@
+"""The sharded (N > 1) path with 2 and 3 ranks on ONE GPU.
+
+RCCL refuses two ranks on one device, so the ranks use the rehearsal transport of include/isle_hip.h
+(isle_hip_comm_init_host): every collective of the library is staged through host memory and completed by gloo.  Everything
+else is the product path: document shards from isle_hip_plan_shards, per-rank operator build, all-reduce of Z per operator
+application, replicated eigensolver, k-means++ over per-shard D^2 prefix sums, centroid sums, stop rules.  The run with N
+ranks must reproduce the single-rank run (same U and seeds injected), and the replicated results must be bit-identical on
+all ranks (that is what keeps the ranks' control flow — restarts, rank decisions, stop rules — in step)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+os.environ["OMP_NUM_THREADS"] = "2"
+from conftest import corpus
+from isle_amd import HotPath
+from tools.synth import Corpus
+
+hp = HotPath(0)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% port, rank=rank, world_size=world)
+    hp.comm_init_host(world, rank, HotPath.gloo_exchange(dist, world, rank))
+res = {}
+
+# ---- thresholding on document shards: global statistics, B placed in the global column numbering
+Vt, Dt, kt = 1500, 4000, 10
+per = Dt // world
+n_loc = per if rank < world - 1 else Dt - per * (world - 1)
+cc = Corpus(Vt, n_loc, kt, 5, doc_base=rank * per)
+cnt, rows, offs = cc.A()
+hp.upload_counts(Vt, cnt, rows, offs, doc_offset=rank * per, docs_global=Dt)
+ti = hp.threshold(kt)
+Bd = hp.get_B()
+res.update(thr_rows=Bd["rows"], thr_vals=Bd["vals"], thr_offs=Bd["offs"], thr_cols=Bd["original_cols"],
+           thr_meta=np.array([hp.doc_offset, hp.D_global, ti["entries_above_threshold"]], np.int64))
+
+# ---- hot path on a shard of B
+k = 20
+B = corpus(3000, 9000, k, 3)
+bounds = HotPath.plan_shards(B["offs"], world).astype(np.int64)
+d0, d1 = int(bounds[rank]), int(bounds[rank + 1])
+o0, o1 = int(B["offs"][d0]), int(B["offs"][d1])
+hp.upload_csc(B["V"], B["vals"][o0:o1], B["rows"][o0:o1], B["offs"][d0:d1 + 1] - o0, doc_offset=d0, docs_global=B["D"])
+res["range"] = np.array([d0, d1], np.int64)
+res["fro"] = np.array([hp.frobenius()], np.float64)
+X = np.random.default_rng(0).standard_normal((B["V"], 10)).astype(np.float32)
+res["Z"] = hp.gram_apply(X)
+X25 = np.random.default_rng(1).standard_normal((B["V"], 25)).astype(np.float32)
+res["Z25"] = hp.gram_apply(X25)
+r = hp.compute_block_ks(k, seed=4)
+res["evals"] = r["evals"]; res["restarts"] = np.array([r["restarts"], r["nconv"]], np.int64)
+res["U"] = hp.get_U(k)
+upath = os.path.join(os.path.dirname(out), "U1.npy")
+if world == 1:
+    np.save(upath, res["U"])
+U = np.load(upath)
+hp.set_U(U)
+free = hp.kmeans_init_on_projected_space(k, rng_seed=9)
+res["free_seeds"] = free["seeds"]; res["free_res"] = np.array([free["residual"]], np.float64)
+spath = os.path.join(os.path.dirname(out), "seeds1.npy")
+if world == 1:
+    np.save(spath, free["seeds"])
+g = hp.kmeans_init_on_projected_space(k, inject_seeds=np.load(spath))
+res["kmpp_C"] = g["C_lowd"]; res["kmpp_res"] = np.array([g["residual"]], np.float64); res["min_dist"] = hp.get_min_dist()
+lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+res["lp_assign"] = lp["assign"]; res["lp_C"] = lp["C_lowd"]; res["lp_it"] = np.array([lp["iters"]])
+hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+ls = hp.run_lloyds(k)
+res["ls_assign"] = ls["assign"]; res["ls_cen"] = ls["centers"]; res["ls_it"] = np.array([ls["iters"]])
+np.savez(out, **res)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+hp.close()
+''' % (ROOT, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, tmp):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        out = os.path.join(tmp, "w%d_r%d.npz" % (world, r))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER, str(r), str(world), str(port), out],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=420)
+            outs.append(o)
+    finally:
+        for p in procs:  # a rank that failed leaves the others waiting in a collective: end exactly those processes
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "world %d rank %d failed:\n%s" % (world, r, (outs[r] if r < len(outs) else "")[-3000:])
+    return [np.load(os.path.join(tmp, "w%d_r%d.npz" % (world, r))) for r in range(world)]
+
+
+@pytest.fixture(scope="module")
+def single(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("multirank"))
+    return tmp, _run(1, tmp)[0]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_n_ranks_reproduce_one_rank(single, world):
+    tmp, one = single
+    rs = _run(world, tmp)
+    # replicated results: bit-identical on every rank
+    for name in ("fro", "Z", "Z25", "evals", "restarts", "U", "free_seeds", "kmpp_C", "lp_C", "lp_it", "ls_cen", "ls_it", "thr_meta"):
+        for r in rs[1:]:
+            if name == "thr_meta":
+                assert np.array_equal(r[name][1:], rs[0][name][1:])
+            else:
+                assert np.array_equal(r[name], rs[0][name]), "%s differs between ranks" % name
+    # the shards tile the documents
+    assert rs[0]["range"][0] == 0 and rs[-1]["range"][1] == one["range"][1]
+    assert all(rs[i]["range"][1] == rs[i + 1]["range"][0] for i in range(world - 1))
+    # thresholding: the shards' B, put side by side, is the single-rank B bit for bit
+    assert np.array_equal(np.concatenate([r["thr_rows"] for r in rs]), one["thr_rows"])
+    assert np.array_equal(np.concatenate([r["thr_vals"] for r in rs]), one["thr_vals"])
+    assert np.array_equal(np.concatenate([r["thr_cols"] for r in rs]), one["thr_cols"])
+    assert np.array_equal(np.concatenate([np.diff(r["thr_offs"]) for r in rs]), np.diff(one["thr_offs"]))
+    assert rs[0]["thr_meta"][2] == one["thr_meta"][2]
+    # operator and eigensolver
+    a = rs[0]
+    assert abs(a["fro"][0] - one["fro"][0]) <= 1e-6 * one["fro"][0]
+    assert _rel(a["Z"], one["Z"]) <= 1e-5 and _rel(a["Z25"], one["Z25"]) <= 1e-5
+    assert np.max(np.abs(a["evals"] - one["evals"]) / one["evals"]) <= 1e-5
+    # k-means with the single-rank U and seeds injected
+    assert _rel(a["kmpp_C"], one["kmpp_C"]) <= 1e-5
+    assert abs(a["kmpp_res"][0] - one["kmpp_res"][0]) <= 1e-4 * one["kmpp_res"][0]
+    md = np.concatenate([r["min_dist"] for r in rs])
+    assert np.abs(md - one["min_dist"]).max() <= 1e-4 * one["min_dist"].max()
+    assert a["lp_it"][0] == one["lp_it"][0] and a["ls_it"][0] == one["ls_it"][0]
+    assert (np.concatenate([r["lp_assign"] for r in rs]) == one["lp_assign"]).mean() >= 0.999
+    assert (np.concatenate([r["ls_assign"] for r in rs]) == one["ls_assign"]).mean() >= 0.999
+    assert _rel(a["lp_C"], one["lp_C"]) <= 1e-4 and _rel(a["ls_cen"], one["ls_cen"]) <= 1e-4
+    # free-running k-means++: the draws walk per-shard D^2 prefix sums joined by the all-gathered totals
+    same = (a["free_seeds"] == one["free_seeds"]).mean()
+    assert same >= 0.9 or abs(a["free_res"][0] - one["free_res"][0]) <= 0.2 * one["free_res"][0], same
