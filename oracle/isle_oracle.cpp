@@ -6,13 +6,14 @@
 // and (2) as the "port" CPU baseline timed by bench.py's cpu_baseline leg.
 // Nothing under isle_amd/ may include, link, load or call this file.
 //
-// PARITY UNPINNED: the reference (microsoft/ISLE) ships no golden vectors or
-// known-answer tests for this path, and its own sources cannot be compiled in this
-// image (every translation unit on the path includes Intel MKL's <mkl.h>, which is
-// absent: include/types.h:9, block-ks/ks_types.h:7).  The oracle is therefore
-// pinned only by (a) fp64 NumPy ground truth (dense eigvalsh / brute-force k-means
-// steps) and (b) the reference's own known-spectrum recipe utils::get_seed_eigs
-// (block-ks/ks_utils.h:136-165) — see tests/test_oracle_*.py.
+// PINNING.  Eigensolver results (block_ks: sigma, U): pinned by a run of reference code — oracle/_ref/spectra_eigs is the
+// reference's vendored Spectra::SymEigsSolver + Eigen compiled where they lie and called as compute_Spectra does
+// (src/sparseMatrix.cpp:1161-1190); its outputs are tests/golden/ref_spectra.npz (tests/test_reference_golden_cpu.py).
+// Everything else — the MKL operator, BlockKs, k-means — is PARITY UNPINNED: the reference ships no golden vectors or
+// known-answer tests for this path, and those sources cannot be compiled in this image (they include Intel MKL's
+// <mkl.h>, which is absent: include/types.h:9, block-ks/ks_types.h:7).  Those parts are pinned only by (a) fp64 NumPy
+// ground truth (dense eigvalsh / brute-force k-means steps) and (b) the reference's own known-spectrum recipe
+// utils::get_seed_eigs (block-ks/ks_utils.h:136-165) — see tests/test_oracle_*.py.
 //
 // Every function cites the reference file:line it restates (paths relative to the
 // reference root).  The restatement follows the reference's ALGORITHM and operation

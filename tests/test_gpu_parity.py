@@ -195,6 +195,26 @@ def test_block_ks_sigma(hp, which, request):
     assert cos.min() >= 1 - 1e-3
 
 
+@pytest.mark.parametrize("name", ["tiny10", "tiny20", "small50", "mid30"])
+def test_block_ks_matches_reference_solver_goldens(hp, name):
+    """sigma and U against the fixtures computed by the reference's own Spectra eigensolver (tests/golden/ref_spectra.npz,
+    tests/golden/make_golden_ref.py; compute_Spectra, /root/reference/src/sparseMatrix.cpp:1161-1190)."""
+    import os
+    from conftest import ROOT, corpus
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_spectra.npz"))
+    V, D, k, seed = (int(x) for x in g[name + "_params"])
+    B = corpus(V, D, k, seed)
+    assert np.array_equal(np.array([B["V"], B["D"], B["nnz"], int(B["rows"].astype(np.int64).sum())]), g[name + "_sig"])
+    upload(hp, B)
+    r = hp.compute_block_ks(k, allow_noconv=True)
+    s, s_ref = np.sqrt(r["evals"].astype(np.float64)), np.sqrt(g[name + "_evalues"].astype(np.float64))
+    assert np.max(np.abs(s - s_ref) / s_ref) <= 1e-4  # BASELINE.json tolerance
+    if name + "_U" in g:
+        assert subspace_cosines(hp.get_U(k)[:, : k - 2], g[name + "_U"]).min() >= 1 - 1e-3
+        Z = hp.gram_apply(g[name + "_U"])  # the reference's eigenvectors under the HIP operator
+        assert np.abs(Z - g[name + "_U"] * g[name + "_evalues"]).max() <= 2e-3 * g[name + "_evalues"][0]
+
+
 def test_block_ks_medium(hp, small50):
     B = small50
     upload(hp, B)
