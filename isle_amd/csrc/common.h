@@ -137,6 +137,8 @@ struct isle_ctx {
   DevBuf<uint32_t> gl_val_a, gl_val_b;
   DevBuf<uint32_t> gl_bst;   // D x (NB1 + 1): first entry of each word band inside a document's column
   DevBuf<uint16_t> gl_cellcnt;   // V x NB2: entries of (word, document band)
+  DevBuf<uint16_t> gl_cellpre;   // V x NB2 (merged streams): entries of the lane's earlier items in the merged group | item tag << 14
+  int gl_merge = 0;              // stream form of both passes: 0 one item per group, 1 four items merged (item changes on super-round boundaries), 2 merged entry by entry
   DevBuf<uint32_t> gl_srsum, gl_sbase;
   DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)
   DevBuf<uint32_t> ccounted;     // D: the centre under which document d is counted in ccount

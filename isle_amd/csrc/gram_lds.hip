@@ -112,12 +112,18 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 // cnt[(wv * NB + band) * 4 + g] = super-rounds of (wave, band, group); srsum[wv * NB + band] = their sum.
 // One workgroup of 4 waves per wave wv (wave g of the workgroup = group g).  PASS 1: lane count = bst differences;
 // PASS 2: lane count = size of cell (word wperm[q], band).
+// Merged streams (merge = 1, 2): the four items of a lane form ONE stream per band (item 0's entries, then item 1's, ...), so
+// the wave pays the maximum over lanes of the SUM of four counts instead of the sum of four maxima; group 0 carries all the
+// super-rounds, groups 1-3 none.  merge = 1 starts every item on a super-round boundary (counts rounded up to 4), merge = 2
+// packs entry by entry.  PASS 2 also stores where an item's entries start inside the lane's stream (cellpre, with the item's
+// tag), for the placement by cursors in gl_hist_fill_k.
 template <int PASS>
 __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ slice_of, uint32_t n_out, uint32_t NB,
                                                  const uint32_t* __restrict__ bst, const uint16_t* __restrict__ cellcnt,
                                                  const uint32_t* __restrict__ wperm, uint16_t* __restrict__ cnt, uint32_t* __restrict__ srsum,
-                                                 int* __restrict__ overflow) {
+                                                 int* __restrict__ overflow, int merge, uint16_t* __restrict__ cellpre) {
   __shared__ uint32_t sh[4];
+  __shared__ uint32_t shn[4][64];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t wv = blockIdx.x;
   const uint32_t sl = slice_of[wv * 4 + g];
@@ -128,7 +134,18 @@ __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ sli
   for (uint32_t band = 0; band < NB; ++band) {
     uint32_t n = 0;
     if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[base + band];
-    const uint32_t sr = (wave_max_u32(n) + 3) >> 2;
+    uint32_t sr;
+    if (merge) {
+      shn[g][lane] = merge == 1 ? ((n + 3u) & ~3u) : n;
+      __syncthreads();
+      uint32_t pre = 0;
+      for (int j = 0; j < g; ++j) pre += shn[j][lane];
+      if (PASS == 2 && live) cellpre[base + band] = (uint16_t)(pre | ((uint32_t)g << 14));  // pre <= 3 * 3412 < 2^14
+      sr = g == 0 ? (wave_max_u32(shn[0][lane] + shn[1][lane] + shn[2][lane] + shn[3][lane]) + 3) >> 2 : 0u;
+      sr = (sr + 3u) & ~3u;  // the apply kernel's id ring is static: whole turns of four super-rounds
+    } else {
+      sr = (wave_max_u32(n) + 3) >> 2;
+    }
     if (lane == 0) {
       if (sr > 0xffffu) *overflow = 1;
       cnt[(wv * NB + band) * 4 + g] = (uint16_t)sr;
@@ -178,6 +195,60 @@ __global__ __launch_bounds__(256) void gl_fill1_k(const uint32_t* __restrict__ s
   }
 }
 
+// ids of pass 1, merged streams: one wave per (wave wv, band) writes the lanes' merged streams (ids carry the item's tag in
+// bits 12-13; padding = the zero row with tag 0)
+__global__ __launch_bounds__(64) void gl_fill1m_k(const uint32_t* __restrict__ slice_of, uint32_t D, uint32_t NB,
+                                                   const uint32_t* __restrict__ bst, const uint32_t* __restrict__ dperm,
+                                                   const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint64_t nnz,
+                                                   const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids,
+                                                   int merge) {
+  const int lane = threadIdx.x;
+  const size_t wb = blockIdx.x;  // wv * NB + band
+  const size_t wv = wb / NB;
+  const uint32_t band = (uint32_t)(wb - wv * NB);
+  const uint32_t n = cnt[wb * 4];
+  if (n == 0) return;
+  const int64_t sr0 = roff[wb];
+  int64_t base[4];
+  uint32_t len[4], start[4];  // start: first stream position of the item's entries
+  uint32_t at0 = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t sl = slice_of[wv * 4 + g];
+    const uint64_t pos = (uint64_t)sl * 64 + lane;
+    base[g] = 0;
+    len[g] = 0;
+    if (sl != GL_NONE && pos < D) {
+      const uint32_t b0 = bst[pos * (NB + 1) + band], b1 = bst[pos * (NB + 1) + band + 1];
+      base[g] = offs[dperm[pos]] + b0;
+      len[g] = b1 - b0;
+    }
+    start[g] = at0;
+    at0 += merge == 1 ? ((len[g] + 3u) & ~3u) : len[g];
+  }
+  const uint32_t r0 = band * GL_RB;
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t id[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t e = 4 * r + t;
+      int sel = 0;
+#pragma unroll
+      for (int g = 1; g < 4; ++g)
+        if (e >= start[g]) sel = g;
+      const uint32_t st = sel == 0 ? start[0] : sel == 1 ? start[1] : sel == 2 ? start[2] : start[3];
+      const uint32_t ln = sel == 0 ? len[0] : sel == 1 ? len[1] : sel == 2 ? len[2] : len[3];
+      const int64_t bs = sel == 0 ? base[0] : sel == 1 ? base[1] : sel == 2 ? base[2] : base[3];
+      const uint32_t j = e - st;
+      int64_t at = bs + j;
+      if (at > (int64_t)nnz - 1) at = (int64_t)nnz - 1;
+      const uint32_t row = rows[at];
+      id[t] = j < ln ? ((row - r0) | ((uint32_t)sel << 12)) : GL_RB;
+    }
+    ids[(size_t)(sr0 + r) * 64 + lane] = make_uint2(id[0] | (id[1] << 16), id[2] | (id[3] << 16));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pass 2 build: (word, document band) cell sizes and the id stream, by LDS histograms over the band's entries.
 // band = position of the document / GL_RB; grid = (bands, vocabulary parts of GL_VP words).
@@ -222,7 +293,8 @@ __global__ __launch_bounds__(256) void gl_rowlen_key_k(const uint16_t* __restric
 
 // sbase[slice * NB + band] = first super-round of (slice, band) in the stream
 __global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ slice_of, const uint16_t* __restrict__ cnt,
-                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase) {
+                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase,
+                                                   int merge) {
   const size_t wb = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (wb >= nwb) return;
   const size_t wv = wb / NB;
@@ -230,8 +302,8 @@ __global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ s
   uint32_t base = (uint32_t)roff[wb];
   for (int g = 0; g < GL_G; ++g) {
     const uint32_t sl = slice_of[wv * 4 + g];
-    if (sl != GL_NONE) sbase[(size_t)sl * NB + band] = base;
-    base += cnt[wb * 4 + g];
+    if (sl != GL_NONE) sbase[(size_t)sl * NB + band] = base;  // merged streams: all four slices share the wave's stream
+    if (!merge) base += cnt[wb * 4 + g];
   }
 }
 
@@ -239,7 +311,7 @@ __global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ s
 __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                               const uint32_t* __restrict__ dperm, uint32_t D, uint32_t V, uint32_t NB,
                                                               const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ sbase,
-                                                              uint16_t* __restrict__ ids16) {
+                                                              uint16_t* __restrict__ ids16, const uint16_t* __restrict__ cellpre /*null: unmerged*/) {
   extern __shared__ uint32_t hist[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t band = blockIdx.x;
@@ -264,16 +336,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) q[u] = in[u] ? wpos[w[u]] : 0u;
-      uint32_t sb[4];
+      uint32_t sb[4], pre[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) sb[u] = in[u] ? sbase[(size_t)(q[u] >> 6) * NB + band] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pre[u] = (cellpre && in[u]) ? (uint32_t)cellpre[(size_t)w[u] * NB + band] : 0u;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (in[u]) {
           const uint32_t odd = (w[u] - w0) & 1u;
           const uint32_t cur = atomicAdd(&hist[(w[u] - w0) >> 1], odd ? 0x10000u : 1u);
-          const uint32_t j = odd ? (cur >> 16) : (cur & 0xffffu);
-          ids16[((size_t)(sb[u] + (j >> 2)) * 64 + (q[u] & 63u)) * 4 + (j & 3u)] = (uint16_t)(p - p0);
+          const uint32_t j = (odd ? (cur >> 16) : (cur & 0xffffu)) + (pre[u] & 0x3fffu);
+          ids16[((size_t)(sb[u] + (j >> 2)) * 64 + (q[u] & 63u)) * 4 + (j & 3u)] = (uint16_t)((p - p0) | ((pre[u] >> 14) << 12));
         }
       }
     }
@@ -313,9 +387,26 @@ __device__ inline void add4(float4& a, const float4 b) {
   a.w += b.w;
 }
 
+// id ring of the merged-stream forms of gl_apply_k (see the comment in the kernel)
+#define GL_LOAD(Q, PTR) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(Q) : "v"(PTR) : "memory")  // tied: the register a round reads is the one it reloads
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ inline void fma4(float4& a, const float4 b, const f2v m) {  // a += m * b as two v_pk_fma_f32
+  f2v lo = {a.x, a.y}, hi = {a.z, a.w};
+  const f2v blo = {b.x, b.y}, bhi = {b.z, b.w};
+  lo = __builtin_elementwise_fma(blo, m, lo);
+  hi = __builtin_elementwise_fma(bhi, m, hi);
+  a = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // LPE float4 per panel row; HALF: the panel's last two columns are padding (b = 4 LPE - 2 or 4 LPE - 3), so only the low
 // half of the last float4 is read and accumulated (b = 10: 40 of 48 bytes per gathered row).
-template <int LPE, bool HALF>
+// MERGE (the stream form, gl_cnt_k): 0 = one item per (lane, group): the rows of a group's super-rounds add into acc[g].
+// 1, 2 = the lane's four items share one stream; bits 12-13 of an id name the item.  The accumulator cannot be indexed per
+// lane, so the row is added into all four with multipliers 1, 0, 0, 0 (exact: x * 1 + a, x * 0 + a).  MERGE 1: an item changes
+// only between super-rounds, so the four rows of a super-round are summed first (3 + 4 operations per float and super-round
+// instead of 4 before); MERGE 2: entry by entry (16 per super-round), no rounding-up of the items' counts.
+template <int LPE, bool HALF, int MERGE>
 __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restrict__ In, uint32_t n_src, const uint2* __restrict__ ids,
                                                           const int64_t* __restrict__ roff, const uint16_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ slice_of, const GlDesc* __restrict__ desc, uint32_t NB,
@@ -324,11 +415,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
                                                           uint32_t out_ld4 /*output row stride in float4*/) {
   extern __shared__ float4 xs[];  // (GL_RB + 1) rows of LPE float4
   constexpr int NF = HALF ? LPE - 1 : LPE;  // whole float4 per row
+  constexpr int NFA = NF > 0 ? NF : 1;
   const GlDesc ds = desc[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool wvalid = (uint32_t)w < ds.nw;  // wave-uniform
   const size_t wv = wvalid ? (size_t)ds.wave0 + (size_t)w * ds.wstride : (size_t)ds.wave0;
-  float4 acc[GL_G][NF > 0 ? NF : 1];
+  float4 acc[GL_G][NFA];
   float2 acch[GL_G];
 #pragma unroll
   for (int g = 0; g < GL_G; ++g) {
@@ -338,7 +430,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   }
   // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
-  uint2 q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
+  // MERGE 0: the ring is rotated in C++ (q0 = q1; ... q3 = *p).  hipcc turns that into register moves that read the newest
+  // load's destination and therefore waits vmcnt(0) in every round: one or two loads in flight, the pass runs at memory latency.
+  // Merged forms: four 64-bit registers that never move — a (wave, band) segment is a multiple of four super-rounds
+  // (gl_cnt_k), round i's ids sit in register i & 3, which is reloaded as soon as it has been read.  The loads are inline asm
+  // with a hand-placed s_waitcnt vmcnt(3): the three younger loads stay in flight.
+  uint2 q0, q1, q2, q3;
+  unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  if (MERGE == 0) {
+    q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
+  } else {
+    GL_LOAD(r0, p);
+    GL_LOAD(r1, p + 64);
+    GL_LOAD(r2, p + 128);
+    GL_LOAD(r3, p + 192);
+  }
   p += 256;
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
     __syncthreads();  // every wave is done with the previous band
@@ -364,28 +470,106 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     const uint2 cc = *reinterpret_cast<const uint2*>(cnt + (wv * NB + band) * 4);
     uint32_t c01 = __builtin_amdgcn_readfirstlane(cc.x), c23 = __builtin_amdgcn_readfirstlane(cc.y);
     if (!wvalid) c01 = c23 = 0;
+    if (MERGE == 0) {
 #pragma unroll
-    for (int g = 0; g < GL_G; ++g) {
-      const uint32_t n = ((g < 2 ? c01 : c23) >> (16 * (g & 1))) & 0xffffu;
-      for (uint32_t r = 0; r < n; ++r) {
-        const uint2 u = q0;
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
-        q3 = *p;
-        p += 64;
-        const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
+      for (int g = 0; g < GL_G; ++g) {
+        const uint32_t n = ((g < 2 ? c01 : c23) >> (16 * (g & 1))) & 0xffffu;
+        for (uint32_t r = 0; r < n; ++r) {
+          const uint2 u = q0;
+          q0 = q1;
+          q1 = q2;
+          q2 = q3;
+          q3 = *p;
+          p += 64;
+          const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < 4; ++t) {
 #pragma unroll
-          for (int l = 0; l < NF; ++l) add4(acc[g][l], xs[a[t] + l]);
-          if (HALF) {
-            const float2 h = *reinterpret_cast<const float2*>(&xs[a[t] + NF]);
-            acch[g].x += h.x;
-            acch[g].y += h.y;
+            for (int l = 0; l < NF; ++l) add4(acc[g][l], xs[a[t] + l]);
+            if (HALF) {
+              const float2 h = *reinterpret_cast<const float2*>(&xs[a[t] + NF]);
+              acch[g].x += h.x;
+              acch[g].y += h.y;
+            }
           }
         }
       }
+    } else {
+      const uint32_t n = c01 & 0xffffu;  // group 0 carries the merged stream: a multiple of 4 super-rounds
+      auto round = [&](const unsigned long long qq) {
+        const uint32_t ux = (uint32_t)qq, uy = (uint32_t)(qq >> 32);
+        const uint32_t e[4] = {ux & 0xffffu, ux >> 16, uy & 0xffffu, uy >> 16};
+        if (MERGE == 1) {
+          float4 sum[NFA];
+          float2 sumh = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int l = 0; l < NF; ++l) sum[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t a = (e[t] & 0xfffu) * LPE;
+#pragma unroll
+            for (int l = 0; l < NF; ++l) add4(sum[l], xs[a + l]);
+            if (HALF) {
+              const float2 h = *reinterpret_cast<const float2*>(&xs[a + NF]);
+              sumh.x += h.x;
+              sumh.y += h.y;
+            }
+          }
+          const uint32_t tag = e[0] >> 12;  // the same for the four entries of a super-round (or padding behind the item's last entry)
+#pragma unroll
+          for (int g = 0; g < GL_G; ++g) {
+            const float m = tag == (uint32_t)g ? 1.f : 0.f;
+            const f2v m2 = {m, m};
+#pragma unroll
+            for (int l = 0; l < NF; ++l) fma4(acc[g][l], sum[l], m2);
+            if (HALF) {
+              f2v ah = {acch[g].x, acch[g].y};
+              const f2v sh2 = {sumh.x, sumh.y};
+              ah = __builtin_elementwise_fma(sh2, m2, ah);
+              acch[g] = make_float2(ah.x, ah.y);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t a = (e[t] & 0xfffu) * LPE;
+            const uint32_t tag = e[t] >> 12;
+            float4 v[NFA];
+            float2 h = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int l = 0; l < NF; ++l) v[l] = xs[a + l];
+            if (HALF) h = *reinterpret_cast<const float2*>(&xs[a + NF]);
+#pragma unroll
+            for (int g = 0; g < GL_G; ++g) {
+              const float m = tag == (uint32_t)g ? 1.f : 0.f;
+              const f2v m2 = {m, m};
+#pragma unroll
+              for (int l = 0; l < NF; ++l) fma4(acc[g][l], v[l], m2);
+              if (HALF) {
+                f2v ah = {acch[g].x, acch[g].y};
+                const f2v h2 = {h.x, h.y};
+                ah = __builtin_elementwise_fma(h2, m2, ah);
+                acch[g] = make_float2(ah.x, ah.y);
+              }
+            }
+          }
+        }
+      };
+#define GL_ROUND(Q)                                                                                                     \
+  {                                                                                                                     \
+    unsigned long long u_; /* the copy is made by the asm itself, after the wait: a C++ copy would share Q's register */ \
+    asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %1" : "=&v"(u_) : "v"(Q) : "memory");                              \
+    GL_LOAD(Q, p);                                                                                                      \
+    p += 64;                                                                                                            \
+    round(u_);                                                                                                          \
+  }
+      for (uint32_t r = 0; r < n; r += 4) {
+        GL_ROUND(r0)
+        GL_ROUND(r1)
+        GL_ROUND(r2)
+        GL_ROUND(r3)
+      }
+#undef GL_ROUND
     }
   }
   if (!wvalid) return;
@@ -556,8 +740,10 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(nwb) + 8));
   HIPCHK(c, c->gl_flag.reserve(4));
   HIPCHK(c, hipMemsetAsync(c->gl_flag.p, 0, sizeof(int), c->stream));
+  const int merge = c->gl_merge;
+  if (PASS == 2 && merge) HIPCHK(c, c->gl_cellpre.reserve((size_t)s.n_out * s.NB));
   hipLaunchKernelGGL((gl_cnt_k<PASS>), dim3(s.nwv), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->gl_cellcnt.p,
-                     c->wperm.p, s.cnt.p, c->gl_srsum.p, c->gl_flag.p);
+                     c->wperm.p, s.cnt.p, c->gl_srsum.p, c->gl_flag.p, merge, c->gl_cellpre.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, c->gl_srsum.p, nwb, s.roff.p, c->gl_scan.p)));
   int overflow = 0;
@@ -573,35 +759,45 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   uint16_t* ids16 = reinterpret_cast<uint16_t*>(s.ids.p);
   if (PASS == 1) {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)GL_RB, n16_all - n16_body, c->stream));
-    if (nwb) hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
-                                c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
+    if (nwb && !merge)
+      hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
+                         c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
+    if (nwb && merge)
+      hipLaunchKernelGGL(gl_fill1m_k, dim3((unsigned)nwb), dim3(64), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
+                         c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p, merge);
     HIPCHK(c, hipGetLastError());
   } else {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
     HIPCHK(c, c->gl_sbase.reserve((size_t)s.nslice * s.NB));
     if (nwb) hipLaunchKernelGGL(gl_sbase_k, dim3(cdiv((long)nwb, 256)), dim3(256), 0, c->stream, s.slice_of.p, s.cnt.p, s.roff.p, nwb, s.NB,
-                                c->gl_sbase.p);
+                                c->gl_sbase.p, merge);
     HIPCHK(c, hipGetLastError());
     const uint32_t nvp = (s.n_out + GL_VP - 1) / GL_VP;
     hipLaunchKernelGGL(gl_hist_fill_k, dim3(s.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, s.n_out,
-                       s.NB, c->wpos.p, c->gl_sbase.p, ids16);
+                       s.NB, c->wpos.p, c->gl_sbase.p, ids16, merge ? c->gl_cellpre.p : nullptr);
     HIPCHK(c, hipGetLastError());
   }
   return 0;
 }
 
-template <int LPE, bool HALF>
-int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap = nullptr,
-                 uint32_t out_ld4 = 0) {
+template <int LPE, bool HALF, int MERGE>
+int launch_apply_m(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)gl_apply_k<LPE, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS));
+    HIPCHK(c, hipFuncSetAttribute((const void*)gl_apply_k<LPE, HALF, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gl_apply_k<LPE, HALF>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
+  hipLaunchKernelGGL((gl_apply_k<LPE, HALF, MERGE>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
                      s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+template <int LPE, bool HALF>
+int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap = nullptr,
+                 uint32_t out_ld4 = 0) {
+  if (c->gl_merge == 1) return launch_apply_m<LPE, HALF, 1>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+  if (c->gl_merge == 2) return launch_apply_m<LPE, HALF, 2>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+  return launch_apply_m<LPE, HALF, 0>(c, s, In, Out, slab_stride, rowmap, out_ld4);
 }
 int launch_apply_any(isle_ctx* c, int LPE, bool half, const GlSide& s, const float4* In, float4* Out, size_t slab_stride) {
   if (LPE == 1) return half ? launch_apply<1, true>(c, s, In, Out, slab_stride) : launch_apply<1, false>(c, s, In, Out, slab_stride);
@@ -648,6 +844,10 @@ int k_gl_detect(isle_ctx* c) {
 
 int k_gl_build(isle_ctx* c) {
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
+  {
+    const char* e = getenv("ISLE_GL_MERGE");  // stream form (gl_cnt_k): 0, 1 or 2
+    c->gl_merge = e ? std::max(0, std::min(2, atoi(e))) : 0;
+  }
   GlSide& s1 = c->gl1;
   GlSide& s2 = c->gl2;
   static bool attr_set = false;

@@ -59,3 +59,13 @@ def test_plan_shards_is_nnz_balanced_and_contiguous():
         nn = np.diff(offs[b.astype(np.int64)])
         assert nn.sum() == offs[-1]
         assert nn.max() - nn.min() <= 2 * lens.max()
+
+
+def test_id_ring_registers_are_left_alone_by_the_compiler():
+    """tools/check_id_ring.py: the merged-stream forms of gl_apply_k load their id ring by inline asm; no compiler-generated
+    instruction may name a ring register while loads can be in flight (cross-compiles gram_lds.hip for gfx950, no GPU)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_id_ring.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("0 foreign uses") == 12
