@@ -888,6 +888,11 @@ struct Ks {
     // costs ~20 us of queue time).  A rank-deficient panel (never seen on thresholded matrices) discards the speculative
     // work and repairs, as the synchronous form (ISLE_KS_SYNC=1) does.
     const bool pipelined = !getenv("ISLE_KS_SYNC");
+    // Passes of block Gram-Schmidt against the basis per step.  The reference makes three (CGS + 2 DGKS, :83-91); the second
+    // already leaves coefficients at rounding level ("twice is enough"), so two are made here and the third
+    // block of coefficients that the reference adds into H is zero.  ISLE_KS_ORTHO_PASSES=3 restores the reference's count.
+    int npass = 2;
+    if (const char* e = getenv("ISLE_KS_ORTHO_PASSES")) npass = std::max(2, std::min(3, atoi(e)));
     constexpr size_t MB_R = 64, MB_COEF = 64 + 32 * 32;  // mailbox offsets (floats): [meta ints | R | coefficients]
     const size_t mb_floats = MB_COEF + 3 * cap_r * blk;
     HIPCHK(c, c->ks_mail.reserve(mb_floats));
@@ -904,18 +909,18 @@ struct Ks {
       float* F = c->Fbuf.p;
       if (!spec) {
         ISLECHK(apply(col(hcn), F));
-        ISLECHK(ortho(F, (int)blk, m, 3, mail + MB_COEF));  // CGS + 2 DGKS passes (:83-91)
+        ISLECHK(ortho(F, (int)blk, m, npass, mail + MB_COEF));
       }
       spec = false;
       if (m + blk > cap_r || hcn + blk > cap_c) return isle_fail(c, ISLE_E_NUMERIC, "expand: projected matrix outgrew its work space");
       ISLECHK(k_panel_qr_kernels(c, F, dim, (int)blk, col(hcn + blk), reinterpret_cast<int*>(mail), mail + MB_R));
       float* hm = host_mail[slot].data();
-      HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + 3 * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + (size_t)npass * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipEventRecord(c->ks_ev[slot], c->stream));
       const bool more = m + blk < ncv;
       if (pipelined && more) {  // speculate: full rank -> next step works on the blk new columns with m + blk basis vectors
         ISLECHK(apply(col(hcn + blk), F));
-        ISLECHK(ortho(F, (int)blk, m + blk, 3, mail + MB_COEF));  // behind the copy on the same stream: no hazard
+        ISLECHK(ortho(F, (int)blk, m + blk, npass, mail + MB_COEF));  // behind the copy on the same stream: no hazard
         spec = true;
       }
       HIPCHK(c, hipEventSynchronize(c->ks_ev[slot]));
@@ -928,7 +933,7 @@ struct Ks {
         for (size_t i = 0; i < m; ++i) {
           float h = hc[j * m + i];
           h = h + hc[m * blk + j * m + i];
-          h = h + hc[2 * m * blk + j * m + i];
+          if (npass > 2) h = h + hc[2 * m * blk + j * m + i];
           W(i, hcn + j) = h;
         }
       for (size_t j = 0; j < blk; ++j)
