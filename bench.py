@@ -192,7 +192,7 @@ def main():
         pass
     device_ms = {f: round(v[0] / steps, 3) for f, v in tm.items() if v[1]}
     form = hp.operator_form()
-    form_kernels = ("LDS-banded form: gl_scale_k + gl_apply_k<3,true> (pass 1) + gl_apply_k<3,true> + gl_reduce_k (pass 2)" if form == 1
+    form_kernels = ("LDS-banded form: gl_scale_k + gl_apply_k<3,true,0> (pass 1) + gl_apply_k<3,true,0> + gl_reduce_k (pass 2)" if form == 1
                     else "gather form: seg_gather_k<3,false> (pass 1) + seg_gather_k<3,true> + reduce_chunks_k (pass 2)")
     if form != 1:
         traffic = None  # profiles/pmc_traffic.json holds the LDS-banded form's counters
