@@ -187,6 +187,11 @@ extern "C" isle_ctx* isle_hip_create(int device_id) {
   }
   const char* br = getenv("ISLE_CHUNK_COLS");
   if (br) c->band_rows = (uint32_t)atoi(br);
+  if (hipHostMalloc((void**)&c->pin, isle_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return nullptr;
+  }
   return c;
 }
 
@@ -195,6 +200,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->pin) (void)hipHostFree(c->pin);
   for (auto& e : c->ev_used) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -898,9 +904,16 @@ struct Ks {
     HIPCHK(c, c->ks_mail.reserve(mb_floats));
     for (int i = 0; i < 2; ++i)
       if (!c->ks_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ks_ev[i], hipEventDisableTiming));
-    std::vector<float> host_mail[2];
-    host_mail[0].resize(mb_floats);
-    host_mail[1].resize(mb_floats);
+    std::vector<float> host_mail_pageable[2];
+    float* host_mail[2];
+    for (int i = 0; i < 2; ++i) {
+      if (mb_floats * sizeof(float) <= isle_ctx::PIN_MAIL_SLOT) {  // page-locked: the copy below then really is asynchronous
+        host_mail[i] = reinterpret_cast<float*>(c->pin + isle_ctx::PIN_MAIL + (size_t)i * isle_ctx::PIN_MAIL_SLOT);
+      } else {
+        host_mail_pageable[i].resize(mb_floats);
+        host_mail[i] = host_mail_pageable[i].data();
+      }
+    }
     float* mail = c->ks_mail.p;
     bool spec = false;  // apply + ortho of the current step already enqueued
     int slot = 0;
@@ -914,7 +927,7 @@ struct Ks {
       spec = false;
       if (m + blk > cap_r || hcn + blk > cap_c) return isle_fail(c, ISLE_E_NUMERIC, "expand: projected matrix outgrew its work space");
       ISLECHK(k_panel_qr_kernels(c, F, dim, (int)blk, col(hcn + blk), reinterpret_cast<int*>(mail), mail + MB_R));
-      float* hm = host_mail[slot].data();
+      float* hm = host_mail[slot];
       HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + (size_t)npass * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipEventRecord(c->ks_ev[slot], c->stream));
       const bool more = m + blk < ncv;
@@ -1183,18 +1196,24 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   double grand = 0.0, last_md = 0.0;
   const int maxdraw = 2 + (int)std::ceil(std::sqrt((double)k));
   std::vector<double> dice(maxdraw);
-  std::vector<uint64_t> drawn(maxdraw);
+  // page-locked staging for the per-round scalars: [my 2 | tot 2 * world | local maxdraw] doubles, then drawn maxdraw u64
+  double* pin_d = reinterpret_cast<double*>(c->pin + isle_ctx::PIN_SMALL);
+  if ((size_t)(2 + 2 * c->world + 2 * maxdraw) * 8 > (128u << 10)) return isle_fail(c, ISLE_E_ARG, "k-means++: staging area too small");
+  double* my = pin_d;
+  double* tot = pin_d + 2;
+  double* local = tot + 2 * c->world;
+  uint64_t* drawn = reinterpret_cast<uint64_t*>(local + maxdraw);
   while ((int)centers.size() < k) {
     rounds++;
     ISLECHK(k_kmpp_update(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p + (centers.size() - new_added) * (size_t)ldk, new_added,
                           c->min_dist.p));
     ISLECHK(k_scan_f2d(c, c->min_dist.p, D, c->cum.p));  // :2170-2172 (double, parallel; the reference's is fp32 sequential)
     // totals (per rank) -> offsets
-    double my[2] = {0.0, 0.0};
+    my[0] = my[1] = 0.0;
     ISLECHK(k_pack2(c, c->cum.p + D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, c->gram.p + 200));
     HIPCHK(c, hipMemcpyAsync(my, c->gram.p + 200, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // one copy, one round trip for both scalars
-    std::vector<double> tot(2 * c->world, 0.0);
+    for (int r = 0; r < 2 * c->world; ++r) tot[r] = 0.0;
     if (multi) {
       double* dv = c->gram.p;
       HIPCHK(c, hipMemcpyAsync(dv + 2 * c->world, my, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1202,7 +1221,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
         TimeScope ts(c, ISLE_T_COMM);
         ISLECHK(isle_allgather(c, dv + 2 * c->world, dv, 2, ISLE_DT_F64));
       }
-      HIPCHK(c, hipMemcpyAsync(tot.data(), dv, 2 * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(tot, dv, 2 * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     } else {
       tot[0] = my[0];
@@ -1221,7 +1240,6 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     ndraw = std::min(ndraw, maxdraw);
     if (!inject) {
       // all ranks draw the same dice; the owner of the interval searches its local prefix sums
-      std::vector<double> local(ndraw, -1.0);
       for (int i = 0; i < ndraw; ++i) {
         dice[i] = grand * rng.fraction();  // :2184
         const double x = dice[i] - my_off;
@@ -1231,21 +1249,21 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
       double* dd = c->gram.p + 64;
       uint64_t* od = (uint64_t*)(c->gram.p + 128);
       if (ndraw <= 16) {
-        ISLECHK(k_search_args(c, c->cum.p, D, local.data(), ndraw, od));  // dice as kernel arguments
+        ISLECHK(k_search_args(c, c->cum.p, D, local, ndraw, od));  // dice as kernel arguments
       } else {
-        HIPCHK(c, hipMemcpyAsync(dd, local.data(), ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
+        HIPCHK(c, hipMemcpyAsync(dd, local, ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
         ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
       }
-      HIPCHK(c, hipMemcpyAsync(drawn.data(), od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(drawn, od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       for (int i = 0; i < ndraw; ++i) {
         if (local[i] < 0.0 || D == 0) drawn[i] = 0;
         else drawn[i] = std::min<uint64_t>(drawn[i], D - 1) + c->doc_offset + 1;  // +1: zero means "not mine"
       }
       if (multi) {
-        HIPCHK(c, hipMemcpy(od, drawn.data(), ndraw * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpyAsync(od, drawn, ndraw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         ISLECHK(allreduce_sum<uint64_t>(c, od, ndraw));
-        HIPCHK(c, hipMemcpyAsync(drawn.data(), od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(drawn, od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
       }
       for (int i = 0; i < ndraw; ++i) drawn[i] = drawn[i] ? drawn[i] - 1 : 0;
@@ -1307,10 +1325,10 @@ struct StopRule {
         HIPCHK(c, c->flags.reserve(16));
         ISLECHK(k_compare_u32(c, assign, c->assign_prev.p, c->D, c->flags.p));
         ISLECHK(allreduce_sum<int>(c, c->flags.p, 1));
-        int f = 0;
-        HIPCHK(c, hipMemcpyAsync(&f, c->flags.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int* f = reinterpret_cast<int*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10));  // page-locked
+        HIPCHK(c, hipMemcpyAsync(f, c->flags.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        changed = f != 0;
+        changed = *f != 0;
       }
       HIPCHK(c, c->assign_prev.reserve(c->D ? c->D : 1));
       if (c->D) HIPCHK(c, hipMemcpyAsync(c->assign_prev.p, assign, c->D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -1324,10 +1342,15 @@ struct StopRule {
 
 static int fetch_sizes(isle_ctx* c, int k, std::vector<long long>& sizes) {
   ISLECHK(allreduce_sum<int>(c, c->counts.p, k));
-  std::vector<int> h(k);
-  HIPCHK(c, hipMemcpyAsync(h.data(), c->counts.p, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  std::vector<int> hv;
+  int* h = reinterpret_cast<int*>(c->pin + isle_ctx::PIN_SMALL + (128u << 10));  // page-locked, 64 KB
+  if ((size_t)k * sizeof(int) > (64u << 10)) {
+    hv.resize(k);
+    h = hv.data();
+  }
+  HIPCHK(c, hipMemcpyAsync(h, c->counts.p, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  sizes.assign(h.begin(), h.end());
+  sizes.assign(h, h + k);
   return 0;
 }
 
@@ -1368,9 +1391,10 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
     } else {
       uint32_t* nact = c->active.p + D;
       ISLECHK(k_hamerly_filter(c, nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, top_dev, c->active.p, nact, ISLE_T_LLOYD_PROJ));
-      uint32_t na = 0;
-      HIPCHK(c, hipMemcpyAsync(&na, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      uint32_t* na_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 64);  // page-locked
+      HIPCHK(c, hipMemcpyAsync(na_pin, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      const uint32_t na = *na_pin;
       ISLECHK(k_proj_assign_active(c, c->P.p, c->pnorm.p, k, ldk, c->Cdev.p, c->cnorm.p, c->active.p, na, c->Pa.p, c->pna.p, c->assign.p,
                                    c->hub.p, c->hlb.p));
     }

@@ -62,6 +62,12 @@ struct isle_ctx {
   std::string err;
   int num_cus = 256;
 
+  // --- page-locked host memory for the small per-iteration copies of the control loops (mailboxes, scalars, flags): a
+  // hipMemcpyAsync to or from pageable memory blocks the host until the copy has run, which serialises the enqueue-ahead
+  // loops (api.cpp); PIN_* are fixed regions of it
+  char* pin = nullptr;
+  static constexpr size_t PIN_MAIL = 0, PIN_MAIL_SLOT = 1u << 20, PIN_SMALL = 2u << 20, PIN_BYTES = (2u << 20) + (256u << 10);
+
   // --- communicator (null for single GPU)
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
