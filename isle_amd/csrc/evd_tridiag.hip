@@ -3,7 +3,8 @@
 //
 // The block Jacobi solver of dense.hip needs 11-13 sweeps on Ritz matrices (clustered spectrum: eight or nine sweeps in which
 // every column pair still rotates), each sweep a chain of n/16 dependent rounds.  Here, in fp64 throughout:
-//   1. Householder tridiagonalisation S = Q T Q^T, one column per step.  Two launches per column: td_step_k (one workgroup:
+//   1. Householder tridiagonalisation S = Q T Q^T, one column per step.  n <= 512: td_persist_k, one launch with the matrix
+//      resident in the LDS of 32 workgroups and two grid barriers per column (see there).  Larger n — two launches per column: td_step_k (one workgroup:
 //      finish p = tau A v from the partial products, w = p - tau/2 (p.v) v, then the next column of the updated matrix and its
 //      reflector) and td_update_symv_k (all workgroups: A -= v w^T + w v^T fused with the partial products A v_next of the
 //      next step, per column block, summed later in fixed order — no atomics, bitwise reproducible).
@@ -201,6 +202,139 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
   td_step_dev<PT>(A, n, j + 1, 0, 1, psum, w, d, e, tau);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of the tridiagonalisation for n <= TD_P_NMAX: ONE launch, TD_P_G workgroups, the matrix resident in LDS.
+// Workgroup g owns the columns c = g (mod TD_P_G) of the (full, symmetric) trailing matrix.  Per column cj:
+//   owner of cj:  d[cj], the reflector v (A[cj+1:, cj] in the layout td_back_k reads), e[cj], tau[cj]   -> grid barrier
+//   everybody:    p_c = tau * <column c, v> for the owned columns c > cj                                   -> grid barrier
+//   everybody:    w = p - tau/2 (p.v) v  (redundantly, same order everywhere), owned columns -= v w_c + w v_c
+// so a column costs two grid barriers instead of a launch (14 us of kernel plus 4-5 us of dependent-launch gap in the chain of
+// td_update_symv_k).  What crosses workgroups (v, p, tau) goes through device-scope relaxed atomics (sc1 accesses: coherent in
+// memory, no cache write-back / invalidate), ordered by a workgroup-scope release (the stores have left the wave) before the
+// counter is bumped.  A barrier gives up after a bounded spin and raises `abort` (a workgroup that is not resident would
+// otherwise hang the GPU); the host then runs the launch chain instead.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TD_P_G = 32;
+constexpr int TD_P_NMAX = 512;
+constexpr int TD_P_T = 256;
+
+__device__ inline double td_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void td_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline bool td_grid_barrier(unsigned int* ctr, unsigned int target, unsigned int* abort) {
+  __shared__ unsigned int ok;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have been issued and acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#ifdef TD_BARRIER_RELAXED  /* 8 % faster at n = 400 (4.6 against 5.0 ms per solve); relies on sc1 accesses being performed at the coherence point once acknowledged */
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    unsigned int spins = 0, good = 1;
+#ifdef TD_BARRIER_RELAXED
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+#else
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+#endif
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 0x3ffu) == 0 && (spins > (1u << 24) || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+    }
+    ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+
+__global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
+                                                        double* __restrict__ tau, double* __restrict__ vbuf, double* __restrict__ pbuf,
+                                                        double* __restrict__ tbuf, unsigned int* __restrict__ ctr, unsigned int* __restrict__ abort) {
+  extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n
+  __shared__ double sh[16];
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ncl = (n + TD_P_G - 1) / TD_P_G;
+  double* slab = lds;
+  double* vs = slab + (size_t)ncl * n;
+  double* ws = vs + n;
+  for (int lc = 0; lc < ncl; ++lc) {
+    const int c = lc * TD_P_G + g;
+    if (c < n)
+      for (int i = t; i < n; i += TD_P_T) slab[(size_t)lc * n + i] = A[(size_t)c * n + i];
+  }
+  __syncthreads();
+  unsigned int phase = 0;
+  for (int cj = 0; cj < n - 1; ++cj) {
+    const int r0 = cj + 1;  // first row / column of the trailing block
+    if (cj % TD_P_G == g) {  // ---- owner: reflector of column cj (formulas of td_step_dev)
+      const double* col = slab + (size_t)(cj / TD_P_G) * n;
+      double nrm2 = 0.0;
+      for (int i = r0 + 1 + t; i < n; i += TD_P_T) nrm2 = fma(col[i], col[i], nrm2);
+      nrm2 = td_block_sum(nrm2, sh);
+      const double alpha = col[r0];
+      double beta = alpha, tv = 0.0, scale = 0.0;
+      if (nrm2 > 0.0) {
+        beta = -copysign(sqrt(fma(alpha, alpha, nrm2)), alpha);
+        tv = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      if (t == 0) {
+        d[cj] = col[cj];
+        e[cj] = beta;
+        tau[cj] = tv;
+        td_st(tbuf, tv);
+      }
+      for (int i = r0 + t; i < n; i += TD_P_T) {
+        const double v = (i == r0) ? 1.0 : col[i] * scale;
+        A[(size_t)cj * n + i] = v;  // for the back-transformation (read by a later launch)
+        td_st(vbuf + i, v);
+      }
+    }
+    if (!td_grid_barrier(ctr, ++phase * TD_P_G, abort)) return;
+    // ---- p_c = tau <column c, v> for the owned columns of the trailing block: one wave per column
+    const double tj = td_ld(tbuf);
+    for (int i = r0 + t; i < n; i += TD_P_T) vs[i] = td_ld(vbuf + i);
+    __syncthreads();
+    for (int lc = wave; lc < ncl; lc += TD_P_T / 64) {
+      const int c = lc * TD_P_G + g;
+      if (c >= r0 && c < n) {  // wave-uniform
+        const double* col = slab + (size_t)lc * n;
+        double s = 0.0;
+        for (int i = r0 + lane; i < n; i += 64) s = fma(col[i], vs[i], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) td_st(pbuf + c, tj * s);
+      }
+    }
+    if (!td_grid_barrier(ctr, ++phase * TD_P_G, abort)) return;
+    // ---- w = p - tau/2 (p.v) v, then the rank-2 update of the owned columns
+    double dot = 0.0;
+    for (int i = r0 + t; i < n; i += TD_P_T) {
+      const double p = td_ld(pbuf + i);
+      ws[i] = p;
+      dot = fma(p, vs[i], dot);
+    }
+    dot = td_block_sum(dot, sh);
+    const double a2 = -0.5 * tj * dot;
+    __syncthreads();
+    for (int i = r0 + t; i < n; i += TD_P_T) ws[i] = fma(a2, vs[i], ws[i]);
+    __syncthreads();
+    for (int lc = wave; lc < ncl; lc += TD_P_T / 64) {
+      const int c = lc * TD_P_G + g;
+      if (c >= r0 && c < n) {
+        double* col = slab + (size_t)lc * n;
+        const double vc = vs[c], wc = ws[c];
+        for (int i = r0 + lane; i < n; i += 64) col[i] -= vs[i] * wc + ws[i] * vc;
+      }
+    }
+    __syncthreads();
+  }
+  if ((n - 1) % TD_P_G == g && t == 0) d[n - 1] = slab[(size_t)((n - 1) / TD_P_G) * n + (n - 1)];
+}
+
 // Eigenvalue number idx (ascending) of the tridiagonal (d, e) by multisection on the Sturm count: one wave per eigenvalue, the
 // 64 lanes count at 64 interior points of the current interval, which shrinks 65-fold per pass (ten passes instead of
 // fifty-odd dependent bisection steps of n divisions each).  Output descending.
@@ -396,7 +530,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
   const int nrb_max = TD_NRB;
-  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8;
+  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8 + 2 * (size_t)n + 8;
   HIPCHK(c, c->jacW.reserve(need));
   double* A = c->jacW.p;
   double* part = A + nn;
@@ -412,32 +546,56 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   unsigned int* worst = reinterpret_cast<unsigned int*>(Z + (size_t)n * nvec);
   unsigned int* tickets = worst + 2;  // n + 1 counters, then n x nrb_max row-block counters
   unsigned int* tickets_rb = tickets + n + 2;
+  // persistent form: v | p | tau_j behind the counters, rounded up to a double boundary
+  double* pv = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tickets_rb + (size_t)n * nrb_max + 2) + 7) & ~(uintptr_t)7);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(c, hipFuncSetAttribute((const void*)td_back_k, hipFuncAttributeMaxDynamicSharedMemorySize, TD_NMAX_BACK * 8 * (int)sizeof(double)));
     attr_set = true;
   }
-  HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
-  HIPCHK(c, hipMemsetAsync(e, 0, (size_t)n * sizeof(double), c->stream));
-  HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4 + (size_t)n * nrb_max + 4) * sizeof(unsigned int), c->stream));
-  // ---- 1. tridiagonalisation
   const bool small = n <= TD_ROWS * 4;
-  if (small) hipLaunchKernelGGL((td_first_k<4>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
-  else hipLaunchKernelGGL((td_first_k<16>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
-  // F_j = update of step j fused with the products of step j + 1 and, in its last workgroup, step j + 1 itself
-  for (int j = -1; j <= n - 3; ++j) {
-    const int m = n - (j + 2);
-    const int ncb = (m + CB - 1) / CB;
-    const dim3 g((m + TD_ROWS - 1) / TD_ROWS, ncb);
-    if (small)
-      hipLaunchKernelGGL((td_update_symv_k<4>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, psum, d, e, tau,
-                         tickets, tickets_rb);
-    else
-      hipLaunchKernelGGL((td_update_symv_k<16>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, psum, d, e, tau,
-                         tickets, tickets_rb);
+  bool persist = n <= TD_P_NMAX && !getenv("ISLE_TD_CHAIN");
+  const size_t p_lds = ((size_t)((n + TD_P_G - 1) / TD_P_G) * n + 2 * (size_t)n) * sizeof(double);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(e, 0, (size_t)n * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4 + (size_t)n * nrb_max + 4) * sizeof(unsigned int), c->stream));
+    // ---- 1. tridiagonalisation
+    if (persist) {
+      // one launch, matrix resident in LDS, two grid barriers per column (td_persist_k); tickets[0] = barrier counter, [1] = abort
+      static bool p_attr = false;
+      if (!p_attr) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)td_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        p_attr = true;
+      }
+      hipLaunchKernelGGL(td_persist_k, dim3(TD_P_G), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, pv + n, pv + 2 * n, tickets, tickets + 1);
+      HIPCHK(c, hipGetLastError());
+      unsigned int aborted = 0;
+      HIPCHK(c, hipMemcpyAsync(&aborted, tickets + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (!aborted) break;
+      fprintf(stderr, "[isle_hip] persistent tridiagonalisation gave up at a grid barrier (n = %d): using the launch chain\n", n);
+      persist = false;
+      continue;
+    }
+    if (small) hipLaunchKernelGGL((td_first_k<4>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
+    else hipLaunchKernelGGL((td_first_k<16>), dim3(1), dim3(TD_ROWS), 0, c->stream, A, n, w, d, e, tau);
+    // F_j = update of step j fused with the products of step j + 1 and, in its last workgroup, step j + 1 itself
+    for (int j = -1; j <= n - 3; ++j) {
+      const int m = n - (j + 2);
+      const int ncb = (m + CB - 1) / CB;
+      const dim3 g((m + TD_ROWS - 1) / TD_ROWS, ncb);
+      if (small)
+        hipLaunchKernelGGL((td_update_symv_k<4>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, psum, d, e, tau,
+                           tickets, tickets_rb);
+      else
+        hipLaunchKernelGGL((td_update_symv_k<16>), g, dim3(TD_ROWS), 3 * CB * sizeof(double), c->stream, A, n, j, j >= 0 ? 1 : 0, CB, w, part, psum, d, e, tau,
+                           tickets, tickets_rb);
+    }
+    HIPCHK(c, hipGetLastError());
+    break;
   }
-  HIPCHK(c, hipGetLastError());
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
   hipLaunchKernelGGL(td_bisect_k, dim3((n + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
   hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
