@@ -204,15 +204,16 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent form of the tridiagonalisation for n <= TD_P_NMAX: ONE launch, TD_P_G workgroups, the matrix resident in LDS.
-// Workgroup g owns the columns c = g (mod TD_P_G) of the (full, symmetric) trailing matrix.  Per column cj:
-//   owner of cj:  d[cj], the reflector v (A[cj+1:, cj] in the layout td_back_k reads), e[cj], tau[cj]   -> grid barrier
-//   everybody:    p_c = tau * <column c, v> for the owned columns c > cj                                   -> grid barrier
-//   everybody:    w = p - tau/2 (p.v) v  (redundantly, same order everywhere), owned columns -= v w_c + w v_c
-// so a column costs two grid barriers instead of a launch (14 us of kernel plus 4-5 us of dependent-launch gap in the chain of
-// td_update_symv_k).  What crosses workgroups (v, p, tau) goes through device-scope relaxed atomics (sc1 accesses: coherent in
-// memory, no cache write-back / invalidate), ordered by a workgroup-scope release (the stores have left the wave) before the
-// counter is bumped.  A barrier gives up after a bounded spin and raises `abort` (a workgroup that is not resident would
-// otherwise hang the GPU); the host then runs the launch chain instead.
+// Workgroup g owns the columns c = g (mod TD_P_G) of the (full, symmetric) trailing matrix.  Every workgroup holds the current
+// reflector v (computed redundantly: same data, same order, same bits).  Per column cj:
+//   everybody:    p_c = tau * <column c, v> for the owned columns c > cj; the owner of column cj + 1 publishes it  -> grid barrier
+//   everybody:    w = p - tau/2 (p.v) v, column cj + 1 of the updated matrix and from it the NEXT reflector (all redundantly),
+//                 owned columns -= v w_c + w v_c;  the owner of cj + 1 writes d, e, tau and the reflector for td_back_k
+// so a column costs ONE grid barrier instead of a launch (14 us of kernel plus 4-5 us of dependent-launch gap in the chain of
+// td_update_symv_k).  What crosses workgroups (p, the published column; double-buffered by the parity of cj) goes through
+// device-scope atomics (sc1 accesses: coherent in memory), ordered by the release / acquire of the barrier counter.  A barrier
+// gives up after a bounded spin and raises `abort` (a workgroup that is not resident would otherwise hang the GPU); the host
+// then runs the launch chain instead.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TD_P_G = 32;
 constexpr int TD_P_NMAX = 512;
@@ -250,54 +251,60 @@ __device__ inline bool td_grid_barrier(unsigned int* ctr, unsigned int target, u
   return ok != 0;
 }
 
+// Reflector of a column held in LDS (cn[r0 - 1 .. n - 1], cn[r0 - 1] the diagonal entry): the formulas of td_step_dev.  Every
+// workgroup runs this on the same data in the same order, so v and tau are bit-identical everywhere without a broadcast.
+// Leaves v in vs[r0 .. n - 1]; returns tau; the owner also writes d, e, tau (the reflector itself goes to A behind the next barrier:
+// column 0 of A is still being read by the other workgroups when the first reflector is ready).
+__device__ inline double td_p_reflector(const double* cn, double* vs, int n, int cj, bool owner, double* __restrict__ d,
+                                        double* __restrict__ e, double* __restrict__ tau, double* sh) {
+  const int t = threadIdx.x, r0 = cj + 1;
+  double nrm2 = 0.0;
+  for (int i = r0 + 1 + t; i < n; i += TD_P_T) nrm2 = fma(cn[i], cn[i], nrm2);
+  nrm2 = td_block_sum(nrm2, sh);
+  const double alpha = cn[r0];
+  double beta = alpha, tv = 0.0, scale = 0.0;
+  if (nrm2 > 0.0) {
+    beta = -copysign(sqrt(fma(alpha, alpha, nrm2)), alpha);
+    tv = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  if (owner && t == 0) {
+    d[cj] = cn[cj];
+    e[cj] = beta;
+    tau[cj] = tv;
+  }
+  for (int i = r0 + t; i < n; i += TD_P_T) vs[i] = (i == r0) ? 1.0 : cn[i] * scale;
+  __syncthreads();
+  return tv;
+}
+
 __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
-                                                        double* __restrict__ tau, double* __restrict__ vbuf, double* __restrict__ pbuf,
-                                                        double* __restrict__ tbuf, unsigned int* __restrict__ ctr, unsigned int* __restrict__ abort) {
-  extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n
+                                                        double* __restrict__ tau, double* __restrict__ xbuf /* 2 x (p | next column), 4 n */,
+                                                        unsigned int* __restrict__ ctr, unsigned int* __restrict__ abort) {
+  extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n | cn n
   __shared__ double sh[16];
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ncl = (n + TD_P_G - 1) / TD_P_G;
   double* slab = lds;
   double* vs = slab + (size_t)ncl * n;
   double* ws = vs + n;
+  double* cn = ws + n;
   for (int lc = 0; lc < ncl; ++lc) {
     const int c = lc * TD_P_G + g;
     if (c < n)
       for (int i = t; i < n; i += TD_P_T) slab[(size_t)lc * n + i] = A[(size_t)c * n + i];
   }
+  // column 0 is read by everybody from the input itself (nothing has been written yet)
+  for (int i = t; i < n; i += TD_P_T) cn[i] = A[i];
   __syncthreads();
+  double tj = td_p_reflector(cn, vs, n, 0, g == 0, d, e, tau, sh);
   unsigned int phase = 0;
   for (int cj = 0; cj < n - 1; ++cj) {
     const int r0 = cj + 1;  // first row / column of the trailing block
-    if (cj % TD_P_G == g) {  // ---- owner: reflector of column cj (formulas of td_step_dev)
-      const double* col = slab + (size_t)(cj / TD_P_G) * n;
-      double nrm2 = 0.0;
-      for (int i = r0 + 1 + t; i < n; i += TD_P_T) nrm2 = fma(col[i], col[i], nrm2);
-      nrm2 = td_block_sum(nrm2, sh);
-      const double alpha = col[r0];
-      double beta = alpha, tv = 0.0, scale = 0.0;
-      if (nrm2 > 0.0) {
-        beta = -copysign(sqrt(fma(alpha, alpha, nrm2)), alpha);
-        tv = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-      }
-      if (t == 0) {
-        d[cj] = col[cj];
-        e[cj] = beta;
-        tau[cj] = tv;
-        td_st(tbuf, tv);
-      }
-      for (int i = r0 + t; i < n; i += TD_P_T) {
-        const double v = (i == r0) ? 1.0 : col[i] * scale;
-        A[(size_t)cj * n + i] = v;  // for the back-transformation (read by a later launch)
-        td_st(vbuf + i, v);
-      }
-    }
-    if (!td_grid_barrier(ctr, ++phase * TD_P_G, abort)) return;
-    // ---- p_c = tau <column c, v> for the owned columns of the trailing block: one wave per column
-    const double tj = td_ld(tbuf);
-    for (int i = r0 + t; i < n; i += TD_P_T) vs[i] = td_ld(vbuf + i);
-    __syncthreads();
+    double* pbuf = xbuf + (size_t)(cj & 1) * 2 * n;  // double-buffered: a fast workgroup writes step cj + 1 while a slow one still reads step cj
+    double* cbuf = pbuf + n;
+    // ---- p_c = tau <column c, v> for the owned columns of the trailing block (one wave per column); the owner of column r0 also
+    //      publishes that column as it is BEFORE this step's update
     for (int lc = wave; lc < ncl; lc += TD_P_T / 64) {
       const int c = lc * TD_P_G + g;
       if (c >= r0 && c < n) {  // wave-uniform
@@ -309,8 +316,14 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
         if (lane == 0) td_st(pbuf + c, tj * s);
       }
     }
+    if (r0 % TD_P_G == g) {
+      const double* col = slab + (size_t)(r0 / TD_P_G) * n;
+      for (int i = r0 + t; i < n; i += TD_P_T) td_st(cbuf + i, col[i]);
+    }
     if (!td_grid_barrier(ctr, ++phase * TD_P_G, abort)) return;
-    // ---- w = p - tau/2 (p.v) v, then the rank-2 update of the owned columns
+    if (cj % TD_P_G == g)  // the reflector where td_back_k (a later launch) reads it
+      for (int i = r0 + t; i < n; i += TD_P_T) A[(size_t)cj * n + i] = vs[i];
+    // ---- w = p - tau/2 (p.v) v  (redundantly, same order everywhere)
     double dot = 0.0;
     for (int i = r0 + t; i < n; i += TD_P_T) {
       const double p = td_ld(pbuf + i);
@@ -322,6 +335,12 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
     __syncthreads();
     for (int i = r0 + t; i < n; i += TD_P_T) ws[i] = fma(a2, vs[i], ws[i]);
     __syncthreads();
+    // ---- column r0 of the updated matrix, by everybody: the next reflector needs no second barrier
+    {
+      const double vr = vs[r0], wr = ws[r0];  // v[r0] = 1
+      for (int i = r0 + t; i < n; i += TD_P_T) cn[i] = td_ld(cbuf + i) - (vs[i] * wr + ws[i] * vr);
+    }
+    // ---- rank-2 update of the owned columns
     for (int lc = wave; lc < ncl; lc += TD_P_T / 64) {
       const int c = lc * TD_P_G + g;
       if (c >= r0 && c < n) {
@@ -331,8 +350,9 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       }
     }
     __syncthreads();
+    if (r0 < n - 1) tj = td_p_reflector(cn, vs, n, r0, r0 % TD_P_G == g, d, e, tau, sh);
+    else if (r0 % TD_P_G == g && t == 0) d[n - 1] = cn[n - 1];
   }
-  if ((n - 1) % TD_P_G == g && t == 0) d[n - 1] = slab[(size_t)((n - 1) / TD_P_G) * n + (n - 1)];
 }
 
 // Eigenvalue number idx (ascending) of the tridiagonal (d, e) by multisection on the Sturm count: one wave per eigenvalue, the
@@ -530,7 +550,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
   const int nrb_max = TD_NRB;
-  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8 + 2 * (size_t)n + 8;
+  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8 + 4 * (size_t)n + 8;
   HIPCHK(c, c->jacW.reserve(need));
   double* A = c->jacW.p;
   double* part = A + nn;
@@ -546,7 +566,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   unsigned int* worst = reinterpret_cast<unsigned int*>(Z + (size_t)n * nvec);
   unsigned int* tickets = worst + 2;  // n + 1 counters, then n x nrb_max row-block counters
   unsigned int* tickets_rb = tickets + n + 2;
-  // persistent form: v | p | tau_j behind the counters, rounded up to a double boundary
+  // persistent form: 2 x (p | next column) behind the counters, rounded up to a double boundary
   double* pv = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tickets_rb + (size_t)n * nrb_max + 2) + 7) & ~(uintptr_t)7);
   static bool attr_set = false;
   if (!attr_set) {
@@ -555,7 +575,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   }
   const bool small = n <= TD_ROWS * 4;
   bool persist = n <= TD_P_NMAX && !getenv("ISLE_TD_CHAIN");
-  const size_t p_lds = ((size_t)((n + TD_P_G - 1) / TD_P_G) * n + 2 * (size_t)n) * sizeof(double);
+  const size_t p_lds = ((size_t)((n + TD_P_G - 1) / TD_P_G) * n + 3 * (size_t)n) * sizeof(double);
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
@@ -569,7 +589,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
         HIPCHK(c, hipFuncSetAttribute((const void*)td_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         p_attr = true;
       }
-      hipLaunchKernelGGL(td_persist_k, dim3(TD_P_G), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, pv + n, pv + 2 * n, tickets, tickets + 1);
+      hipLaunchKernelGGL(td_persist_k, dim3(TD_P_G), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, tickets, tickets + 1);
       HIPCHK(c, hipGetLastError());
       unsigned int aborted = 0;
       HIPCHK(c, hipMemcpyAsync(&aborted, tickets + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
