@@ -203,8 +203,8 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Persistent form of the tridiagonalisation for n <= TD_P_NMAX: ONE launch, TD_P_G workgroups, the matrix resident in LDS.
-// Workgroup g owns the columns c = g (mod TD_P_G) of the (full, symmetric) trailing matrix.  Every workgroup holds the current
+// Persistent form of the tridiagonalisation: ONE launch, G workgroups (32 for n <= 512, up to one per CU for n <= 2048), the
+// matrix resident in LDS.  Workgroup g owns the columns c = g (mod G) of the (full, symmetric) trailing matrix.  Every workgroup holds the current
 // reflector v (computed redundantly: same data, same order, same bits).  Per column cj:
 //   everybody:    p_c = tau * <column c, v> for the owned columns c > cj; the owner of column cj + 1 publishes it  -> grid barrier
 //   everybody:    w = p - tau/2 (p.v) v, column cj + 1 of the updated matrix and from it the NEXT reflector (all redundantly),
@@ -215,9 +215,10 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
 // gives up after a bounded spin and raises `abort` (a workgroup that is not resident would otherwise hang the GPU); the host
 // then runs the launch chain instead.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int TD_P_G = 32;
-constexpr int TD_P_NMAX = 512;
+constexpr int TD_P_GSMALL = 32;   // workgroups for n <= 512 (more only add barrier latency)
 constexpr int TD_P_T = 256;
+constexpr int TD_P_MAXPT = TD_NMAX_BACK / TD_P_T;  // column entries per thread
+constexpr size_t TD_P_LDS = 160 * 1024 - 512;  // dynamic part: the kernel also has a few static words
 
 __device__ inline double td_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void td_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -239,7 +240,7 @@ __device__ inline bool td_grid_barrier(unsigned int* ctr, unsigned int target, u
     while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
 #endif
       __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 0x3ffu) == 0 && (spins > (1u << 24) || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      if ((++spins & 0x3ffu) == 0 && (spins > (1u << 21) || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         good = 0;
         break;
@@ -281,23 +282,23 @@ __device__ inline double td_p_reflector(const double* cn, double* vs, int n, int
 __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
                                                         double* __restrict__ tau, double* __restrict__ xbuf /* 2 x (p | next column), 4 n */,
                                                         unsigned int* __restrict__ ctr, unsigned int* __restrict__ abort) {
-  extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n | cn n
+  extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n
   __shared__ double sh[16];
+  const int G = (int)gridDim.x;
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int ncl = (n + TD_P_G - 1) / TD_P_G;
+  const int ncl = (n + G - 1) / G;
   double* slab = lds;
   double* vs = slab + (size_t)ncl * n;
-  double* ws = vs + n;
-  double* cn = ws + n;
+  double* ws = vs + n;  // w; afterwards the next column (the input of the next reflector)
   for (int lc = 0; lc < ncl; ++lc) {
-    const int c = lc * TD_P_G + g;
+    const int c = lc * G + g;
     if (c < n)
       for (int i = t; i < n; i += TD_P_T) slab[(size_t)lc * n + i] = A[(size_t)c * n + i];
   }
   // column 0 is read by everybody from the input itself (nothing has been written yet)
-  for (int i = t; i < n; i += TD_P_T) cn[i] = A[i];
+  for (int i = t; i < n; i += TD_P_T) ws[i] = A[i];
   __syncthreads();
-  double tj = td_p_reflector(cn, vs, n, 0, g == 0, d, e, tau, sh);
+  double tj = td_p_reflector(ws, vs, n, 0, g == 0, d, e, tau, sh);
   unsigned int phase = 0;
   for (int cj = 0; cj < n - 1; ++cj) {
     const int r0 = cj + 1;  // first row / column of the trailing block
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
     // ---- p_c = tau <column c, v> for the owned columns of the trailing block (one wave per column); the owner of column r0 also
     //      publishes that column as it is BEFORE this step's update
     for (int lc = wave; lc < ncl; lc += TD_P_T / 64) {
-      const int c = lc * TD_P_G + g;
+      const int c = lc * G + g;
       if (c >= r0 && c < n) {  // wave-uniform
         const double* col = slab + (size_t)lc * n;
         double s = 0.0;
@@ -316,12 +317,12 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
         if (lane == 0) td_st(pbuf + c, tj * s);
       }
     }
-    if (r0 % TD_P_G == g) {
-      const double* col = slab + (size_t)(r0 / TD_P_G) * n;
+    if (r0 % G == g) {
+      const double* col = slab + (size_t)(r0 / G) * n;
       for (int i = r0 + t; i < n; i += TD_P_T) td_st(cbuf + i, col[i]);
     }
-    if (!td_grid_barrier(ctr, ++phase * TD_P_G, abort)) return;
-    if (cj % TD_P_G == g)  // the reflector where td_back_k (a later launch) reads it
+    if (!td_grid_barrier(ctr, ++phase * (unsigned int)G, abort)) return;
+    if (cj % G == g)  // the reflector where td_back_k (a later launch) reads it
       for (int i = r0 + t; i < n; i += TD_P_T) A[(size_t)cj * n + i] = vs[i];
     // ---- w = p - tau/2 (p.v) v  (redundantly, same order everywhere)
     double dot = 0.0;
@@ -335,14 +336,19 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
     __syncthreads();
     for (int i = r0 + t; i < n; i += TD_P_T) ws[i] = fma(a2, vs[i], ws[i]);
     __syncthreads();
-    // ---- column r0 of the updated matrix, by everybody: the next reflector needs no second barrier
+    // ---- column r0 of the updated matrix, by everybody (registers: it replaces w once the update has used w)
+    double cnr[TD_P_MAXPT];
     {
       const double vr = vs[r0], wr = ws[r0];  // v[r0] = 1
-      for (int i = r0 + t; i < n; i += TD_P_T) cn[i] = td_ld(cbuf + i) - (vs[i] * wr + ws[i] * vr);
+#pragma unroll
+      for (int q = 0; q < TD_P_MAXPT; ++q) {
+        const int i = r0 + t + q * TD_P_T;
+        cnr[q] = i < n ? td_ld(cbuf + i) - (vs[i] * wr + ws[i] * vr) : 0.0;
+      }
     }
     // ---- rank-2 update of the owned columns
     for (int lc = wave; lc < ncl; lc += TD_P_T / 64) {
-      const int c = lc * TD_P_G + g;
+      const int c = lc * G + g;
       if (c >= r0 && c < n) {
         double* col = slab + (size_t)lc * n;
         const double vc = vs[c], wc = ws[c];
@@ -350,8 +356,14 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       }
     }
     __syncthreads();
-    if (r0 < n - 1) tj = td_p_reflector(cn, vs, n, r0, r0 % TD_P_G == g, d, e, tau, sh);
-    else if (r0 % TD_P_G == g && t == 0) d[n - 1] = cn[n - 1];
+#pragma unroll
+    for (int q = 0; q < TD_P_MAXPT; ++q) {
+      const int i = r0 + t + q * TD_P_T;
+      if (i < n) ws[i] = cnr[q];
+    }
+    __syncthreads();
+    if (r0 < n - 1) tj = td_p_reflector(ws, vs, n, r0, r0 % G == g, d, e, tau, sh);
+    else if (r0 % G == g && t == 0) d[n - 1] = ws[n - 1];
   }
 }
 
@@ -574,8 +586,16 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     attr_set = true;
   }
   const bool small = n <= TD_ROWS * 4;
-  bool persist = n <= TD_P_NMAX && !getenv("ISLE_TD_CHAIN");
-  const size_t p_lds = ((size_t)((n + TD_P_G - 1) / TD_P_G) * n + 3 * (size_t)n) * sizeof(double);
+  // persistent form: G workgroups, each with its columns (ncl of them) plus v and w in LDS
+  int pG = TD_P_GSMALL;
+  {
+    const int ncl_max = (int)(TD_P_LDS / sizeof(double) / (size_t)n) - 2;
+    if (ncl_max >= 1) pG = std::max(pG, (n + ncl_max - 1) / ncl_max);
+    else pG = 1 << 30;
+  }
+  if (const char* eg = getenv("ISLE_TD_G")) pG = std::max(pG, atoi(eg));
+  bool persist = pG <= c->num_cus && n <= TD_NMAX_BACK && !getenv("ISLE_TD_CHAIN");  // one workgroup per CU at most: all must be resident
+  const size_t p_lds = ((size_t)((n + pG - 1) / pG) * n + 2 * (size_t)n) * sizeof(double);
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
@@ -586,10 +606,10 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
       // one launch, matrix resident in LDS, two grid barriers per column (td_persist_k); tickets[0] = barrier counter, [1] = abort
       static bool p_attr = false;
       if (!p_attr) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)td_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void*)td_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TD_P_LDS));
         p_attr = true;
       }
-      hipLaunchKernelGGL(td_persist_k, dim3(TD_P_G), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, tickets, tickets + 1);
+      hipLaunchKernelGGL(td_persist_k, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, tickets, tickets + 1);
       HIPCHK(c, hipGetLastError());
       unsigned int aborted = 0;
       HIPCHK(c, hipMemcpyAsync(&aborted, tickets + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
