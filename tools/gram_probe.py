@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing probe for the Gram apply at C2 size: device ms of pass 1 / pass 2 / operator build for a list of environment
-settings (each setting re-uploads B, which rebuilds the operator).  usage: gram_probe.py ['ENV=VAL,ENV=VAL' ...]"""
+settings (each setting re-uploads B, which rebuilds the operator).  usage: gram_probe.py ['ENV=VAL,ENV=VAL' ...]
+(GRAM_PROBE_WORKLOAD=c3shard: vocab 100k, 1.25M documents instead)"""
 import os
 import sys
 
@@ -12,6 +13,8 @@ from isle_amd import HotPath  # noqa: E402
 from tools.synth import Corpus  # noqa: E402
 
 V, D, k, seed = 50_000, 1_000_000, 200, 2024
+if os.environ.get("GRAM_PROBE_WORKLOAD") == "c3shard":  # one GPU's share of BASELINE config 3
+    V, D, k, seed = 100_000, 1_250_000, 1000, 31337
 B = Corpus(V, D, k, seed).threshold(k, free_A=True)
 hp = HotPath(0)
 X = np.random.default_rng(0).standard_normal((V, 10)).astype(np.float32)
