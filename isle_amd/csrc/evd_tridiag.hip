@@ -588,12 +588,12 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   const bool small = n <= TD_ROWS * 4;
   // persistent form: G workgroups, each with its columns (ncl of them) plus v and w in LDS
   int pG = TD_P_GSMALL;
+  if (const char* eg = getenv("ISLE_TD_G")) pG = std::max(1, atoi(eg));  // tuning knob
   {
     const int ncl_max = (int)(TD_P_LDS / sizeof(double) / (size_t)n) - 2;
-    if (ncl_max >= 1) pG = std::max(pG, (n + ncl_max - 1) / ncl_max);
+    if (ncl_max >= 1) pG = std::max(pG, (n + ncl_max - 1) / ncl_max);  // what the LDS needs
     else pG = 1 << 30;
   }
-  if (const char* eg = getenv("ISLE_TD_G")) pG = std::max(pG, atoi(eg));
   bool persist = pG <= c->num_cus && n <= TD_NMAX_BACK && !getenv("ISLE_TD_CHAIN");  // one workgroup per CU at most: all must be resident
   const size_t p_lds = ((size_t)((n + pG - 1) / pG) * n + 2 * (size_t)n) * sizeof(double);
   for (int attempt = 0; attempt < 2; ++attempt) {
