@@ -301,6 +301,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   c->gl_mode = -1;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->lift_valid = false;
   c->members_valid = false;
   c->U_k = 0;
   c->centers_ready = false;
@@ -540,6 +541,7 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   c->gl_mode = -1;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->lift_valid = false;
   c->members_valid = false;
   c->U_k = 0;
   c->centers_ready = false;
@@ -1061,6 +1063,7 @@ static int install_U(isle_ctx* c, const float* Ucm_dev, int k) {
   c->U_k = k;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->lift_valid = false;
   c->centers_ready = false;
   return 0;
 }
@@ -1446,6 +1449,12 @@ extern "C" int isle_hip_lift_centers(isle_ctx* c, const float* in, int ld_in, in
   HIPCHK(c, c->centers_cm.reserve((size_t)c->V * ncols));
   ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, c->U_k, c->Csum.p, ld_in, ncols, c->centers_cm.p));
   ISLECHK(install_centers(c, ncols));
+  // the centres lie in span(U): Lloyd on B can take its first assignment from the projection (isle_hip_lloyds_sparse)
+  HIPCHK(c, c->lift_C.reserve((size_t)ld_in * ncols));
+  HIPCHK(c, hipMemcpyAsync(c->lift_C.p, c->Csum.p, (size_t)ld_in * ncols * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->lift_ld = ld_in;
+  c->lift_k = ncols;
+  c->lift_valid = true;
   if (centers) HIPCHK(c, hipMemcpyAsync(centers, c->centers_cm.p, (size_t)c->V * ncols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -1462,6 +1471,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     HIPCHK(c, c->centers_cm.reserve((size_t)V * k));
     HIPCHK(c, hipMemcpy(c->centers_cm.p, centers_in, (size_t)V * k * sizeof(float), hipMemcpyHostToDevice));
     ISLECHK(install_centers(c, k));
+    c->lift_valid = false;
   } else if (!c->centers_ready || c->centers_k != k) {
     return isle_fail(c, ISLE_E_ARG, "lloyds_sparse: no device-resident centres for k = %d (call isle_hip_lift_centers)", k);
   }
@@ -1489,13 +1499,31 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   gmax_dev = c->Csum.p + 2 * k + 16;  // G floats
   HamTop* top_dev = reinterpret_cast<HamTop*>(c->Csum.p + 2 * k + 12);
   StopRule stop(c, k);
+  // first assignment through the projection: only for centres that came from isle_hip_lift_centers with the current U and P, and
+  // while the dense product (2 D k^2 flop) is cheaper than the sparse one (ISLE_FIRST_ASSIGN=sparse keeps the sparse product)
+  const char* fa = getenv("ISLE_FIRST_ASSIGN");
+  const bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
+                              D > 0 && k <= 384 && !(fa && !strcmp(fa, "sparse"));
+  c->lift_valid = false;  // the centres move below
   int it = 0;
   for (; it < max_reps; ++it) {
     {
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, c->cnorm.p));  // :1604
     }
-    if (it == 0 || !hamerly) {
+    if (it == 0 && via_projection) {
+      // B^T (U C^T) = (U^T B)^T C^T: the k-wide sparse product of the first assignment (distsq_docs_to_centers, :1494-1550) is a dense
+      // D x k x k product on the projection that k-means++ / Lloyd in span(U) left on the device — one MFMA GEMM, a transposition into
+      // the doc-major layout and the same distance / bound epilogue (norms of centres and documents are the word-space ones)
+      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+      HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+      ISLECHK(k_gemm_nn(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
+      c->P_ready = false;  // P now holds the dot products (as with the LDS-banded wide product)
+      c->Pt_ready = false;
+      if (ld != k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, (size_t)D * ld * sizeof(float), c->stream));
+      ISLECHK(k_transpose(c, c->dotsT.p, D, (uint64_t)k, D, c->P.p, (uint64_t)ld));
+      ISLECHK(k_dots_assign(c, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->hub.p, yinyang ? c->yglb.p : c->hlb.p, yinyang ? G : 0));
+    } else if (it == 0 || !hamerly) {
       // documents are visited grouped by their previous centre (cache locality of the centre rows); results are order-independent
       ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p,
                                  c->members_valid ? c->members.p : nullptr, nullptr, c->hub.p, yinyang ? c->yglb.p : c->hlb.p,

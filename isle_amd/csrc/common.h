@@ -184,6 +184,10 @@ struct isle_ctx {
   DevBuf<float> pnorm;     // D
   bool P_ready = false;
   DevBuf<float> Pt;        // ldk x D coordinate-major copy (projected assignment), only for ldk <= 256
+  DevBuf<float> dotsT;     // D x k centre-major dot products (first assignment of Lloyd on B through the projection)
+  DevBuf<float> lift_C;    // the k x k coefficients the device-resident centres were lifted from (centres = U lift_C^T)
+  int lift_ld = 0, lift_k = 0;
+  bool lift_valid = false;
   bool Pt_ready = false;
   DevBuf<float> min_dist;  // D
   DevBuf<double> cum;      // D + 1
@@ -261,6 +265,7 @@ int k_band_build_chunked(isle_ctx* c);   // chunk-major cells for the gather pat
 enum { ISLE_DT_F32 = 0, ISLE_DT_F64 = 1, ISLE_DT_I32 = 2, ISLE_DT_U32 = 3, ISLE_DT_U64 = 4 };
 int isle_allreduce(isle_ctx* c, void* buf, size_t count, int dtype, bool max_op = false);  // in place
 int isle_allgather(isle_ctx* c, const void* send, void* recv, size_t count_per_rank, int dtype);  // recv: world * count_per_rank
+int k_dots_assign(isle_ctx* c, int k, int ldk, const float* cn, const float* dn, uint32_t* assign, float* ub, float* lb, int G);
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
@@ -325,7 +330,7 @@ int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, c
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
 int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, int* meta_dev /*2 + 32*/, float* Rout_dev /*w*w*/);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
-int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C);  // col-major, lda = ldc = M
+int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family = ISLE_T_ROTATE);  // col-major, lda = ldc = M
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl
 int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x n col-major*/);
 int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec);  // evd_tridiag.hip; 1 = use another solver

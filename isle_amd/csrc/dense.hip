@@ -516,8 +516,8 @@ __global__ __launch_bounds__(256) void gemm_nn_k(const float* __restrict__ A, ui
     }
   }
 }
-int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C) {
-  TimeScope ts(c, ISLE_T_ROTATE);
+int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family) {
+  TimeScope ts(c, family);
   if (M == 0 || N == 0) return 0;
   dim3 g(cdiv(M, GM), cdiv(N, GN)), blk(256);
   hipLaunchKernelGGL(gemm_nn_k, g, blk, 0, c->stream, A, M, K, B, ldb, N, C);

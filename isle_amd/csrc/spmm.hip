@@ -518,6 +518,23 @@ __global__ __launch_bounds__(256) void dots_assign_k(const float4* __restrict__ 
   wide_assign_epilogue<NIT>(acc, lane, d, nq, k, cn, dn, assign, ub, lb, G);
 }
 
+// Assignment (and bounds) from dot products held doc-major in c->P (D x ldk): dist = (-2 dot + |C_c|^2) + |b_d|^2
+int k_dots_assign(isle_ctx* c, int k, int ldk, const float* cn, const float* dn, uint32_t* assign, float* ub, float* lb, int G) {
+  const uint32_t D = (uint32_t)c->D;
+  if (D == 0) return 0;
+  const int nq = ldk / 4, nit = cdiv(nq, 64);
+  const dim3 g(cdiv(D, 4)), b(256);
+#define DA(N) hipLaunchKernelGGL((dots_assign_k<N>), g, b, 0, c->stream, (const float4*)c->P.p, nq, k, D, cn, dn, assign, ub, lb, G)
+  if (nit <= 1) DA(1);
+  else if (nit <= 2) DA(2);
+  else if (nit <= 4) DA(4);
+  else if (nit <= 8) DA(8);
+  else return isle_fail(c, ISLE_E_ARG, "assignment: k = %d too large (max 2048)", k);
+#undef DA
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms) {
   TimeScope ts(c, ISLE_T_PROJECT);
   ISLECHK(k_gl_detect(c));
@@ -539,17 +556,7 @@ int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const floa
     c->P_ready = false;
     c->Pt_ready = false;
     ISLECHK(k_gl_wide(c, Mrm, k, ldk, c->P.p));
-    const int nq = ldk / 4, nit = cdiv(nq, 64);
-    const dim3 g(cdiv(D, 4)), b(256);
-#define DA(N) hipLaunchKernelGGL((dots_assign_k<N>), g, b, 0, c->stream, (const float4*)c->P.p, nq, k, D, cn, dn, assign, ub, lb, G)
-    if (nit <= 1) DA(1);
-    else if (nit <= 2) DA(2);
-    else if (nit <= 4) DA(4);
-    else if (nit <= 8) DA(8);
-    else return isle_fail(c, ISLE_E_ARG, "assignment: k = %d too large (max 2048)", k);
-#undef DA
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    return k_dots_assign(c, k, ldk, cn, dn, assign, ub, lb, G);
   }
   return launch_wide<WIDE_ASSIGN>(c, Mrm, k, ldk, nullptr, nullptr, cn, dn, assign, perm, nslots, ub, lb, G);
 }

@@ -334,6 +334,37 @@ def test_lift_and_sparse_lloyds_match_oracle(hp, small50):
     assert (sg2["assign"] == so["assign"]).mean() >= 0.99
 
 
+@pytest.mark.parametrize("k", [50, 37])
+def test_first_sparse_assignment_through_the_projection(hp, small50, monkeypatch, k):
+    """Lloyd on B after lift: the centres are U C^T, so the first assignment's k-wide sparse product B^T C equals the dense product
+    P C^T on the projection already on the device (api.cpp, isle_hip_lloyds_sparse).  Same partition as the sparse product
+    (ISLE_FIRST_ASSIGN=sparse), same as the oracle, same iteration count; host-provided centres keep the sparse product."""
+    from oracle.oracle import lift
+    B = small50
+    U = B["oracle"].block_ks(k)["U"]
+    seeds = np.random.default_rng(k).choice(B["D"], size=k, replace=False).astype(np.uint64)
+    res = {}
+    for mode in ("projection", "sparse"):
+        monkeypatch.setenv("ISLE_FIRST_ASSIGN", mode)
+        upload(hp, B)
+        hp.set_U(U)
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=seeds)
+        lg = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lg["C_lowd"], fetch=False)
+        hp.timing_enable(True)
+        hp.timing_reset()
+        sg = hp.run_lloyds(k)
+        res[mode] = (sg["assign"], sg["centers"], sg["iters"], lg["C_lowd"])
+        hp.timing_enable(False)
+    monkeypatch.delenv("ISLE_FIRST_ASSIGN")
+    a, b = res["projection"], res["sparse"]
+    assert a[2] == b[2]
+    assert (a[0] == b[0]).mean() >= 0.999 and relerr(a[1], b[1]) <= 1e-4
+    so = B["oracle"].lloyds_sparse(lift(U, a[3]))
+    assert (a[0] == so["assign"]).mean() >= 0.99 and a[2] == so["iters"]
+    assert relerr(a[1], so["centers"]) <= 1e-3
+
+
 def test_gather_form_forced_by_env(hp, small50, monkeypatch):
     """ISLE_GRAM_LDS=0 keeps the gather kernels (and the chunk-major cells the centroid update then walks) covered on a
     thresholded matrix: same sigma, same sparse-Lloyd partition as the LDS-banded form."""
