@@ -42,6 +42,11 @@ def log(*a):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: libraries that write to file descriptor 1 on their own (Gloo reports its
+    # connections there when a process group is created) are sent to stderr, the result goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -353,7 +358,8 @@ def main():
         "cpu_baseline": cpu,
         "other_stages": up,
     }
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
