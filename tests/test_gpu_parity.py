@@ -258,6 +258,23 @@ def test_block_ks_matches_reference_solver_goldens(hp, name):
         assert np.abs(Z - g[name + "_U"] * g[name + "_evalues"]).max() <= 2e-3 * g[name + "_evalues"][0]
 
 
+def test_two_gram_schmidt_passes_equal_the_references_three(hp, small50, monkeypatch):
+    """BlockKs::expand orthogonalises three times (CGS + 2 DGKS, restarted_block_ks.h:83-91); the HIP path makes two passes by default
+    (the third block of coefficients is at rounding level).  Same sigma, same number of restarts and operator applications."""
+    B, k = small50, 50
+    res = {}
+    for passes in ("2", "3"):
+        monkeypatch.setenv("ISLE_KS_ORTHO_PASSES", passes)
+        upload(hp, B)
+        r = hp.compute_block_ks(k, seed=3)
+        U = hp.get_U(k)
+        res[passes] = (r["evals"], r["restarts"], r["napplies"], np.abs(U.astype(np.float64).T @ U - np.eye(k)).max())
+    a, b = res["2"], res["3"]
+    assert np.max(np.abs(a[0] - b[0]) / b[0]) <= 2e-6
+    assert a[1] == b[1] and a[2] == b[2]
+    assert a[3] <= 1e-4 and b[3] <= 1e-4
+
+
 def test_block_ks_medium(hp, small50):
     B = small50
     upload(hp, B)
