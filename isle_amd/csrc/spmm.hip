@@ -623,6 +623,29 @@ int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, flo
   return 0;
 }
 
+// Slot of this thread's item in an append-only list: ONE atomic per workgroup on the list's counter (ballots give the waves'
+// counts, thread 0 claims the workgroup's range).  One atomic per wave put 15 600 atomics per pass on a single address at
+// D = 1M — they serialise in L2 at ~10 ns each, 150 us of a 177 us kernel whose memory traffic needs 10.  Every thread of the
+// workgroup must call it (it synchronises); order inside the list is arbitrary anyway.
+__device__ inline uint32_t block_append_slot(bool act, uint32_t* __restrict__ counter) {
+  __shared__ uint32_t wcnt[16], wbase[17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  const unsigned long long m = __ballot(act);
+  __syncthreads();  // the previous call's readers are done
+  if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < nw; ++w) {
+      wbase[w] = t;
+      t += wcnt[w];
+    }
+    wbase[16] = t ? atomicAdd(counter, t) : 0u;
+  }
+  __syncthreads();
+  return wbase[16] + wbase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 // Hamerly's bounds for Lloyd on the sparse matrix (an EXACT acceleration: a document is skipped only when its bounds
 // prove that its closest centre cannot have changed).  ub >= distance to the assigned centre, lb <= distance to the
 // second-closest (both already widened by the fp32 error of the distance evaluation, see hamerly.h); after the centres
@@ -633,25 +656,23 @@ __global__ __launch_bounds__(256) void hamerly_filter_k(const uint32_t* __restri
                                                          const HamTop* __restrict__ top, uint32_t* __restrict__ active,
                                                          uint32_t* __restrict__ nactive) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= D) return;
+  const bool in = i < D;
   const uint32_t amax = top->amax;
   const float d1 = top->d1, d2 = top->d2;
-  const uint32_t d = order ? order[i] : i;
-  const uint32_t a = assign[d];
-  const float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of these two updates
-  float l = lb[d] - (a == amax ? d2 : d1) * 1.000001f;
-  l = l > 0.f ? l * 0.999999f : l;
-  ub[d] = u;
-  lb[d] = l;
-  const bool act = u >= l;  // one atomic per wave
-  const unsigned long long m = __ballot(act);
-  if (m) {
-    const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(nactive, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, first);
-    if (act) active[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
+  uint32_t d = 0;
+  bool act = false;
+  if (in) {
+    d = order ? order[i] : i;
+    const uint32_t a = assign[d];
+    const float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of these two updates
+    float l = lb[d] - (a == amax ? d2 : d1) * 1.000001f;
+    l = l > 0.f ? l * 0.999999f : l;
+    ub[d] = u;
+    lb[d] = l;
+    act = u >= l;
   }
+  const uint32_t slot = block_append_slot(act, nactive);
+  if (act) active[slot] = d;
 }
 // delta[i] <- rounded-up movement of centre i (from its squared movement); top <- {index of the largest, largest, second largest}.
 // One workgroup; replaces a device -> host -> device round trip per Lloyd iteration.
@@ -736,7 +757,8 @@ __global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* _
     tile[i] = l;
   }
   __syncthreads();
-  for (uint32_t j = threadIdx.x; j < (uint32_t)docs_per_block; j += 256) {  // uniform trip count: the ballot below needs whole waves
+  for (uint32_t j0 = 0; j0 < (uint32_t)docs_per_block; j0 += 256) {  // the same trip count for every thread: block_append_slot synchronises
+    const uint32_t j = j0 + threadIdx.x;
     const bool in = j < nd;
     const uint32_t d = d0 + (in ? j : 0u);
     float u = 0.f, lmin = 3.4e38f;
@@ -745,16 +767,9 @@ __global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* _
       for (int g = 0; g < G; ++g) lmin = fminf(lmin, tile[j * (uint32_t)G + g]);
       ub[d] = u;
     }
-    // append with one atomic per wave (a third of the documents stay active: one atomic each serialises on a single address)
     const bool act = in && u >= lmin;
-    const unsigned long long m = __ballot(act);
-    if (m) {
-      const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
-      uint32_t base = 0;
-      if (lane == first) base = atomicAdd(nactive, (uint32_t)__popcll(m));
-      base = (uint32_t)__shfl((int)base, first);
-      if (act) active[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
-    }
+    const uint32_t slot = block_append_slot(act, nactive);
+    if (act) active[slot] = d;
   }
 }
 
