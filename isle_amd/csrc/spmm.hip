@@ -692,22 +692,33 @@ __global__ __launch_bounds__(256) void ham_delta_k(float* __restrict__ delta, in
       d2 = dv;
     }
   }
-  s1[threadIdx.x] = d1;
-  s2[threadIdx.x] = d2;
-  si[threadIdx.x] = a;
+  // merge (largest, its first index, second largest): butterfly inside the wave, then the four waves in order — the serial merge
+  // of 256 entries by one thread took 25 of this kernel's 30 us, twenty times per step
+  auto merge = [](float& x1, float& x2, uint32_t& xi, float y1, float y2, uint32_t yi) {
+    if (y1 > x1 || (y1 == x1 && y1 > 0.f && yi < xi)) {
+      x2 = fmaxf(x1, y2);
+      x1 = y1;
+      xi = yi;
+    } else {
+      x2 = fmaxf(x2, y1);
+    }
+  };
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float y1 = __shfl_xor(d1, off), y2 = __shfl_xor(d2, off);
+    const uint32_t yi = (uint32_t)__shfl_xor((int)a, off);
+    merge(d1, d2, a, y1, y2, yi);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s1[threadIdx.x >> 6] = d1;
+    s2[threadIdx.x >> 6] = d2;
+    si[threadIdx.x >> 6] = a;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float b1 = 0.f, b2 = 0.f;
-    uint32_t bi = 0;
-    for (int t = 0; t < 256; ++t) {  // merge in thread order: the same (largest, first index) the host loop found
-      if (s1[t] > b1 || (s1[t] == b1 && s1[t] > 0.f && si[t] < bi)) {
-        b2 = fmaxf(b1, s2[t]);
-        b1 = s1[t];
-        bi = si[t];
-      } else {
-        b2 = fmaxf(b2, s1[t]);
-      }
-    }
+    float b1 = s1[0], b2 = s2[0];
+    uint32_t bi = si[0];
+    for (int w = 1; w < 4; ++w) merge(b1, b2, bi, s1[w], s2[w], si[w]);
     top->amax = bi;
     top->d1 = b1;
     top->d2 = b2;
