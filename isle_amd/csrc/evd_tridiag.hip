@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gridbar.h"
 
 namespace {
 
@@ -220,37 +221,9 @@ constexpr int TD_P_T = 256;
 constexpr int TD_P_MAXPT = TD_NMAX_BACK / TD_P_T;  // column entries per thread
 constexpr size_t TD_P_LDS = 160 * 1024 - 512;  // dynamic part: the kernel also has a few static words
 
-__device__ inline double td_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline void td_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ inline bool td_grid_barrier(unsigned int* ctr, unsigned int target, unsigned int* abort) {
-  __shared__ unsigned int ok;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have been issued and acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#ifdef TD_BARRIER_RELAXED  /* 8 % faster at n = 400 (4.6 against 5.0 ms per solve); relies on sc1 accesses being performed at the coherence point once acknowledged */
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-    unsigned int spins = 0, good = 1;
-#ifdef TD_BARRIER_RELAXED
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-#else
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-#endif
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 0x3ffu) == 0 && (spins > (1u << 21) || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        good = 0;
-        break;
-      }
-    }
-    ok = good;
-  }
-  __syncthreads();
-  return ok != 0;
-}
+__device__ inline double td_ld(const double* p) { return gb_ld(p); }
+__device__ inline void td_st(double* p, double v) { gb_st(p, v); }
+__device__ inline bool td_grid_barrier(unsigned int* ctr, unsigned int target, unsigned int* abort) { return gb_barrier(ctr, target, abort); }
 
 // Reflector of a column held in LDS (cn[r0 - 1 .. n - 1], cn[r0 - 1] the diagonal entry): the formulas of td_step_dev.  Every
 // workgroup runs this on the same data in the same order, so v and tau are bit-identical everywhere without a broadcast.
