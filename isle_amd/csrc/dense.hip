@@ -295,20 +295,29 @@ __global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ p
   __shared__ double sh_nrm;
   const int t = threadIdx.x;
   const int w = (pass == 1) ? wmax : meta[0];
-  for (int o = t; o < w * w; o += 256) {
-    const int i = o / w, j = o - i * w;  // G(i, j), upper triangle stored at [j*w + i]
-    const int u = (i <= j) ? j * w + i : i * w + j;
-    double s = 0.0;
-    int p = 0;
-    for (; p + 8 <= nparts; p += 8) {  // eight loads in flight, summed in index order
-      double v[8];
+  {
+    // sum of the partial Gram matrices in index order, two threads per entry (first and second half of the slabs, combined
+    // first + second): the 98-way sum is a chain of dependent load batches, most of this kernel's time
+    const int half = t >> 7, p0 = half ? nparts / 2 : 0, p1 = half ? nparts : nparts / 2;
+    for (int o = t & 127; o < w * w; o += 128) {
+      const int i = o / w, j = o - i * w;  // G(i, j), upper triangle stored at [j*w + i]
+      const int u = (i <= j) ? j * w + i : i * w + j;
+      double s = 0.0;
+      int p = p0;
+      for (; p + 8 <= p1; p += 8) {  // eight loads in flight, summed in index order
+        double v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
+        for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += v[q];
+        for (int q = 0; q < 8; ++q) s += v[q];
+      }
+      for (; p < p1; ++p) s += part[(size_t)p * (PQ_W * PQ_W) + u];
+      if (half) X[i][j] = s;  // X is free until the inverse below
+      else G[i][j] = s;
     }
-    for (; p < nparts; ++p) s += part[(size_t)p * (PQ_W * PQ_W) + u];
-    G[i][j] = s;
+    __syncthreads();
+    for (int o = t; o < w * w; o += 256) G[o / w][o % w] += X[o / w][o % w];
+    __syncthreads();
   }
   for (int o = t; o < PQ_W * PQ_W; o += 256) {
     Rm[o / PQ_W][o % PQ_W] = 0.0;
