@@ -1,0 +1,52 @@
+"""bench.py's output contract: stdout is exactly ONE line, a JSON object with the agreed keys — also when a process group exists
+(Gloo reports its connections on file descriptor 1; bench.py sends everything but the result to stderr).  Tiny workload; the
+2-rank run shares GPU 0 through the rehearsal transport (ISLE_BENCH_REHEARSE=1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline"]
+
+
+def _check(stdout, n_gpus, steps):
+    lines = stdout.splitlines()
+    assert len(lines) == 1, stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["unit"] == "docs/sec" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    return d
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 1, 2)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "docs/sec"
+
+
+def test_two_rank_line_through_the_launcher():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ISLE_BENCH_REHEARSE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 2, 1)
+    assert "REHEARSAL" in d["config"]["parallelism"]
