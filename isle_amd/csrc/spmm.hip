@@ -844,6 +844,18 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
   const int q = lane & 1, e = lane >> 1;
   float* gl = glb + (size_t)d * G;
 
+  // the document's entries, fetched once (not once per scanned group) while it has at most 64 * YY_NCH of them
+  constexpr int YY_NCH = 4;
+  const int len = (int)(end - beg);
+  const bool small = len <= 64 * YY_NCH;  // wave-uniform
+  uint32_t rrow[YY_NCH];
+  float rval[YY_NCH];
+#pragma unroll
+  for (int ch = 0; ch < YY_NCH; ++ch) {
+    const bool in = small && 64 * ch + lane < len;
+    rrow[ch] = in ? rows[beg + 64 * ch + lane] : 0u;
+    rval[ch] = in ? vals[beg + 64 * ch + lane] : 0.f;
+  }
   // distances of the document to the YY_GROUP centres of group g; lane parity q holds centres 8g+4q .. 8g+4q+3
   auto scan_group = [&](int g, float dist[4]) {
     const int col = YY_GROUP * g + 4 * q;
@@ -851,6 +863,25 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
     const float4* base = reinterpret_cast<const float4*>(C + min(col, ld - 4));
     const size_t rstride = (size_t)ld / 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (small) {
+      // all gathers of the group in flight together (the loop below keeps two): same products, same order of accumulation
+      float4 gv[2 * YY_NCH];
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * YY_NCH; ++s2) {
+        gv[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (32 * s2 < len) {  // wave-uniform
+          const uint32_t r = __shfl(rrow[s2 >> 1], (s2 & 1) * 32 + e);
+          gv[s2] = base[(size_t)r * rstride];
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * YY_NCH; ++s2) {
+        if (32 * s2 < len) {
+          const float v = __shfl(rval[s2 >> 1], (s2 & 1) * 32 + e) * live;  // 0 beyond the document's end
+          acc = f4_fma(v, gv[s2], acc);
+        }
+      }
+    } else
     for (int64_t b0 = beg; b0 < end; b0 += 64) {
       const int cnt = (int)min((int64_t)64, end - b0);
       const uint32_t myrow = (lane < cnt) ? rows[b0 + lane] : 0u;
