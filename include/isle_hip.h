@@ -148,12 +148,30 @@ int isle_hip_operator_form(isle_ctx* ctx, int* form);
  * (k, 2k + BLOCK_KS_BLOCK_SIZE, 100, 10, 1e-4) (include/hyperparams.h:38-40).
  * evals: nev Ritz values, descending (= sigma_i^2).  U (V x nev) stays on the device for the
  * k-means calls (fetch with isle_hip_get_U).  seed: start-block RNG seed (the reference uses
- * unseeded rand(); parity does not depend on it).  Returns ISLE_E_NOCONV (not 0) if maxit
+ * unseeded rand(); parity does not depend on it).  nev / ncv need not be multiples of blk: a
+ * decomposition grows block by block until it has at least ncv rows (the reference overruns its
+ * basis in that case).  Returns ISLE_E_NOCONV (not 0) if maxit
  * restarts were exhausted — the reference reports full convergence in that case
  * (SURVEY.md App. C #7); evals/U are still the last Ritz pairs.
  * nconv/restarts/napplies may be NULL. */
 int isle_hip_block_ks(isle_ctx* ctx, int nev, int ncv, int maxit, int blk, float tol, uint64_t seed,
                       float* evals, int* nconv, int* restarts, int* napplies);
+
+/* The same solver on a caller-supplied dense symmetric operator: BlockKs<ProdOp> is a template over any symmetric
+ * operator with multiply()/rows()/cols() (block-ks/restarted_block_ks.h:18-40); this entry is its instantiation with
+ * utils::ArmaMatProdOp (block-ks/ks_utils.h:167-182, multiply(X) = A * X), the operator the reference pairs with its
+ * known-spectrum recipe utils::get_seed_eigs (ks_utils.h:136-165).  It runs the SAME host loop and device kernels as
+ * isle_hip_block_ks (init / expand / truncate / compute, panel QR, rank repair, small EVD, Ritz rotation); only the
+ * operator application is a dense product.  A: n x n col-major symmetric (host).  start_block: NULL, or n x blk
+ * col-major values for the first draw of init()'s start block (:211-218 redraws at random while it is rank deficient).
+ * evals: nev Ritz values, descending.  U (nullable): n x nev col-major Ritz vectors.  nconv: Ritz pairs that passed the
+ * residual test of the last restart.  nconv_ref_rule (nullable): what the reference itself would report — equal to nconv
+ * on convergence; after maxit restarts its rule (:303-317) looks at the expanded H without dividing and therefore says
+ * nev, while this library returns ISLE_E_NOCONV with the honest count.  The context's B, U and
+ * k-means state are not touched.  Single rank only. */
+int isle_hip_block_ks_dense(isle_ctx* ctx, const float* A_colmajor, uint64_t n, int nev, int ncv, int maxit, int blk,
+                            float tol, uint64_t seed, const float* start_block, float* evals, float* U_colmajor,
+                            int* nconv, int* nconv_ref_rule, int* restarts, int* napplies);
 
 /* U_colmajor (V x nev), what compute_block_ks memcpy's at src/sparseMatrix.cpp:1214. */
 int isle_hip_get_U(isle_ctx* ctx, float* U_colmajor);

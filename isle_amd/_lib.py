@@ -32,6 +32,7 @@ SYMBOLS = {
     "isle_hip_operator_form": (_I, [_P, _P]),
     "isle_hip_infer": (_I, [_P, C.c_uint64, _I, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "isle_hip_block_ks": (_I, [_P, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P]),
+    "isle_hip_block_ks_dense": (_I, [_P, _P, _U64, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P, _P, _P]),
     "isle_hip_get_U": (_I, [_P, _P]),
     "isle_hip_set_U": (_I, [_P, _P, _I]),
     "isle_hip_eig_sym": (_I, [_P, _P, _I, _P, _P]),

@@ -809,6 +809,10 @@ struct Ks {
   size_t vcols = 0, nconv = 0, n_restarts = 0, last_j = 0;
   long napplies = 0;
   uint64_t seed, draws = 0;
+  // The ProdOp plug-in (block-ks/restarted_block_ks.h:18-40): the context's B B^T (MKL_SpSpTrProd, include/matUtils.h:336-365), or a
+  // dense symmetric dim x dim matrix on the device (ArmaMatProdOp, block-ks/ks_utils.h:167-182) when dense_A is set.
+  const float* dense_A = nullptr;
+  const float* start_dev = nullptr;  // optional dim x blk start block (first try of init's draw loop)
   float* Vb() { return c->basis.p; }
   float* col(size_t j) { return c->basis.p + j * dim; }
 
@@ -848,14 +852,18 @@ struct Ks {
 
   int apply(const float* X, float* Z) {
     napplies++;
+    if (dense_A) return k_gemm_nn(c, dense_A, dim, (int)dim, X, (int)dim, (int)blk, Z, ISLE_T_GRAM_PASS1);
     return gram_apply_dev(c, X, (int)blk, Z);
   }
 
   int init() {  // :203-259
     std::vector<float> R;
     int rank = 0;
-    do {
-      ISLECHK(randu(c->Fbuf.p, blk));
+    bool first = true;
+    do {  // :211-218: redrawn until the start block has full rank
+      if (first && start_dev) HIPCHK(c, hipMemcpyAsync(c->Fbuf.p, start_dev, dim * blk * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      else ISLECHK(randu(c->Fbuf.p, blk));
+      first = false;
       ISLECHK(dev_qr(c, c->Fbuf.p, dim, (int)blk, col(0), R, &rank));
     } while ((size_t)rank < blk);
     float* V1 = c->Fbuf.p;
@@ -1068,49 +1076,94 @@ static int install_U(isle_ctx* c, const float* Ucm_dev, int k) {
   return 0;
 }
 
-extern "C" int isle_hip_block_ks(isle_ctx* c, int nev, int ncv, int maxit, int blk, float tol, uint64_t seed, float* evals, int* nconv,
-                                 int* restarts, int* napplies) {
-  if (!c || !evals) return ISLE_E_ARG;
-  if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
-  HIPCHK(c, hipSetDevice(c->device));
-  if (nev < 1 || blk < 1 || blk > 32) return isle_fail(c, ISLE_E_ARG, "bad nev/blk");
-  Ks ks;
+// Shared driver of both eigensolver entries: BlockKs(op, nev, ncv, maxit, blk, tol); init(); compute()  (:190-321).
+// ncv and nev need not be multiples of the block size: a decomposition grows by whole blocks until it has AT LEAST ncv
+// rows (the reference sizes V for exactly ncv columns and overruns it in that case), so the basis holds up to
+// ncv + blk - 1 vectors.
+static int ks_solve(isle_ctx* c, Ks& ks, int nev, int ncv, int maxit, int blk, float tol, uint64_t seed, float* evals, int* nconv,
+                    int* restarts, int* napplies, int* nconv_ref_rule) {
+  if (nev < 1 || blk < 1 || blk > 32 || maxit < 1) return isle_fail(c, ISLE_E_ARG, "bad nev/blk/maxit (nev >= 1, 1 <= blk <= 32, maxit >= 1)");
   ks.c = c;
   ks.nev = nev;
   ks.ncv = ncv;
   ks.maxit = maxit;
   ks.blk = (blk < nev) ? blk : 1;  // block-ks/restarted_block_ks.h:198
-  ks.dim = c->V;
   ks.tol = tol;
   ks.seed = seed;
-  if ((size_t)ncv < (size_t)nev + 2 * ks.blk || (uint64_t)ncv + ks.blk > c->V)
-    return isle_fail(c, ISLE_E_ARG, "need nev + 2*blk <= ncv and ncv + blk <= vocab_size (nev=%d ncv=%d blk=%zu V=%llu)", nev, ncv,
-                     ks.blk, (unsigned long long)c->V);
-  if ((ncv - nev) % ks.blk != 0 || ncv % ks.blk != 0)
-    return isle_fail(c, ISLE_E_ARG, "nev and ncv - nev must be multiples of the block size (reference asserts the same implicitly)");
-  HIPCHK(c, c->basis.reserve((size_t)c->V * (ncv + ks.blk)));
-  HIPCHK(c, c->Fbuf.reserve((size_t)c->V * ks.blk));
-  HIPCHK(c, c->Tmp.reserve((size_t)c->V * std::max<size_t>(nev, ks.blk)));
-  c->band_ready = false;  // the operator (CSR copy) is rebuilt per solve, as in src/sparseMatrix.cpp:1199
+  if ((size_t)ncv < (size_t)nev + 2 * ks.blk || (uint64_t)ncv + ks.blk > ks.dim)
+    return isle_fail(c, ISLE_E_ARG, "need nev + 2*blk <= ncv and ncv + blk <= operator dimension (nev=%d ncv=%d blk=%zu dim=%llu)", nev, ncv,
+                     ks.blk, (unsigned long long)ks.dim);
+  HIPCHK(c, c->basis.reserve((size_t)ks.dim * (ncv + 2 * ks.blk)));
+  HIPCHK(c, c->Fbuf.reserve((size_t)ks.dim * ks.blk));
+  HIPCHK(c, c->Tmp.reserve((size_t)ks.dim * std::max<size_t>(nev, ks.blk)));
   ISLECHK(ks.init());
   ISLECHK(ks.compute());
   int rc = 0;
-  size_t nc = ks.nconv;
+  size_t nc = ks.nconv, nc_ref = ks.nconv;
   if (ks.n_restarts == (size_t)maxit) {
-    // The reference recomputes residuals from the expanded H without dividing (:303-317) and always
-    // ends up reporting nev; we report non-convergence instead but return the same Ritz pairs.
+    // The reference recomputes residuals from the EXPANDED H without dividing by the Ritz value (:303-317); the last blk rows of
+    // an expanded H are [0 ... 0 R], so that rule reports min(first column of the last block, nev) = nev whatever happened
+    // (SURVEY App. C #7).  Here: the count of the last restart's residual test, status ISLE_E_NOCONV, and the same Ritz pairs;
+    // the reference's figure is available through nconv_ref_rule.
+    nc_ref = ks.first_unconverged(false);
     nc = std::min(ks.last_j, (size_t)nev);
     if (nc < (size_t)nev) rc = ISLE_E_NOCONV;
   }
   nc = std::min(nc, (size_t)nev);
+  nc_ref = std::min(nc_ref, (size_t)nev);
   for (int i = 0; i < nev; ++i) evals[i] = ks.H(i, i);  // src/sparseMatrix.cpp:1212-1213
   if (nconv) *nconv = (int)nc;
+  if (nconv_ref_rule) *nconv_ref_rule = (int)nc_ref;
   if (restarts) *restarts = (int)ks.n_restarts;
   if (napplies) *napplies = (int)ks.napplies;
+  return rc;
+}
+
+extern "C" int isle_hip_block_ks(isle_ctx* c, int nev, int ncv, int maxit, int blk, float tol, uint64_t seed, float* evals, int* nconv,
+                                 int* restarts, int* napplies) {
+  if (!c || !evals) return ISLE_E_ARG;
+  if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  Ks ks;
+  ks.dim = c->V;
+  c->band_ready = false;  // the operator (CSR copy) is rebuilt per solve, as in src/sparseMatrix.cpp:1199
+  int nc = 0;
+  const int rc = ks_solve(c, ks, nev, ncv, maxit, blk, tol, seed, evals, &nc, restarts, napplies, nullptr);
+  if (nconv) *nconv = nc;
+  if (rc != 0 && rc != ISLE_E_NOCONV) return rc;
   ISLECHK(install_U(c, c->basis.p, nev));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (rc == ISLE_E_NOCONV) return isle_fail(c, rc, "block KS: %d restarts exhausted, %zu of %d Ritz pairs converged", maxit, nc, nev);
+  if (rc == ISLE_E_NOCONV) return isle_fail(c, rc, "block KS: %d restarts exhausted, %d of %d Ritz pairs converged", maxit, nc, nev);
   return 0;
+}
+
+extern "C" int isle_hip_block_ks_dense(isle_ctx* c, const float* A, uint64_t n, int nev, int ncv, int maxit, int blk, float tol,
+                                       uint64_t seed, const float* start_block, float* evals, float* U, int* nconv, int* nconv_ref_rule,
+                                       int* restarts, int* napplies) {
+  if (!c || !A || !evals || n < 2 || n > 46340) return isle_fail(c, ISLE_E_ARG, "block_ks_dense: bad arguments (2 <= n <= 46340)");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->multi()) return isle_fail(c, ISLE_E_ARG, "block_ks_dense: the dense operator is not sharded (single rank only)");
+  const int b_eff = (blk < nev) ? blk : 1;
+  DevBuf<float> Adev, Sdev;
+  HIPCHK(c, Adev.reserve((size_t)n * n));
+  HIPCHK(c, hipMemcpy(Adev.p, A, (size_t)n * n * sizeof(float), hipMemcpyHostToDevice));
+  Ks ks;
+  ks.dim = n;
+  ks.dense_A = Adev.p;
+  if (start_block && b_eff >= 1) {
+    HIPCHK(c, Sdev.reserve((size_t)n * b_eff));
+    HIPCHK(c, hipMemcpy(Sdev.p, start_block, (size_t)n * b_eff * sizeof(float), hipMemcpyHostToDevice));
+    ks.start_dev = Sdev.p;
+  }
+  int nc = 0;
+  const int rc = ks_solve(c, ks, nev, ncv, maxit, blk, tol, seed, evals, &nc, restarts, napplies, nconv_ref_rule);
+  if (nconv) *nconv = nc;
+  hipError_t he = hipStreamSynchronize(c->stream);
+  if (he == hipSuccess && (rc == 0 || rc == ISLE_E_NOCONV) && U)
+    he = hipMemcpy(U, c->basis.p, (size_t)n * nev * sizeof(float), hipMemcpyDeviceToHost);
+  HIPCHK(c, he);
+  if (rc == ISLE_E_NOCONV) return isle_fail(c, rc, "block KS (dense operator): %d restarts exhausted, %d of %d Ritz pairs converged", maxit, nc, nev);
+  return rc;
 }
 
 extern "C" int isle_hip_get_U(isle_ctx* c, float* U) {

@@ -248,6 +248,22 @@ class HotPath:
         self._chk(rc, allow=(-3,) if allow_noconv else ())
         return dict(rc=rc, evals=ev, nconv=nconv.value, restarts=rst.value, napplies=nap.value)
 
+    def block_ks_dense(self, A, nev, blk=BLOCK_KS_BLOCK_SIZE, ncv=None, maxit=BLOCK_KS_MAX_ITERS, tol=BLOCK_KS_TOLERANCE, seed=1,
+                       start_block=None, allow_noconv=False):
+        """BlockKs<utils::ArmaMatProdOp> (block-ks/ks_utils.h:167-182): the solver of compute_block_ks on a dense symmetric A."""
+        A = np.asfortranarray(A, dtype=np.float32)
+        n = A.shape[0]
+        assert A.shape == (n, n)
+        ncv = 2 * nev + BLOCK_KS_BLOCK_SIZE if ncv is None else ncv
+        ev = np.empty(nev, np.float32)
+        U = np.empty((n, nev), np.float32, order="F")
+        sb = None if start_block is None else np.asfortranarray(start_block, dtype=np.float32)
+        nconv, nref, rst, nap = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rc = self._lib.isle_hip_block_ks_dense(self._h, _p(A), n, nev, ncv, maxit, blk, tol, seed, _p(sb), _p(ev), _p(U), C.byref(nconv),
+                                               C.byref(nref), C.byref(rst), C.byref(nap))
+        self._chk(rc, allow=(-3,) if allow_noconv else ())
+        return dict(rc=rc, evals=ev, U=U, nconv=nconv.value, nconv_ref_rule=nref.value, restarts=rst.value, napplies=nap.value)
+
     def get_U(self, k):
         U = np.empty((self.V, k), np.float32, order="F")
         self._chk(self._lib.isle_hip_get_U(self._h, _p(U)))
