@@ -9,8 +9,13 @@ device-resident thresholded matrix B: compute_block_ks -> kmeans_init_on_project
 run_lloyds_on_projected_space -> left_multiply_by_U -> run_lloyds, with the reference's hyper-parameters
 (include/hyperparams.h).  Metric = docs/sec = (documents of all ranks) * steps / wall time, inputs already in
 HBM when the timed region starts.  Workload at N = 1: BASELINE.json configs[1] (vocab 50k, 1M docs,
-~100M nnz, k = 200, sample = 0); at N > 1 each rank holds its own 1M-document shard of a larger corpus
-(weak scaling; Gram / centroid sums are all-reduced with RCCL inside libisle_hip.so).
+~100M nnz, k = 200, sample = 0).  At N > 1: BASELINE.json configs[2] — ONE corpus of vocab 100k x 10M docs x ~1B nnz,
+k = 1000, column-sharded N ways (strong scaling: rank r holds documents [r D/N, (r+1) D/N); Gram / centroid sums are
+all-reduced with RCCL inside libisle_hip.so).  `--workload c2` at N > 1 keeps the earlier weak-scaling run (1M documents of
+the C2 shape per rank).
+
+Inside the timed region only the Gram-apply launches are bracketed by HIP events (the `roofline` object needs their average
+duration over exactly those steps); the per-family breakdown `device_ms_per_step` comes from one more, untimed pass.
 
 One JSON line on stdout (rank 0).  See DESIGN.md §Measurement for the roofline arithmetic.
 """
@@ -29,6 +34,7 @@ WORKLOADS = {
     # name: (vocab, docs per GPU, topics, generator seed)          BASELINE.json configs
     "c1": (10_000, 50_000, 50, 12345),     # configs[0] (reference's CPU-runnable case)
     "c2": (50_000, 1_000_000, 200, 2024),  # configs[1]  <- bench default
+    "c3": (100_000, 10_000_000, 1000, 31337),      # configs[2], column-sharded over all ranks (strong scaling)  <- default at N > 1
     "c3shard": (100_000, 1_250_000, 1000, 31337),  # one GPU's share of configs[2]
     "c3full": (100_000, 10_000_000, 1000, 31337),  # ALL of configs[2] on one GPU (fits: ~110 GB of 288 GB)
     "tiny": (2_000, 5_000, 10, 0),
@@ -51,7 +57,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU, c3 (one 10M-document corpus sharded over the ranks) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-upstream", action="store_true", help="skip the (untimed-region) device thresholding check")
     ap.add_argument("--blk", type=int, default=0, help="experiment: block size of the eigensolver (0 = the reference's 10)")
@@ -62,6 +69,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:  # the ranks share the node's cores (corpus generation, thresholding)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // max(local_world, 1)))
+    if args.workload is None:
+        args.workload = "c2" if world == 1 else "c3"
+    strong = args.workload == "c3"
     import torch
     dist = None
     if world > 1:
@@ -74,6 +87,11 @@ def main():
     from tools.synth import Corpus, effective_cpus
 
     V, D_per, k, seed = WORKLOADS[args.workload]
+    doc_base = rank * D_per
+    if strong:  # one corpus, documents [doc_base, doc_base + D_per) on this rank (the generator seeds every document by its global id)
+        D_total = D_per
+        doc_base = (D_total * rank) // world
+        D_per = (D_total * (rank + 1)) // world - doc_base
 
     def allreduce_np(a):
         if dist is not None:
@@ -83,15 +101,17 @@ def main():
 
     # ---------------- synthetic input (not timed): planted-topic Zipf corpus -> thresholded B ------------
     t0 = time.time()
-    corp = Corpus(V, D_per, k, seed, doc_base=rank * D_per)
+    corp = Corpus(V, D_per, k, seed, doc_base=doc_base)
     nnz_A = corp.nnz_A
     upstream = world == 1 and not args.no_upstream
     A_host = corp.A() if upstream else None
     tdf_text = corp.tdf_bytes() if upstream else None
     t_thr0 = time.time()
+    planted_all = corp.planted()
     B = corp.threshold(k, free_A=True, allreduce=allreduce_np if dist is not None else None)
+    planted = planted_all[B["original_cols"].astype(np.int64)]  # dominant planted topic of every column of B (local numbering)
     t_thr_cpu = time.time() - t_thr0
-    del corp
+    del corp, planted_all
     t_gen = time.time() - t0
     D_loc, nnz_loc = B["D"], B["nnz"]
     counts = np.zeros(world, np.int64)
@@ -148,7 +168,7 @@ def main():
 
     for i in range(args.warmup):
         step(-1 - i)
-    hp.timing_enable(True)
+    hp.timing_enable(2)  # events around the Gram-apply launches only (roofline); everything else runs as in production
     hp.timing_reset()
     fence()
     t0 = time.perf_counter()
@@ -157,24 +177,51 @@ def main():
         last = step(i)
     fence()
     dt = time.perf_counter() - t0
+    tm_gram = hp.timing_get()
+    # per-family breakdown: one more pass, untimed, with events around every launch
+    hp.timing_enable(1)
+    hp.timing_reset()
+    step(-50)
+    fence()
     tm = hp.timing_get()
-    hp.timing_enable(False)
+    hp.timing_enable(0)
     dtt = np.array([dt], np.float64)
     if dist is not None:
         t = torch.from_numpy(dtt)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(dtt[0])
 
-    # ---------------- accuracy: size-independent check of the eigenpairs ---------------------------------
-    # |lambda_i - lambda_true| <= ||A u_i - lambda_i u_i||  =>  sigma rel-err <= resid_i / (2 lambda_i)
+    # ---------------- accuracy (outside the timed region) -----------------------------------------------------------------
+    # sigma: |lambda_i - lambda_true| <= ||A u_i - lambda_i u_i||  =>  sigma rel-err <= resid_i / (2 lambda_i), with A u_i computed by the
+    # CPU oracle's operator (an independent implementation: a self-consistent but wrong HIP operator would not pass).  One GPU: all k
+    # Ritz pairs; several ranks: 32 pairs spread over the spectrum (each rank applies its shard on the CPU, partial products are summed).
+    from oracle.oracle import OracleCsc
     ev = last["ks"]["evals"].astype(np.float64)
     U = hp.get_U(k)
-    AU = hp.gram_apply(U[:, :16]) if k > 16 else hp.gram_apply(U)
-    kk = AU.shape[1]
-    resid = np.linalg.norm(AU.astype(np.float64) - U[:, :kk].astype(np.float64) * ev[:kk], axis=0) / ev[:kk]
+    t_acc0 = time.time()
+    o_full = OracleCsc(V, D_loc, B["vals"], B["rows"], B["offs"])
+    pick = np.arange(k) if world == 1 else np.unique(np.concatenate([np.arange(min(16, k)), np.linspace(0, k - 1, 16).astype(np.int64)]))
+    resid = np.empty(len(pick))
+    for j0 in range(0, len(pick), 50):
+        cols = pick[j0:j0 + 50]
+        AU = o_full.gram_apply(np.asfortranarray(U[:, cols])).astype(np.float64)
+        if dist is not None:
+            AU = np.ascontiguousarray(AU)
+            allreduce_np(AU)
+        resid[j0:j0 + len(cols)] = np.linalg.norm(AU - U[:, cols].astype(np.float64) * ev[cols], axis=0) / ev[cols]
+    ortho = float(np.abs(U[:, :min(k, 200)].astype(np.float64).T @ U[:, :min(k, 200)] - np.eye(min(k, 200))).max())
+    t_acc = time.time() - t_acc0
     sizes = np.bincount(last["assign"], minlength=k).astype(np.int64)
     allreduce_np(sizes)
+    # k-means quality of the timed run's partition: agreement with the planted dominant topics (majority label per cluster; the
+    # reference itself reaches 0.81-0.87 on this kind of corpus)
+    maj = np.zeros((k, k), np.int64)
+    np.add.at(maj, (last["assign"].astype(np.int64), planted.astype(np.int64) % k), 1)
+    allreduce_np(maj)
+    purity = float(maj.max(1).sum() / max(D_glob, 1))
 
+    if rank != 0:
+        return
     if rank != 0:
         return
 
@@ -184,8 +231,8 @@ def main():
 
     # ---------------- roofline of the dominant sparse kernel family (Gram apply) --------------------------
     b = (args.blk or 10) if k > 10 else 1
-    n_apply = tm["gram_pass1"][1]
-    t_apply_ms = (tm["gram_pass1"][0] + tm["gram_pass2"][0]) / max(n_apply, 1)
+    n_apply = tm_gram["gram_pass1"][1]  # events of the timed region
+    t_apply_ms = (tm_gram["gram_pass1"][0] + tm_gram["gram_pass2"][0]) / max(n_apply, 1)
     # bytes per application = 8*nnz + 8*(D+1) + 2*4*V*b   (this rank's shard)
     alg_bytes = 8.0 * nnz_loc + 8.0 * (D_loc + 1) + 8.0 * V * b
     achieved = alg_bytes / (t_apply_ms * 1e-3) / 1e9 if n_apply else 0.0
@@ -195,20 +242,70 @@ def main():
             traffic = json.load(f).get(args.workload, {}).get("gram_apply_hbm_bytes_per_launch")
     except Exception:
         pass
-    device_ms = {f: round(v[0] / steps, 3) for f, v in tm.items() if v[1]}
+    device_ms = {f: round(v[0], 3) for f, v in tm.items() if v[1]}  # the one untimed pass with events around every launch
+    launches_per_step = int(sum(v[1] for v in tm.values()))
     form = hp.operator_form()
     form_kernels = ("LDS-banded form: gl_scale_k + gl_apply_k<3,true,0> (pass 1) + gl_apply_k<3,true,0> + gl_reduce_k (pass 2)" if form == 1
                     else "gather form: seg_gather_k<3,false> (pass 1) + seg_gather_k<3,true> + reduce_chunks_k (pass 2)")
     if form != 1:
         traffic = None  # profiles/pmc_traffic.json holds the LDS-banded form's counters
 
+    # ---------------- k-means parity on a sub-sample: the HIP path and the CPU oracle from the same U and the same injected seeds ------
+    km = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import lift
+        n_sub = min(D_loc, 50_000)
+        e_sub = int(B["offs"][n_sub])
+        Bs = dict(vals=B["vals"][:e_sub], rows=B["rows"][:e_sub], offs=B["offs"][:n_sub + 1])
+        o_sub = OracleCsc(V, n_sub, Bs["vals"], Bs["rows"], Bs["offs"])
+        t1 = time.time()
+        ko = o_sub.kmeanspp(U, k, seed=11)
+        lo = o_sub.lloyds_projected(U, ko["C_lowd"])
+        so = o_sub.lloyds_sparse(lift(U, lo["C_lowd"]))
+        t_cpu_km = time.time() - t1
+        hp2 = HotPath(local_rank)
+        hp2.upload_csc(V, Bs["vals"], Bs["rows"], Bs["offs"])
+        hp2.set_U(U)
+        g2 = hp2.kmeans_init_on_projected_space(k, inject_seeds=ko["seeds"])
+        lp2 = hp2.run_lloyds_on_projected_space(k, g2["C_lowd"])
+        hp2.left_multiply_by_U(lp2["C_lowd"], fetch=False)
+        ls2 = hp2.run_lloyds(k)
+        hp2.close()
+
+        def objective(assign, centers):  # sum_d |b_d - c_a(d)|^2 in fp64
+            import scipy.sparse as sp
+            S = sp.csc_matrix((Bs["vals"].astype(np.float64), Bs["rows"], Bs["offs"]), shape=(V, n_sub))
+            Cn = centers.astype(np.float64)
+            cn2 = (Cn ** 2).sum(0)
+            tot_ = 0.0
+            for c0 in range(0, n_sub, 8192):
+                a = assign[c0:c0 + 8192].astype(np.int64)
+                Sb = S[:, c0:c0 + 8192]
+                d2 = np.asarray(Sb.multiply(Sb).sum(0)).ravel() + cn2[a] - 2.0 * np.asarray(Sb.multiply(Cn[:, a]).sum(0)).ravel()
+                tot_ += float(d2.sum())
+            return tot_
+
+        pl = planted[:n_sub].astype(np.int64) % k
+
+        def purity_of(a):
+            m = np.zeros((k, k), np.int64)
+            np.add.at(m, (a.astype(np.int64), pl), 1)
+            return float(m.max(1).sum() / n_sub)
+
+        km = {"sample": "first %d documents of B, U of the timed run, seeds drawn by the oracle's k-means++ and injected into the HIP path" % n_sub,
+              "partition_agreement_projected": round(float((lp2["assign"] == lo["assign"]).mean()), 5),
+              "partition_agreement_word_space": round(float((ls2["assign"] == so["assign"]).mean()), 5),
+              "iterations_hip": [lp2["iters"], ls2["iters"]], "iterations_oracle": [lo["iters"], so["iters"]],
+              "objective_hip": objective(ls2["assign"], ls2["centers"]), "objective_oracle": objective(so["assign"], so["centers"]),
+              "planted_topic_agreement_hip": round(purity_of(ls2["assign"]), 4), "planted_topic_agreement_oracle": round(purity_of(so["assign"]), 4),
+              "oracle_seconds": round(t_cpu_km, 1)}
+
     # ---------------- CPU baseline: the oracle ("port") on a bounded sample of the same work --------------
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle.oracle import OracleCsc
         cores = effective_cpus()
         tc0 = time.time()
-        o = OracleCsc(V, D_loc, B["vals"], B["rows"], B["offs"])
+        o = o_full
         X = np.random.default_rng(0).standard_normal((V, b)).astype(np.float32)
         o.gram_apply(X)
         t1 = time.time()
@@ -281,7 +378,7 @@ def main():
         del got
         # downstream stage on the partition the last timed step left on the device ... after re-running the hot path on the
         # device-built B (identical to the uploaded one), outside the timed region
-        from oracle.oracle import catchword_rank, model_rank_threshold
+        from isle_amd.hot_path import catchword_rank, model_rank_threshold  # the trainer's formulae live in the binding
         step(-100)
         hp.timing_enable(True)
         hp.timing_reset()
@@ -332,28 +429,33 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "synthetic planted-topic Zipf corpus (%s): vocab=%d, docs=%d (%d per GPU), nnz(A)=%d, nnz(B)=%d, "
-                        "num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
-                        % (args.workload, V, D_glob, D_per, int(tot[1]), nnz_glob, k),
+            "workload": "synthetic planted-topic Zipf corpus (%s = BASELINE.json configs[%d]): vocab=%d, docs=%d (%d on rank 0), nnz(A)=%d, "
+                        "nnz(B)=%d, num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
+                        % (args.workload, {"c1": 0, "c2": 1}.get(args.workload, 2), V, D_glob, D_loc, int(tot[1]), nnz_glob, k),
             "block_ks": {"nev": k, "ncv": 2 * k + 10, "blk": b, "tol": 1e-4, "maxit": 100,
-                         "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"]},
+                         "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"],
+                         "converged": bool(last["ks"]["rc"] == 0 and last["ks"]["nconv"] == k)},
             "kmeans": {"kmpp_rounds": last["kmpp_rounds"], "lloyd_projected_iters": last["lp_iters"],
                        "lloyd_sparse_iters": last["ls_iters"], "nonempty_clusters": int((sizes > 0).sum())},
             "parallelism": ("REHEARSAL (not a measurement): %d ranks sharing GPU 0, host-staged collectives" % world if rehearse
                             else "docs column-sharded x%d, RCCL all-reduce" % world if world > 1 else "single GPU"),
         },
-        "accuracy": {"sigma_rel_err_bound": float(np.max(resid) / 2.0), "checked_pairs": int(kk),
-                     "note": "|sigma-sigma_true|/sigma <= ||A u - lambda u|| / (2 lambda), residual computed with the HIP Gram apply"},
+        "accuracy": {"sigma_rel_err_bound": float(np.max(resid) / 2.0), "checked_pairs": int(len(pick)), "of": k,
+                     "U_orthonormality_defect": ortho, "seconds": round(t_acc, 1),
+                     "note": "|sigma-sigma_true|/sigma <= ||A u - lambda u|| / (2 lambda); A u computed by the CPU ORACLE's operator "
+                             "(oracle/isle_oracle.cpp, fp32 OpenMP), not by the library under test",
+                     "planted_topic_agreement": round(purity, 4), "kmeans_vs_oracle": km},
         "roofline": {"bound": "hbm", "kernel": "gram_apply (Z = B(B^T X), b=%d) = %s" % (b, form_kernels),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},
         "device_ms_per_step": device_ms,
+        "launches_per_step": launches_per_step,
         "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
         "cpu_baseline": cpu,
         "other_stages": up,

@@ -29,8 +29,21 @@ int isle_fail(isle_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
+int isle_max_lds(isle_ctx* c, const void* fn, int bytes) {
+  for (auto& e : c->lds_attr)
+    if (e.first == fn) {
+      if (e.second >= bytes) return 0;
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      e.second = bytes;
+      return 0;
+    }
+  HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  c->lds_attr.emplace_back(fn, bytes);
+  return 0;
+}
+
 TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
-  if (!c->timing) return;
+  if (!c->timing || !((c->timing_mask >> fam) & 1u)) return;
   if (!c->ev_free.empty()) {
     ep = c->ev_free.back();
     c->ev_free.pop_back();
@@ -120,6 +133,37 @@ static int allreduce_sum(isle_ctx* c, T* buf, size_t count) {
   if (!c->multi()) return 0;
   TimeScope ts(c, ISLE_T_COMM);
   return isle_allreduce(c, buf, count, DtOf<T>::v);
+}
+
+// Control decisions of the replicated parts (rank of a Krylov block, restart index, form of the small EVD) are taken per rank from
+// replicated data.  Identical GPUs running identical kernels on identical inputs give identical bits, but nothing else
+// enforces it; a rank that decided differently would issue a different sequence of collectives and the job would hang.
+// Every such decision therefore goes through an all-reduce(MAX) of (v, -v): all ranks see the same pair, so either all of
+// them carry on or all of them return ISLE_E_COMM at the same point.  Device-side variant for the pipelined expand loop:
+// ks_agree_pack_k + the same all-reduce on the mailbox, no extra host round trip.
+static int agree_i32(isle_ctx* c, int v, const char* what) {
+  if (!c->multi()) return 0;
+  HIPCHK(c, c->flags.reserve(16));
+  int* h = reinterpret_cast<int*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 128);  // page-locked
+  h[0] = v;
+  h[1] = -v;
+  HIPCHK(c, hipMemcpyAsync(c->flags.p + 8, h, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  {
+    TimeScope ts(c, ISLE_T_COMM);
+    ISLECHK(isle_allreduce(c, c->flags.p + 8, 2, ISLE_DT_I32, true));
+  }
+  HIPCHK(c, hipMemcpyAsync(h, c->flags.p + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h[0] != -h[1]) return isle_fail(c, ISLE_E_COMM, "ranks disagree on %s (min %d, max %d): replicated state diverged", what, -h[1], h[0]);
+  return 0;
+}
+constexpr int KS_AGREE = 40;  // int slots [40, 43) of the expand mailbox: max rank, -min rank, max status over all ranks
+__global__ void ks_agree_pack_k(int* meta) {
+  if (threadIdx.x == 0) {
+    meta[KS_AGREE] = meta[0];
+    meta[KS_AGREE + 1] = -meta[0];
+    meta[KS_AGREE + 2] = meta[1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -383,8 +427,9 @@ extern "C" int isle_hip_ingest_tdf(isle_ctx* c, const char* text, uint64_t nbyte
   HIPCHK(c, he);
   ISLECHK(rc);
   if (err[0]) {
-    static const char* what[] = {"", "bad character", "more than three fields", "fewer than three fields", "doc/word id is 0 or exceeds <num_docs>/<vocab_size>"};
-    return isle_fail(c, ISLE_E_ARG, "ingest_tdf: %s on line %llu", what[err[0] < 5 ? err[0] : 0], (unsigned long long)(err[1] + 1));
+    static const char* what[] = {"", "bad character", "more than three fields", "fewer than three fields", "doc/word id is 0 or exceeds <num_docs>/<vocab_size>",
+                                 "count is 0"};
+    return isle_fail(c, ISLE_E_ARG, "ingest_tdf: %s on line %llu", what[err[0] < 6 ? err[0] : 0], (unsigned long long)(err[1] + 1));
   }
   if (max_entries && nread != max_entries)  // include/utils.h:227
     return isle_fail(c, ISLE_E_ARG, "ingest_tdf: file has %llu entries, <max_entries> says %llu", (unsigned long long)nread, (unsigned long long)max_entries);
@@ -791,6 +836,7 @@ static int dev_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, std::ve
   std::vector<float> Rfull((size_t)w * w, 0.f);
   int rk = 0;
   ISLECHK(k_panel_qr(c, F, n, w, Qdst, Rfull.data(), &rk));
+  ISLECHK(agree_i32(c, rk, "the rank of a start / repair block"));
   *rank_out = rk;
   R.assign(Rfull.begin(), Rfull.begin() + (size_t)rk * w);
   return 0;
@@ -937,6 +983,12 @@ struct Ks {
       spec = false;
       if (m + blk > cap_r || hcn + blk > cap_c) return isle_fail(c, ISLE_E_NUMERIC, "expand: projected matrix outgrew its work space");
       ISLECHK(k_panel_qr_kernels(c, F, dim, (int)blk, col(hcn + blk), reinterpret_cast<int*>(mail), mail + MB_R));
+      if (c->multi()) {  // the ranks' verdicts on this block travel with the mailbox (see agree_i32)
+        hipLaunchKernelGGL(ks_agree_pack_k, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<int*>(mail));
+        HIPCHK(c, hipGetLastError());
+        TimeScope ts(c, ISLE_T_COMM);
+        ISLECHK(isle_allreduce(c, reinterpret_cast<int*>(mail) + KS_AGREE, 3, ISLE_DT_I32, true));
+      }
       float* hm = host_mail[slot];
       HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + (size_t)npass * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipEventRecord(c->ks_ev[slot], c->stream));
@@ -948,7 +1000,11 @@ struct Ks {
       }
       HIPCHK(c, hipEventSynchronize(c->ks_ev[slot]));
       const int* meta = reinterpret_cast<const int*>(hm);
-      if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
+      if (c->multi() && meta[KS_AGREE] != -meta[KS_AGREE + 1])
+        return isle_fail(c, ISLE_E_COMM, "ranks disagree on the rank of a Krylov block (min %d, max %d): replicated state diverged",
+                         -meta[KS_AGREE + 1], meta[KS_AGREE]);
+      if (meta[1] || (c->multi() && meta[KS_AGREE + 2]))
+        return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
       const int rk = meta[0];
       const float* hc = hm + MB_COEF;
       const float* Rfull = hm + MB_R;
@@ -1046,6 +1102,7 @@ struct Ks {
     while (n_restarts < maxit) {
       ISLECHK(truncate());
       const size_t j = first_unconverged(true);
+      ISLECHK(agree_i32(c, (int)j, "the number of converged Ritz pairs"));
       last_j = j;
       if (j == H.c) {
         nconv = H.c;
@@ -1652,6 +1709,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
 extern "C" int isle_hip_timing_enable(isle_ctx* c, int on) {
   if (!c) return ISLE_E_ARG;
   c->timing = on != 0;
+  c->timing_mask = on == 2 ? ((1u << ISLE_T_GRAM_PASS1) | (1u << ISLE_T_GRAM_PASS2)) : 0xffffffffu;
   return 0;
 }
 extern "C" int isle_hip_timing_reset(isle_ctx* c) {

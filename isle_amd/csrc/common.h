@@ -217,8 +217,14 @@ struct isle_ctx {
   hipEvent_t ks_ev[2] = {nullptr, nullptr};
   DevBuf<float> ks_mail;
 
+  // largest dynamic-LDS size requested so far per kernel ON THIS CONTEXT'S DEVICE (hipFuncSetAttribute is per device; a
+  // process-wide flag would leave the kernels of a second GPU at the 64 KB default)
+  std::vector<std::pair<const void*, int>> lds_attr;
+  bool td_persist_failed = false;  // the persistent tridiagonalisation hit its barrier time-out once (GPU shared): launch chain from now on
+
   // --- timing
   bool timing = false;
+  uint32_t timing_mask = 0xffffffffu;  // families whose launches are bracketed by events while timing is on
   std::vector<isle_event_pair> ev_used;
   std::vector<isle_event_pair> ev_free;
   double t_ms[ISLE_T_COUNT] = {0};
@@ -226,6 +232,8 @@ struct isle_ctx {
 };
 
 int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
+int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
 
 #define HIPCHK(ctx, call)                                                                   \
   do {                                                                                      \

@@ -553,11 +553,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   unsigned int* tickets_rb = tickets + n + 2;
   // persistent form: 2 x (p | next column) behind the counters, rounded up to a double boundary
   double* pv = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tickets_rb + (size_t)n * nrb_max + 2) + 7) & ~(uintptr_t)7);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)td_back_k, hipFuncAttributeMaxDynamicSharedMemorySize, TD_NMAX_BACK * 8 * (int)sizeof(double)));
-    attr_set = true;
-  }
+  ISLECHK(isle_max_lds(c, (const void*)td_back_k, TD_NMAX_BACK * 8 * (int)sizeof(double)));
   const bool small = n <= TD_ROWS * 4;
   // persistent form: G workgroups, each with its columns (ncl of them) plus v and w in LDS
   int pG = TD_P_GSMALL;
@@ -567,7 +563,17 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     if (ncl_max >= 1) pG = std::max(pG, (n + ncl_max - 1) / ncl_max);  // what the LDS needs
     else pG = 1 << 30;
   }
-  bool persist = pG <= c->num_cus && n <= TD_NMAX_BACK && !getenv("ISLE_TD_CHAIN");  // one workgroup per CU at most: all must be resident
+  // one workgroup per CU at most: all must be resident.  A time-out at the grid barrier (the GPU is shared with other work) is
+  // remembered: later solves of this context go straight to the launch chain instead of paying the time-out again.
+  bool persist = pG <= c->num_cus && n <= TD_NMAX_BACK && !getenv("ISLE_TD_CHAIN") && !c->td_persist_failed;
+  if (c->multi()) {  // every rank must take the same form (their roundings differ): the form is agreed, like the bail-out below
+    unsigned int no = persist ? 0u : 1u;
+    HIPCHK(c, hipMemcpyAsync(tickets + 1, &no, sizeof no, hipMemcpyHostToDevice, c->stream));
+    ISLECHK(isle_allreduce(c, tickets + 1, 1, ISLE_DT_U32, true));
+    HIPCHK(c, hipMemcpyAsync(&no, tickets + 1, sizeof no, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    persist = no == 0u;
+  }
   const size_t p_lds = ((size_t)((n + pG - 1) / pG) * n + 2 * (size_t)n) * sizeof(double);
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -577,18 +583,26 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     // ---- 1. tridiagonalisation
     if (persist) {
       // one launch, matrix resident in LDS, two grid barriers per column (td_persist_k); tickets[0] = barrier counter, [1] = abort
-      static bool p_attr = false;
-      if (!p_attr) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)td_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TD_P_LDS));
-        p_attr = true;
-      }
+      ISLECHK(isle_max_lds(c, (const void*)td_persist_k, (int)TD_P_LDS));
       hipLaunchKernelGGL(td_persist_k, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, tickets, tickets + 1);
       HIPCHK(c, hipGetLastError());
+      if (const char* fb = getenv("ISLE_TD_FORCE_BAIL_RANK")) {  // test hook: this rank behaves as if its barrier had timed out
+        if (atoi(fb) == c->rank) {
+          const unsigned int one = 1u;
+          HIPCHK(c, hipMemcpyAsync(tickets + 1, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        }
+      }
+      // The bail-out depends on timing, and the launch chain rounds differently from the persistent form: in a sharded run every
+      // rank must take the same one, or their replicated Ritz data (and then restart decisions, and then the sequence of
+      // collectives) drift apart.  One rank bailing out sends all of them to the chain.
+      if (c->multi()) ISLECHK(isle_allreduce(c, tickets + 1, 1, ISLE_DT_U32, true));
       unsigned int aborted = 0;
       HIPCHK(c, hipMemcpyAsync(&aborted, tickets + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (!aborted) break;
-      fprintf(stderr, "[isle_hip] persistent tridiagonalisation gave up at a grid barrier (n = %d): using the launch chain\n", n);
+      if (!c->td_persist_failed)
+        fprintf(stderr, "[isle_hip] persistent tridiagonalisation gave up at a grid barrier (n = %d): using the launch chain from now on\n", n);
+      c->td_persist_failed = true;
       persist = false;
       continue;
     }

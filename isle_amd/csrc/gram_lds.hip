@@ -22,9 +22,9 @@
 //
 // The build never materialises a transposed copy of B: per document band one workgroup histograms the band's entries by
 // word in LDS (two u16 counters per dword) — first to count the (word, band) cells, then again as placement cursors
-// that drop every entry's band-local document id straight into its slot of the pass-2 stream.  The summation order
-// inside a (word, document band) cell therefore follows those LDS atomics, so Z may differ between runs by fp32 rounding
-// only (as with the chunked-CSR copy of spmm.hip).
+// that drop every entry's band-local document id straight into its slot of the pass-2 stream; gl_sort2_k then puts the
+// ids of every cell in ascending order, so the summation order — and every bit of Z — depends on B alone, not on the
+// arrival order of those LDS atomics (the reference's operator is bitwise reproducible).
 //
 // The same row-constant structure turns the centroid update of Lloyd on B (lloyds_iter, src/sparseMatrix.cpp:1631-1646)
 // into integer counting: centre_c[w] = s_w * #{members of c that contain w} / |c|  (cc_hist_k below).
@@ -349,6 +349,50 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
           const uint32_t j = (odd ? (cur >> 16) : (cur & 0xffffu)) + (pre[u] & 0x3fffu);
           ids16[((size_t)(sb[u] + (j >> 2)) * 64 + (q[u] & 63u)) * 4 + (j & 3u)] = (uint16_t)((p - p0) | ((pre[u] >> 14) << 12));
         }
+      }
+    }
+  }
+}
+
+// The cursors above hand out a cell's slots in the order the LDS atomics arrive, which differs from run to run; this pass puts
+// the ids of every (word, document band) cell in ascending order, so that the stream — and with it the summation order of pass
+// 2 and every bit of Z — is a function of B alone (the reference's operator is bitwise reproducible).  Ids of a
+// cell are distinct band-local document positions < GL_RB: a lane marks them in a bitmap of its own (one LDS column per lane,
+// no atomics, no cross-lane traffic) and writes them back in bit order.  One wave per (wave wv, band, group).
+constexpr int GL_BMW = ((GL_RB + 31) / 32 + 3) & ~3;  // bitmap words per lane, a multiple of 4
+__global__ __launch_bounds__(128) void gl_sort2_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
+                                                   uint2* __restrict__ ids) {
+  __shared__ uint32_t bm[2][GL_BMW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.y * 2 + wave;
+  const size_t wb = blockIdx.x;  // wv * NB + band
+  const uint16_t* cc = cnt + wb * 4;
+  const uint32_t n = cc[g];
+  if (n == 0) return;
+  int64_t sr0 = roff[wb];
+  for (int j = 0; j < g; ++j) sr0 += cc[j];
+  for (int wd = 0; wd < GL_BMW; ++wd) bm[wave][wd][lane] = 0u;
+  uint2* s = ids + (size_t)sr0 * 64 + lane;
+  for (uint32_t r = 0; r < n; ++r) {
+    const uint2 u = s[(size_t)r * 64];
+    const uint32_t id[4] = {u.x & 0xffffu, u.x >> 16, u.y & 0xffffu, u.y >> 16};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (id[t] < GL_RB) bm[wave][id[t] >> 5][lane] |= 1u << (id[t] & 31u);
+  }
+  uint16_t* s16 = reinterpret_cast<uint16_t*>(s);
+  uint32_t j = 0;
+  for (int wd0 = 0; wd0 < GL_BMW; wd0 += 4) {  // four bitmap words in flight per step (the loop is a chain of LDS latencies otherwise)
+    uint32_t bw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bw[u] = bm[wave][wd0 + u][lane];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint32_t bits = bw[u];
+      while (bits) {
+        const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+        bits &= bits - 1u;
+        s16[(size_t)(j >> 2) * 256 + (j & 3u)] = (uint16_t)((wd0 + u) * 32 + b);  // slot j of this lane: super-round j / 4, entry j % 4
+        ++j;
       }
     }
   }
@@ -776,17 +820,17 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
     hipLaunchKernelGGL(gl_hist_fill_k, dim3(s.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, s.n_out,
                        s.NB, c->wpos.p, c->gl_sbase.p, ids16, merge ? c->gl_cellpre.p : nullptr);
     HIPCHK(c, hipGetLastError());
+    if (nwb && !merge && !getenv("ISLE_GL_NOSORT")) {  // merged streams (experiments) keep the arrival order
+      hipLaunchKernelGGL(gl_sort2_k, dim3((unsigned)nwb, 2), dim3(128), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p);
+      HIPCHK(c, hipGetLastError());
+    }
   }
   return 0;
 }
 
 template <int LPE, bool HALF, int MERGE>
 int launch_apply_m(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)gl_apply_k<LPE, HALF, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS));
-    attr_set = true;
-  }
+  ISLECHK(isle_max_lds(c, (const void*)gl_apply_k<LPE, HALF, MERGE>, GL_LDS));
   hipLaunchKernelGGL((gl_apply_k<LPE, HALF, MERGE>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
                      s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE);
   HIPCHK(c, hipGetLastError());
@@ -850,12 +894,8 @@ int k_gl_build(isle_ctx* c) {
   }
   GlSide& s1 = c->gl1;
   GlSide& s2 = c->gl2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)gl_hist_count_k, hipFuncAttributeMaxDynamicSharedMemorySize, GL_HLDS));
-    HIPCHK(c, hipFuncSetAttribute((const void*)gl_hist_fill_k, hipFuncAttributeMaxDynamicSharedMemorySize, GL_HLDS));
-    attr_set = true;
-  }
+  ISLECHK(isle_max_lds(c, (const void*)gl_hist_count_k, GL_HLDS));
+  ISLECHK(isle_max_lds(c, (const void*)gl_hist_fill_k, GL_HLDS));
   // ---- documents by decreasing length
   HIPCHK(c, c->dperm.reserve(D));
   HIPCHK(c, c->dpos.reserve(D));
@@ -1073,11 +1113,7 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
   (void)k;
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)cc_hist_k, hipFuncAttributeMaxDynamicSharedMemorySize, GL_HLDS));
-    attr_set = true;
-  }
+  ISLECHK(isle_max_lds(c, (const void*)cc_hist_k, GL_HLDS));
   const size_t n = (size_t)V * ld;
   HIPCHK(c, c->ccount.reserve(n));
   HIPCHK(c, c->ccounted.reserve(D ? D : 1));

@@ -606,7 +606,7 @@ int k_infer(isle_ctx* c, uint64_t V, int k, const float* model_by_word, uint64_t
     if (D) {
 #define INF(KERNEL)                                                                                                                     \
   do {                                                                                                                                  \
-    HIPCHK(c, hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INF_LDS));                      \
+    ISLECHK(isle_max_lds(c, (const void*)KERNEL, (int)INF_LDS));                                                                         \
     hipLaunchKernelGGL(KERNEL, dim3((unsigned)D), dim3(INF_T), lds, c->stream, (const float4*)dM.p, k, nq, doffs.p, dfw.p, dfa.p, dnk.p, \
                        D, iters, Lfguess, avg_doc_sz, cap_rows, weights ? dW.p : nullptr, dtt.p, dtw.p, dllh.p, dnc.p);                 \
   } while (0)

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(IT) void ing_parse_k(const unsigned char* __restric
   if (!bad && any) {
     if (state != 2) bad = 3;
     else if (f[0] == 0 || f[1] == 0 || f[0] > D || f[1] > V) bad = 4;
+    else if (f[2] == 0) bad = 5;  // a document made of zero counts would normalise to 0 / 0 (src/sparseMatrix.cpp:136-167)
     else {
       ok = 1;
       key[l] = ((f[0] - 1) << wbits) | (f[1] - 1);

@@ -454,7 +454,7 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
 #define LR(NS, CM)                                                                                                            \
   do {                                                                                                                        \
     const size_t lds = (size_t)2 * (CM * 32) * (PR_SL + 1) * sizeof(float);                                                   \
-    HIPCHK(c, hipFuncSetAttribute((const void*)proj_assign_reg_k<NS, CM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    ISLECHK(isle_max_lds(c, (const void*)proj_assign_reg_k<NS, CM, MODE>, (int)lds));                                        \
     hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, Pt, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist, map, ub, lb); \
     *done = true;                                                                                                             \
   } while (0)

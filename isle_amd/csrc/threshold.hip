@@ -70,7 +70,7 @@ __global__ __launch_bounds__(TH_T) void th_round_k(const float* __restrict__ cnt
     for (int64_t i = s + lane; i < e; i += 64) sum += cnt[i];
     sum = wave_sum_f32(sum);
     for (int64_t i = s + lane; i < e; i += 64) {
-      const float r = roundf(avg * (cnt[i] / sum));
+      const float r = sum > 0.f ? roundf(avg * (cnt[i] / sum)) : 0.f;  // counts are > 0 at both entry points; never let 0 / 0 through
       const uint32_t v = (uint32_t)fminf(r, (float)maxv);
       q[i] = (uint16_t)v;
       if (v > 0) atomicAdd(&hist[(size_t)rows[i] * ldh + v], 1u);

@@ -343,8 +343,13 @@ int main(int argv, char** argc) {
     delete[] closest_docs;
     delete B_fl_CSC;
   } catch (const std::exception& e) {
-    std::cerr << "ISLE Trainer failed: " << e.what() << std::endl;  // reference: message only, exit code 0 (drivers/ISLETrain.cpp:48-50)
+    // the reference prints the message and still exits with 0 (drivers/ISLETrain.cpp:48-50): a failed training
+    // run then looks like a good one to a calling script.  Deliberate deviation: status 1.
+    std::cerr << "ISLE Trainer failed: " << e.what() << std::endl;
+    return 1;
   } catch (...) {
     std::cerr << "ISLE Trainer failed" << std::endl;
+    return 1;
   }
+  return 0;
 }

@@ -44,6 +44,7 @@ class FPSparseMatrixHip {
   isle_ctx* ctx_ = nullptr;
   bool uploaded_ = false;
   doc_id_t U_cols_ = 0;
+  int last_nconv_ = 0;  // Ritz pairs that really passed the residual test in the last compute_block_ks
 
   void check(int rc, const char* what) const {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + isle_hip_last_error(ctx_));
@@ -162,6 +163,15 @@ class FPSparseMatrixHip {
                                      ISLE_BLOCK_KS_BLOCK_SIZE, ISLE_BLOCK_KS_TOLERANCE, 1, ev.data(), &nconv, &restarts, &napplies);
     // the reference reports nconv = nev even when maxit is exhausted and asserts on it (:1207)
     if (rc != 0 && rc != ISLE_E_NOCONV) check(rc, "compute_block_ks");
+    if (rc == ISLE_E_NOCONV) {
+      // the reference's log line says nconv = num_topics here and its assert passes; keep its line, but say what happened
+      std::fprintf(stderr, "WARNING: block Krylov-Schur used all %d restarts; only %d of %d Ritz pairs passed the residual test "
+                           "(tolerance %g). The unconverged Ritz vectors are used as they are, as the reference does.\n",
+                   ISLE_BLOCK_KS_MAX_ITERS, nconv, (int)num_topics, (double)ISLE_BLOCK_KS_TOLERANCE);
+      last_nconv_ = nconv;
+    } else {
+      last_nconv_ = (int)num_topics;
+    }
     std::printf("Completed with %d restarts, nconv = %d\n", restarts, rc == ISLE_E_NOCONV ? (int)num_topics : nconv);
     for (doc_id_t i = 0; i < num_topics; ++i) evalues.push_back(ev[i]);
     U_cols_ = num_topics;

@@ -1,6 +1,6 @@
 // isle_amd/host/hot_path_main.cpp — the hot slice of ISLETrainer::train() (src/trainer.cpp:490-571) as a
 // standalone C++ program over ISLE::FPSparseMatrixHip, with the reference's own log lines
-// (include/logUtils.h:101-122 "Eigvals:"; trainer.cpp:490 "Frob(B_fl_CSC):").
+// (the "Eigvals:" block in the format of include/logUtils.h:101-122; trainer.cpp:490 "Frob(B_fl_CSC):").
 //
 //   hot_path_main <B.bin> <num_topics> <out.bin>
 // B.bin  : u64 V, u64 D, u64 nnz, f32 vals[nnz], u64 rows[nnz], i64 offs[D+1]   (the reference's 8-byte types)
@@ -9,24 +9,34 @@
 // Exit code != 0 on failure (unlike drivers/ISLETrain.cpp:48-50, which swallows every exception).
 #include <cmath>
 #include <cstdio>
-#include <numeric>
-#include <sstream>
+#include <string>
 
 #include "fpsparse_hip.h"
 
 using namespace ISLE;
 
-static void print_eigen_data(std::vector<FPTYPE>& evalues, doc_id_t num_topics) {  // include/logUtils.h:101-122
-  std::ostringstream ostr;
-  ostr << "Eigvals:  ";
-  for (doc_id_t t = 0; t < num_topics; ++t) ostr << "(" << t << "): " << std::sqrt(evalues[t]) << "\t";
-  ostr << std::endl;
-  std::vector<FPTYPE> eig_sum_slabs(num_topics / 100 + 1, 0.0);
-  for (doc_id_t t = 0; t < num_topics; ++t) eig_sum_slabs[t / 100] += evalues[t];
-  for (doc_id_t slab = 0; slab < num_topics / 100; ++slab)
-    ostr << "Sum of Top-" << (slab + 1) * 100 << " eig vals: "
-         << std::accumulate(eig_sum_slabs.begin(), eig_sum_slabs.begin() + 1 + slab, (FPTYPE)0.0) << "\n";
-  std::cout << ostr.str();
+// The "Eigvals:" log block of the reference's trainer (its text is a parity surface: include/logUtils.h:101-122 defines the
+// format — singular values as "(i): sigma" separated by tabs, then the running sum of the eigenvalues after every full hundred).
+// Floats are printed as the reference's ostream does (six significant digits, "%g"); hundreds are summed first and then
+// chained, which is the rounding order the reference's figures have.
+static void log_spectrum(const std::vector<FPTYPE>& lambda, doc_id_t k) {
+  std::string line = "Eigvals:  ";
+  char buf[64];
+  for (doc_id_t i = 0; i < k; ++i) {
+    std::snprintf(buf, sizeof buf, "(%llu): %g\t", (unsigned long long)i, (double)std::sqrt(lambda[i]));
+    line += buf;
+  }
+  line += "\n";
+  FPTYPE running = 0;
+  for (doc_id_t h = 0; (h + 1) * 100 <= k; ++h) {
+    FPTYPE hundred = 0;
+    for (doc_id_t i = h * 100; i < (h + 1) * 100; ++i) hundred += lambda[i];
+    running += hundred;
+    std::snprintf(buf, sizeof buf, "Sum of Top-%llu eig vals: %g\n", (unsigned long long)((h + 1) * 100), (double)running);
+    line += buf;
+  }
+  std::fputs(line.c_str(), stdout);
+  std::fflush(stdout);
 }
 
 int main(int argc, char** argv) {
@@ -55,7 +65,8 @@ int main(int argc, char** argv) {
     std::vector<FPTYPE> evalues;
     B_fl_CSC->initialize_for_eigensolver(num_topics);
     B_fl_CSC->compute_block_ks(num_topics, evalues);
-    print_eigen_data(evalues, num_topics);
+    std::cout.flush();
+    log_spectrum(evalues, num_topics);
     auto& B_fl = B_fl_CSC;
 
     std::vector<doc_id_t> best_kmeans_seeds;

@@ -48,6 +48,7 @@ inline void read_tdf(const std::string& path, uint64_t max_entries, std::vector<
     switch (ch) {
       case '\r': break;
       case '\n':
+        if (any && state == 3 && count == 0) throw std::runtime_error("tdf file: count is 0 (entry " + std::to_string(entries.size() + 1) + ")");
         if (any) entries.push_back({doc - 1, word - 1, (uint32_t)count});
         doc = word = count = 0;
         state = 1;

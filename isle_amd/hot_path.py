@@ -20,6 +20,23 @@ MAX_KMEANS_LOWD_REPS = 10     # include/hyperparams.h:60
 MAX_KMEANS_REPS = 10          # include/hyperparams.h:68
 
 
+W0_C, EPS2_C, EPS3_C, RHO_C = 1.0, 1.0 / 3.0, 5.0, 1.1   # include/hyperparams.h:8-12
+
+
+def catchword_rank(num_docs, num_topics, sample_rate=None):
+    """The rank r that ISLETrainer::train passes to rth_highest_element (src/trainer.cpp:579-583): eps2_c * w0_c * num_docs
+    (* sample_rate) / (2 num_topics), float operands in double arithmetic, floored."""
+    x = EPS2_C * W0_C * float(np.float32(num_docs))
+    if sample_rate is not None:
+        x = x * float(np.float32(sample_rate))
+    return int(np.floor(x / float(np.float32(2.0 * num_topics))))
+
+
+def model_rank_threshold(num_docs, num_topics):
+    """rank_threshold of SparseMatrix::construct_topic_model (src/sparseMatrix.cpp:720)."""
+    return int(EPS3_C * W0_C * float(np.float32(num_docs)) / (float(np.float32(num_topics)) * 2.0))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -343,7 +360,8 @@ class HotPath:
         return dict(weights=W, top_topic=tt, top_weight=tw, llh=llh, nconverged=int(nc.value), avg_doc_sz=avg_doc_sz)
 
     def timing_enable(self, on=True):
-        self._chk(self._lib.isle_hip_timing_enable(self._h, 1 if on else 0))
+        """0 / False: off; 1 / True: events around every launch; 2: around the Gram-apply launches only."""
+        self._chk(self._lib.isle_hip_timing_enable(self._h, int(on)))
 
     def timing_reset(self):
         self._chk(self._lib.isle_hip_timing_reset(self._h))

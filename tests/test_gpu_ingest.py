@@ -69,6 +69,8 @@ def test_ingest_errors(hp):
         hp.ingest_tdf(b"6 1 1\n", 5, 5)
     with pytest.raises(Exception, match="max_entries"):
         hp.ingest_tdf(b"1 1 1\n2 2 2\n", 5, 5, max_entries=3)
+    with pytest.raises(Exception, match="count is 0 on line 2"):  # a document of zero counts would normalise to 0 / 0
+        hp.ingest_tdf(b"1 1 1\n2 2 0\n", 5, 5)
 
 
 def test_ingest_then_threshold_equals_upload(hp, tmp_path):
