@@ -243,9 +243,9 @@ def main():
     except Exception:
         pass
     device_ms = {f: round(v[0], 3) for f, v in tm.items() if v[1]}  # the one untimed pass with events around every launch
-    launches_per_step = int(sum(v[1] for v in tm.values()))
+    scopes_per_step = int(sum(v[1] for v in tm.values()))  # event-bracketed scopes (a scope may hold several launches; rocprof has the launch count)
     form = hp.operator_form()
-    form_kernels = ("LDS-banded form: gl_scale_k + gl_apply_k<3,true,0> (pass 1) + gl_apply_k<3,true,0> + gl_reduce_k (pass 2)" if form == 1
+    form_kernels = ("LDS-banded form: gl_pack_scale_k + gl_apply_k<3,true,0> (pass 1) + gl_apply_k<3,true,0> + gl_reduce_cm_k (pass 2)" if form == 1
                     else "gather form: seg_gather_k<3,false> (pass 1) + seg_gather_k<3,true> + reduce_chunks_k (pass 2)")
     if form != 1:
         traffic = None  # profiles/pmc_traffic.json holds the LDS-banded form's counters
@@ -455,7 +455,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},
         "device_ms_per_step": device_ms,
-        "launches_per_step": launches_per_step,
+        "timed_scopes_per_step": scopes_per_step,
         "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
         "cpu_baseline": cpu,
         "other_stages": up,

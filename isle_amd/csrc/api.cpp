@@ -783,13 +783,8 @@ static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
     for (int j0 = 0; j0 < b; j0 += 12) {
       const int bg = std::min(12, b - j0);
       const int BPg = panel_width(bg);
-      HIPCHK(c, c->Xrm.reserve((size_t)c->V * BPg));
-      HIPCHK(c, c->Zrm.reserve((size_t)c->V * BPg));
-      HIPCHK(c, c->Yrm.reserve((size_t)c->D * BPg));
-      ISLECHK(k_pack_rm(c, Xcm + (size_t)j0 * c->V, c->V, bg, BPg, c->Xrm.p));
-      ISLECHK(k_gl_apply(c, bg, BPg));
-      ISLECHK(allreduce_sum<float>(c, c->Zrm.p, (size_t)c->V * BPg));
-      ISLECHK(k_unpack_cm(c, c->Zrm.p, c->V, bg, BPg, Zcm + (size_t)j0 * c->V));
+      ISLECHK(k_gl_apply_cm(c, Xcm + (size_t)j0 * c->V, bg, BPg, Zcm + (size_t)j0 * c->V));
+      ISLECHK(allreduce_sum<float>(c, Zcm + (size_t)j0 * c->V, (size_t)c->V * bg));
     }
     return 0;
   }

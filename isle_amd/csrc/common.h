@@ -146,6 +146,7 @@ struct isle_ctx {
   DevBuf<uint16_t> gl_cellpre;   // V x NB2 (merged streams): entries of the lane's earlier items in the merged group | item tag << 14
   int gl_merge = 0;              // stream form of both passes: 0 one item per group, 1 four items merged (item changes on super-round boundaries), 2 merged entry by entry
   DevBuf<uint32_t> gl_srsum, gl_sbase;
+  DevBuf<uint32_t> gl_biglist;   // [count | (wave, band, group) triples whose pass-2 cells are too long for the register sort]
   DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)
   DevBuf<uint32_t> ccounted;     // D: the centre under which document d is counted in ccount
   DevBuf<int64_t> gl_scan;
@@ -278,7 +279,7 @@ int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (n
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
 int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out);  // Out (D x ld) = B^T M, LDS-banded form only
-int k_gl_apply(isle_ctx* c, int b, int BP);  // Zrm = B (B^T Xrm), b columns in a panel of BP in {4, 8, 12}
+int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm);  // Zcm (V x b col-major) = B (B^T Xcm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip
 int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);
 int k_frobenius(isle_ctx* c, double* out_host);

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ sli
       sh[g] = sr;
     }
     __syncthreads();
-    if (threadIdx.x == 0) srsum[wv * NB + band] = sh[0] + sh[1] + sh[2] + sh[3];
+    // the apply kernel's id ring is static (round i of a (wave, band) segment sits in ring register i & 3): whole turns of four
+    // super-rounds per segment; the filler rounds behind the last group hold the padding id
+    if (threadIdx.x == 0) srsum[wv * NB + band] = (sh[0] + sh[1] + sh[2] + sh[3] + 3u) & ~3u;
     __syncthreads();
   }
 }
@@ -356,43 +358,101 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
 
 // The cursors above hand out a cell's slots in the order the LDS atomics arrive, which differs from run to run; this pass puts
 // the ids of every (word, document band) cell in ascending order, so that the stream — and with it the summation order of pass
-// 2 and every bit of Z — is a function of B alone (the reference's operator is bitwise reproducible).  Ids of a
-// cell are distinct band-local document positions < GL_RB: a lane marks them in a bitmap of its own (one LDS column per lane,
-// no atomics, no cross-lane traffic) and writes them back in bit order.  One wave per (wave wv, band, group).
-constexpr int GL_BMW = ((GL_RB + 31) / 32 + 3) & ~3;  // bitmap words per lane, a multiple of 4
-__global__ __launch_bounds__(128) void gl_sort2_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
-                                                   uint2* __restrict__ ids) {
-  __shared__ uint32_t bm[2][GL_BMW][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.y * 2 + wave;
+// 2 and every bit of Z — is a function of B alone (the reference's operator is bitwise reproducible).  A lane's slots
+// of one (wave, band, group) hold the cell's ids (distinct band-local document positions < GL_RB) followed by padding (GL_RB).
+// gl_sort2_k: up to 16 super-rounds (64 slots) are sorted in registers by a bitonic network (no LDS, full occupancy); longer
+// cells (frequent words) go on a list for gl_sort2_big_k, where a lane marks its ids in a bitmap of its own (one LDS column per
+// lane, no atomics, no cross-lane traffic) and writes them back in bit order.
+template <int N>
+__device__ inline void gl_sort_regs(uint2* __restrict__ s, uint32_t n) {  // n <= N / 4 super-rounds of this lane, stride 64
+  uint32_t v[N];
+#pragma unroll
+  for (int r = 0; r < N / 4; ++r) {
+    const uint2 u = s[(size_t)min((uint32_t)r, n - 1) * 64];  // clamped address, masked value: the loads stay unconditional
+    const bool live = (uint32_t)r < n;
+    v[4 * r] = live ? (u.x & 0xffffu) : 0xffffu;
+    v[4 * r + 1] = live ? (u.x >> 16) : 0xffffu;
+    v[4 * r + 2] = live ? (u.y & 0xffffu) : 0xffffu;
+    v[4 * r + 3] = live ? (u.y >> 16) : 0xffffu;
+  }
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t a = v[i], b = v[l];
+          const uint32_t lo = min(a, b), hi = max(a, b);
+          const bool up = (i & k) == 0;
+          v[i] = up ? lo : hi;
+          v[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < N / 4; ++r)
+    if ((uint32_t)r < n) s[(size_t)r * 64] = make_uint2(v[4 * r] | (v[4 * r + 1] << 16), v[4 * r + 2] | (v[4 * r + 3] << 16));
+}
+
+// one workgroup of 4 waves per (wave wv, band); wave g sorts group g's slots.  big[0] = number of entries that follow.
+__global__ __launch_bounds__(256) void gl_sort2_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
+                                                   uint2* __restrict__ ids, uint32_t* __restrict__ big) {
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t wb = blockIdx.x;  // wv * NB + band
   const uint16_t* cc = cnt + wb * 4;
   const uint32_t n = cc[g];
   if (n == 0) return;
   int64_t sr0 = roff[wb];
   for (int j = 0; j < g; ++j) sr0 += cc[j];
-  for (int wd = 0; wd < GL_BMW; ++wd) bm[wave][wd][lane] = 0u;
   uint2* s = ids + (size_t)sr0 * 64 + lane;
-  for (uint32_t r = 0; r < n; ++r) {
-    const uint2 u = s[(size_t)r * 64];
-    const uint32_t id[4] = {u.x & 0xffffu, u.x >> 16, u.y & 0xffffu, u.y >> 16};
+  if (n <= 2) gl_sort_regs<8>(s, n);
+  else if (n <= 4) gl_sort_regs<16>(s, n);
+  else if (n <= 8) gl_sort_regs<32>(s, n);
+  else if (n <= 16) gl_sort_regs<64>(s, n);
+  else if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = (uint32_t)(wb * 4 + g);  // the list's order does not matter
+}
+
+constexpr int GL_BMW = ((GL_RB + 31) / 32 + 3) & ~3;  // bitmap words per lane, a multiple of 4
+__global__ __launch_bounds__(128) void gl_sort2_big_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
+                                                       uint2* __restrict__ ids, const uint32_t* __restrict__ big) {
+  __shared__ uint32_t bm[2][GL_BMW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nbig = big[0];
+  for (uint32_t it = blockIdx.x * 2 + wave; it < nbig; it += gridDim.x * 2) {
+    const uint32_t e = big[1 + it];
+    const size_t wb = e >> 2;
+    const int g = (int)(e & 3u);
+    const uint16_t* cc = cnt + wb * 4;
+    const uint32_t n = cc[g];
+    int64_t sr0 = roff[wb];
+    for (int j = 0; j < g; ++j) sr0 += cc[j];
+    for (int wd = 0; wd < GL_BMW; ++wd) bm[wave][wd][lane] = 0u;
+    uint2* s = ids + (size_t)sr0 * 64 + lane;
+    for (uint32_t r = 0; r < n; ++r) {
+      const uint2 u = s[(size_t)r * 64];
+      const uint32_t id[4] = {u.x & 0xffffu, u.x >> 16, u.y & 0xffffu, u.y >> 16};
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (id[t] < GL_RB) bm[wave][id[t] >> 5][lane] |= 1u << (id[t] & 31u);
-  }
-  uint16_t* s16 = reinterpret_cast<uint16_t*>(s);
-  uint32_t j = 0;
-  for (int wd0 = 0; wd0 < GL_BMW; wd0 += 4) {  // four bitmap words in flight per step (the loop is a chain of LDS latencies otherwise)
-    uint32_t bw[4];
+      for (int t = 0; t < 4; ++t)
+        if (id[t] < GL_RB) bm[wave][id[t] >> 5][lane] |= 1u << (id[t] & 31u);
+    }
+    uint16_t* s16 = reinterpret_cast<uint16_t*>(s);
+    uint32_t j = 0;
+    for (int wd0 = 0; wd0 < GL_BMW; wd0 += 4) {  // four bitmap words in flight per step (a chain of LDS latencies otherwise)
+      uint32_t bw[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bw[u] = bm[wave][wd0 + u][lane];
+      for (int u = 0; u < 4; ++u) bw[u] = bm[wave][wd0 + u][lane];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      uint32_t bits = bw[u];
-      while (bits) {
-        const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
-        bits &= bits - 1u;
-        s16[(size_t)(j >> 2) * 256 + (j & 3u)] = (uint16_t)((wd0 + u) * 32 + b);  // slot j of this lane: super-round j / 4, entry j % 4
-        ++j;
+      for (int u = 0; u < 4; ++u) {
+        uint32_t bits = bw[u];
+        while (bits) {
+          const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+          bits &= bits - 1u;
+          s16[(size_t)(j >> 2) * 256 + (j & 3u)] = (uint16_t)((wd0 + u) * 32 + b);  // slot j of this lane: super-round j / 4, entry j % 4
+          ++j;
+        }
       }
     }
   }
@@ -474,21 +534,16 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   }
   // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
-  // MERGE 0: the ring is rotated in C++ (q0 = q1; ... q3 = *p).  hipcc turns that into register moves that read the newest
-  // load's destination and therefore waits vmcnt(0) in every round: one or two loads in flight, the pass runs at memory latency.
-  // Merged forms: four 64-bit registers that never move — a (wave, band) segment is a multiple of four super-rounds
-  // (gl_cnt_k), round i's ids sit in register i & 3, which is reloaded as soon as it has been read.  The loads are inline asm
-  // with a hand-placed s_waitcnt vmcnt(3): the three younger loads stay in flight.
-  uint2 q0, q1, q2, q3;
+  // The ring is four 64-bit registers that never move — a (wave, band) segment is a multiple of four super-rounds (gl_cnt_k),
+  // round i's ids sit in register i & 3, which is reloaded as soon as it has been read.  The loads are inline asm with a
+  // hand-placed s_waitcnt vmcnt(3): the three younger loads stay in flight.  (A ring rotated in C++ — q0 = q1; ... q3 = *p —
+  // becomes register moves that read the newest load's destination: hipcc then waits vmcnt(0) in every round, one load in
+  // flight, and the pass runs at memory latency; round 1 shipped that form for MERGE 0.)
   unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-  if (MERGE == 0) {
-    q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
-  } else {
-    GL_LOAD(r0, p);
-    GL_LOAD(r1, p + 64);
-    GL_LOAD(r2, p + 128);
-    GL_LOAD(r3, p + 192);
-  }
+  GL_LOAD(r0, p);
+  GL_LOAD(r1, p + 64);
+  GL_LOAD(r2, p + 128);
+  GL_LOAD(r3, p + 192);
   p += 256;
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
     __syncthreads();  // every wave is done with the previous band
@@ -515,29 +570,40 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     uint32_t c01 = __builtin_amdgcn_readfirstlane(cc.x), c23 = __builtin_amdgcn_readfirstlane(cc.y);
     if (!wvalid) c01 = c23 = 0;
     if (MERGE == 0) {
-#pragma unroll
-      for (int g = 0; g < GL_G; ++g) {
-        const uint32_t n = ((g < 2 ? c01 : c23) >> (16 * (g & 1))) & 0xffffu;
-        for (uint32_t r = 0; r < n; ++r) {
-          const uint2 u = q0;
-          q0 = q1;
-          q1 = q2;
-          q2 = q3;
-          q3 = *p;
-          p += 64;
-          const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int l = 0; l < NF; ++l) add4(acc[g][l], xs[a[t] + l]);
-            if (HALF) {
-              const float2 h = *reinterpret_cast<const float2*>(&xs[a[t] + NF]);
-              acch[g].x += h.x;
-              acch[g].y += h.y;
-            }
-          }
-        }
+      // one item per (lane, group): rounds [0, e0) add into acc[0], [e0, e1) into acc[1], ...; the group of a round is a scalar
+      // comparison (the counts are wave-uniform), so the four accumulator sets are addressed statically inside scalar branches
+      const uint32_t e0 = c01 & 0xffffu, e1 = e0 + (c01 >> 16), e2 = e1 + (c23 & 0xffffu);
+      const uint32_t R = (e2 + (c23 >> 16) + 3u) & ~3u;  // filler rounds (padding ids: the zero row) land in the last group
+#define GL_ACC(G, QQ)                                                                                         \
+  {                                                                                                           \
+    const uint32_t ux_ = (uint32_t)(QQ), uy_ = (uint32_t)((QQ) >> 32);                                        \
+    const uint32_t a_[4] = {(ux_ & 0xffffu) * LPE, (ux_ >> 16) * LPE, (uy_ & 0xffffu) * LPE, (uy_ >> 16) * LPE}; \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
+      _Pragma("unroll") for (int l = 0; l < NF; ++l) add4(acc[G][l], xs[a_[t] + l]);                          \
+      if (HALF) {                                                                                             \
+        const float2 h_ = *reinterpret_cast<const float2*>(&xs[a_[t] + NF]);                                  \
+        acch[G].x += h_.x;                                                                                    \
+        acch[G].y += h_.y;                                                                                    \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+#define GL_ROUND0(Q, I)                                                                                                  \
+  {                                                                                                                      \
+    unsigned long long u_; /* the copy is made by the asm itself, after the wait: a C++ copy would share Q's register */ \
+    asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %1" : "=&v"(u_) : "v"(Q) : "memory");                              \
+    GL_LOAD(Q, p);                                                                                                       \
+    p += 64;                                                                                                             \
+    const uint32_t i_ = (I);                                                                                             \
+    if (i_ < e0) GL_ACC(0, u_) else if (i_ < e1) GL_ACC(1, u_) else if (i_ < e2) GL_ACC(2, u_) else GL_ACC(3, u_)        \
+  }
+      for (uint32_t r = 0; r < R; r += 4) {
+        GL_ROUND0(r0, r)
+        GL_ROUND0(r1, r + 1)
+        GL_ROUND0(r2, r + 2)
+        GL_ROUND0(r3, r + 3)
       }
+#undef GL_ROUND0
+#undef GL_ACC
     } else {
       const uint32_t n = c01 & 0xffffu;  // group 0 carries the merged stream: a multiple of 4 super-rounds
       auto round = [&](const unsigned long long qq) {
@@ -646,25 +712,26 @@ __global__ __launch_bounds__(256) void gl_pack_panel_k(const float* __restrict__
   Xs[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// Xs[w, :] = s_w * X[w, :]
-__global__ __launch_bounds__(256) void gl_scale_k(const float4* __restrict__ X, const float* __restrict__ rowval, size_t n4, int LPE,
-                                                   float4* __restrict__ Xs) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const float s = rowval[i / LPE];
-  float4 v = X[i];
-  v.x *= s;
-  v.y *= s;
-  v.z *= s;
-  v.w *= s;
-  Xs[i] = v;
+// Xs[w, :] = s_w * X[w, :] straight from the eigensolver's column-major block (V x b, leading dimension V): the row-major
+// packing and the scaling in one pass (columns >= b of the panel are zero)
+__global__ __launch_bounds__(256) void gl_pack_scale_k(const float* __restrict__ Xcm, size_t V, int b, int LPE, const float* __restrict__ rowval,
+                                                        float4* __restrict__ Xs) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // i = l * V + w: consecutive threads read consecutive rows of a column
+  if (i >= V * (size_t)LPE) return;
+  const int l = (int)(i / V);
+  const size_t w = i - (size_t)l * V;
+  const float s = rowval[w];
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = (4 * l + t < b) ? s * Xcm[(size_t)(4 * l + t) * V + w] : 0.f;
+  Xs[w * LPE + l] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// Z[wperm[q], :] = s_w * sum over the slabs of q's word block (fixed order)
-__global__ __launch_bounds__(256) void gl_reduce_k(const float4* __restrict__ part, const uint32_t* __restrict__ slab0,
-                                                    const uint32_t* __restrict__ nch, const uint32_t* __restrict__ wperm,
-                                                    const float* __restrict__ rowval, uint32_t V, int LPE, uint32_t bitems,
-                                                    float4* __restrict__ Z) {
+// gl_reduce_k writing the eigensolver's column-major block: Zcm[wperm[q] + j V] = s_w * sum over the slabs (fixed order), j < b
+__global__ __launch_bounds__(256) void gl_reduce_cm_k(const float4* __restrict__ part, const uint32_t* __restrict__ slab0,
+                                                       const uint32_t* __restrict__ nch, const uint32_t* __restrict__ wperm,
+                                                       const float* __restrict__ rowval, uint32_t V, int LPE, int b, uint32_t bitems,
+                                                       float* __restrict__ Zcm) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)V * LPE) return;
   const uint32_t q = (uint32_t)(i / LPE);
@@ -677,11 +744,10 @@ __global__ __launch_bounds__(256) void gl_reduce_k(const float4* __restrict__ pa
   for (uint32_t ch = 1; ch < n; ++ch) add4(s, src[(size_t)ch * stride]);
   const uint32_t w = wperm[q];
   const float v = rowval[w];
-  s.x *= v;
-  s.y *= v;
-  s.z *= v;
-  s.w *= v;
-  Z[(size_t)w * LPE + l] = s;
+  const float o[4] = {s.x * v, s.y * v, s.z * v, s.w * v};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (4 * l + t < b) Zcm[(size_t)(4 * l + t) * V + w] = o[t];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -802,7 +868,8 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   const size_t n16_all = ((size_t)s.total_sr + 2 * GL_PF) * 64 * 4, n16_body = (size_t)s.total_sr * 64 * 4;
   uint16_t* ids16 = reinterpret_cast<uint16_t*>(s.ids.p);
   if (PASS == 1) {
-    HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)GL_RB, n16_all - n16_body, c->stream));
+    // everything: the filler rounds that round a (wave, band) segment up to a whole ring turn are written by no fill kernel
+    HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
     if (nwb && !merge)
       hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
                          c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
@@ -821,7 +888,10 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
                        s.NB, c->wpos.p, c->gl_sbase.p, ids16, merge ? c->gl_cellpre.p : nullptr);
     HIPCHK(c, hipGetLastError());
     if (nwb && !merge && !getenv("ISLE_GL_NOSORT")) {  // merged streams (experiments) keep the arrival order
-      hipLaunchKernelGGL(gl_sort2_k, dim3((unsigned)nwb, 2), dim3(128), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p);
+      HIPCHK(c, c->gl_biglist.reserve(nwb * 4 + 1));
+      HIPCHK(c, hipMemsetAsync(c->gl_biglist.p, 0, sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(gl_sort2_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p, c->gl_biglist.p);
+      hipLaunchKernelGGL(gl_sort2_big_k, dim3(2 * c->num_cus), dim3(128), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p, c->gl_biglist.p);
       HIPCHK(c, hipGetLastError());
     }
   }
@@ -1081,26 +1151,27 @@ int k_gl_build(isle_ctx* c) {
   return 0;
 }
 
-// Zrm (V x BP) = B (B^T Xrm); Xrm / Yrm / Zrm of the context; b columns in a panel of BP = 4, 8 or 12
-int k_gl_apply(isle_ctx* c, int b, int BP) {
+// Zcm (V x b column-major) = B (B^T Xcm): the operator application on the eigensolver's own layout, panel of BP = 4, 8 or 12 columns
+// (the row-major packing of X is fused with its scaling, the slab reduction writes the column-major block)
+int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm) {
   const int LPE = BP / 4;
   if (LPE < 1 || LPE > 3 || b > BP || b <= BP - 4) return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: b = %d in a panel of %d", b, BP);
   const bool half = b <= BP - 2;
   const uint32_t V = (uint32_t)c->V;
   const size_t nx4 = (size_t)V * LPE;
   HIPCHK(c, c->gl_Xs.reserve((size_t)V * BP));
+  HIPCHK(c, c->Yrm.reserve((size_t)c->D * BP));
   {
     TimeScope ts(c, ISLE_T_GRAM_PASS1);
-    hipLaunchKernelGGL(gl_scale_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->Xrm.p, c->rowval.p, nx4, LPE,
-                       (float4*)c->gl_Xs.p);
+    hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, Xcm, (size_t)V, b, LPE, c->rowval.p, (float4*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
     ISLECHK(launch_apply_any(c, LPE, half, c->gl1, (const float4*)c->gl_Xs.p, (float4*)c->Yrm.p, 0));
   }
   {
     TimeScope ts(c, ISLE_T_GRAM_PASS2);
     ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)c->gl_block_items * LPE));
-    hipLaunchKernelGGL(gl_reduce_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->gl_part.p, c->gl_slab0.p,
-                       c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, c->gl_block_items, (float4*)c->Zrm.p);
+    hipLaunchKernelGGL(gl_reduce_cm_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->gl_part.p, c->gl_slab0.p,
+                       c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, b, c->gl_block_items, Zcm);
     HIPCHK(c, hipGetLastError());
   }
   return 0;

@@ -37,7 +37,7 @@ def test_oracle_against_fp64_brute_force(name):
     R = np.random.default_rng(12345).standard_normal((V, 8))
     assert np.linalg.norm(U @ (U.T @ R) - f["sketch"]) / np.linalg.norm(f["sketch"]) <= 1e-3
     ko = o.kmeanspp(r["U"], k, inject=f["seeds"])
-    assert np.abs(ko["min_dist"][f["min_d2_idx"]] - f["min_d2_val"]).max() <= 1e-4 * f["min_d2_val"].max()
+    assert np.abs(ko["min_dist"][f["min_d2_idx"]] - f["min_d2_val"]).max() <= 5e-4 * f["min_d2_val"].max()
     lo = o.lloyds_projected(r["U"], ko["C_lowd"])
     assert lo["iters"] == int(f["lp_iters"])
     assert (lo["assign"] == f["lp_assign"]).mean() >= 0.999
