@@ -152,9 +152,7 @@ __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ sli
       sh[g] = sr;
     }
     __syncthreads();
-    // the apply kernel's id ring is static (round i of a (wave, band) segment sits in ring register i & 3): whole turns of four
-    // super-rounds per segment; the filler rounds behind the last group hold the padding id
-    if (threadIdx.x == 0) srsum[wv * NB + band] = (sh[0] + sh[1] + sh[2] + sh[3] + 3u) & ~3u;
+    if (threadIdx.x == 0) srsum[wv * NB + band] = sh[0] + sh[1] + sh[2] + sh[3];
     __syncthreads();
   }
 }
@@ -534,16 +532,24 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   }
   // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
-  // The ring is four 64-bit registers that never move — a (wave, band) segment is a multiple of four super-rounds (gl_cnt_k),
-  // round i's ids sit in register i & 3, which is reloaded as soon as it has been read.  The loads are inline asm with a
-  // hand-placed s_waitcnt vmcnt(3): the three younger loads stay in flight.  (A ring rotated in C++ — q0 = q1; ... q3 = *p —
-  // becomes register moves that read the newest load's destination: hipcc then waits vmcnt(0) in every round, one load in
-  // flight, and the pass runs at memory latency; round 1 shipped that form for MERGE 0.)
+  // MERGE 0: the ring is rotated in C++ (q0 = q1; ... q3 = *p).  (Round 2 measured the static ring below for this form too —
+  // segments padded to whole turns, the group of a round chosen by scalar branches: 0.496 -> 0.520 ms per apply at C2, the 9 %
+  // filler rounds cost more than the deeper prefetch gains, because this form is bound by LDS issue, not by id latency.)
+  //  hipcc turns that into register moves that read the newest
+  // load's destination and therefore waits vmcnt(0) in every round: one or two loads in flight, the pass runs at memory latency.
+  // Merged forms: four 64-bit registers that never move — a (wave, band) segment is a multiple of four super-rounds
+  // (gl_cnt_k), round i's ids sit in register i & 3, which is reloaded as soon as it has been read.  The loads are inline asm
+  // with a hand-placed s_waitcnt vmcnt(3): the three younger loads stay in flight.
+  uint2 q0, q1, q2, q3;
   unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-  GL_LOAD(r0, p);
-  GL_LOAD(r1, p + 64);
-  GL_LOAD(r2, p + 128);
-  GL_LOAD(r3, p + 192);
+  if (MERGE == 0) {
+    q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
+  } else {
+    GL_LOAD(r0, p);
+    GL_LOAD(r1, p + 64);
+    GL_LOAD(r2, p + 128);
+    GL_LOAD(r3, p + 192);
+  }
   p += 256;
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
     __syncthreads();  // every wave is done with the previous band
@@ -570,40 +576,29 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     uint32_t c01 = __builtin_amdgcn_readfirstlane(cc.x), c23 = __builtin_amdgcn_readfirstlane(cc.y);
     if (!wvalid) c01 = c23 = 0;
     if (MERGE == 0) {
-      // one item per (lane, group): rounds [0, e0) add into acc[0], [e0, e1) into acc[1], ...; the group of a round is a scalar
-      // comparison (the counts are wave-uniform), so the four accumulator sets are addressed statically inside scalar branches
-      const uint32_t e0 = c01 & 0xffffu, e1 = e0 + (c01 >> 16), e2 = e1 + (c23 & 0xffffu);
-      const uint32_t R = (e2 + (c23 >> 16) + 3u) & ~3u;  // filler rounds (padding ids: the zero row) land in the last group
-#define GL_ACC(G, QQ)                                                                                         \
-  {                                                                                                           \
-    const uint32_t ux_ = (uint32_t)(QQ), uy_ = (uint32_t)((QQ) >> 32);                                        \
-    const uint32_t a_[4] = {(ux_ & 0xffffu) * LPE, (ux_ >> 16) * LPE, (uy_ & 0xffffu) * LPE, (uy_ >> 16) * LPE}; \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
-      _Pragma("unroll") for (int l = 0; l < NF; ++l) add4(acc[G][l], xs[a_[t] + l]);                          \
-      if (HALF) {                                                                                             \
-        const float2 h_ = *reinterpret_cast<const float2*>(&xs[a_[t] + NF]);                                  \
-        acch[G].x += h_.x;                                                                                    \
-        acch[G].y += h_.y;                                                                                    \
-      }                                                                                                       \
-    }                                                                                                         \
-  }
-#define GL_ROUND0(Q, I)                                                                                                  \
-  {                                                                                                                      \
-    unsigned long long u_; /* the copy is made by the asm itself, after the wait: a C++ copy would share Q's register */ \
-    asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %1" : "=&v"(u_) : "v"(Q) : "memory");                              \
-    GL_LOAD(Q, p);                                                                                                       \
-    p += 64;                                                                                                             \
-    const uint32_t i_ = (I);                                                                                             \
-    if (i_ < e0) GL_ACC(0, u_) else if (i_ < e1) GL_ACC(1, u_) else if (i_ < e2) GL_ACC(2, u_) else GL_ACC(3, u_)        \
-  }
-      for (uint32_t r = 0; r < R; r += 4) {
-        GL_ROUND0(r0, r)
-        GL_ROUND0(r1, r + 1)
-        GL_ROUND0(r2, r + 2)
-        GL_ROUND0(r3, r + 3)
+#pragma unroll
+      for (int g = 0; g < GL_G; ++g) {
+        const uint32_t n = ((g < 2 ? c01 : c23) >> (16 * (g & 1))) & 0xffffu;
+        for (uint32_t r = 0; r < n; ++r) {
+          const uint2 u = q0;
+          q0 = q1;
+          q1 = q2;
+          q2 = q3;
+          q3 = *p;
+          p += 64;
+          const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int l = 0; l < NF; ++l) add4(acc[g][l], xs[a[t] + l]);
+            if (HALF) {
+              const float2 h = *reinterpret_cast<const float2*>(&xs[a[t] + NF]);
+              acch[g].x += h.x;
+              acch[g].y += h.y;
+            }
+          }
+        }
       }
-#undef GL_ROUND0
-#undef GL_ACC
     } else {
       const uint32_t n = c01 & 0xffffu;  // group 0 carries the merged stream: a multiple of 4 super-rounds
       auto round = [&](const unsigned long long qq) {
@@ -868,8 +863,7 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   const size_t n16_all = ((size_t)s.total_sr + 2 * GL_PF) * 64 * 4, n16_body = (size_t)s.total_sr * 64 * 4;
   uint16_t* ids16 = reinterpret_cast<uint16_t*>(s.ids.p);
   if (PASS == 1) {
-    // everything: the filler rounds that round a (wave, band) segment up to a whole ring turn are written by no fill kernel
-    HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
+    HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)GL_RB, n16_all - n16_body, c->stream));
     if (nwb && !merge)
       hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
                          c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
@@ -1071,58 +1065,105 @@ int k_gl_build(isle_ctx* c) {
         }
       }
     ISLECHK(build_side<2>(c, s2, so));
-    // Band zones (experiment, off by default: ISLE_GL_ZONES=8): workgroup i runs on XCD i % 8, so descriptor i is taken from
-    // zone i % 8 of the document bands, hoping that the word blocks walking one zone share its L2 (every one of the 13 word
-    // blocks at C2 stages every band of Y: 0.62 GB per application).  Measured slower at C2 (0.36 vs 0.30 ms): the zones'
-    // workgroups do not stay in step and the load balance over XCDs gets worse.
-    const char* e_nz = getenv("ISLE_GL_ZONES");
-    const uint32_t NZ = (e_nz && atoi(e_nz) == 8 && s2.NB >= 64) ? 8u : 1u;
-    HIPCHK(c, c->gl_blocktot.reserve((size_t)nblk * NZ));
-    hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, NZ), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, wpb, s2.NB, NZ, c->gl_blocktot.p);
-    HIPCHK(c, hipGetLastError());
-    std::vector<unsigned long long> tot((size_t)nblk * NZ);
-    HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // band chunks per (word block, zone) in proportion to cost; about two workgroups per CU in total.  Cost = super-rounds
-    // (LDS-bound, ~50 ns of CU time each) + GL_BAND_COST per band staged; without the second term a block of rare words
-    // would walk a whole zone in a single workgroup
     const char* e_bc = getenv("ISLE_GL_BAND_COST");   // tuning knobs (defaults measured at C2)
     const char* e_wg = getenv("ISLE_GL_WGS_PER_CU");
     const double bc = e_bc ? atof(e_bc) : GL_BAND_COST;
-    double all = 0;
-    for (auto t : tot) all += (double)t;
-    all += bc * (double)s2.NB * nblk;
-    const double target = std::max(1.0, all / ((e_wg ? atof(e_wg) : 2.0) * c->num_cus));
+    const double wgs_per_cu = e_wg ? atof(e_wg) : 2.0;
     std::vector<uint32_t> slab0(nblk), nch(nblk, 0);
-    std::vector<std::vector<GlDesc>> zone(NZ);
+    std::vector<GlDesc> ds;
     uint32_t nslab = 0;
-    for (uint32_t ob = 0; ob < nblk; ++ob) {
-      slab0[ob] = nslab;
-      for (uint32_t z = 0; z < NZ; ++z) {
-        const uint32_t zb0 = (uint32_t)((uint64_t)z * s2.NB / NZ), zb1 = (uint32_t)((uint64_t)(z + 1) * s2.NB / NZ);
-        const uint32_t nzb = zb1 - zb0;
-        if (nzb == 0) continue;
-        const double cost = (double)tot[(size_t)ob * NZ + z] + bc * nzb;
+    const char* e_col = getenv("ISLE_GL_COLUMNS");
+    const bool columns = e_col && atoi(e_col) == 1 && s2.NB >= 16;  // experiment, off: measured slower at C2 (see below)
+    std::vector<unsigned long long> tot;
+    if (columns) {
+      // Band columns shared through L2.  Every word block walks every document band, so Y (48 MB at C2) would be staged from HBM
+      // once per word block (13 x 48 MB = 0.62 GB of the 1.2 GB pass 2 moved in round 1).  Here the document bands are cut into
+      // NC "columns" of equal total cost, the SAME cut for all word blocks, and the workgroups (word block x column) of one
+      // column are queued back to back on ONE XCD (workgroup i runs on XCD i % 8): they start together, stage the same bands at
+      // about the same time, and all but the first find them in that XCD's 4 MB L2.  The XCDs' queues carry equal cost (NC is a
+      // multiple of 8, columns have equal cost); inside a queue the heaviest word block of a column goes first.
+      // MEASURED (round 2, C2, 40 columns x 13 blocks): pass 2 0.301 -> 0.349 ms.  A column's workgroups differ 5x in cost (the
+      // word blocks are ordered by row length), and with ~65 workgroups per XCD queue the heavy ones set the makespan; the per-block
+      // chunking below gives equal-cost workgroups instead.  Kept selectable (ISLE_GL_COLUMNS=1), not used by default.
+      const uint32_t NB = s2.NB;
+      HIPCHK(c, c->gl_blocktot.reserve((size_t)nblk * NB));
+      hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, NB), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, wpb, NB, NB, c->gl_blocktot.p);
+      HIPCHK(c, hipGetLastError());
+      tot.resize((size_t)nblk * NB);
+      HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      std::vector<double> bcost(NB, 0.0);
+      double all = 0;
+      for (uint32_t bnd = 0; bnd < NB; ++bnd) {
+        for (uint32_t ob = 0; ob < nblk; ++ob) bcost[bnd] += (double)tot[(size_t)ob * NB + bnd] + bc;
+        all += bcost[bnd];
+      }
+      uint32_t NC = 8u * (uint32_t)std::max(1.0, std::ceil(wgs_per_cu * c->num_cus / (8.0 * nblk)));
+      NC = std::min(NC, (NB / 8u) * 8u);
+      std::vector<uint32_t> cut(NC + 1, 0);  // column cc = bands [cut[cc], cut[cc + 1])
+      {
+        double pre = 0;
+        uint32_t cc = 1;
+        for (uint32_t bnd = 0; bnd < NB && cc < NC; ++bnd) {
+          pre += bcost[bnd];
+          // close column cc - 1 behind this band once its share of the cost is reached, leaving at least one band per later column
+          while (cc < NC && (pre >= all * cc / NC || NB - (bnd + 1) <= NC - cc) && bnd + 1 > cut[cc - 1]) cut[cc++] = bnd + 1;
+        }
+        while (cc <= NC) cut[cc++] = NB;
+        cut[NC] = NB;
+      }
+      std::vector<std::vector<GlDesc>> xq(8);
+      std::vector<std::pair<double, uint32_t>> order(nblk);
+      for (uint32_t cc = 0; cc < NC; ++cc) {
+        const uint32_t b0 = cut[cc], b1 = cut[cc + 1];
+        if (b1 <= b0) continue;  // (cannot happen with the guards above; an empty column would leave its slabs unwritten)
+        for (uint32_t ob = 0; ob < nblk; ++ob) {
+          double t = 0;
+          for (uint32_t bnd = b0; bnd < b1; ++bnd) t += (double)tot[(size_t)ob * NB + bnd];
+          order[ob] = {-t, ob};
+        }
+        std::sort(order.begin(), order.end());
+        for (auto& o : order) xq[cc % 8].push_back(GlDesc{o.second * wpb, 1u, wpb, b0, b1, o.second * NC + cc, o.second * bitems, 0u});
+      }
+      for (uint32_t cc = 0; cc + 1 <= NC; ++cc)
+        if (cut[cc + 1] <= cut[cc]) return isle_fail(c, ISLE_E_NUMERIC, "operator build: empty band column");
+      size_t qmax = 0;
+      for (auto& q : xq) qmax = std::max(qmax, q.size());
+      ds.reserve(qmax * 8);
+      for (size_t j = 0; j < qmax; ++j)
+        for (uint32_t x = 0; x < 8; ++x) ds.push_back(j < xq[x].size() ? xq[x][j] : GlDesc{0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u});  // empty: no wave is valid
+      for (uint32_t ob = 0; ob < nblk; ++ob) {
+        slab0[ob] = ob * NC;
+        nch[ob] = NC;
+      }
+      nslab = nblk * NC;
+    } else {
+      // per word block: band chunks in proportion to the block's cost (round 1's form; small matrices, or ISLE_GL_COLUMNS=0).
+      // Cost = super-rounds (LDS-bound, ~50 ns of CU time each) + GL_BAND_COST per band staged; without the second term a block
+      // of rare words would walk all bands in a single workgroup
+      HIPCHK(c, c->gl_blocktot.reserve((size_t)nblk));
+      hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, 1), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, wpb, s2.NB, 1u, c->gl_blocktot.p);
+      HIPCHK(c, hipGetLastError());
+      tot.resize(nblk);
+      HIPCHK(c, hipMemcpyAsync(tot.data(), c->gl_blocktot.p, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      double all = 0;
+      for (auto t : tot) all += (double)t;
+      all += bc * (double)s2.NB * nblk;
+      const double target = std::max(1.0, all / (wgs_per_cu * c->num_cus));
+      for (uint32_t ob = 0; ob < nblk; ++ob) {
+        slab0[ob] = nslab;
+        const uint32_t nzb = s2.NB;
+        const double cost = (double)tot[ob] + bc * nzb;
         const uint32_t n = (uint32_t)std::min<double>((double)nzb, std::max(1.0, std::ceil(cost / target)));
         for (uint32_t ch = 0; ch < n; ++ch) {
-          const uint32_t b0 = zb0 + (uint32_t)((uint64_t)ch * nzb / n), b1 = zb0 + (uint32_t)((uint64_t)(ch + 1) * nzb / n);
-          zone[z].push_back(GlDesc{ob * wpb, 1u, wpb, b0, b1, nslab, ob * bitems, 0u});
+          const uint32_t b0 = (uint32_t)((uint64_t)ch * nzb / n), b1 = (uint32_t)((uint64_t)(ch + 1) * nzb / n);
+          ds.push_back(GlDesc{ob * wpb, 1u, wpb, b0, b1, nslab, ob * bitems, 0u});
           ++nslab;
           ++nch[ob];
         }
       }
     }
-    size_t zmax = 0;
-    for (auto& zl : zone) {
-      // inside a zone: by first band, so that the workgroups in flight on that XCD stage neighbouring bands
-      if (getenv("ISLE_GL_SORT")) std::stable_sort(zl.begin(), zl.end(), [](const GlDesc& a, const GlDesc& b) { return a.b0 < b.b0; });
-      zmax = std::max(zmax, zl.size());
-    }
-    std::vector<GlDesc> ds;
-    ds.reserve(zmax * NZ);
-    for (size_t j = 0; j < zmax; ++j)
-      for (uint32_t z = 0; z < NZ; ++z)
-        ds.push_back(j < zone[z].size() ? zone[z][j] : GlDesc{0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u});  // empty: no wave is valid
     s2.ndesc = (uint32_t)ds.size();
     HIPCHK(c, s2.desc.reserve(ds.size()));
     HIPCHK(c, c->gl_slab0.reserve(nblk));
@@ -1133,10 +1174,11 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, c->gl_part.reserve((size_t)nslab * bitems * 12));  // sized for the widest panel (BP = 12)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (getenv("ISLE_GL_VERBOSE")) {
-      fprintf(stderr, "[gram_lds] pass-2 word blocks (super-rounds, chunks):");
+      fprintf(stderr, "[gram_lds] pass-2 %s, word blocks (super-rounds, chunks):", columns ? "band columns shared per XCD" : "per-block band chunks");
+      const size_t per = columns ? s2.NB : 1;
       for (uint32_t ob = 0; ob < nblk; ++ob) {
         unsigned long long t = 0;
-        for (uint32_t z = 0; z < NZ; ++z) t += tot[(size_t)ob * NZ + z];
+        for (size_t z = 0; z < per; ++z) t += tot[(size_t)ob * per + z];
         fprintf(stderr, " %llu/%u", t, nch[ob]);
       }
       fprintf(stderr, "\n");

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Build-time check of a code-generation property all forms of gl_apply_k (gram_lds.hip) rely on.
+"""Build-time check of a code-generation property the merged-stream forms of gl_apply_k (gram_lds.hip) rely on.
 
 Their id ring is four 64-bit VGPR pairs loaded by inline-asm global_load_dwordx2 with hand-placed s_waitcnt vmcnt(3): the
 compiler does not know that those registers are written asynchronously, so it must never touch them outside the asm blocks
 (a copy, a spill or a phi move would read a register whose load is still in flight).  This script compiles gram_lds.hip to
-gfx950 assembly and verifies, for every instantiation, that after the first ring load no compiler-generated
+gfx950 assembly and verifies, for every merged instantiation, that after the first ring load no compiler-generated
 instruction names a ring register.  usage: check_id_ring.py  (exit 0 = property holds)"""
 import os
 import re
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def check(asm_text):
-    names = re.findall(r'^(_ZN\S*gl_apply_kILi(\d)ELb(\d)ELi([012])E\S*):', asm_text, re.M)
+    names = re.findall(r'^(_ZN\S*gl_apply_kILi(\d)ELb(\d)ELi([12])E\S*):', asm_text, re.M)
     report, bad = [], 0
     for full, lpe, half, m in names:
         i = asm_text.index('\n' + full + ':')
