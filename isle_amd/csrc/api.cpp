@@ -1489,11 +1489,56 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   }
   float* delta_dev = hamerly ? c->Cold.p + (size_t)k * ldk : nullptr;
   HamTop* top_dev = hamerly ? reinterpret_cast<HamTop*>(c->Cold.p + (size_t)k * ldk + ((k + 3) & ~3)) : nullptr;
+  // k > 224 (more than 7 tiles of 32 centres): one lower bound per tile instead of Hamerly's single one, which prunes nothing at
+  // k = 1000 (kmeans.hip PR_TILES, spmm.hip pt_filter_k).  ISLE_PROJ_BOUNDS=hamerly keeps the single bound.
+  const int T = (k + 31) / 32, TL = (T + 3) & ~3;
+  const char* pbm = getenv("ISLE_PROJ_BOUNDS");
+  const bool tiles = hamerly && k > 224 && T <= 32 && !(pbm && !strcmp(pbm, "hamerly"));
+  float* tmove_dev = nullptr;
+  if (tiles) {
+    HIPCHK(c, c->ptlb.reserve((size_t)(D ? D : 1) * TL));
+    HIPCHK(c, c->pneed.reserve(D ? D : 1));
+    HIPCHK(c, c->small.reserve(4096));
+    tmove_dev = c->small.p;  // T floats
+  }
   StopRule stop(c, k);
   int it = 0;
   for (; it < max_reps; ++it) {
     ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
-    if (it == 0 || !hamerly) {
+    if (tiles) {
+      if (it == 0) {
+        ISLECHK(k_proj_assign_tiles(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->hub.p, c->ptlb.p, TL, nullptr, 0,
+                                    nullptr, nullptr, nullptr));                                           // :1947
+      } else {
+        uint32_t* nact = c->active.p + D;
+        // documents are taken grouped by their centre (member lists of the previous iteration): a workgroup of the re-examination
+        // then holds neighbours, whose needed tiles coincide
+        ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
+                            c->pneed.p, c->active.p, nact));
+        uint32_t* na_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 64);  // page-locked
+        HIPCHK(c, hipMemcpyAsync(na_pin, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t na = *na_pin;
+        if (getenv("ISLE_DEBUG_HAMERLY")) {  // debug only: how many tiles the active documents ask for
+          std::vector<uint32_t> act(na), need(D);
+          if (na) HIPCHK(c, hipMemcpy(act.data(), c->active.p, na * sizeof(uint32_t), hipMemcpyDeviceToHost));
+          if (D) HIPCHK(c, hipMemcpy(need.data(), c->pneed.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost));
+          double tiles_sum = 0, union_sum = 0;
+          for (uint32_t i = 0; i < na; i += 128) {
+            uint32_t u = 0;
+            for (uint32_t j = i; j < std::min(na, i + 128); ++j) {
+              tiles_sum += __builtin_popcount(need[act[j]]);
+              u |= need[act[j]];
+            }
+            union_sum += __builtin_popcount(u);
+          }
+          fprintf(stderr, "[tile bounds, projected] iter %d active %u of %llu, tiles per document %.1f, per workgroup (union) %.1f of %d\n", it, na,
+                  (unsigned long long)D, na ? tiles_sum / na : 0.0, na ? union_sum / ((na + 127) / 128) : 0.0, T);
+        }
+        ISLECHK(k_proj_assign_tiles(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->hub.p, c->ptlb.p, TL, c->active.p, na,
+                                    c->pneed.p, c->Pa.p, c->pna.p));
+      }
+    } else if (it == 0 || !hamerly) {
       ISLECHK(k_proj_assign(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p,
                             hamerly ? c->hub.p : nullptr, hamerly ? c->hlb.p : nullptr));                // :1947
     } else {
@@ -1516,7 +1561,8 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
     ISLECHK(k_proj_finalize(c, c->Csum.p, c->counts.p, k, ldk, c->Cdev.p));                             // :1988-1992
     if (hamerly && it + 1 < max_reps) {
       ISLECHK(k_rownorms_diff(c, c->Cdev.p, c->Cold.p, k, k, ldk, delta_dev));
-      ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));  // rounded-up movements and their top two, on the device
+      if (tiles) ISLECHK(k_yy_delta(c, delta_dev, k, T, 32, tmove_dev));  // rounded-up movements and their maxima per tile
+      else ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));  // rounded-up movements and their top two, on the device
     }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));

@@ -17,11 +17,11 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int CS_ITEMS = 16;  // documents per thread in the histogram-style kernels
-enum { PR_ARGMIN = 0, PR_MINDIST = 1 };
+enum { PR_ARGMIN = 0, PR_MINDIST = 1, PR_TILES = 2 };
 template <int MODE>
 static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
                            float* min_dist, bool* done, const float* Pt = nullptr, const uint32_t* map = nullptr, float* ub = nullptr,
-                           float* lb = nullptr);
+                           float* lb = nullptr, const uint32_t* need = nullptr, int TL = 0);
 
 // ------------------------------------------------------------------------------------------
 // min_dist[d] = min(min_dist[d], max(|p_d|^2 + |c|^2 - 2 p_d.c, 0)) over the nc newest centres.
@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
                                                              uint32_t D, int k, int ldk, const float* __restrict__ C,
                                                              const float* __restrict__ cn, uint32_t* __restrict__ assign,
                                                              float* __restrict__ min_dist, const uint32_t* __restrict__ map,
-                                                             float* __restrict__ ub, float* __restrict__ lb) {
+                                                             float* __restrict__ ub, float* __restrict__ lb,
+                                                             const uint32_t* __restrict__ need /*PR_TILES: tiles to examine per document, null = all*/,
+                                                             int TL /*PR_TILES: row stride of lb = tile bounds*/) {
   constexpr int KHC = NSLAB * PR_SL;  // coordinates per lane half held in registers at a time
   constexpr int CG = CTMAX * 32;      // centres per group (their accumulators live side by side)
   extern __shared__ float Cs[];       // [2][CG][PR_SL + 1]
@@ -355,8 +357,23 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
   const float* col = Pt + (size_t)h * KH * D + min(myd, D - 1);
   float best = 3.4e38f, second = 3.4e38f, cmax = 0.f;
   uint32_t bidx = 0xffffffffu;
+  // PR_TILES (bounds per tile of 32 centres, see pt_filter_k): the workgroup examines the union of the tiles its documents need
+  const uint32_t dst = (myd < D) ? (map ? map[myd] : myd) : 0u;
+  uint32_t wneed = 0xffffffffu, btile = 0;
+  float btc = 0.f;
+  if (MODE == PR_TILES && need) {
+    __shared__ uint32_t sh_need;
+    if (threadIdx.x == 0) sh_need = 0u;
+    __syncthreads();
+    const uint32_t mine = (myd < D && h == 0) ? need[dst] : 0u;
+    if (mine) atomicOr(&sh_need, mine);
+    __syncthreads();
+    wneed = sh_need;
+  }
   // k <= CG and KH <= KHC (e.g. k = 200) is a single pass: P is then read from HBM exactly once per call.
   for (int cg0 = 0; cg0 < k; cg0 += CG) {
+    const uint32_t gmask = (wneed >> (cg0 >> 5)) & ((CTMAX >= 32) ? 0xffffffffu : ((1u << CTMAX) - 1u));
+    if (MODE == PR_TILES && gmask == 0u) continue;  // uniform over the workgroup
     floatx16 acc[CTMAX];
 #pragma unroll
     for (int t = 0; t < CTMAX; ++t) acc[t] = (floatx16){0};
@@ -376,13 +393,14 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
             const int cc = (idx / PR_SL) % CG;
             const int hh = idx / (PR_SL * CG);
             const int coord = cb0 + ii;
+            if (MODE == PR_TILES && !((gmask >> (cc >> 5)) & 1u)) continue;  // tile not examined: its LDS rows are never read
             const float cv = C[(size_t)min(cg0 + cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)];  // unconditional, masked below
             Cs[(hh * CG + cc) * (PR_SL + 1) + ii] = cv * ((cg0 + cc < k && coord < KH) ? 1.f : 0.f);
           }
           __syncthreads();
 #pragma unroll
           for (int t = 0; t < CTMAX; ++t) {
-            if (cg0 + 32 * t < k) {
+            if (cg0 + 32 * t < k && (MODE != PR_TILES || ((gmask >> t) & 1u))) {
               const float* cb = &Cs[(h * CG + 32 * t + l31) * (PR_SL + 1)];
 #pragma unroll
               for (int ii = 0; ii < PR_SL; ++ii) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[ii], p[s * PR_SL + ii], acc[t], 0, 0, 0);
@@ -391,9 +409,59 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
         }
       }
     }
+    if (MODE == PR_TILES) {
+      // per tile: the two smallest |distances| and the first index of the smallest over its 32 centres (both lane halves); the
+      // tile's bound is stored at once, the running best keeps the runner-up of ITS tile (a tile bound excludes the assigned centre)
+#pragma unroll
+      for (int t = 0; t < CTMAX; ++t) {
+        if (cg0 + 32 * t < k && ((gmask >> t) & 1u)) {
+          float m1 = 3.4e38f, m2 = 3.4e38f, tc = 0.f;
+          uint32_t i1 = 0xffffffffu;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cc = cg0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (cc < k) {
+              tc = fmaxf(tc, cn[cc]);
+              const float dist = fabsf((-2.0f * acc[t][r] + cn[cc]) + nd);
+              if (dist < m1 || (dist == m1 && (uint32_t)cc < i1)) {
+                m2 = m1;
+                m1 = dist;
+                i1 = (uint32_t)cc;
+              } else {
+                m2 = fminf(m2, dist);
+              }
+            }
+          }
+          const float om1 = __shfl_xor(m1, 32), om2 = __shfl_xor(m2, 32);
+          const uint32_t oi1 = (uint32_t)__shfl_xor((int)i1, 32);
+          tc = fmaxf(tc, __shfl_xor(tc, 32));
+          if (om1 < m1 || (om1 == m1 && oi1 < i1)) {
+            m2 = fminf(m1, om2);
+            m1 = om1;
+            i1 = oi1;
+          } else {
+            m2 = fminf(m2, om1);
+          }
+          const uint32_t T = (uint32_t)(cg0 >> 5) + (uint32_t)t;
+          if (m1 < best || (m1 == best && i1 < bidx)) {
+            best = m1;
+            bidx = i1;
+            second = m2;
+            btile = T;
+            btc = tc;
+          }
+          cmax = fmaxf(cmax, tc);
+          if (h == 0 && myd < D) {
+            float uu, ll;
+            hamerly_store_bounds(m1, m1, nd + tc, &uu, &ll);
+            lb[(size_t)dst * TL + T] = ll;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < CTMAX; ++t) {
-      if (cg0 + 32 * t < k) {
+      if (MODE != PR_TILES && cg0 + 32 * t < k) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cc = cg0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -416,6 +484,17 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
         }
       }
     }
+  }
+  if (MODE == PR_TILES) {  // both lane halves hold the same (best, index, runner-up of the best's tile)
+    if (h == 0 && myd < D) {
+      assign[dst] = bidx;
+      float uu, ll, l2;
+      hamerly_store_bounds(best, second, nd + btc, &uu, &l2);
+      hamerly_store_bounds(best, best, nd + cmax, &uu, &ll);
+      ub[dst] = uu;
+      lb[(size_t)dst * TL + btile] = l2;  // the assigned centre's tile: closest OTHER centre in it
+    }
+    return;
   }
   const float ob = __shfl_xor(best, 32);
   const float os = __shfl_xor(second, 32);
@@ -443,7 +522,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
 // dispatch over (coordinate slabs, centre tiles); returns false if the shape is not covered
 template <int MODE>
 static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
-                           float* min_dist, bool* done, const float* Pt, const uint32_t* map, float* ub, float* lb) {
+                           float* min_dist, bool* done, const float* Pt, const uint32_t* map, float* ub, float* lb, const uint32_t* need, int TL) {
   *done = false;
   if (!D || !c->Pt_ready) return 0;
   if (!Pt) Pt = c->Pt.p;
@@ -455,9 +534,16 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
   do {                                                                                                                        \
     const size_t lds = (size_t)2 * (CM * 32) * (PR_SL + 1) * sizeof(float);                                                   \
     ISLECHK(isle_max_lds(c, (const void*)proj_assign_reg_k<NS, CM, MODE>, (int)lds));                                        \
-    hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, Pt, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist, map, ub, lb); \
+    hipLaunchKernelGGL((proj_assign_reg_k<NS, CM, MODE>), g, b, lds, c->stream, Pt, pn, (uint32_t)D, k, ldk, C, cn, assign, min_dist, map, ub, lb, \
+                       need, TL);                                                                                             \
     *done = true;                                                                                                             \
   } while (0)
+  if (MODE == PR_TILES) {  // only the shape that needs it: more than 7 tiles or slabs (k > 224), at most 32 tiles
+    if (ct > 32) return 0;
+    LR(8, 8);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   if (ct <= 1) {
     if (nslab <= 2) LR(2, 1);
     else if (nslab <= 4) LR(4, 1);
@@ -507,6 +593,25 @@ int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, in
   bool done = false;
   ISLECHK(launch_proj_reg<PR_ARGMIN>(c, n, k, ldk, C, cn, pna, assign, nullptr, &done, Pa, active, ub, lb));
   if (!done) return isle_fail(c, ISLE_E_ARG, "projected assignment: register kernel unavailable");
+  return 0;
+}
+
+// Tile bounds (pt_filter_k, spmm.hip): full assignment that also leaves, per document, an upper bound on the distance to its
+// centre and one lower bound per tile of 32 centres (row stride TL); need == null examines every tile, otherwise the n documents
+// of `active` (compacted into Pa) examine the tiles their masks name.
+int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
+                        float* ub, float* tlb, int TL, const uint32_t* active, uint32_t n, const uint32_t* need, float* Pa, float* pna) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  bool done = false;
+  if (!active) {
+    ISLECHK(launch_proj_reg<PR_TILES>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done, nullptr, nullptr, ub, tlb, nullptr, TL));
+  } else {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(compact_rows_k, dim3(cdiv(n, 32)), dim3(256), 0, c->stream, P, pn, ldk, active, n, Pa, pna);
+    HIPCHK(c, hipGetLastError());
+    ISLECHK(launch_proj_reg<PR_TILES>(c, n, k, ldk, C, cn, pna, assign, nullptr, &done, Pa, active, ub, tlb, need, TL));
+  }
+  if (!done) return isle_fail(c, ISLE_E_ARG, "projected assignment with tile bounds: shape not covered (k = %d)", k);
   return 0;
 }
 

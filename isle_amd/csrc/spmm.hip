@@ -742,6 +742,60 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
   return 0;
 }
 
+// Tile bounds for Lloyd in span(U) at large k (Yinyang's group bounds with a group = one 32-centre MFMA tile of
+// proj_assign_reg_k).  Hamerly's single lower bound prunes nothing at k = 1000: it falls by the LARGEST centre movement per
+// iteration.  Here tlb[d][t] <= distance from d to the closest centre of tile t (other than d's own), lowered per iteration by the
+// largest movement INSIDE tile t; a document whose upper bound stays below all of them is skipped, any other re-examines only the
+// tiles whose bound it reaches (plus its own centre's), by matrix-core tiles on the compacted active list.  Exact: the
+// partition is the full scan's (tests: all bound modes identical).  One thread per document, rows of TL floats.
+__global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ order, uint32_t D, const uint32_t* __restrict__ assign,
+                                                    float* __restrict__ ub, float* __restrict__ tlb, int T, int TL, const float* __restrict__ delta,
+                                                    const float* __restrict__ tmove, uint32_t* __restrict__ need, uint32_t* __restrict__ active,
+                                                    uint32_t* __restrict__ nactive) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < D;
+  uint32_t d = 0;
+  bool act = false;
+  if (in) {
+    d = order ? order[i] : i;
+    const uint32_t a = assign[d];
+    const float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of the updates
+    ub[d] = u;
+    float4* row = reinterpret_cast<float4*>(tlb + (size_t)d * TL);
+    uint32_t mask = 0u;
+    for (int q = 0; q < TL / 4; ++q) {
+      float4 v = row[q];
+      float l[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = 4 * q + e;
+        if (t < T) {
+          float x = l[e] - tmove[t] * 1.000001f;
+          x = x > 0.f ? x * 0.999999f : x;
+          l[e] = x;
+          if (u >= x) mask |= 1u << t;
+        }
+      }
+      row[q] = make_float4(l[0], l[1], l[2], l[3]);
+    }
+    act = mask != 0u;
+    if (act) need[d] = mask | (1u << (a >> 5));  // the own centre's tile is always re-examined: it holds the exact new distance
+  }
+  const uint32_t slot = block_append_slot(act, nactive);
+  if (act) active[slot] = d;
+}
+int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* tlb, int T, int TL, const float* delta_dev,
+                const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  const uint32_t D = (uint32_t)c->D;
+  HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(pt_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, tlb, T, TL, delta_dev, tmove_dev, need, active,
+                     nactive);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Yinyang bounds for Lloyd on the sparse matrix (Ding et al., ICML 2015) — like Hamerly's an EXACT acceleration, with one
 // lower bound per GROUP of YY_GROUP centres instead of one per document: after an update a group's bound only shrinks by

@@ -125,13 +125,16 @@ def test_same_input_parity_with_the_cpu_oracle(solved, hp):
 
 
 def test_bound_modes_agree_at_k1000(hp, monkeypatch):
-    """Yinyang (125 groups), Hamerly and no bounds give the same partition at k = 1000, for both Lloyd loops."""
+    """Exact accelerations: Yinyang (125 groups) / Hamerly / no bounds for Lloyd on B, tile bounds (32 tiles) / Hamerly / no bounds for
+    Lloyd in span(U) — the same partition and iteration counts at k = 1000 in every mode."""
     f, B, k = load_case("c3k1000")
     upload(hp, B)
     hp.compute_block_ks(k, allow_noconv=True)
     res = {}
-    for mode in ("yinyang", "hamerly", "none"):
+    for mode in ("yinyang", "hamerly", "none"):  # projected loop: tile bounds (default at k > 224), Hamerly's single bound, none
         monkeypatch.setenv("ISLE_KMEANS_BOUNDS", mode)
+        if mode == "hamerly":
+            monkeypatch.setenv("ISLE_PROJ_BOUNDS", "hamerly")
         if mode == "none":
             monkeypatch.setenv("ISLE_NO_HAMERLY", "1")
         g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
@@ -141,6 +144,7 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         res[mode] = (lp["assign"], lp["iters"], ls["assign"], ls["iters"])
     monkeypatch.delenv("ISLE_KMEANS_BOUNDS")
     monkeypatch.delenv("ISLE_NO_HAMERLY")
+    monkeypatch.delenv("ISLE_PROJ_BOUNDS")
     for mode in ("hamerly", "none"):
         assert res[mode][1] == res["yinyang"][1] and res[mode][3] == res["yinyang"][3]
         assert np.array_equal(res[mode][0], res["yinyang"][0])

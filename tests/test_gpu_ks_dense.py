@@ -127,7 +127,7 @@ def test_maxit_exhaustion_reports_noconv_with_the_references_rule(hp):
     # of a 50-dimensional Krylov space's quality
     for ev in (r["evals"].astype(np.float64), o["evals"].astype(np.float64)):
         assert np.all(np.diff(ev) <= 1e-6) and np.all(ev <= evs[:k] + 1e-5)
-        assert np.max(evs[:k] - ev) <= 0.05
+        assert np.max(evs[:k] - ev) <= 0.25  # two restarts on a spectrum with gaps of 1 / n: far from converged, as intended
     U = r["U"].astype(np.float64)
     assert np.abs(U.T @ U - np.eye(k)).max() <= 5e-5
     assert np.abs(np.sum(U * (A @ U), axis=0) - r["evals"]).max() <= 1e-4  # the values ARE the Rayleigh quotients of the returned vectors
