@@ -1498,6 +1498,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   if (tiles) {
     HIPCHK(c, c->ptlb.reserve((size_t)(D ? D : 1) * TL));
     HIPCHK(c, c->pneed.reserve(D ? D : 1));
+    HIPCHK(c, c->pcand.reserve(D + 1));
     HIPCHK(c, c->small.reserve(4096));
     tmove_dev = c->small.p;  // T floats
   }
@@ -1513,8 +1514,16 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
         uint32_t* nact = c->active.p + D;
         // documents are taken grouped by their centre (member lists of the previous iteration): a workgroup of the re-examination
         // then holds neighbours, whose needed tiles coincide
-        ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
-                            c->pneed.p, c->active.p, nact));
+        if (getenv("ISLE_PROJ_NOTIGHTEN")) {
+          ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
+                              c->pneed.p, c->active.p, nact));
+        } else {  // candidates by the grown upper bounds, then the exact distance to the own centre for those (pt_tighten_k)
+          uint32_t* ncand = c->pcand.p + D;
+          ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
+                              c->pneed.p, c->pcand.p, ncand));
+          ISLECHK(k_pt_tighten(c, c->P.p, c->pnorm.p, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->pcand.p, ncand, c->hub.p, c->ptlb.p, T, TL,
+                               c->pneed.p, c->active.p, nact));
+        }
         uint32_t* na_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 64);  // page-locked
         HIPCHK(c, hipMemcpyAsync(na_pin, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -211,6 +211,7 @@ struct isle_ctx {
   DevBuf<float> yglb;      // D x G Yinyang group bounds (sparse Lloyd)
   DevBuf<float> ptlb;      // D x TL tile bounds (projected Lloyd at k > 224)
   DevBuf<uint32_t> pneed;  // D: tiles a document has to re-examine
+  DevBuf<uint32_t> pcand;  // D + 1: candidates of the first filter stage (last = count)
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<float> centers_old;  // V x ldk
   DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
@@ -364,6 +365,8 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
                         float* ub, float* tlb, int TL, const uint32_t* active, uint32_t n, const uint32_t* need, float* Pa, float* pna);
 int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* tlb, int T, int TL, const float* delta_dev,
                 const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive);
+int k_pt_tighten(isle_ctx* c, const float* P, const float* pn, int ldk, const float* C, const float* cn, const uint32_t* assign, const uint32_t* cand,
+                 const uint32_t* ncand, float* ub, const float* tlb, int T, int TL, uint32_t* need, uint32_t* active, uint32_t* nactive);
 int k_rownorms_diff(isle_ctx* c, const float* A, const float* B, int rows, int k, int ldk, float* out);
 int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out);
 int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts);

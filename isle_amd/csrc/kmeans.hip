@@ -345,6 +345,8 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
                                                              float* __restrict__ ub, float* __restrict__ lb,
                                                              const uint32_t* __restrict__ need /*PR_TILES: tiles to examine per document, null = all*/,
                                                              int TL /*PR_TILES: row stride of lb = tile bounds*/) {
+  const int dbg = TL >> 16;  // timing experiments only (ISLE_PT_DBG): 1 = no tile-bound stores, 2 = no tile epilogue at all
+  TL &= 0xffff;
   constexpr int KHC = NSLAB * PR_SL;  // coordinates per lane half held in registers at a time
   constexpr int CG = CTMAX * 32;      // centres per group (their accumulators live side by side)
   extern __shared__ float Cs[];       // [2][CG][PR_SL + 1]
@@ -388,14 +390,65 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
         const int cb0 = kc0 + s * PR_SL;  // first coordinate (within a half) of this slab
         if (cb0 < KH) {
           __syncthreads();
-          for (int idx = threadIdx.x; idx < 2 * CG * PR_SL; idx += 256) {
-            const int ii = idx % PR_SL;
-            const int cc = (idx / PR_SL) % CG;
-            const int hh = idx / (PR_SL * CG);
+          if (MODE != PR_TILES || gmask == ((CTMAX >= 32) ? 0xffffffffu : ((1u << CTMAX) - 1u))) {
+            if (NSLAB * 16 + CTMAX * 16 > 224) {
+              // 2 halves x CG centres x 16 coordinates: thread (ii = tid % 16, c16 = tid / 16) takes centres c16, c16 + 16, ... of both
+              // halves.  All loads of a batch are issued before the first LDS store (a rolled loop waited for every load in turn:
+              // 8 us of staging per 3.4 us of matrix-core work at k = 1000)
+              const int ii = threadIdx.x % PR_SL, c16 = threadIdx.x / PR_SL;
+              const int coord = cb0 + ii;
+              const float cmask = coord < KH ? 1.f : 0.f;
+              constexpr int NLD = 2 * CG / 16;  // loads per thread
+              constexpr int NBW = 16;
+              constexpr int NB_ = NLD < NBW ? NLD : NBW;
+  #pragma unroll
+              for (int u0 = 0; u0 < NLD; u0 += NB_) {
+                float v[NB_];
+  #pragma unroll
+                for (int u = 0; u < NB_; ++u) {
+                  if (u0 + u >= NLD) break;
+                  const int hh = (u0 + u) / (CG / 16), cc = c16 + 16 * ((u0 + u) % (CG / 16));
+                  v[u] = C[(size_t)min(cg0 + cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)] * ((cg0 + cc < k) ? cmask : 0.f);  // unconditional, masked
+                }
+  #pragma unroll
+                for (int u = 0; u < NB_; ++u) {
+                  if (u0 + u >= NLD) break;
+                  const int hh = (u0 + u) / (CG / 16), cc = c16 + 16 * ((u0 + u) % (CG / 16));
+                  Cs[(hh * CG + cc) * (PR_SL + 1) + ii] = v[u];
+                }
+              }
+            } else {  // two workgroups per CU: no registers to spare for a batch (it spills), and the other workgroup hides the latency
+              for (int idx = threadIdx.x; idx < 2 * CG * PR_SL; idx += 256) {
+                const int ii = idx % PR_SL;
+                const int cc = (idx / PR_SL) % CG;
+                const int hh = idx / (PR_SL * CG);
+                const int coord = cb0 + ii;
+                const float cv = C[(size_t)min(cg0 + cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)];  // unconditional, masked below
+                Cs[(hh * CG + cc) * (PR_SL + 1) + ii] = cv * ((cg0 + cc < k && coord < KH) ? 1.f : 0.f);
+              }
+            }
+          } else {
+            // only the tiles that are examined: a tile is 2 halves x 32 centres x 16 coordinates = 1024 floats, four per thread,
+            // loaded together (the tile test is uniform over the workgroup: a scalar branch around unconditional loads)
+            const int ii = threadIdx.x % PR_SL, c16 = threadIdx.x / PR_SL;  // 16 centres per 256 threads
             const int coord = cb0 + ii;
-            if (MODE == PR_TILES && !((gmask >> (cc >> 5)) & 1u)) continue;  // tile not examined: its LDS rows are never read
-            const float cv = C[(size_t)min(cg0 + cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)];  // unconditional, masked below
-            Cs[(hh * CG + cc) * (PR_SL + 1) + ii] = cv * ((cg0 + cc < k && coord < KH) ? 1.f : 0.f);
+            const float cmask = coord < KH ? 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < CTMAX; ++t) {
+              if ((gmask >> t) & 1u) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int hh = q >> 1, cc = 32 * t + 16 * (q & 1) + c16;
+                  v[q] = C[(size_t)min(cg0 + cc, k - 1) * ldk + hh * KH + min(coord, KH - 1)] * ((cg0 + cc < k) ? cmask : 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int hh = q >> 1, cc = 32 * t + 16 * (q & 1) + c16;
+                  Cs[(hh * CG + cc) * (PR_SL + 1) + ii] = v[q];
+                }
+              }
+            }
           }
           __syncthreads();
 #pragma unroll
@@ -414,7 +467,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
       // tile's bound is stored at once, the running best keeps the runner-up of ITS tile (a tile bound excludes the assigned centre)
 #pragma unroll
       for (int t = 0; t < CTMAX; ++t) {
-        if (cg0 + 32 * t < k && ((gmask >> t) & 1u)) {
+        if (cg0 + 32 * t < k && ((gmask >> t) & 1u) && !(dbg & 2)) {
           float m1 = 3.4e38f, m2 = 3.4e38f, tc = 0.f;
           uint32_t i1 = 0xffffffffu;
 #pragma unroll
@@ -451,7 +504,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
             btc = tc;
           }
           cmax = fmaxf(cmax, tc);
-          if (h == 0 && myd < D) {
+          if (h == 0 && myd < D && !(dbg & 1)) {
             float uu, ll;
             hamerly_store_bounds(m1, m1, nd + tc, &uu, &ll);
             lb[(size_t)dst * TL + T] = ll;
@@ -461,14 +514,14 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
     }
 #pragma unroll
     for (int t = 0; t < CTMAX; ++t) {
-      if (MODE != PR_TILES && cg0 + 32 * t < k) {
+      if ((MODE != PR_TILES || (dbg & 2)) && cg0 + 32 * t < k) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cc = cg0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (cc < k) {
             cmax = fmaxf(cmax, cn[cc]);
             const float raw = (-2.0f * acc[t][r] + cn[cc]) + nd;
-            if (MODE == PR_ARGMIN) {
+            if (MODE == PR_ARGMIN || MODE == PR_TILES) {
               const float dist = fabsf(raw);
               if (dist < best || (dist == best && (uint32_t)cc < bidx)) {
                 second = best;
@@ -485,7 +538,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
       }
     }
   }
-  if (MODE == PR_TILES) {  // both lane halves hold the same (best, index, runner-up of the best's tile)
+  if (MODE == PR_TILES && !(dbg & 2)) {  // both lane halves hold the same (best, index, runner-up of the best's tile)
     if (h == 0 && myd < D) {
       assign[dst] = bidx;
       float uu, ll, l2;
@@ -500,7 +553,7 @@ __global__ __launch_bounds__(256, (NSLAB * 16 + CTMAX * 16 > 224) ? 1 : 2) void 
   const float os = __shfl_xor(second, 32);
   const uint32_t oi = __shfl_xor(bidx, 32);
   cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-  if (MODE == PR_ARGMIN) {
+  if (MODE == PR_ARGMIN || MODE == PR_TILES) {
     if (ob < best || (ob == best && oi < bidx)) {
       second = fminf(best, os);
       best = ob;
@@ -540,6 +593,7 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
   } while (0)
   if (MODE == PR_TILES) {  // only the shape that needs it: more than 7 tiles or slabs (k > 224), at most 32 tiles
     if (ct > 32) return 0;
+    if (const char* e = getenv("ISLE_PT_DBG")) TL |= atoi(e) << 16;
     LR(8, 8);
     HIPCHK(c, hipGetLastError());
     return 0;

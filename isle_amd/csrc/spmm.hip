@@ -784,6 +784,65 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
   const uint32_t slot = block_append_slot(act, nactive);
   if (act) active[slot] = d;
 }
+// Second stage of the filter: the upper bound of a candidate has grown by its centre's movement in every iteration since the
+// document was last examined; here it is replaced by the exact distance to its centre (one 4k-byte dot product per candidate, a
+// wave each) and the tile test is repeated.  Most candidates drop out: their centre moved, but they did not get closer to any
+// other tile.  A wave takes 64 candidates in turn; lane j keeps the verdict on the j-th for the block-level append.
+__global__ __launch_bounds__(256) void pt_tighten_k(const float* __restrict__ P, const float* __restrict__ pn, int ldk, const float* __restrict__ C,
+                                                     const float* __restrict__ cn, const uint32_t* __restrict__ assign,
+                                                     const uint32_t* __restrict__ cand, const uint32_t* __restrict__ ncand, float* __restrict__ ub,
+                                                     const float* __restrict__ tlb, int T, int TL, uint32_t* __restrict__ need,
+                                                     uint32_t* __restrict__ active, uint32_t* __restrict__ nactive) {
+  const uint32_t n = *ncand;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t base = blockIdx.x * 256 + (uint32_t)wave * 64;
+  bool flag = false;
+  uint32_t mydoc = 0;
+  const int nq = ldk >> 2;
+  for (int j = 0; j < 64; ++j) {
+    const uint32_t i = base + (uint32_t)j;
+    if (i >= n) break;  // wave-uniform
+    const uint32_t d = cand[i];
+    const uint32_t a = assign[d];
+    const float4* pr = reinterpret_cast<const float4*>(P + (size_t)d * ldk);
+    const float4* cr = reinterpret_cast<const float4*>(C + (size_t)a * ldk);
+    float s = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const float4 x = pr[q], y = cr[q];
+      s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float nd = pn[d], cc = cn[a];
+    const float dist = fabsf((-2.0f * s + cc) + nd);
+    float uu, ll;
+    hamerly_store_bounds(dist, dist, nd + cc, &uu, &ll);
+    const float l = lane < T ? tlb[(size_t)d * TL + lane] : 3.4e38f;
+    const uint32_t mask = (uint32_t)__ballot(uu >= l);
+    if (lane == j) {
+      flag = mask != 0u;
+      mydoc = d;
+    }
+    if (lane == 0) {
+      ub[d] = uu;
+      if (mask) need[d] = mask | (1u << (a >> 5));
+    }
+  }
+  const uint32_t slot = block_append_slot(flag, nactive);
+  if (flag) active[slot] = mydoc;
+}
+int k_pt_tighten(isle_ctx* c, const float* P, const float* pn, int ldk, const float* C, const float* cn, const uint32_t* assign, const uint32_t* cand,
+                 const uint32_t* ncand, float* ub, const float* tlb, int T, int TL, uint32_t* need, uint32_t* active, uint32_t* nactive) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  const uint32_t D = (uint32_t)c->D;
+  HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(pt_tighten_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, P, pn, ldk, C, cn, assign, cand, ncand, ub, tlb, T, TL, need, active,
+                     nactive);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* tlb, int T, int TL, const float* delta_dev,
                 const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
