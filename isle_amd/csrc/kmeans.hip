@@ -712,49 +712,53 @@ __global__ __launch_bounds__(256) void member_fill_k(const uint32_t* __restrict_
   }
 }
 
-// Csum[c][:] += sum of P rows of the members [j*MC, (j+1)*MC) of centre c.  grid = (chunks, k).
-// Each wave sums whole rows (coalesced 4*k-byte reads), waves are combined in LDS, one atomicAdd per (block, coordinate).
+// Member sums of the projected Lloyd update in a FIXED order (the reference's centres are bitwise reproducible; float atomics over
+// chunks that finish in any order are not).  grid = (S, k): workgroup (s, c) takes the 256-member chunks s, s + S, s + 2S, ... of
+// centre c one after the other, every wave sums whole rows (coalesced 4k-byte reads) in member order — the member lists are in
+// ascending document order (k_member_lists) — the four waves are combined in LDS, and the S partial rows of a centre are added in
+// order by proj_segsum_reduce_k.  No atomics.
 constexpr int SEG_MC = 256;
 template <int NIT>  // float4 chunks per lane: ldk / 4 <= 64 NIT
 __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P, int k, int ldk, const int* __restrict__ off,
-                                                      const uint32_t* __restrict__ members, float* __restrict__ Csum) {
+                                                      const uint32_t* __restrict__ members, float* __restrict__ part /*[S][k][ldk]*/) {
   extern __shared__ float red[];  // 4 x ldk
-  const int cc = blockIdx.y;
-  const int beg = off[cc] + blockIdx.x * SEG_MC;
-  const int end = min(off[cc + 1], beg + SEG_MC);
-  if (beg >= end) return;
+  const int cc = blockIdx.y, S = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = ldk / 4;
   float4 acc[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // this wave's members: beg + wave, + 4, ... (at most 64): ids by one load and shuffles, four 16-byte row loads in flight
-  const int myi = beg + wave + 4 * lane;
-  const uint32_t mym = myi < end ? members[myi] : 0u;
-  const int cnt = end > beg + wave ? min(64, (end - beg - wave + 3) / 4) : 0;
-  for (int j = 0; j < cnt; j += 4) {
-    float4 v[4][NIT];
+  const int cend = off[cc + 1];
+  for (int beg = off[cc] + (int)blockIdx.x * SEG_MC; beg < cend; beg += S * SEG_MC) {
+    const int end = min(cend, beg + SEG_MC);
+    // this wave's members: beg + wave, + 4, ... (at most 64): ids by one load and shuffles, four 16-byte row loads in flight
+    const int myi = beg + wave + 4 * lane;
+    const uint32_t mym = myi < end ? members[myi] : 0u;
+    const int cnt = end > beg + wave ? min(64, (end - beg - wave + 3) / 4) : 0;
+    for (int j = 0; j < cnt; j += 4) {
+      float4 v[4][NIT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t mj = (uint32_t)__shfl((int)mym, min(j + u, cnt - 1));
-      const float4* row = reinterpret_cast<const float4*>(P + (size_t)mj * ldk);
-      const float live = j + u < cnt ? 1.f : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t mj = (uint32_t)__shfl((int)mym, min(j + u, cnt - 1));
+        const float4* row = reinterpret_cast<const float4*>(P + (size_t)mj * ldk);
+        const float live = j + u < cnt ? 1.f : 0.f;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int q = lane + 64 * it;
-        const float4 x = q < nq ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[u][it] = make_float4(x.x * live, x.y * live, x.z * live, x.w * live);
+        for (int it = 0; it < NIT; ++it) {
+          const int q = lane + 64 * it;
+          const float4 x = q < nq ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[u][it] = make_float4(x.x * live, x.y * live, x.z * live, x.w * live);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          acc[it].x += v[u][it].x;
+          acc[it].y += v[u][it].y;
+          acc[it].z += v[u][it].z;
+          acc[it].w += v[u][it].w;
+        }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        acc[it].x += v[u][it].x;
-        acc[it].y += v[u][it].y;
-        acc[it].z += v[u][it].z;
-        acc[it].w += v[u][it].w;
-      }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -762,9 +766,21 @@ __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P
     if (q < nq) reinterpret_cast<float4*>(red + (size_t)wave * ldk)[q] = acc[it];
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < k; j += 256) {
-    const float sum = (red[j] + red[ldk + j]) + (red[2 * ldk + j] + red[3 * ldk + j]);
-    atomicAdd(&Csum[(size_t)cc * ldk + j], sum);
+  float* out = part + ((size_t)blockIdx.x * k + cc) * ldk;
+  for (int j = threadIdx.x; j < ldk; j += 256) out[j] = (red[j] + red[ldk + j]) + (red[2 * ldk + j] + red[3 * ldk + j]);
+}
+__global__ __launch_bounds__(256) void proj_segsum_reduce_k(const float* __restrict__ part, int S, size_t n /*k * ldk*/, float* __restrict__ Csum) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = part[i];
+  for (int q = 1; q < S; ++q) s += part[(size_t)q * n + i];
+  Csum[i] = s;
+}
+__global__ __launch_bounds__(256) void member_keys_k(const uint32_t* __restrict__ assign, uint32_t D, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d < D) {
+    key[d] = assign[d];
+    val[d] = d;
   }
 }
 
@@ -838,49 +854,62 @@ int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev) {
 }
 
 // members = local documents grouped by centre (counts_dev = LOCAL cluster sizes from k_count_sizes).
+// members[off[c] .. off[c+1]) = documents assigned to centre c in ASCENDING document order: a stable radix sort of the documents by
+// centre (k_sort_pairs_u64, ingest.hip), so that everything summed over a list has one order, run after run.
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out) {
-  std::vector<int> h(k), off(k + 1, 0);
+  std::vector<int> h(k);
   HIPCHK(c, hipMemcpyAsync(h.data(), counts_dev, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int mx = 0;
-  for (int i = 0; i < k; ++i) {
-    off[i + 1] = off[i] + h[i];
-    mx = std::max(mx, h[i]);
-  }
+  for (int i = 0; i < k; ++i) mx = std::max(mx, h[i]);
   if (max_out) *max_out = mx;
   HIPCHK(c, c->members.reserve(D ? D : 1));
   HIPCHK(c, c->moff.reserve(2 * (size_t)k + 2));
   int* offd = c->moff.p;
   int* cur = c->moff.p + k + 1;
-  HIPCHK(c, hipMemcpyAsync(offd, off.data(), (size_t)(k + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(cur, 0, (size_t)k * sizeof(int), c->stream));
-  if (D)
-    hipLaunchKernelGGL(member_fill_k, dim3(cdiv(D, 256 * CS_ITEMS)), dim3(256), 2 * (size_t)k * sizeof(int), c->stream, assign, (uint32_t)D, k,
-                       offd, cur, c->members.p);
+  hipLaunchKernelGGL(member_offsets_k, dim3(1), dim3(256), 0, c->stream, counts_dev, k, offd, cur);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // `off` is pageable host memory
+  if (D) {
+    HIPCHK(c, c->gl_key_a.reserve(D));
+    HIPCHK(c, c->gl_key_b.reserve(D));
+    HIPCHK(c, c->gl_val_a.reserve(D));
+    HIPCHK(c, c->gl_val_b.reserve(D));
+    hipLaunchKernelGGL(member_keys_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, assign, (uint32_t)D, c->gl_key_a.p, c->gl_val_a.p);
+    HIPCHK(c, hipGetLastError());
+    int bits = 1;
+    while ((1 << bits) < k) ++bits;
+    bool in_a = true;
+    ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, D, bits, &in_a));
+    HIPCHK(c, hipMemcpyAsync(c->members.p, in_a ? c->gl_val_a.p : c->gl_val_b.p, D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  }
   c->members_valid = true;
   return 0;
 }
 
 int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
-  HIPCHK(c, hipMemsetAsync(Csum, 0, (size_t)k * ldk * sizeof(float), c->stream));
-  if (D == 0) return 0;
+  const size_t n = (size_t)k * ldk;
+  if (D == 0) {
+    HIPCHK(c, hipMemsetAsync(Csum, 0, n * sizeof(float), c->stream));
+    return 0;
+  }
   int mx = 0;
   ISLECHK(k_member_lists(c, assign, D, k, counts, &mx));
   int* offd = c->moff.p;
-  if (mx == 0) return 0;
-  dim3 g(cdiv(mx, SEG_MC), k), b(256);
+  const int S = std::max(1, std::min({16, cdiv(2048, k), cdiv(mx, SEG_MC)}));  // ~2048 workgroups, never more splits than chunks
+  HIPCHK(c, c->Pa.reserve((size_t)S * n));  // partial rows (Pa is free between two assignment steps)
+  dim3 g(S, k), b(256);
   const size_t lds = 4 * (size_t)ldk * sizeof(float);
   const int nit = cdiv(ldk / 4, 64);  // float4 chunks per lane
-#define LS(N) hipLaunchKernelGGL(proj_segsum_k<N>, g, b, lds, c->stream, P, k, ldk, offd, c->members.p, Csum)
+#define LS(N) hipLaunchKernelGGL(proj_segsum_k<N>, g, b, lds, c->stream, P, k, ldk, offd, c->members.p, c->Pa.p)
   if (nit <= 1) LS(1);
   else if (nit <= 2) LS(2);
   else if (nit <= 4) LS(4);
   else if (nit <= 8) LS(8);
   else return isle_fail(c, ISLE_E_ARG, "k too large");
 #undef LS
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(proj_segsum_reduce_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, c->Pa.p, S, n, Csum);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import upload
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -66,3 +68,17 @@ def test_incremental_centroid_counts_are_exact():
         assert inc[key]["cen"] == fresh[key]["cen"]
         assert inc[key]["sizes"] == gather[key]["sizes"] or sum(abs(a - b) for a, b in zip(inc[key]["sizes"], gather[key]["sizes"])) <= 0.002 * sum(inc[key]["sizes"])
         assert abs(inc[key]["cen"] - gather[key]["cen"]) <= 1e-4 * gather[key]["cen"]
+
+
+def test_projected_lloyd_is_bitwise_reproducible(hp, small50):
+    """Centroid sums of Lloyd in span(U) run in a fixed order (member lists in ascending document order by a stable sort, chunk
+    partials added in sequence, no float atomics): the same call gives the same bits, as the reference's loop does."""
+    B, k = small50, 50
+    upload(hp, B)
+    hp.compute_block_ks(k, seed=2)
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=5)
+    runs = [hp.run_lloyds_on_projected_space(k, g["C_lowd"]) for _ in range(4)]
+    for r in runs[1:]:
+        assert r["iters"] == runs[0]["iters"]
+        assert np.array_equal(r["assign"], runs[0]["assign"])
+        assert np.array_equal(r["C_lowd"].view(np.uint32), runs[0]["C_lowd"].view(np.uint32))
