@@ -212,6 +212,8 @@ struct isle_ctx {
   DevBuf<float> ptlb;      // D x TL tile bounds (projected Lloyd at k > 224)
   DevBuf<uint32_t> pneed;  // D: tiles a document has to re-examine
   DevBuf<uint32_t> pcand;  // D + 1: candidates of the first filter stage (last = count)
+  DevBuf<int> seg_desc;    // projected centroid sums: chunk descriptors (beg, end) and the centres' first chunks
+  DevBuf<float> seg_part;  // one partial row per chunk
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<float> centers_old;  // V x ldk
   DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
@@ -301,7 +303,7 @@ struct HamTop {  // largest and second largest centre movement of an iteration (
 int k_ham_delta(isle_ctx* c, float* delta_dev /*in: squared movements, out: rounded-up movements*/, int k, HamTop* top_dev);
 int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* lb, const float* delta_dev, const HamTop* top_dev,
                      uint32_t* active, uint32_t* nactive, int fam = ISLE_T_SPARSE_ASSIGN);
-int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out);
+int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out, std::vector<int>* counts_host = nullptr);
 int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev);  // no host round trip
 int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev);
 int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev);

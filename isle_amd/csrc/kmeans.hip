@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+
 #include "common.h"
 #include "hamerly.h"
 #include "scan.h"
@@ -713,52 +715,51 @@ __global__ __launch_bounds__(256) void member_fill_k(const uint32_t* __restrict_
 }
 
 // Member sums of the projected Lloyd update in a FIXED order (the reference's centres are bitwise reproducible; float atomics over
-// chunks that finish in any order are not).  grid = (S, k): workgroup (s, c) takes the 256-member chunks s, s + S, s + 2S, ... of
-// centre c one after the other, every wave sums whole rows (coalesced 4k-byte reads) in member order — the member lists are in
-// ascending document order (k_member_lists) — the four waves are combined in LDS, and the S partial rows of a centre are added in
-// order by proj_segsum_reduce_k.  No atomics.
+// chunks that finish in any order are not).  The member lists are in ascending document order (k_member_lists); every centre's
+// list is cut into chunks of 256 members, one workgroup per chunk (clusters differ 10x in size: a fixed split per centre left the
+// largest one on a single workgroup), every wave sums whole rows (coalesced 4k-byte reads) in member order, the four waves are
+// combined in LDS, and proj_segsum_reduce_k adds a centre's chunk rows in chunk order.  No atomics.
 constexpr int SEG_MC = 256;
+struct SegChunk {
+  int beg, end;  // members [beg, end) of one centre
+};
 template <int NIT>  // float4 chunks per lane: ldk / 4 <= 64 NIT
-__global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P, int k, int ldk, const int* __restrict__ off,
-                                                      const uint32_t* __restrict__ members, float* __restrict__ part /*[S][k][ldk]*/) {
+__global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P, int ldk, const SegChunk* __restrict__ chunks,
+                                                      const uint32_t* __restrict__ members, float* __restrict__ part /*[chunk][ldk]*/) {
   extern __shared__ float red[];  // 4 x ldk
-  const int cc = blockIdx.y, S = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = ldk / 4;
+  const int beg = chunks[blockIdx.x].beg, end = chunks[blockIdx.x].end;
   float4 acc[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int cend = off[cc + 1];
-  for (int beg = off[cc] + (int)blockIdx.x * SEG_MC; beg < cend; beg += S * SEG_MC) {
-    const int end = min(cend, beg + SEG_MC);
-    // this wave's members: beg + wave, + 4, ... (at most 64): ids by one load and shuffles, four 16-byte row loads in flight
-    const int myi = beg + wave + 4 * lane;
-    const uint32_t mym = myi < end ? members[myi] : 0u;
-    const int cnt = end > beg + wave ? min(64, (end - beg - wave + 3) / 4) : 0;
-    for (int j = 0; j < cnt; j += 4) {
-      float4 v[4][NIT];
+  // this wave's members: beg + wave, + 4, ... (at most 64): ids by one load and shuffles, four 16-byte row loads in flight
+  const int myi = beg + wave + 4 * lane;
+  const uint32_t mym = myi < end ? members[myi] : 0u;
+  const int cnt = end > beg + wave ? min(64, (end - beg - wave + 3) / 4) : 0;
+  for (int j = 0; j < cnt; j += 4) {
+    float4 v[4][NIT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t mj = (uint32_t)__shfl((int)mym, min(j + u, cnt - 1));
-        const float4* row = reinterpret_cast<const float4*>(P + (size_t)mj * ldk);
-        const float live = j + u < cnt ? 1.f : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t mj = (uint32_t)__shfl((int)mym, min(j + u, cnt - 1));
+      const float4* row = reinterpret_cast<const float4*>(P + (size_t)mj * ldk);
+      const float live = j + u < cnt ? 1.f : 0.f;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int q = lane + 64 * it;
-          const float4 x = q < nq ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-          v[u][it] = make_float4(x.x * live, x.y * live, x.z * live, x.w * live);
-        }
+      for (int it = 0; it < NIT; ++it) {
+        const int q = lane + 64 * it;
+        const float4 x = q < nq ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u][it] = make_float4(x.x * live, x.y * live, x.z * live, x.w * live);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          acc[it].x += v[u][it].x;
-          acc[it].y += v[u][it].y;
-          acc[it].z += v[u][it].z;
-          acc[it].w += v[u][it].w;
-        }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        acc[it].x += v[u][it].x;
+        acc[it].y += v[u][it].y;
+        acc[it].z += v[u][it].z;
+        acc[it].w += v[u][it].w;
+      }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -766,15 +767,17 @@ __global__ __launch_bounds__(256) void proj_segsum_k(const float* __restrict__ P
     if (q < nq) reinterpret_cast<float4*>(red + (size_t)wave * ldk)[q] = acc[it];
   }
   __syncthreads();
-  float* out = part + ((size_t)blockIdx.x * k + cc) * ldk;
+  float* out = part + (size_t)blockIdx.x * ldk;
   for (int j = threadIdx.x; j < ldk; j += 256) out[j] = (red[j] + red[ldk + j]) + (red[2 * ldk + j] + red[3 * ldk + j]);
 }
-__global__ __launch_bounds__(256) void proj_segsum_reduce_k(const float* __restrict__ part, int S, size_t n /*k * ldk*/, float* __restrict__ Csum) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = part[i];
-  for (int q = 1; q < S; ++q) s += part[(size_t)q * n + i];
-  Csum[i] = s;
+// Csum[c][:] = sum of the chunk rows [c0[c], c0[c + 1]) in order (zero for an empty centre)
+__global__ __launch_bounds__(256) void proj_segsum_reduce_k(const float* __restrict__ part, const int* __restrict__ c0, int ldk, float* __restrict__ Csum) {
+  const int cc = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ldk) return;
+  float s = 0.f;
+  for (int q = c0[cc]; q < c0[cc + 1]; ++q) s += part[(size_t)q * ldk + j];
+  Csum[(size_t)cc * ldk + j] = s;
 }
 __global__ __launch_bounds__(256) void member_keys_k(const uint32_t* __restrict__ assign, uint32_t D, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
@@ -856,13 +859,14 @@ int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev) {
 // members = local documents grouped by centre (counts_dev = LOCAL cluster sizes from k_count_sizes).
 // members[off[c] .. off[c+1]) = documents assigned to centre c in ASCENDING document order: a stable radix sort of the documents by
 // centre (k_sort_pairs_u64, ingest.hip), so that everything summed over a list has one order, run after run.
-int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out) {
+int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out, std::vector<int>* counts_host) {
   std::vector<int> h(k);
   HIPCHK(c, hipMemcpyAsync(h.data(), counts_dev, (size_t)k * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int mx = 0;
   for (int i = 0; i < k; ++i) mx = std::max(mx, h[i]);
   if (max_out) *max_out = mx;
+  if (counts_host) *counts_host = h;
   HIPCHK(c, c->members.reserve(D ? D : 1));
   HIPCHK(c, c->moff.reserve(2 * (size_t)k + 2));
   int* offd = c->moff.p;
@@ -874,13 +878,17 @@ int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const
     HIPCHK(c, c->gl_key_b.reserve(D));
     HIPCHK(c, c->gl_val_a.reserve(D));
     HIPCHK(c, c->gl_val_b.reserve(D));
-    hipLaunchKernelGGL(member_keys_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, assign, (uint32_t)D, c->gl_key_a.p, c->gl_val_a.p);
-    HIPCHK(c, hipGetLastError());
     int bits = 1;
     while ((1 << bits) < k) ++bits;
+    // the sort ping-pongs between two payload buffers, one pass per 8 key bits: `members` is placed so that the last pass lands in it
+    const bool odd = (((bits + 7) / 8) & 1) != 0;
+    uint32_t* va = odd ? c->gl_val_a.p : c->members.p;
+    uint32_t* vb = odd ? c->members.p : c->gl_val_a.p;
+    hipLaunchKernelGGL(member_keys_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, assign, (uint32_t)D, c->gl_key_a.p, va);
+    HIPCHK(c, hipGetLastError());
     bool in_a = true;
-    ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, D, bits, &in_a));
-    HIPCHK(c, hipMemcpyAsync(c->members.p, in_a ? c->gl_val_a.p : c->gl_val_b.p, D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, va, c->gl_key_b.p, vb, D, bits, &in_a));
+    if ((in_a ? va : vb) != c->members.p) return isle_fail(c, ISLE_E_NUMERIC, "member lists: unexpected number of sort passes");
   }
   c->members_valid = true;
   return 0;
@@ -894,23 +902,51 @@ int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, c
     return 0;
   }
   int mx = 0;
-  ISLECHK(k_member_lists(c, assign, D, k, counts, &mx));
-  int* offd = c->moff.p;
-  const int S = std::max(1, std::min({16, cdiv(2048, k), cdiv(mx, SEG_MC)}));  // ~2048 workgroups, never more splits than chunks
-  HIPCHK(c, c->Pa.reserve((size_t)S * n));  // partial rows (Pa is free between two assignment steps)
-  dim3 g(S, k), b(256);
+  std::vector<int> h;
+  ISLECHK(k_member_lists(c, assign, D, k, counts, &mx, &h));
+  // chunk descriptors: centre c owns chunks [c0[c], c0[c + 1]) of <= 256 members each
+  std::vector<SegChunk> ch;
+  std::vector<int> c0(k + 1, 0);
+  ch.reserve(D / SEG_MC + k);
+  int at = 0;
+  for (int cc = 0; cc < k; ++cc) {
+    for (int b0 = 0; b0 < h[cc]; b0 += SEG_MC) ch.push_back(SegChunk{at + b0, at + std::min(h[cc], b0 + SEG_MC)});
+    at += h[cc];
+    c0[cc + 1] = (int)ch.size();
+  }
+  const size_t nch = ch.size();
+  static_assert(sizeof(SegChunk) == 2 * sizeof(int), "");
+  HIPCHK(c, c->seg_desc.reserve(2 * nch + (size_t)k + 1));
+  HIPCHK(c, c->seg_part.reserve((nch ? nch : 1) * (size_t)ldk));
+  int* c0_dev = c->seg_desc.p + 2 * nch;
+  // descriptors travel through the page-locked mailbox area (free outside the eigensolver): the copies are then really asynchronous
+  const size_t desc_bytes = nch * sizeof(SegChunk) + ((size_t)k + 1) * sizeof(int);
+  const bool pinned = desc_bytes <= 2 * isle_ctx::PIN_MAIL_SLOT;
+  char* stage = c->pin + isle_ctx::PIN_MAIL;
+  if (pinned) {
+    if (nch) memcpy(stage, ch.data(), nch * sizeof(SegChunk));
+    memcpy(stage + nch * sizeof(SegChunk), c0.data(), ((size_t)k + 1) * sizeof(int));
+    HIPCHK(c, hipMemcpyAsync(c->seg_desc.p, stage, desc_bytes, hipMemcpyHostToDevice, c->stream));
+  } else {
+    if (nch) HIPCHK(c, hipMemcpyAsync(c->seg_desc.p, ch.data(), nch * sizeof(SegChunk), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c0_dev, c0.data(), ((size_t)k + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
   const size_t lds = 4 * (size_t)ldk * sizeof(float);
   const int nit = cdiv(ldk / 4, 64);  // float4 chunks per lane
-#define LS(N) hipLaunchKernelGGL(proj_segsum_k<N>, g, b, lds, c->stream, P, k, ldk, offd, c->members.p, c->Pa.p)
-  if (nit <= 1) LS(1);
-  else if (nit <= 2) LS(2);
-  else if (nit <= 4) LS(4);
-  else if (nit <= 8) LS(8);
-  else return isle_fail(c, ISLE_E_ARG, "k too large");
+  if (nch) {
+    dim3 g((unsigned)nch), b(256);
+#define LS(N) hipLaunchKernelGGL(proj_segsum_k<N>, g, b, lds, c->stream, P, ldk, reinterpret_cast<const SegChunk*>(c->seg_desc.p), c->members.p, c->seg_part.p)
+    if (nit <= 1) LS(1);
+    else if (nit <= 2) LS(2);
+    else if (nit <= 4) LS(4);
+    else if (nit <= 8) LS(8);
+    else return isle_fail(c, ISLE_E_ARG, "k too large");
 #undef LS
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(proj_segsum_reduce_k, dim3(cdiv(ldk, 256), k), dim3(256), 0, c->stream, c->seg_part.p, c0_dev, ldk, Csum);
   HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(proj_segsum_reduce_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, c->Pa.p, S, n, Csum);
-  HIPCHK(c, hipGetLastError());
+  if (!pinned) HIPCHK(c, hipStreamSynchronize(c->stream));  // ch / c0 are pageable host memory
   return 0;
 }
 
