@@ -175,6 +175,7 @@ struct isle_ctx {
   DevBuf<double> jacW, jacV;  // n x n each
   DevBuf<double> jacS;        // per-pair Gram / rotation scratch
   DevBuf<float> Wf;        // n x n float eigenvectors
+  DevBuf<float> evd_in;    // n x n: the fp32 matrix handed to the small EVD
   int U_k = 0;             // number of columns of U available
   DevBuf<float> Ucm;       // V x k col-major  (copy of basis[:, :k])
   DevBuf<float> Urm;       // V x ldk row-major
@@ -283,7 +284,8 @@ int k_dots_assign(isle_ctx* c, int k, int ldk, const float* cn, const float* dn,
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
-int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out);  // Out (D x ld) = B^T M, LDS-banded form only
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out);
+int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out);  // Out (D x ld) = B^T W, W V x nc col-major, nc <= 32  // Out (D x ld) = B^T M, LDS-banded form only
 int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm);  // Zcm (V x b col-major) = B (B^T Xcm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip
 int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);

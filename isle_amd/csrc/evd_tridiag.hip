@@ -468,32 +468,34 @@ __global__ __launch_bounds__(64) void td_vectors_k(const double* __restrict__ d,
 
 // Z (n x nvec row-major, fp64) <- Q Z, Q = H_0 ... H_{n-3} (reflector j: v = A[j+1:, j], tau[j]); result as fp32 col-major n x nvec.
 // One workgroup per 8 eigenvectors, tile in LDS.
+template <int NC>  // eigenvectors per workgroup: 8, or 4 when there are too few of them to give every CU a workgroup
 __global__ __launch_bounds__(256) void td_back_k(const double* __restrict__ A, const double* __restrict__ tau, int n, const double* __restrict__ Z, int nvec,
                                                   float* __restrict__ out) {
-  extern __shared__ double zs[];  // n x 8
-  __shared__ double red[32][9];
-  const int c0 = blockIdx.x * 8;
-  const int t = threadIdx.x, c = t & 7, rl = t >> 3;  // 32 row lanes x 8 columns
+  extern __shared__ double zs[];  // n x NC
+  __shared__ double red[4][NC];
+  constexpr int RL = 256 / NC;  // row lanes
+  const int c0 = blockIdx.x * NC;
+  const int t = threadIdx.x, c = t & (NC - 1), rl = t / NC, lane = t & 63, wave = t >> 6;
   const bool live = c0 + c < nvec;
-  for (int i = rl; i < n; i += 32) zs[i * 8 + c] = live ? Z[(size_t)i * nvec + c0 + c] : 0.0;
+  for (int i = rl; i < n; i += RL) zs[i * NC + c] = live ? Z[(size_t)i * nvec + c0 + c] : 0.0;
   __syncthreads();
   for (int j = n - 3; j >= 0; --j) {
     const double tj = tau[j];
     if (tj == 0.0) continue;  // uniform
     const double* vj = A + (size_t)j * n;
     double s = 0.0;
-    for (int i = j + 1 + rl; i < n; i += 32) s = fma(vj[i], zs[i * 8 + c], s);
-    red[rl][c] = s;
-    __syncthreads();
-    double tot = 0.0;
+    for (int i = j + 1 + rl; i < n; i += RL) s = fma(vj[i], zs[i * NC + c], s);
+    // the row lanes of a column inside the wave by butterflies, the four waves in LDS: a fixed order
 #pragma unroll
-    for (int q = 0; q < 32; ++q) tot += red[q][c];  // fixed order
-    tot *= tj;
-    for (int i = j + 1 + rl; i < n; i += 32) zs[i * 8 + c] = fma(-tot, vj[i], zs[i * 8 + c]);
+    for (int off = NC; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    if (lane < NC) red[wave][lane] = s;
+    __syncthreads();
+    const double tot = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * tj;
+    for (int i = j + 1 + rl; i < n; i += RL) zs[i * NC + c] = fma(-tot, vj[i], zs[i * NC + c]);
     __syncthreads();
   }
   if (live)
-    for (int i = rl; i < n; i += 32) out[(size_t)(c0 + c) * n + i] = (float)zs[i * 8 + c];
+    for (int i = rl; i < n; i += RL) out[(size_t)(c0 + c) * n + i] = (float)zs[i * NC + c];
 }
 
 // max over vectors of | <z_c, z_{c+q}> | (q = 1..4) and | |z_c|^2 - 1 |, as the bits of a non-negative float
@@ -517,6 +519,13 @@ __global__ __launch_bounds__(256) void td_check_k(const float* __restrict__ Zc, 
   if (threadIdx.x == 0) atomicMax(worst, __float_as_uint((float)dev));
 }
 
+// A (fp64, column-major) = the symmetric matrix whose upper triangle is S's
+__global__ __launch_bounds__(256) void td_sym_k(const float* __restrict__ S, int n, double* __restrict__ A) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * n) return;
+  const int jj = (int)(idx / n), i = (int)(idx - (size_t)jj * n);
+  A[idx] = (i <= jj) ? (double)S[(size_t)jj * n + i] : (double)S[(size_t)i * n + jj];
+}
 }  // namespace
 
 // evals_host: all n eigenvalues, descending; vecs_dev: the nvec leading eigenvectors (n x nvec col-major fp32).
@@ -525,10 +534,10 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   if (n < 3 || n > TD_NMAX_BACK || n > TD_ROWS * 16) return 1;
   nvec = std::max(1, std::min(nvec, n));
   const size_t nn = (size_t)n * n;
-  std::vector<double> Ah(nn);
-  // LAPACK 'U' semantics: the upper triangle defines the matrix
-  for (int jj = 0; jj < n; ++jj)
-    for (int i = 0; i < n; ++i) Ah[(size_t)jj * n + i] = (i <= jj) ? (double)S_host[(size_t)jj * n + i] : (double)S_host[(size_t)i * n + jj];
+  // the fp32 matrix goes up once; td_sym_k makes the fp64 working copy from its upper triangle (LAPACK 'U' semantics) on the
+  // device — at n = 2000 the host loop and the 32 MB pageable copy it replaced cost ~10 ms per solve
+  HIPCHK(c, c->evd_in.reserve(nn));
+  HIPCHK(c, hipMemcpyAsync(c->evd_in.p, S_host, nn * sizeof(float), hipMemcpyHostToDevice, c->stream));
   int CB = 16;
   while (CB < 64 && (n + CB - 1) / CB > 32) CB *= 2;
   if (const char* e = getenv("ISLE_TD_CB")) CB = std::max(8, std::min(128, atoi(e)));  // tuning knob
@@ -553,7 +562,8 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   unsigned int* tickets_rb = tickets + n + 2;
   // persistent form: 2 x (p | next column) behind the counters, rounded up to a double boundary
   double* pv = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tickets_rb + (size_t)n * nrb_max + 2) + 7) & ~(uintptr_t)7);
-  ISLECHK(isle_max_lds(c, (const void*)td_back_k, TD_NMAX_BACK * 8 * (int)sizeof(double)));
+  ISLECHK(isle_max_lds(c, (const void*)td_back_k<8>, TD_NMAX_BACK * 8 * (int)sizeof(double)));
+  ISLECHK(isle_max_lds(c, (const void*)td_back_k<4>, TD_NMAX_BACK * 4 * (int)sizeof(double)));
   const bool small = n <= TD_ROWS * 4;
   // persistent form: G workgroups, each with its columns (ncl of them) plus v and w in LDS
   int pG = TD_P_GSMALL;
@@ -576,7 +586,8 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   }
   const size_t p_lds = ((size_t)((n + pG - 1) / pG) * n + 2 * (size_t)n) * sizeof(double);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    HIPCHK(c, hipMemcpyAsync(A, Ah.data(), nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(td_sym_k, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, c->evd_in.p, n, A);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemsetAsync(tau, 0, (size_t)n * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(e, 0, (size_t)n * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4 + (size_t)n * nrb_max + 4) * sizeof(unsigned int), c->stream));
@@ -626,7 +637,10 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
   hipLaunchKernelGGL(td_bisect_k, dim3((n + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
   hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
-  hipLaunchKernelGGL(td_back_k, dim3((nvec + 7) / 8), dim3(256), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
+  if ((nvec + 7) / 8 > c->num_cus / 2)
+    hipLaunchKernelGGL(td_back_k<8>, dim3((nvec + 7) / 8), dim3(256), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
+  else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread
+    hipLaunchKernelGGL(td_back_k<4>, dim3((nvec + 3) / 4), dim3(256), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
   hipLaunchKernelGGL(td_check_k, dim3(nvec), dim3(256), 0, c->stream, vecs_dev, n, nvec, worst);
   HIPCHK(c, hipGetLastError());
   std::vector<double> ev(n);

@@ -1249,6 +1249,40 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
   return 0;
 }
 
+// Columns per pass of the k-wide / thin products through the pass-1 stream.  A 12-column panel (three ds_read_b128 per slot, 48
+// accumulator registers) runs 2.2x as long as an 8-column one (two reads, 32 registers) — 0.77 against 0.35 ms per pass at the
+// C3-shard shape, 324 against ~150 us at C2 — so 8 columns per pass move more columns per second.  ISLE_GL_PANEL=12 restores 12.
+static int gl_panel_width() {
+  const char* e = getenv("ISLE_GL_PANEL");
+  return (e && atoi(e) == 12) ? 12 : 8;
+}
+
+// Out (D x ld row-major, natural document order, ld = 4 ceil(nc / 4)) = B^T W for a THIN column-major operand W (V x nc, nc <= 32):
+// ceil(nc / 12) passes of the pass-1 stream.  The k-means++ round of a large shard: against the nc newest seeds the reference
+// itself forms B^T (U C_new^T) (SURVEY §8d "sparse form"): 8 nnz bytes per 12 columns instead of re-reading the D x k projection.
+int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out) {
+  ISLECHK(k_band_build(c));
+  if (c->gl_mode != 1) return isle_fail(c, ISLE_E_ARG, "k_gl_thin needs the LDS-banded form");
+  if (ld % 4 || nc > ld) return isle_fail(c, ISLE_E_ARG, "k_gl_thin: bad leading dimension");
+  const uint32_t V = (uint32_t)c->V;
+  HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
+  const int PW = gl_panel_width();
+  for (int j0 = 0; j0 < nc; j0 += PW) {
+    const int ncol = std::min(PW, nc - j0);
+    const int LPE = (ncol + 3) / 4;
+    const size_t n4 = (size_t)V * LPE;
+    hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Wcm + (size_t)j0 * V, (size_t)V, ncol, LPE, c->rowval.p,
+                       (float4*)c->gl_Xs.p);
+    HIPCHK(c, hipGetLastError());
+    float4* out = (float4*)(Out + j0);  // 48-byte steps: 16-byte aligned
+    const uint32_t ld4 = (uint32_t)(ld / 4);
+    if (LPE == 1) ISLECHK((launch_apply<1, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+    if (LPE == 2) ISLECHK((launch_apply<2, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+    if (LPE == 3) ISLECHK((launch_apply<3, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+  }
+  return 0;
+}
+
 // Out (D x ld row-major, natural document order) = B^T M for a wide row-major operand M (V x ld, k <= ld columns): the k-wide SpMM
 // of FPSparseMatrix::multiply_with (src/sparseMatrix.cpp:1749-1782) as ceil(k / 12) passes of the pass-1 stream, twelve
 // columns of diag(s) M staged per pass.  Per gathered nonzero the operand comes from LDS instead of the L2 / Infinity Cache
@@ -1259,8 +1293,9 @@ int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
   if (ld % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: leading dimension %d not a multiple of 4", ld);
   const uint32_t V = (uint32_t)c->V;
   HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
-  for (int j0 = 0; j0 < k; j0 += 12) {
-    const int ncol = std::min(12, k - j0);
+  const int PW = gl_panel_width();
+  for (int j0 = 0; j0 < k; j0 += PW) {
+    const int ncol = std::min(PW, k - j0);
     const int LPE = (ncol + 3) / 4;
     const size_t n4 = (size_t)V * LPE;
     hipLaunchKernelGGL(gl_pack_panel_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Mrm, ld, j0, ncol, LPE, c->rowval.p, n4,

@@ -146,12 +146,50 @@ int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out
   return 0;
 }
 
+// min_dist[d] = min(min_dist[d], max(pn[d] + cn[j] - 2 dots[d][j], 0)) over the nc new seeds
+__global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__ dots, int ld, const float* __restrict__ pn, const float* __restrict__ cn,
+                                                        int nc, uint32_t D, float* __restrict__ min_dist) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float nd = pn[d];
+  float m = min_dist[d];
+  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)d * ld);
+  for (int q = 0; q < ld / 4; ++q) {
+    const float4 v = row[q];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < nc) m = fminf(m, fmaxf((-2.0f * x[e] + cn[4 * q + e]) + nd, 0.0f));
+  }
+  min_dist[d] = m;
+}
+
 int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc,
                   float* min_dist) {
   TimeScope ts(c, ISLE_T_KMPP);
   if (D == 0 || nc == 0) return 0;
   HIPCHK(c, c->cnorm.reserve((size_t)std::max(k, nc)));
   ISLECHK(k_rownorms(c, newC, nc, k, ldk, c->cnorm.p));
+  // The reference's own formulation: P_d . P_c = b_d^T (U P_c), a thin product of B with the V x nc matrix U C_new^T —
+  // 8 nnz bytes per 12 new seeds instead of the 4 k D bytes of the materialised projection.  Pays on a large shard at k = 1000
+  // (1 GB per 12 seeds against 5 GB), not at C2 (0.8 GB against 0.8 GB); ISLE_KMPP_SPARSE=0/1 forces the choice.
+  {
+    const char* e = getenv("ISLE_KMPP_SPARSE");
+    const int passes = (nc + 7) / 8;  // 8 columns per pass of the pass-1 stream (gram_lds.hip gl_panel_width)
+    bool sparse = c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k &&
+                  1.25 * 8.0 * (double)c->nnz * passes < 4.0 * (double)ldk * (double)D;
+    if (e) sparse = atoi(e) != 0 && c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k;
+    if (sparse) {
+      const int ld = (nc + 3) & ~3;
+      HIPCHK(c, c->Tmp.reserve((size_t)c->V * 32));
+      HIPCHK(c, c->dotsT.reserve((size_t)D * 32));
+      ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, k, newC, ldk, nc, c->Tmp.p, ISLE_T_KMPP));  // W = U C_new^T  (V x nc col-major)
+      ISLECHK(k_gl_thin(c, c->Tmp.p, nc, ld, c->dotsT.p));
+      hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p, nc, (uint32_t)D, min_dist);
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    }
+  }
   if (nc <= 16 && c->Pt_ready && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024 && !getenv("ISLE_KMPP_MFMA")) {
     // streaming pass over the coordinate-major copy (the centres fit the default 64 KB of dynamic LDS)
     const int nq = (nc + 3) / 4;

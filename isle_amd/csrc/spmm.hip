@@ -498,7 +498,7 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
 static bool wide_through_lds(const isle_ctx* c) {
   if (getenv("ISLE_WIDE_GATHER")) return false;
   if (getenv("ISLE_WIDE_LDS")) return true;
-  return c->V <= 20 * 3412;
+  return c->V <= 32 * 3412;  // 8-column panels (gram_lds.hip gl_panel_width): measured 46.7 against 51.7 ms at 30 word bands (V = 100k, k = 1000)
 }
 
 // Assignment from stored dot products (dots = B^T C computed by the LDS-banded wide SpMM, gram_lds.hip): one wave per document.
