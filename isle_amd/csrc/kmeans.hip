@@ -177,7 +177,7 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
     const char* e = getenv("ISLE_KMPP_SPARSE");
     const int passes = (nc + 7) / 8;  // 8 columns per pass of the pass-1 stream (gram_lds.hip gl_panel_width)
     bool sparse = c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k &&
-                  1.25 * 8.0 * (double)c->nnz * passes < 4.0 * (double)ldk * (double)D;
+                  8.0 * (double)c->nnz * passes < 4.0 * (double)ldk * (double)D;
     if (e) sparse = atoi(e) != 0 && c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k;
     if (sparse) {
       const int ld = (nc + 3) & ~3;
