@@ -205,6 +205,26 @@ HMat hsub(const HMat& m, size_t r0, size_t c0, size_t r1, size_t c1) {  // inclu
 }  // namespace
 
 static int round4(int k) { return (k + 3) & ~3; }
+static bool getenv_is_zero(const char* name) {
+  const char* e = getenv(name);
+  return e && atoi(e) == 0;
+}
+
+// rows [r0, r0 + nl) of a column-major n x w matrix <-> a packed nloc x w block (rows beyond nl zero)
+__global__ void slice_rows_k(float* __restrict__ M, uint64_t n, int w, uint64_t r0, uint64_t nl, uint64_t nloc, float* __restrict__ blk, int pack) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nloc * (uint64_t)w) return;
+  const uint64_t j = i / nloc, r = i - j * nloc;
+  if (pack) blk[i] = r < nl ? M[j * n + r0 + r] : 0.f;
+  else if (r < nl) M[j * n + r0 + r] = blk[i];
+}
+static int k_slice_rows(isle_ctx* c, float* M, uint64_t n, int w, uint64_t r0, uint64_t nl, uint64_t nloc, float* blk, bool pack) {
+  const uint64_t tot = nloc * (uint64_t)w;
+  if (!tot) return 0;
+  hipLaunchKernelGGL(slice_rows_k, dim3(cdiv((long)tot, 256)), dim3(256), 0, c->stream, M, n, w, r0, nl, nloc, blk, pack ? 1 : 0);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -863,10 +883,39 @@ struct Ks {
   int ortho(float* F, int w, size_t m, int passes, float* coef_dev = nullptr) {
     HIPCHK(c, c->coef.reserve(3 * (c->basis.cap / dim) * 32));
     float* base = coef_dev ? coef_dev : c->coef.p;
+    // Several ranks: the basis is replicated, but nobody needs to orthogonalise ALL rows.  Rank r takes rows [r nloc, (r+1) nloc):
+    // its share of V^T F, an all-reduce of the m x w coefficients (80 kB at m = 2000), the update of its rows — for every pass —
+    // and at the end the slices of F are all-gathered (4 MB at V = 100k), so every rank again holds the whole, bitwise equal F for
+    // the replicated panel QR.  The step is HBM-bound on reading the basis (0.15 s of a 1.15 s C3-shard step): it now divides by
+    // the number of ranks at the price of passes + 1 small collectives per step.  ISLE_KS_ROWSHARD=0 keeps it replicated.
+    const bool shard = c->multi() && !dense_A && !getenv_is_zero("ISLE_KS_ROWSHARD");
+    if (!shard) {
+      for (int p = 0; p < passes; ++p) {
+        float* cf = base + (size_t)p * m * w;
+        ISLECHK(k_vtf(c, Vb(), dim, (int)m, F, w, cf));
+        ISLECHK(k_update(c, F, dim, w, Vb(), (int)m, cf));
+      }
+      return 0;
+    }
+    const uint64_t nloc = (((dim + c->world - 1) / c->world) + 3) & ~3ull;  // rows per rank, a multiple of 4 (16-byte aligned slices)
+    const uint64_t r0 = std::min<uint64_t>(dim, (uint64_t)c->rank * nloc), r1 = std::min<uint64_t>(dim, r0 + nloc);
+    const uint64_t nl = r1 - r0;
     for (int p = 0; p < passes; ++p) {
       float* cf = base + (size_t)p * m * w;
-      ISLECHK(k_vtf(c, Vb(), dim, (int)m, F, w, cf));
-      ISLECHK(k_update(c, F, dim, w, Vb(), (int)m, cf));
+      ISLECHK(k_vtf(c, Vb() + r0, nl, (int)m, F + r0, w, cf, dim));
+      ISLECHK(allreduce_sum<float>(c, cf, m * (size_t)w));
+      ISLECHK(k_update(c, F + r0, nl, w, Vb() + r0, (int)m, cf, dim));
+    }
+    HIPCHK(c, c->ks_gather.reserve((size_t)c->world * nloc * w));
+    float* mine = c->ks_gather.p + (size_t)c->rank * nloc * w;
+    ISLECHK(k_slice_rows(c, F, dim, w, r0, nl, nloc, mine, true));  // pack my rows (zero padded to nloc)
+    {
+      TimeScope ts(c, ISLE_T_COMM);
+      ISLECHK(isle_allgather(c, mine, c->ks_gather.p, nloc * (size_t)w, ISLE_DT_F32));
+    }
+    for (int r = 0; r < c->world; ++r) {
+      const uint64_t q0 = std::min<uint64_t>(dim, (uint64_t)r * nloc), q1 = std::min<uint64_t>(dim, q0 + nloc);
+      if (r != c->rank && q1 > q0) ISLECHK(k_slice_rows(c, F, dim, w, q0, q1 - q0, nloc, c->ks_gather.p + (size_t)r * nloc * w, false));
     }
     return 0;
   }

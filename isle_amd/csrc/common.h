@@ -223,6 +223,7 @@ struct isle_ctx {
   // one copy; the events that mark its arrival
   hipEvent_t ks_ev[2] = {nullptr, nullptr};
   DevBuf<float> ks_mail;
+  DevBuf<float> ks_gather;  // row-sharded orthogonalisation: the ranks' slices of F (world x nloc x blk)
 
   // largest dynamic-LDS size requested so far per kernel ON THIS CONTEXT'S DEVICE (hipFuncSetAttribute is per device; a
   // process-wide flag would leave the kernels of a second GPU at the 64 KB default)
@@ -341,8 +342,8 @@ int k_post_model(isle_ctx* c, uint32_t k);
 int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, float* edge_dev);
 
 // dense.hip
-int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/);
-int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef);
+int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/, uint64_t ld = 0);
+int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef, uint64_t ld = 0);
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
 int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, int* meta_dev /*2 + 32*/, float* Rout_dev /*w*w*/);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);

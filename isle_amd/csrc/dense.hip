@@ -22,7 +22,7 @@ constexpr int VTF_CG = 32;    // basis columns per workgroup (8 per wave)
 constexpr int vtf_rc(int BT) { return BT <= 12 ? 1024 : (BT <= 16 ? 512 : 256); }
 
 template <int BT>
-__global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ Vb, uint64_t n, int m, const float* __restrict__ F,
+__global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ Vb, uint64_t n, uint64_t ld, int m, const float* __restrict__ F,
                                                       int b, double* __restrict__ part /*[chunk][m][BT]*/) {
   constexpr int VTF_RC = vtf_rc(BT);
   __shared__ float Fs[BT][VTF_RC];
@@ -30,14 +30,14 @@ __global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ V
   const int rc = (int)min((uint64_t)VTF_RC, n - r0);
   for (int idx = threadIdx.x; idx < BT * VTF_RC; idx += 256) {
     const int j = idx / VTF_RC, r = idx - j * VTF_RC;
-    Fs[j][r] = (j < b && r < rc) ? F[(uint64_t)j * n + r0 + r] : 0.f;
+    Fs[j][r] = (j < b && r < rc) ? F[(uint64_t)j * ld + r0 + r] : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int ci = wave; ci < VTF_CG; ci += 4) {
     const int i = blockIdx.y * VTF_CG + ci;
     if (i >= m) break;
-    const float* v = Vb + (uint64_t)i * n + r0;
+    const float* v = Vb + (uint64_t)i * ld + r0;
     double acc[BT];
 #pragma unroll
     for (int j = 0; j < BT; ++j) acc[j] = 0.0;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ V
 // matrix of the panel QR keeps the fp64 VALU kernel above.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int VM_RC = 1024;
-__global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, int m, const float* __restrict__ F, int b,
+__global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, uint64_t ld, int m, const float* __restrict__ F, int b,
                                                    int BT, double* __restrict__ part /*[chunk][m][BT]*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, 
   if (col0 >= m) return;
   const uint64_t r0 = (uint64_t)blockIdx.x * VM_RC;
   const uint64_t r1 = min(n, r0 + VM_RC);
-  const float* va = Vb + (uint64_t)min(col0 + l15, m - 1) * n;  // clamped: rows of H beyond m are not written
-  const float* fb = F + (uint64_t)min(l15, b - 1) * n;
+  const float* va = Vb + (uint64_t)min(col0 + l15, m - 1) * ld;  // clamped: rows of H beyond m are not written
+  const float* fb = F + (uint64_t)min(l15, b - 1) * ld;
   const float bmask = (l15 < b) ? 1.f : 0.f;
   floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   uint64_t r = r0;
-  if ((n & 3) == 0) {  // columns are 16-byte aligned
+  if ((ld & 3) == 0 && (((uintptr_t)Vb | (uintptr_t)F) & 15) == 0) {  // columns are 16-byte aligned
     for (; r + 64 <= r1; r += 64) {
       float4 av[4], fv[4];
 #pragma unroll
@@ -132,18 +132,18 @@ __global__ __launch_bounds__(256) void vtf_reduce_k(const double* __restrict__ p
 static int bt_of(int b) { return b <= 4 ? 4 : b <= 8 ? 8 : b <= 12 ? 12 : b <= 16 ? 16 : 32; }
 
 template <class Tout>
-static int vtf_impl(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, Tout* out_dev) {
+static int vtf_impl(isle_ctx* c, const float* Vb, uint64_t n, uint64_t ld, int m, const float* F, int b, Tout* out_dev) {
   if (b > 32 || b < 1) return isle_fail(c, ISLE_E_ARG, "block width %d not in [1,32]", b);
   const int BT = bt_of(b);
   const int nchunks = cdiv(n, vtf_rc(BT));
   HIPCHK(c, c->part.reserve((size_t)nchunks * m * BT));
   dim3 g(nchunks, cdiv(m, VTF_CG)), blk(256);
   switch (BT) {
-    case 4: hipLaunchKernelGGL(vtf_partial_k<4>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
-    case 8: hipLaunchKernelGGL(vtf_partial_k<8>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
-    case 12: hipLaunchKernelGGL(vtf_partial_k<12>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
-    case 16: hipLaunchKernelGGL(vtf_partial_k<16>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
-    default: hipLaunchKernelGGL(vtf_partial_k<32>, g, blk, 0, c->stream, Vb, n, m, F, b, c->part.p); break;
+    case 4: hipLaunchKernelGGL(vtf_partial_k<4>, g, blk, 0, c->stream, Vb, n, ld, m, F, b, c->part.p); break;
+    case 8: hipLaunchKernelGGL(vtf_partial_k<8>, g, blk, 0, c->stream, Vb, n, ld, m, F, b, c->part.p); break;
+    case 12: hipLaunchKernelGGL(vtf_partial_k<12>, g, blk, 0, c->stream, Vb, n, ld, m, F, b, c->part.p); break;
+    case 16: hipLaunchKernelGGL(vtf_partial_k<16>, g, blk, 0, c->stream, Vb, n, ld, m, F, b, c->part.p); break;
+    default: hipLaunchKernelGGL(vtf_partial_k<32>, g, blk, 0, c->stream, Vb, n, ld, m, F, b, c->part.p); break;
   }
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(vtf_reduce_k<Tout>, dim3(cdiv((long)m * BT, 256)), dim3(256), 0, c->stream, c->part.p, nchunks, m, BT, b, out_dev);
@@ -151,19 +151,25 @@ static int vtf_impl(isle_ctx* c, const float* Vb, uint64_t n, int m, const float
   return 0;
 }
 
-int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef) {
+// Vb, F: column-major with leading dimension ld (0 = n); n rows take part (a row slice when the step is sharded over ranks)
+int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef, uint64_t ld) {
   TimeScope ts(c, ISLE_T_ORTHO);
+  if (ld == 0) ld = n;
+  if (n == 0) {  // an empty slice contributes zeros
+    HIPCHK(c, hipMemsetAsync(coef, 0, (size_t)m * b * sizeof(float), c->stream));
+    return 0;
+  }
   if (b <= 16 && m >= 64 && !getenv("ISLE_VTF_VALU")) {  // matrix-core path (enough columns to fill the chip)
     const int BT = bt_of(b);
     const int nch = cdiv(n, VM_RC);
     HIPCHK(c, c->part.reserve((size_t)nch * m * BT));
-    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 64)), dim3(256), 0, c->stream, Vb, n, m, F, b, BT, c->part.p);
+    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 64)), dim3(256), 0, c->stream, Vb, n, ld, m, F, b, BT, c->part.p);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(vtf_reduce_k<float>, dim3(cdiv((long)m * BT, 256)), dim3(256), 0, c->stream, c->part.p, nch, m, BT, b, coef);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-  return vtf_impl<float>(c, Vb, n, m, F, b, coef);
+  return vtf_impl<float>(c, Vb, n, ld, m, F, b, coef);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -174,7 +180,7 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
 // The four partial sums of a row are added in fixed order.
 constexpr int UPD_TILE = 128;
 template <int BT>
-__global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t n, int b, const float* __restrict__ Vb, int m,
+__global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t n, uint64_t ld, int b, const float* __restrict__ Vb, int m,
                                                  const float* __restrict__ coef /*m x b col-major*/) {
   __shared__ float Cs[UPD_TILE][BT];
   __shared__ float red[3][64][BT + 1];
@@ -194,10 +200,10 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
     __syncthreads();
     if (live) {
       const int ib = q * (UPD_TILE / 4), ie = min(cnt, ib + UPD_TILE / 4);
-      const float* v = Vb + (uint64_t)i0 * n + r;
+      const float* v = Vb + (uint64_t)i0 * ld + r;
 #pragma unroll 8
       for (int ii = ib; ii < ie; ++ii) {
-        const float x = v[(uint64_t)ii * n];
+        const float x = v[(uint64_t)ii * ld];
 #pragma unroll
         for (int j = 0; j < BT; ++j) acc[j] = fmaf(x, Cs[ii][j], acc[j]);
       }
@@ -211,20 +217,22 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
   if (q == 0 && live) {
 #pragma unroll
     for (int j = 0; j < BT; ++j)
-      if (j < b) F[(uint64_t)j * n + r] -= ((acc[j] + red[0][lane][j]) + red[1][lane][j]) + red[2][lane][j];
+      if (j < b) F[(uint64_t)j * ld + r] -= ((acc[j] + red[0][lane][j]) + red[1][lane][j]) + red[2][lane][j];
   }
 }
 
-int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef) {
+int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef, uint64_t ld) {
   TimeScope ts(c, ISLE_T_ORTHO);
+  if (ld == 0) ld = n;
+  if (n == 0) return 0;
   const int BT = bt_of(b);
   dim3 g(cdiv(n, 64)), blk(256);
   switch (BT) {
-    case 4: hipLaunchKernelGGL(update_k<4>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
-    case 8: hipLaunchKernelGGL(update_k<8>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
-    case 12: hipLaunchKernelGGL(update_k<12>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
-    case 16: hipLaunchKernelGGL(update_k<16>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
-    default: hipLaunchKernelGGL(update_k<32>, g, blk, 0, c->stream, F, n, b, Vb, m, coef); break;
+    case 4: hipLaunchKernelGGL(update_k<4>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;
+    case 8: hipLaunchKernelGGL(update_k<8>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;
+    case 12: hipLaunchKernelGGL(update_k<12>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;
+    case 16: hipLaunchKernelGGL(update_k<16>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;
+    default: hipLaunchKernelGGL(update_k<32>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;
   }
   HIPCHK(c, hipGetLastError());
   return 0;
