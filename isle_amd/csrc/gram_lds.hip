@@ -736,7 +736,15 @@ __global__ __launch_bounds__(256) void gl_reduce_cm_k(const float4* __restrict__
   const float4* src = part + (size_t)slab0[ob] * stride + (size_t)(q - ob * bitems) * LPE + l;
   float4 s = src[0];
   const uint32_t n = nch[ob];
-  for (uint32_t ch = 1; ch < n; ++ch) add4(s, src[(size_t)ch * stride]);
+  uint32_t ch = 1;
+  for (; ch + 8 <= n; ch += 8) {  // eight slab loads in flight, added in slab order (a rolled loop kept one)
+    float4 v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = src[(size_t)(ch + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) add4(s, v8[u]);
+  }
+  for (; ch < n; ++ch) add4(s, src[(size_t)ch * stride]);
   const uint32_t w = wperm[q];
   const float v = rowval[w];
   const float o[4] = {s.x * v, s.y * v, s.z * v, s.w * v};

@@ -172,12 +172,14 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   ISLECHK(k_rownorms(c, newC, nc, k, ldk, c->cnorm.p));
   // The reference's own formulation: P_d . P_c = b_d^T (U P_c), a thin product of B with the V x nc matrix U C_new^T —
   // 8 nnz bytes per 12 new seeds instead of the 4 k D bytes of the materialised projection.  Pays on a large shard at k = 1000
-  // (1 GB per 12 seeds against 5 GB), not at C2 (0.8 GB against 0.8 GB); ISLE_KMPP_SPARSE=0/1 forces the choice.
+  // (1 GB per 8 seeds against 5 GB), not at C2 (0.8 GB against 0.8 GB); ISLE_KMPP_SPARSE=0/1 forces the choice.  The rule compares
+  // measured rates: a pass of the pass-1 stream costs ~2.8 ps per nonzero (= 15.4 bytes of streaming at 5.5 TB/s), the materialised
+  // projection streams at 5.5 TB/s for <= 16 new seeds (kmpp_min_pt_k) and 2.3x slower through the matrix-core tile beyond.
   {
     const char* e = getenv("ISLE_KMPP_SPARSE");
     const int passes = (nc + 7) / 8;  // 8 columns per pass of the pass-1 stream (gram_lds.hip gl_panel_width)
     bool sparse = c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k &&
-                  8.0 * (double)c->nnz * passes < 4.0 * (double)ldk * (double)D;
+                  15.4 * (double)c->nnz * passes < 4.0 * (double)ldk * (double)D * (nc <= 16 ? 1.0 : 2.3);
     if (e) sparse = atoi(e) != 0 && c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k;
     if (sparse) {
       const int ld = (nc + 3) & ~3;
