@@ -921,7 +921,7 @@ int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const
     int bits = 1;
     while ((1 << bits) < k) ++bits;
     // the sort ping-pongs between two payload buffers, one pass per 8 key bits: `members` is placed so that the last pass lands in it
-    const bool odd = (((bits + 7) / 8) & 1) != 0;
+    const bool odd = D >= 2 && (((bits + 7) / 8) & 1) != 0;  // (a single document is not sorted at all: it stays in the first buffer)
     uint32_t* va = odd ? c->gl_val_a.p : c->members.p;
     uint32_t* vb = odd ? c->members.p : c->gl_val_a.p;
     hipLaunchKernelGGL(member_keys_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, assign, (uint32_t)D, c->gl_key_a.p, va);

@@ -82,3 +82,38 @@ def test_projected_lloyd_is_bitwise_reproducible(hp, small50):
         assert r["iters"] == runs[0]["iters"]
         assert np.array_equal(r["assign"], runs[0]["assign"])
         assert np.array_equal(r["C_lowd"].view(np.uint32), runs[0]["C_lowd"].view(np.uint32))
+
+
+@pytest.mark.parametrize("D,k", [(1, 1), (2, 2), (7, 3), (40, 5)])
+def test_tiny_and_degenerate_partitions(hp, D, k):
+    """Edge sizes of the k-means chain (a single document; as many centres as documents; duplicate documents, which leave
+    centres empty after the first update): member lists, chunked centroid sums and the stop rule against the oracle."""
+    from oracle.oracle import OracleCsc, lift
+    rng = np.random.default_rng(10 * D + k)
+    V = 60
+    base = [np.sort(rng.choice(V, size=int(n), replace=False)).astype(np.uint32) for n in rng.integers(3, 9, size=max(1, (D + 1) // 2))]
+    cols = [base[i % len(base)] for i in range(D)]  # every document appears about twice
+    offs = np.zeros(D + 1, np.int64)
+    offs[1:] = np.cumsum([len(c) for c in cols])
+    rows = np.concatenate(cols)
+    s = rng.uniform(0.5, 2.0, size=V).astype(np.float32)
+    vals = s[rows]
+    hp.upload_csc(V, vals, rows, offs)
+    o = OracleCsc(V, D, vals, rows, offs)
+    U, _ = np.linalg.qr(rng.standard_normal((V, k)))
+    U = np.asfortranarray(U.astype(np.float32))
+    hp.set_U(U)
+    seeds = np.arange(k, dtype=np.uint64) * max(1, D // k)
+    seeds = np.unique(seeds)[:k]
+    if len(seeds) < k:
+        seeds = np.arange(k, dtype=np.uint64)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=seeds)
+    ko = o.kmeanspp(U, k, inject=seeds)
+    assert np.abs(g["C_lowd"] - ko["C_lowd"]).max() <= 1e-5 * max(1.0, np.abs(ko["C_lowd"]).max())
+    lg, lo = hp.run_lloyds_on_projected_space(k, g["C_lowd"]), o.lloyds_projected(U, ko["C_lowd"])
+    assert lg["iters"] == lo["iters"] and np.array_equal(lg["assign"], lo["assign"])
+    assert np.abs(lg["C_lowd"] - lo["C_lowd"]).max() <= 1e-5 * max(1.0, np.abs(lo["C_lowd"]).max())
+    hp.left_multiply_by_U(lo["C_lowd"], fetch=False)
+    sg, so = hp.run_lloyds(k), o.lloyds_sparse(lift(U, lo["C_lowd"]))
+    assert sg["iters"] == so["iters"] and np.array_equal(sg["assign"], so["assign"])
+    assert np.abs(sg["centers"] - so["centers"]).max() <= 1e-5 * max(1.0, np.abs(so["centers"]).max())
