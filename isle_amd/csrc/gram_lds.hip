@@ -1081,18 +1081,17 @@ int k_gl_build(isle_ctx* c) {
     std::vector<GlDesc> ds;
     uint32_t nslab = 0;
     const char* e_col = getenv("ISLE_GL_COLUMNS");
-    const bool columns = e_col && atoi(e_col) == 1 && s2.NB >= 16;  // experiment, off: measured slower at C2 (see below)
+    const bool columns = !(e_col && atoi(e_col) == 0) && s2.NB >= 16;  // ISLE_GL_COLUMNS=0: per-block chunking only
     std::vector<unsigned long long> tot;
     if (columns) {
-      // Band columns shared through L2.  Every word block walks every document band, so Y (48 MB at C2) would be staged from HBM
-      // once per word block (13 x 48 MB = 0.62 GB of the 1.2 GB pass 2 moved in round 1).  Here the document bands are cut into
-      // NC "columns" of equal total cost, the SAME cut for all word blocks, and the workgroups (word block x column) of one
-      // column are queued back to back on ONE XCD (workgroup i runs on XCD i % 8): they start together, stage the same bands at
-      // about the same time, and all but the first find them in that XCD's 4 MB L2.  The XCDs' queues carry equal cost (NC is a
-      // multiple of 8, columns have equal cost); inside a queue the heaviest word block of a column goes first.
-      // MEASURED (round 2, C2, 40 columns x 13 blocks): pass 2 0.301 -> 0.349 ms.  A column's workgroups differ 5x in cost (the
-      // word blocks are ordered by row length), and with ~65 workgroups per XCD queue the heavy ones set the makespan; the per-block
-      // chunking below gives equal-cost workgroups instead.  Kept selectable (ISLE_GL_COLUMNS=1), not used by default.
+      // Band columns shared through L2.  Every word block walks every document band, so Y (48 MB at C2) is staged from HBM once
+      // per word block (13 x 48 MB = 0.62 GB of the 1.2 GB pass 2 moves; 25 x 60 MB = 1.5 of 2.6 GB at a C3 shard, where pass 2 runs
+      // at the HBM rate).  Here the document bands are cut into NC "columns" of equal total cost — at most GL_COL_BANDS bands, 1.3 MB
+      // of Y — the SAME cut for all word blocks, and all workgroups of a column are queued back to back on ONE XCD (workgroup i
+      // runs on XCD i % 8), so the column's bands are fetched from HBM once and found in that XCD's 4 MB L2 by the other word
+      // blocks (measured with one workgroup per (block, column): FETCH_SIZE of pass 2 1.11 -> 0.66 GB).  Inside a column a word
+      // block is cut into sub-chunks of about the same cost as everybody else's (the word blocks differ 5x in cost; with whole
+      // columns per workgroup the heavy ones set the makespan: 0.301 -> 0.349 ms at C2).
       const uint32_t NB = s2.NB;
       HIPCHK(c, c->gl_blocktot.reserve((size_t)nblk * NB));
       hipLaunchKernelGGL(gl_blocktot_k, dim3(nblk, NB), dim3(256), 0, c->stream, c->gl_srsum.p, s2.nwv, wpb, NB, NB, c->gl_blocktot.p);
@@ -1106,8 +1105,13 @@ int k_gl_build(isle_ctx* c) {
         for (uint32_t ob = 0; ob < nblk; ++ob) bcost[bnd] += (double)tot[(size_t)ob * NB + bnd] + bc;
         all += bcost[bnd];
       }
-      uint32_t NC = 8u * (uint32_t)std::max(1.0, std::ceil(wgs_per_cu * c->num_cus / (8.0 * nblk)));
-      NC = std::min(NC, (NB / 8u) * 8u);
+      const char* e_cb = getenv("ISLE_GL_COL_BANDS");
+      // <= 12 bands (1.9 MB of Y) per column: measured at C2 / C3 shard, pass 2 in ms — per-block chunks 0.291 / 0.474, columns of
+      // <= 8 bands 0.294 / 0.459, <= 12 bands 0.283 / 0.436, <= 16 bands 0.282 / 0.464
+      const uint32_t colbands = e_cb ? (uint32_t)std::max(1, atoi(e_cb)) : 12u;
+      const double W = wgs_per_cu * c->num_cus;
+      uint32_t NC = 8u * (uint32_t)std::ceil(std::max(W / (1.25 * nblk), (double)NB / colbands) / 8.0);
+      NC = std::max(8u, std::min(NC, (NB / 8u) * 8u));
       std::vector<uint32_t> cut(NC + 1, 0);  // column cc = bands [cut[cc], cut[cc + 1])
       {
         double pre = 0;
@@ -1120,31 +1124,47 @@ int k_gl_build(isle_ctx* c) {
         while (cc <= NC) cut[cc++] = NB;
         cut[NC] = NB;
       }
+      for (uint32_t cc = 0; cc < NC; ++cc)
+        if (cut[cc + 1] <= cut[cc]) return isle_fail(c, ISLE_E_NUMERIC, "operator build: empty band column");
+      const double target = std::max(1.0, all / W);
+      // sub-chunks per (block, column), then the blocks' slab ranges, then the descriptors in XCD queues
+      std::vector<uint32_t> nsub((size_t)nblk * NC);
+      for (uint32_t ob = 0; ob < nblk; ++ob) {
+        slab0[ob] = nslab;
+        for (uint32_t cc = 0; cc < NC; ++cc) {
+          double cost = 0;
+          for (uint32_t bnd = cut[cc]; bnd < cut[cc + 1]; ++bnd) cost += (double)tot[(size_t)ob * NB + bnd] + bc;
+          const uint32_t nb = cut[cc + 1] - cut[cc];
+          const uint32_t n = (uint32_t)std::min<double>((double)nb, std::max(1.0, std::floor(cost / target + 0.5)));
+          nsub[(size_t)ob * NC + cc] = n;
+          nch[ob] += n;
+          nslab += n;
+        }
+      }
       std::vector<std::vector<GlDesc>> xq(8);
       std::vector<std::pair<double, uint32_t>> order(nblk);
+      std::vector<uint32_t> next(nblk);
+      for (uint32_t ob = 0; ob < nblk; ++ob) next[ob] = slab0[ob];
       for (uint32_t cc = 0; cc < NC; ++cc) {
-        const uint32_t b0 = cut[cc], b1 = cut[cc + 1];
-        if (b1 <= b0) continue;  // (cannot happen with the guards above; an empty column would leave its slabs unwritten)
+        const uint32_t b0 = cut[cc], b1 = cut[cc + 1], nb = b1 - b0;
         for (uint32_t ob = 0; ob < nblk; ++ob) {
           double t = 0;
           for (uint32_t bnd = b0; bnd < b1; ++bnd) t += (double)tot[(size_t)ob * NB + bnd];
-          order[ob] = {-t, ob};
+          order[ob] = {-t / nsub[(size_t)ob * NC + cc], ob};
         }
-        std::sort(order.begin(), order.end());
-        for (auto& o : order) xq[cc % 8].push_back(GlDesc{o.second * wpb, 1u, wpb, b0, b1, o.second * NC + cc, o.second * bitems, 0u});
+        std::sort(order.begin(), order.end());  // heaviest workgroups of the column first
+        for (auto& o : order) {
+          const uint32_t ob = o.second, n = nsub[(size_t)ob * NC + cc];
+          for (uint32_t q = 0; q < n; ++q)
+            xq[cc % 8].push_back(GlDesc{ob * wpb, 1u, wpb, b0 + (uint32_t)((uint64_t)q * nb / n), b0 + (uint32_t)((uint64_t)(q + 1) * nb / n), next[ob]++,
+                                        ob * bitems, 0u});
+        }
       }
-      for (uint32_t cc = 0; cc + 1 <= NC; ++cc)
-        if (cut[cc + 1] <= cut[cc]) return isle_fail(c, ISLE_E_NUMERIC, "operator build: empty band column");
       size_t qmax = 0;
       for (auto& q : xq) qmax = std::max(qmax, q.size());
       ds.reserve(qmax * 8);
       for (size_t j = 0; j < qmax; ++j)
         for (uint32_t x = 0; x < 8; ++x) ds.push_back(j < xq[x].size() ? xq[x][j] : GlDesc{0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u});  // empty: no wave is valid
-      for (uint32_t ob = 0; ob < nblk; ++ob) {
-        slab0[ob] = ob * NC;
-        nch[ob] = NC;
-      }
-      nslab = nblk * NC;
     } else {
       // per word block: band chunks in proportion to the block's cost (round 1's form; small matrices, or ISLE_GL_COLUMNS=0).
       // Cost = super-rounds (LDS-bound, ~50 ns of CU time each) + GL_BAND_COST per band staged; without the second term a block
