@@ -934,7 +934,21 @@ __global__ __launch_bounds__(256) void colnorm_partial_k(const float* __restrict
     const int cc = c0 + cl;
     double s = 0.0;
     if (cc < k) {
-      for (uint64_t r = r0 + rg; r < r1; r += 4) {
+      uint64_t r = r0 + rg;
+      for (; r + 28 < r1; r += 32) {  // eight rows in flight per thread, accumulated in row order
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a[u] = Mrm[(r + 4 * u) * ldk + cc];
+          b[u] = Sub ? Sub[(r + 4 * u) * ldk + cc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double x = (double)a[u] - (double)b[u];
+          s = fma(x, x, s);
+        }
+      }
+      for (; r < r1; r += 4) {
         const double x = (double)Mrm[r * ldk + cc] - (Sub ? (double)Sub[r * ldk + cc] : 0.0);
         s = fma(x, x, s);
       }
@@ -951,8 +965,17 @@ __global__ __launch_bounds__(256) void colnorm_reduce_k(const double* __restrict
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int cc = blockIdx.x * 64 + cl;
   double s = 0.0;
-  if (cc < k)
-    for (int ch = rg; ch < nchunks; ch += 4) s += part[(size_t)ch * k + cc];
+  if (cc < k) {
+    int ch = rg;
+    for (; ch + 28 < nchunks; ch += 32) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(ch + 4 * u) * k + cc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; ch < nchunks; ch += 4) s += part[(size_t)ch * k + cc];
+  }
   sh[rg][cl] = s;
   __syncthreads();
   if (rg == 0 && cc < k) out[cc] = (float)((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]));

@@ -816,7 +816,16 @@ __global__ __launch_bounds__(256) void proj_segsum_reduce_k(const float* __restr
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= ldk) return;
   float s = 0.f;
-  for (int q = c0[cc]; q < c0[cc + 1]; ++q) s += part[(size_t)q * ldk + j];
+  int q = c0[cc];
+  const int qe = c0[cc + 1];
+  for (; q + 8 <= qe; q += 8) {  // eight chunk rows in flight, added in chunk order (a rolled loop kept one: 177 us per call at C2)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * ldk + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; q < qe; ++q) s += part[(size_t)q * ldk + j];
   Csum[(size_t)cc * ldk + j] = s;
 }
 __global__ __launch_bounds__(256) void member_keys_k(const uint32_t* __restrict__ assign, uint32_t D, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
