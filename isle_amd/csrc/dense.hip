@@ -312,12 +312,19 @@ __global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ p
       const int u = (i <= j) ? j * w + i : i * w + j;
       double s = 0.0;
       int p = p0;
-      for (; p + 8 <= p1; p += 8) {  // eight loads in flight, summed in index order
-        double v[8];
+      for (; p + 16 <= p1; p += 16) {  // sixteen loads in flight, summed in index order
+        double v[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
+        for (int q = 0; q < 16; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += v[q];
+        for (int q = 0; q < 16; ++q) s += v[q];
+      }
+      for (; p + 4 <= p1; p += 4) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += v[q];
       }
       for (; p < p1; ++p) s += part[(size_t)p * (PQ_W * PQ_W) + u];
       if (half) X[i][j] = s;  // X is free until the inverse below
@@ -429,6 +436,62 @@ __global__ __launch_bounds__(256) void pqr_apply_k(const float* F, uint64_t n, i
   }
 }
 
+// pqr_apply_k of pass 1 fused with pqr_gram_k of pass 2: a workgroup forms Q1 = F T for its PQ_SUB slabs of 256 rows, writes them, and
+// accumulates their partial Gram matrix from the copy it keeps in LDS — one launch and one sweep over Q1 fewer per panel QR
+// (61 per step at C2, 300 at a C3 shard; the chain is latency-bound).  Same arithmetic and summation order as the two kernels.
+__global__ __launch_bounds__(256) void pqr_apply_gram_k(const float* F, uint64_t n, int b, const float* __restrict__ T, const int* __restrict__ meta,
+                                                         float* Q, double* __restrict__ part /*[block][PQ_W*PQ_W]*/) {
+  __shared__ float Ts[PQ_W * PQ_W];
+  __shared__ float Ft[PQ_W][PQ_ROWS + 1];
+  const int rk = meta[0];
+  const int w = rk;
+  for (int idx = threadIdx.x; idx < b * rk; idx += 256) Ts[idx] = T[idx];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int sub = 0; sub < PQ_SUB; ++sub) {
+    const uint64_t r0 = ((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS;
+    if (r0 >= n) break;
+    __syncthreads();  // Ts is staged; the previous slab's Ft has been consumed
+    const uint64_t r = r0 + threadIdx.x;
+    const bool live = r < n;
+    float f[PQ_W];
+#pragma unroll
+    for (int j = 0; j < PQ_W; ++j) f[j] = (j < b && live) ? F[(uint64_t)j * n + r] : 0.f;
+    for (int cc = 0; cc < rk; ++cc) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < PQ_W; ++j)
+        if (j < b) s = fmaf(f[j], Ts[cc * b + j], s);
+      if (live) Q[(uint64_t)cc * n + r] = s;
+      Ft[cc][threadIdx.x] = live ? s : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = threadIdx.x + 256 * q;
+      if (o >= w * w) break;
+      const int i = o / w, j = o - i * w;
+      if (j < i) continue;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains, combined in a fixed order (as pqr_gram_k)
+#pragma unroll 4
+      for (int rr = 0; rr < PQ_ROWS; rr += 4) {
+        s0 = fma((double)Ft[i][rr], (double)Ft[j][rr], s0);
+        s1 = fma((double)Ft[i][rr + 1], (double)Ft[j][rr + 1], s1);
+        s2 = fma((double)Ft[i][rr + 2], (double)Ft[j][rr + 2], s2);
+        s3 = fma((double)Ft[i][rr + 3], (double)Ft[j][rr + 3], s3);
+      }
+      acc[q] += (s0 + s1) + (s2 + s3);
+    }
+  }
+  double* out = part + (size_t)blockIdx.x * (PQ_W * PQ_W);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = threadIdx.x + 256 * q;
+    if (o >= w * w) break;
+    const int i = o / w, j = o - i * w;
+    if (j >= i) out[j * w + i] = acc[q];
+  }
+}
+
 // F: n x w (device, destroyed).  Q: n x rank at Qdst.  R_host: room for w*w floats, rank x w as [j*rank + r].
 // Kernels only.  meta_dev (2 + PQ_W ints: rank, status, pivots) and Rout_dev (rank x w, leading dimension rank) are device
 // buffers of the caller's choice, so that a pipelined caller can fetch them, together with whatever else it needs from the
@@ -443,8 +506,7 @@ int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, in
   const dim3 rows(cdiv((long)n, 256));
   hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, F, n, w, (const int*)nullptr, c->pq_part.p);
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 1, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
-  hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, F, n, w, 1, c->pq_T.p, meta_dev, Qdst);
-  hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, Qdst, n, w, meta_dev, c->pq_part.p);
+  hipLaunchKernelGGL(pqr_apply_gram_k, dim3(nparts), dim3(256), 0, c->stream, F, n, w, c->pq_T.p, meta_dev, Qdst, c->pq_part.p);
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
   hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, meta_dev, Qdst);
   HIPCHK(c, hipGetLastError());
