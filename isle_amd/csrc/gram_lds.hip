@@ -266,9 +266,20 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_count_k(const uint32_t* __
   // GL_SUB lanes per document: 64 / GL_SUB independent load -> atomic chains per wave (the loop is latency-bound)
   for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
     const uint32_t d = dperm[p];
-    for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
-      const uint32_t w = rows[i];
-      if (w >= w0 && w < w1) atomicAdd(&hist[(w - w0) >> 1], ((w - w0) & 1u) ? 0x10000u : 1u);
+    const int64_t iend = offs[d + 1];
+    for (int64_t i = offs[d] + sl; i < iend; i += 4 * GL_SUB) {  // four row ids in flight per lane
+      uint32_t w[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t iu = i + (int64_t)u * GL_SUB;
+        const bool live = iu < iend;
+        w[u] = rows[live ? iu : iend - 1];
+        in[u] = live && w[u] >= w0 && w[u] < w1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (in[u]) atomicAdd(&hist[(w[u] - w0) >> 1], ((w[u] - w0) & 1u) ? 0x10000u : 1u);
     }
   }
   __syncthreads();
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
                                                               const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ sbase,
                                                               uint16_t* __restrict__ ids16, const uint16_t* __restrict__ cellpre /*null: unmerged*/) {
   extern __shared__ uint32_t hist[];
+  constexpr int NU = 8;  // entries in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t band = blockIdx.x;
   const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
@@ -322,27 +334,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
   for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
     const uint32_t d = dperm[p];
     const int64_t iend = offs[d + 1];
-    // four entries per lane and pass: the chain row id -> cursor -> word position -> slice base -> store is five dependent
+    // eight entries per lane and pass (four in round 1): the chain row id -> cursor -> word position -> slice base -> store is five dependent
     // round trips, so independent entries are kept in flight together
-    for (int64_t i = offs[d] + sl; i < iend; i += 4 * GL_SUB) {
-      uint32_t w[4], q[4];
-      bool in[4];
+    for (int64_t i = offs[d] + sl; i < iend; i += NU * GL_SUB) {
+      uint32_t w[NU], q[NU];
+      bool in[NU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int64_t iu = i + (int64_t)u * GL_SUB;
         const bool live = iu < iend;
         w[u] = rows[live ? iu : iend - 1];
         in[u] = live && w[u] >= w0 && w[u] < w1;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[u] = in[u] ? wpos[w[u]] : 0u;
-      uint32_t sb[4], pre[4];
+      for (int u = 0; u < NU; ++u) q[u] = in[u] ? wpos[w[u]] : 0u;
+      uint32_t sb[NU], pre[NU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sb[u] = in[u] ? sbase[(size_t)(q[u] >> 6) * NB + band] : 0u;
+      for (int u = 0; u < NU; ++u) sb[u] = in[u] ? sbase[(size_t)(q[u] >> 6) * NB + band] : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) pre[u] = (cellpre && in[u]) ? (uint32_t)cellpre[(size_t)w[u] * NB + band] : 0u;
+      for (int u = 0; u < NU; ++u) pre[u] = (cellpre && in[u]) ? (uint32_t)cellpre[(size_t)w[u] * NB + band] : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         if (in[u]) {
           const uint32_t odd = (w[u] - w0) & 1u;
           const uint32_t cur = atomicAdd(&hist[(w[u] - w0) >> 1], odd ? 0x10000u : 1u);
@@ -778,9 +790,20 @@ __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restri
     const uint32_t mend = min(m1, (uint32_t)moff[cc + 1]);  // centre cc owns members [moff[cc], moff[cc + 1])
     for (uint32_t idx = m + wave * (64 / GL_SUB) + sub; idx < mend; idx += GL_WAVES * (64 / GL_SUB)) {
       const uint32_t d = members[idx];
-      for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
-        const uint32_t w = rows[i];
-        if (w >= w0 && w < w1) atomicAdd(&hist[(w - w0) >> 1], ((w - w0) & 1u) ? 0x10000u : 1u);
+      const int64_t iend = offs[d + 1];
+      for (int64_t i = offs[d] + sl; i < iend; i += 4 * GL_SUB) {  // four row ids in flight per lane
+        uint32_t w[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t iu = i + (int64_t)u * GL_SUB;
+          const bool live = iu < iend;
+          w[u] = rows[live ? iu : iend - 1];
+          in[u] = live && w[u] >= w0 && w[u] < w1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (in[u]) atomicAdd(&hist[(w[u] - w0) >> 1], ((w[u] - w0) & 1u) ? 0x10000u : 1u);
       }
     }
     __syncthreads();
