@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c2 on one GPU, c3 (one 10M-document corpus sharded over the ranks) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fetch-centers", action="store_true", help="also copy the final V x k centres to the host inside the timed step")
     ap.add_argument("--no-upstream", action="store_true", help="skip the (untimed-region) device thresholding check")
     ap.add_argument("--blk", type=int, default=0, help="experiment: block size of the eigensolver (0 = the reference's 10)")
     args = ap.parse_args()
@@ -139,7 +140,7 @@ def main():
 
     phase_wall = {"block_ks": 0.0, "kmeanspp": 0.0, "lloyd_projected": 0.0, "lift": 0.0, "lloyd_sparse": 0.0}
 
-    def step(i):
+    def step(i, wall=True):
         t = [time.perf_counter()]
         if args.blk:
             r = hp.compute_block_ks(k, blk=args.blk, ncv=2 * k + args.blk, seed=1 + i, allow_noconv=True)
@@ -152,9 +153,12 @@ def main():
         t.append(time.perf_counter())
         hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
         t.append(time.perf_counter())
-        ls = hp.run_lloyds(k, fetch_centers=True)  # the trainer consumes centers + partition (trainer.cpp:563-575)
+        # The trainer reads only the partition after this call (closest_docs, src/trainer.cpp:566-575; `centers` is not touched again), so
+        # the V x k centres stay in device memory, as they do in isle_amd/host/ISLETrain.cpp.  --fetch-centers copies them to the host as
+        # well (the PCIe-inclusive figure quoted in DESIGN.md section 7).
+        ls = hp.run_lloyds(k, fetch_centers=args.fetch_centers)
         t.append(time.perf_counter())
-        if i >= 0:
+        if wall:
             for j, name in enumerate(phase_wall):
                 phase_wall[name] += t[j + 1] - t[j]
         return dict(ks=r, kmpp_rounds=g["rounds"], lp_iters=lp["iters"], ls_iters=ls["iters"], assign=ls["assign"])
@@ -167,7 +171,7 @@ def main():
             dist.barrier()
 
     for i in range(args.warmup):
-        step(-1 - i)
+        step(-1 - i, wall=False)
     hp.timing_enable(2)  # events around the Gram-apply launches only (roofline); everything else runs as in production
     hp.timing_reset()
     fence()
@@ -181,7 +185,7 @@ def main():
     # per-family breakdown: one more pass, untimed, with events around every launch
     hp.timing_enable(1)
     hp.timing_reset()
-    step(-50)
+    step(args.steps - 1, wall=False)  # the last timed step again (same seeds), so that the per-family device times describe a timed step
     fence()
     tm = hp.timing_get()
     hp.timing_enable(0)

@@ -8,6 +8,7 @@
 // the host keeps only the small projected matrix H (<= (2k+b) x 2k floats) and scalars.
 // There is no CPU fallback.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -40,6 +41,16 @@ int isle_max_lds(isle_ctx* c, const void* fn, int bytes) {
   HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   c->lds_attr.emplace_back(fn, bytes);
   return 0;
+}
+
+void isle_host_mark(const char* what) {
+  static const bool on = getenv("ISLE_HOST_TRACE") != nullptr;
+  if (!on) return;
+  static auto last = std::chrono::steady_clock::now();
+  const auto now = std::chrono::steady_clock::now();
+  const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+  last = now;
+  if (ms >= 0.2) fprintf(stderr, "[host] %8.3f ms before %s\n", ms, what);
 }
 
 TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
@@ -189,12 +200,15 @@ struct HostRng {
 };
 
 struct HMat {  // small col-major float matrix on the host (the projected matrix H)
-  size_t r = 0, c = 0;
+  size_t r = 0, c = 0, ld = 0, cap_c = 0;  // r x c in use inside an ld x cap_c allocation (zero outside what was written)
   std::vector<float> a;
   HMat() {}
-  HMat(size_t r_, size_t c_) : r(r_), c(c_), a(r_ * c_, 0.f) {}
-  float& operator()(size_t i, size_t j) { return a[j * r + i]; }
-  float operator()(size_t i, size_t j) const { return a[j * r + i]; }
+  HMat(size_t r_, size_t c_) : r(r_), c(c_), ld(r_), cap_c(c_), a(r_ * c_, 0.f) {}
+  // room to grow: the Krylov expansion appends blocks of rows and columns in place (at ncv = 2010 the matrix is 16 MB, and every
+  // fresh copy of it cost the host 2 - 6 ms with the GPU idle)
+  HMat(size_t r_, size_t c_, size_t cap_r_, size_t cap_c_) : r(r_), c(c_), ld(std::max(r_, cap_r_)), cap_c(std::max(c_, cap_c_)), a(ld * cap_c, 0.f) {}
+  float& operator()(size_t i, size_t j) { return a[j * ld + i]; }
+  float operator()(size_t i, size_t j) const { return a[j * ld + i]; }
 };
 HMat hsub(const HMat& m, size_t r0, size_t c0, size_t r1, size_t c1) {  // inclusive bounds (arma submat)
   HMat o(r1 - r0 + 1, c1 - c0 + 1);
@@ -265,6 +279,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->pin_stage) (void)hipHostFree(c->pin_stage);
   for (auto& e : c->ev_used) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -962,7 +977,7 @@ struct Ks {
     std::vector<float> hc(2 * blk * blk);
     HIPCHK(c, hipMemcpyAsync(hc.data(), c->coef.p, hc.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     ISLECHK(dev_qr(c, V1, dim, (int)blk, col(blk), R, &rank));  // synchronises the stream
-    H = HMat(2 * blk, blk);
+    H = HMat(2 * blk, blk, std::max<size_t>(ncv, 2 * blk) + blk, blk + (std::max<size_t>(ncv, 2 * blk) + blk - 2 * blk));
     for (size_t j = 0; j < blk; ++j) {
       for (size_t i = 0; i < blk; ++i) H(i, j) = hc[j * blk + i] + hc[blk * blk + j * blk + i];
       for (int i = 0; i < rank; ++i) H(blk + i, j) = R[j * rank + i];
@@ -976,16 +991,19 @@ struct Ks {
   int expand() {  // :62-136
     // H grows by blk rows and columns per step; it is kept in a work matrix of the final size while the loop runs (copying
     // the whole of H at every step cost ~10 ms of host time per solve at ncv = 410, with the GPU idle behind the QR's sync)
+    isle_host_mark("expand: entry");
     const size_t cap_r = std::max<size_t>(ncv, H.r) + blk, cap_c = H.c + (cap_r - H.r);
-    HMat W(cap_r, cap_c);
-    for (size_t j = 0; j < H.c; ++j)
-      for (size_t i = 0; i < H.r; ++i) W(i, j) = H(i, j);
+    if (H.ld < cap_r || H.cap_c < cap_c) {  // init() and truncate() allocate with this room, so this copy is the exception
+      HMat W(H.r, H.c, cap_r, cap_c);
+      for (size_t j = 0; j < H.c; ++j)
+        for (size_t i = 0; i < H.r; ++i) W(i, j) = H(i, j);
+      H = std::move(W);
+    }
+    HMat& W = H;  // grows in place: rows hr.. and columns hcn.. are zero until a step writes them
     size_t hr = H.r, hcn = H.c;
-    auto shrink = [&]() {  // H = W[:hr, :hcn]
-      HMat Hn(hr, hcn);
-      for (size_t j = 0; j < hcn; ++j)
-        for (size_t i = 0; i < hr; ++i) Hn(i, j) = W(i, j);
-      H = Hn;
+    auto shrink = [&]() {
+      H.r = hr;
+      H.c = hcn;
     };
     // Pipelined: after the QR of step i is enqueued, the operator application and orthogonalisation of step i + 1 are
     // enqueued too (they only need Q on the device, assuming full rank), and the host then waits for an event recorded
@@ -1014,6 +1032,7 @@ struct Ks {
         host_mail[i] = host_mail_pageable[i].data();
       }
     }
+    isle_host_mark("expand: work matrix ready");
     float* mail = c->ks_mail.p;
     bool spec = false;  // apply + ortho of the current step already enqueued
     int slot = 0;
@@ -1075,27 +1094,51 @@ struct Ks {
       }
       slot ^= 1;
     }
+    isle_host_mark("expand: loop done");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    isle_host_mark("expand: synchronised");
     shrink();
+    isle_host_mark("expand: shrink");
     vcols = H.r;
     return 0;
   }
 
   int truncate() {  // :138-187
+    isle_host_mark("truncate: entry");
     const size_t n = H.c - nconv;
-    HMat subH = hsub(H, nconv, nconv, H.c - 1, H.c - 1);
-    std::vector<float> eH(n), vH(n * n);
-    HIPCHK(c, c->Wf.reserve(n * n));
     const size_t keep = nev - nconv;  // only the leading `keep` eigenvectors are used below
-    ISLECHK(k_eig_small(c, subH.a.data(), (int)n, eH.data(), c->Wf.p, (int)keep));
-    HIPCHK(c, hipMemcpyAsync(vH.data(), c->Wf.p, n * keep * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    // Everything that crosses the bus here lives in the context's page-locked staging area — [subH n x n | vH n x keep | locked
+    // rows of H nconv x n | top nconv x keep], 36 MB at k = 1000: copies from freshly allocated pageable vectors blocked the host
+    // (registration with the driver) and made their release slow, with the GPU idle in between.
+    HIPCHK(c, c->pin_stage_reserve((n * n + n * keep + nconv * n + nconv * keep) * sizeof(float)));
+    float* subH = reinterpret_cast<float*>(c->pin_stage);
+    float* vH = subH + n * n;
+    float* blkH = vH + n * keep;
+    float* top = blkH + nconv * n;
+    for (size_t j = 0; j < n; ++j) memcpy(subH + j * n, &H(nconv, nconv + j), n * sizeof(float));  // H(nconv:, nconv:), square
+    isle_host_mark("truncate: subH extracted");
+    std::vector<float> eH(n);
+    HIPCHK(c, c->Wf.reserve(n * n));
+    ISLECHK(k_eig_small(c, subH, (int)n, eH.data(), c->Wf.p, (int)keep));
+    isle_host_mark("truncate: eig_small returned");
+    HIPCHK(c, hipMemcpyAsync(vH, c->Wf.p, n * keep * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     // V = [ V(:, :nconv) | V(:, nconv : ncols-blk) * vH(:, :keep) | V(:, tail blk) ]
     ISLECHK(k_gemm_nn(c, col(nconv), dim, (int)n, c->Wf.p, (int)n, (int)keep, c->Tmp.p));
+    // top = H(0:nconv, nconv:) * vH(:, :keep)  (:176-178), the coupling of the locked columns with the rotated block: nconv x n x keep
+    // multiply-adds — 0.3 G at k = 1000 with 600 pairs locked, 31 ms of host time with the GPU idle when it was a host loop
+    if (nconv > 0) {
+      HIPCHK(c, c->ks_top.reserve(nconv * n + nconv * keep));
+      for (size_t t = 0; t < n; ++t) memcpy(blkH + t * nconv, &H(0, nconv + t), nconv * sizeof(float));
+      HIPCHK(c, hipMemcpyAsync(c->ks_top.p, blkH, nconv * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      ISLECHK(k_gemm_nn(c, c->ks_top.p, nconv, (int)n, c->Wf.p, (int)n, (int)keep, c->ks_top.p + nconv * n));
+      HIPCHK(c, hipMemcpyAsync(top, c->ks_top.p + nconv * n, nconv * keep * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(c->Fbuf.p, col(vcols - blk), blk * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(col(nconv), c->Tmp.p, keep * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(col(nev), c->Fbuf.p, blk * dim * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     vcols = nev + blk;
+    isle_host_mark("truncate: device part synchronised");
     // Transform H (:169-184)
     auto vh = [&](size_t i, size_t j) { return vH[j * n + i]; };
     HMat last = hsub(H, H.r - blk, H.c - blk, H.r - 1, H.c - 1);  // blk x blk
@@ -1105,16 +1148,8 @@ struct Ks {
         const float v = vh(n - blk + t, j);
         for (size_t i = 0; i < blk; ++i) newrows(i, j) += last(i, t) * v;
       }
-    HMat top;
-    if (nconv > 0) {
-      top = HMat(nconv, keep);
-      for (size_t j = 0; j < keep; ++j)
-        for (size_t t = 0; t < n; ++t) {
-          const float v = vh(t, j);
-          for (size_t i = 0; i < nconv; ++i) top(i, j) += H(i, nconv + t) * v;
-        }
-    }
-    HMat Hn(nev + blk, nev);
+    const size_t grow_r = std::max<size_t>(ncv, nev + blk) + blk;  // what the next expand() asks for
+    HMat Hn(nev + blk, nev, grow_r, nev + (grow_r - (nev + blk)));
     for (size_t j = 0; j < nconv; ++j) {  // locked columns keep their entries (rows < nev from the old H; residual rows too)
       for (size_t i = 0; i < nev; ++i) Hn(i, j) = H(i, j);
       for (size_t i = 0; i < blk; ++i) Hn(nev + i, j) = H(nev + i, j);
@@ -1122,9 +1157,10 @@ struct Ks {
     for (size_t j = nconv; j < nev; ++j) {
       Hn(j, j) = eH[j - nconv];
       for (size_t i = 0; i < blk; ++i) Hn(nev + i, j) = newrows(i, j - nconv);
-      for (size_t i = 0; i < nconv; ++i) Hn(i, j) = top(i, j - nconv);
+      for (size_t i = 0; i < nconv; ++i) Hn(i, j) = top[(j - nconv) * nconv + i];
     }
-    H = Hn;
+    H = std::move(Hn);
+    isle_host_mark("truncate: H transformed");
     return 0;
   }
 
@@ -1197,8 +1233,11 @@ static int ks_solve(isle_ctx* c, Ks& ks, int nev, int ncv, int maxit, int blk, f
   HIPCHK(c, c->basis.reserve((size_t)ks.dim * (ncv + 2 * ks.blk)));
   HIPCHK(c, c->Fbuf.reserve((size_t)ks.dim * ks.blk));
   HIPCHK(c, c->Tmp.reserve((size_t)ks.dim * std::max<size_t>(nev, ks.blk)));
+  isle_host_mark("ks_solve: entry");
   ISLECHK(ks.init());
+  isle_host_mark("ks_solve: init done");
   ISLECHK(ks.compute());
+  isle_host_mark("ks_solve: compute done");
   int rc = 0;
   size_t nc = ks.nconv, nc_ref = ks.nconv;
   if (ks.n_restarts == (size_t)maxit) {
@@ -1234,6 +1273,7 @@ extern "C" int isle_hip_block_ks(isle_ctx* c, int nev, int ncv, int maxit, int b
   if (rc != 0 && rc != ISLE_E_NOCONV) return rc;
   ISLECHK(install_U(c, c->basis.p, nev));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  isle_host_mark("block_ks: U installed, exit");
   if (rc == ISLE_E_NOCONV) return isle_fail(c, rc, "block KS: %d restarts exhausted, %d of %d Ritz pairs converged", maxit, nc, nev);
   return 0;
 }
@@ -1334,7 +1374,9 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   if (!c || !seeds_out || !C_lowd || k < 1) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   if ((uint64_t)k > c->D_global) return isle_fail(c, ISLE_E_ARG, "k > number of documents");
+  isle_host_mark("kmeanspp: entry");
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2144
+  isle_host_mark("kmeanspp: projection enqueued");
   const uint64_t D = c->D, Dg = c->D_global;
   const int ldk = c->ldk;
   const bool multi = c->multi();
@@ -1439,16 +1481,20 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     if (inject && new_added == 0) return isle_fail(c, ISLE_E_ARG, "injected seeds contain duplicates");
     if (rounds > 100 * k) return isle_fail(c, ISLE_E_NUMERIC, "k-means++ cannot find %d distinct seeds", k);
   }
+  isle_host_mark("kmeanspp: rounds done");
   // best_centers_coords[c] = U^T b_seed[c]  (:2232-2234)
-  std::vector<float> Ch((size_t)k * ldk);
-  HIPCHK(c, hipMemcpyAsync(Ch.data(), c->Cdev.p, Ch.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  const size_t ch_bytes = (size_t)k * ldk * sizeof(float);
+  HIPCHK(c, c->pin_stage_reserve(ch_bytes));
+  const float* Ch = reinterpret_cast<const float*>(c->pin_stage);
+  HIPCHK(c, hipMemcpyAsync(c->pin_stage, c->Cdev.p, ch_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int cc = 0; cc < k; ++cc) {
     seeds_out[cc] = centers[cc];
-    memcpy(C_lowd + (size_t)cc * k, Ch.data() + (size_t)cc * ldk, (size_t)k * sizeof(float));
+    memcpy(C_lowd + (size_t)cc * k, Ch + (size_t)cc * ldk, (size_t)k * sizeof(float));
   }
   if (residual) *residual = (float)(grand - last_md);  // dist_cumul[num_docs - 1]  (:2208; App. C #9)
   if (rounds_out) *rounds_out = rounds;
+  isle_host_mark("kmeanspp: exit");
   return 0;
 }
 
@@ -1514,6 +1560,7 @@ static int fetch_sizes(isle_ctx* c, int k, std::vector<long long>& sizes) {
 extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int max_reps, int* iters_run, uint32_t* assign_out) {
   if (!c || !C_lowd || k < 1) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  isle_host_mark("lloyds_projected: entry");
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2032
   const uint64_t D = c->D;
   const int ldk = c->ldk;
@@ -1523,9 +1570,14 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   HIPCHK(c, c->counts.reserve(k));
   HIPCHK(c, c->assign.reserve(D ? D : 1));
   c->assign_valid = false;
-  std::vector<float> Ch((size_t)k * ldk, 0.f);
-  for (int cc = 0; cc < k; ++cc) memcpy(Ch.data() + (size_t)cc * ldk, C_lowd + (size_t)cc * k, (size_t)k * sizeof(float));
-  HIPCHK(c, hipMemcpy(c->Cdev.p, Ch.data(), Ch.size() * sizeof(float), hipMemcpyHostToDevice));
+  const size_t ch_bytes = (size_t)k * ldk * sizeof(float);
+  HIPCHK(c, c->pin_stage_reserve(ch_bytes));
+  float* Ch = reinterpret_cast<float*>(c->pin_stage);
+  if (ldk != k) memset(Ch, 0, ch_bytes);
+  for (int cc = 0; cc < k; ++cc) memcpy(Ch + (size_t)cc * ldk, C_lowd + (size_t)cc * k, (size_t)k * sizeof(float));
+  HIPCHK(c, hipMemcpyAsync(c->Cdev.p, Ch, ch_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is written again at the end of this call
+  isle_host_mark("lloyds_projected: centres uploaded");
   // Hamerly bounds (exact skip of documents whose closest centre provably did not change), as in the sparse Lloyd
   const bool hamerly = !getenv("ISLE_NO_HAMERLY") && c->Pt_ready;
   if (hamerly) {
@@ -1553,6 +1605,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   }
   StopRule stop(c, k);
   int it = 0;
+  isle_host_mark("lloyds_projected: loop starts");
   for (; it < max_reps; ++it) {
     ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
     if (tiles) {
@@ -1629,11 +1682,13 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
       break;
     }
   }
-  HIPCHK(c, hipMemcpyAsync(Ch.data(), c->Cdev.p, Ch.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  isle_host_mark("lloyds_projected: loop done");
+  HIPCHK(c, hipMemcpyAsync(Ch, c->Cdev.p, ch_bytes, hipMemcpyDeviceToHost, c->stream));
   if (assign_out && D) HIPCHK(c, hipMemcpyAsync(assign_out, c->assign.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (int cc = 0; cc < k; ++cc) memcpy(C_lowd + (size_t)cc * k, Ch.data() + (size_t)cc * ldk, (size_t)k * sizeof(float));
+  for (int cc = 0; cc < k; ++cc) memcpy(C_lowd + (size_t)cc * k, Ch + (size_t)cc * ldk, (size_t)k * sizeof(float));
   if (iters_run) *iters_run = it;
+  isle_host_mark("lloyds_projected: exit");
   return 0;
 }
 
@@ -1654,8 +1709,14 @@ extern "C" int isle_hip_lift_centers(isle_ctx* c, const float* in, int ld_in, in
   if (!c || !in || ncols < 1) return ISLE_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->U_k == 0 || ld_in < c->U_k) return isle_fail(c, ISLE_E_ARG, "lift: need U and ld_in >= k");
+  isle_host_mark("lift: entry");
   HIPCHK(c, c->Csum.reserve((size_t)ld_in * ncols));
-  HIPCHK(c, hipMemcpy(c->Csum.p, in, (size_t)ld_in * ncols * sizeof(float), hipMemcpyHostToDevice));
+  {
+    const size_t in_bytes = (size_t)ld_in * ncols * sizeof(float);
+    HIPCHK(c, c->pin_stage_reserve(in_bytes));
+    memcpy(c->pin_stage, in, in_bytes);
+    HIPCHK(c, hipMemcpyAsync(c->Csum.p, c->pin_stage, in_bytes, hipMemcpyHostToDevice, c->stream));  // the call synchronises before it returns
+  }
   HIPCHK(c, c->centers_cm.reserve((size_t)c->V * ncols));
   ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, c->U_k, c->Csum.p, ld_in, ncols, c->centers_cm.p));
   ISLECHK(install_centers(c, ncols));
@@ -1667,6 +1728,7 @@ extern "C" int isle_hip_lift_centers(isle_ctx* c, const float* in, int ld_in, in
   c->lift_valid = true;
   if (centers) HIPCHK(c, hipMemcpyAsync(centers, c->centers_cm.p, (size_t)c->V * ncols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  isle_host_mark("lift: exit");
   return 0;
 }
 
@@ -1675,6 +1737,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   if (!c || k < 1) return ISLE_E_ARG;
   if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
   HIPCHK(c, hipSetDevice(c->device));
+  isle_host_mark("lloyds_sparse: entry");
   const uint64_t D = c->D, V = c->V;
   const int ld = round4(k);
   if (centers_in) {
@@ -1716,6 +1779,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
                               D > 0 && k <= 384 && !(fa && !strcmp(fa, "sparse"));
   c->lift_valid = false;  // the centres move below
   int it = 0;
+  isle_host_mark("lloyds_sparse: loop starts");
   for (; it < max_reps; ++it) {
     {
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
@@ -1789,6 +1853,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       break;
     }
   }
+  isle_host_mark("lloyds_sparse: loop done");
   c->assign_valid = true;  // the partition stays resident for isle_hip_catchwords
   if (assign && D) HIPCHK(c, hipMemcpyAsync(assign, c->assign.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   if (centers_out) {
@@ -1798,6 +1863,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     HIPCHK(c, hipMemcpyAsync(centers_out, c->centers_cm.p, (size_t)V * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  isle_host_mark("lloyds_sparse: exit");
   if (iters_run) *iters_run = it;
   return 0;
 }

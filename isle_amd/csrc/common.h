@@ -66,6 +66,19 @@ struct isle_ctx {
   // hipMemcpyAsync to or from pageable memory blocks the host until the copy has run, which serialises the enqueue-ahead
   // loops (api.cpp); PIN_* are fixed regions of it
   char* pin = nullptr;
+  // growable page-locked staging for the k x k centre matrices that cross the boundary at the ends of the k-means calls (4 MB at
+  // k = 1000): hipMemcpyAsync from freshly allocated pageable memory was seen to block for 26 ms there (api.cpp, lloyds_projected)
+  char* pin_stage = nullptr;
+  size_t pin_stage_cap = 0;
+  hipError_t pin_stage_reserve(size_t bytes) {
+    if (bytes <= pin_stage_cap) return hipSuccess;
+    if (pin_stage) (void)hipHostFree(pin_stage);
+    pin_stage = nullptr;
+    pin_stage_cap = 0;
+    hipError_t e = hipHostMalloc((void**)&pin_stage, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) pin_stage_cap = bytes;
+    return e;
+  }
   static constexpr size_t PIN_MAIL = 0, PIN_MAIL_SLOT = 1u << 20, PIN_SMALL = 2u << 20, PIN_BYTES = (2u << 20) + (256u << 10);
 
   // --- communicator (null for single GPU)
@@ -223,6 +236,7 @@ struct isle_ctx {
   // one copy; the events that mark its arrival
   hipEvent_t ks_ev[2] = {nullptr, nullptr};
   DevBuf<float> ks_mail;
+  DevBuf<float> ks_top;     // truncation: the locked rows of H next to the rotated block, and their product with the Ritz rotation
   DevBuf<float> ks_gather;  // row-sharded orthogonalisation: the ranks' slices of F (world x nloc x blk)
 
   // largest dynamic-LDS size requested so far per kernel ON THIS CONTEXT'S DEVICE (hipFuncSetAttribute is per device; a
@@ -242,6 +256,9 @@ struct isle_ctx {
 int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
+// ISLE_HOST_TRACE=1: host wall time since the previous mark, to stderr (marks that follow within 0.2 ms stay silent).  Finds GPU-idle
+// stretches that are host work, which no kernel profile shows.
+void isle_host_mark(const char* what);
 
 #define HIPCHK(ctx, call)                                                                   \
   do {                                                                                      \

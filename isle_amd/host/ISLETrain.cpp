@@ -215,7 +215,9 @@ int main(int argv, char** argc) {
     log.next_time_secs("K-means seeds initialization");
 
     B_fl_CSC->run_lloyds_on_projected_space(num_topics, centers_lowd, NULL, 10);
-    FPTYPE* centers = new FPTYPE[(size_t)vocab_size * num_topics];
+    // The reference allocates centers[vocab_size * num_topics] here (src/trainer.cpp:284) and hands it through both calls below, but
+    // reads nothing of it afterwards (only closest_docs, :566-575): the lifted centres and Lloyd's result stay in device memory.
+    FPTYPE* centers = nullptr;
     B_fl_CSC->left_multiply_by_U_Spectra(centers, centers_lowd, num_topics, num_topics);
     delete[] centers_lowd;
     log.next_time_secs("Converging LLoyds k-means on B_k");

@@ -209,10 +209,13 @@ class FPSparseMatrixHip {
     fill_partition(assign.data(), closest_docs, num_centers);
     return 0.0f;  // the reference returns the (disabled) residual: always 0 (:1995-1998)
   }
+  // out == NULL: the product stays on the device as the start point of run_lloyds(k, NULL, ...)
   void left_multiply_by_U_Spectra(FPTYPE* const out, const FPTYPE* in, const doc_id_t ld_in, const doc_id_t ncols) {  // :1438-1450
     assert(ld_in >= U_cols_);
     check(isle_hip_lift_centers(ctx_, in, (int)ld_in, (int)ncols, out), "left_multiply_by_U_Spectra");
   }
+  // centers == NULL: start from the centres left_multiply_by_U_Spectra(NULL, ...) left on the device and do not copy the result back
+  // (src/trainer.cpp reads only closest_docs after this call; V x k floats are 400 MB at vocab 100k, k = 1000).
   FPTYPE run_lloyds(const doc_id_t num_centers, FPTYPE* centers, std::vector<doc_id_t>* closest_docs, const int max_reps) {  // :1690-1746
     if (closest_docs)
       for (doc_id_t c = 0; c < num_centers; ++c) assert(closest_docs[c].size() == 0);
