@@ -289,7 +289,8 @@ enum {
   ISLE_T_INFER = 16,       /* ISLEInfer: multiplicative-weights inference */
   ISLE_T_COUNT = 17
 };
-/* on: 0 = off, 1 = events around every launch, 2 = around the Gram-apply launches only (what bench.py's timed region uses). */
+/* on: 0 = off, 1 = events around every launch, 2 = around the Gram applications only (what bench.py's timed region uses): the
+ * LDS-banded form then books one event pair per application — both passes and the gap between them — under ISLE_T_GRAM_PASS1. */
 int isle_hip_timing_enable(isle_ctx* ctx, int on);
 int isle_hip_timing_reset(isle_ctx* ctx);
 /* ms[ISLE_T_COUNT], launches[ISLE_T_COUNT] */

@@ -54,7 +54,7 @@ void isle_host_mark(const char* what) {
 }
 
 TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
-  if (!c->timing || !((c->timing_mask >> fam) & 1u)) return;
+  if (fam < 0 || !c->timing || !((c->timing_mask >> fam) & 1u)) return;
   if (!c->ev_free.empty()) {
     ep = c->ev_free.back();
     c->ev_free.pop_back();
@@ -1397,7 +1397,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   std::vector<double> dice(maxdraw);
   // page-locked staging for the per-round scalars: [my 2 | tot 2 * world | local maxdraw] doubles, then drawn maxdraw u64
   double* pin_d = reinterpret_cast<double*>(c->pin + isle_ctx::PIN_SMALL);
-  if ((size_t)(2 + 2 * c->world + 2 * maxdraw) * 8 > (128u << 10)) return isle_fail(c, ISLE_E_ARG, "k-means++: staging area too small");
+  if ((size_t)(2 + 2 * c->world + 2 * maxdraw + 42) * 8 > (128u << 10)) return isle_fail(c, ISLE_E_ARG, "k-means++: staging area too small");
   double* my = pin_d;
   double* tot = pin_d + 2;
   double* local = tot + 2 * c->world;
@@ -1407,65 +1407,80 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     ISLECHK(k_kmpp_update(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p + (centers.size() - new_added) * (size_t)ldk, new_added,
                           c->min_dist.p));
     ISLECHK(k_scan_f2d(c, c->min_dist.p, D, c->cum.p));  // :2170-2172 (double, parallel; the reference's is fp32 sequential)
-    // totals (per rank) -> offsets
-    my[0] = my[1] = 0.0;
-    ISLECHK(k_pack2(c, c->cum.p + D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, c->gram.p + 200));
-    HIPCHK(c, hipMemcpyAsync(my, c->gram.p + 200, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // one copy, one round trip for both scalars
-    for (int r = 0; r < 2 * c->world; ++r) tot[r] = 0.0;
-    if (multi) {
-      double* dv = c->gram.p;
-      HIPCHK(c, hipMemcpyAsync(dv + 2 * c->world, my, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-      {
-        TimeScope ts(c, ISLE_T_COMM);
-        ISLECHK(isle_allgather(c, dv + 2 * c->world, dv, 2, ISLE_DT_F64));
-      }
-      HIPCHK(c, hipMemcpyAsync(tot, dv, 2 * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-    } else {
-      tot[0] = my[0];
-      tot[1] = my[1];
-    }
-    grand = 0.0;
-    double my_off = 0.0;
-    for (int r = 0; r < c->world; ++r) {
-      if (r == c->rank) my_off = grand;
-      grand += tot[2 * r];
-    }
-    last_md = tot[2 * (c->world - 1) + 1];
     const int s = (int)centers.size();
     int ndraw = 0;
     for (int cc = 0; cc < 1 + std::sqrt((double)(s - 5 > 0 ? s - 5 : 0)); ++cc) ndraw++;  // :2183 (upper bound on draws)
     ndraw = std::min(ndraw, maxdraw);
-    if (!inject) {
-      // all ranks draw the same dice; the owner of the interval searches its local prefix sums
-      for (int i = 0; i < ndraw; ++i) {
-        dice[i] = grand * rng.fraction();  // :2184
-        const double x = dice[i] - my_off;
-        const bool mine = (x >= 0.0 && x < my[0]) || (c->world == 1);
-        local[i] = mine ? std::min(std::max(x, 0.0), my[0]) : -1.0;
-      }
-      double* dd = c->gram.p + 64;
+    if (!multi && !inject && ndraw <= 40) {
+      // one rank: the dice are products of the total with host-drawn fractions, so the device can throw them itself — the totals, the
+      // dice and their search come back in one copy (search_frac_k), one host round trip per round
+      for (int i = 0; i < ndraw; ++i) dice[i] = rng.fraction();  // :2184
       uint64_t* od = (uint64_t*)(c->gram.p + 128);
-      if (ndraw <= 16) {
-        ISLECHK(k_search_args(c, c->cum.p, D, local, ndraw, od));  // dice as kernel arguments
-      } else {
-        HIPCHK(c, hipMemcpyAsync(dd, local, ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
-        ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
-      }
-      HIPCHK(c, hipMemcpyAsync(drawn, od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, od));
+      uint64_t* res = drawn + maxdraw;  // page-locked, 42 entries
+      HIPCHK(c, hipMemcpyAsync(res, od, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      for (int i = 0; i < ndraw; ++i) {
-        if (local[i] < 0.0 || D == 0) drawn[i] = 0;
-        else drawn[i] = std::min<uint64_t>(drawn[i], D - 1) + c->doc_offset + 1;  // +1: zero means "not mine"
-      }
+      memcpy(my, res + 40, 2 * sizeof(double));
+      grand = my[0];
+      last_md = my[1];
+      for (int i = 0; i < ndraw; ++i) drawn[i] = std::min<uint64_t>(res[i], D - 1) + c->doc_offset;
+    } else {
+      // totals (per rank) -> offsets
+      my[0] = my[1] = 0.0;
+      ISLECHK(k_pack2(c, c->cum.p + D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, c->gram.p + 200));
+      HIPCHK(c, hipMemcpyAsync(my, c->gram.p + 200, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // one copy, one round trip for both scalars
+      for (int r = 0; r < 2 * c->world; ++r) tot[r] = 0.0;
       if (multi) {
-        HIPCHK(c, hipMemcpyAsync(od, drawn, ndraw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        ISLECHK(allreduce_sum<uint64_t>(c, od, ndraw));
+        double* dv = c->gram.p;
+        HIPCHK(c, hipMemcpyAsync(dv + 2 * c->world, my, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        {
+          TimeScope ts(c, ISLE_T_COMM);
+          ISLECHK(isle_allgather(c, dv + 2 * c->world, dv, 2, ISLE_DT_F64));
+        }
+        HIPCHK(c, hipMemcpyAsync(tot, dv, 2 * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+      } else {
+        tot[0] = my[0];
+        tot[1] = my[1];
+      }
+      grand = 0.0;
+      double my_off = 0.0;
+      for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) my_off = grand;
+        grand += tot[2 * r];
+      }
+      last_md = tot[2 * (c->world - 1) + 1];
+      if (!inject) {
+        // all ranks draw the same dice; the owner of the interval searches its local prefix sums
+        for (int i = 0; i < ndraw; ++i) {
+          dice[i] = grand * rng.fraction();  // :2184
+          const double x = dice[i] - my_off;
+          const bool mine = (x >= 0.0 && x < my[0]) || (c->world == 1);
+          local[i] = mine ? std::min(std::max(x, 0.0), my[0]) : -1.0;
+        }
+        double* dd = c->gram.p + 64;
+        uint64_t* od = (uint64_t*)(c->gram.p + 128);
+        if (ndraw <= 16) {
+          ISLECHK(k_search_args(c, c->cum.p, D, local, ndraw, od));  // dice as kernel arguments
+        } else {
+          HIPCHK(c, hipMemcpyAsync(dd, local, ndraw * sizeof(double), hipMemcpyHostToDevice, c->stream));  // `local` outlives the sync below
+          ISLECHK(k_search(c, c->cum.p, D, dd, ndraw, od));
+        }
         HIPCHK(c, hipMemcpyAsync(drawn, od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < ndraw; ++i) {
+          if (local[i] < 0.0 || D == 0) drawn[i] = 0;
+          else drawn[i] = std::min<uint64_t>(drawn[i], D - 1) + c->doc_offset + 1;  // +1: zero means "not mine"
+        }
+        if (multi) {
+          HIPCHK(c, hipMemcpyAsync(od, drawn, ndraw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+          ISLECHK(allreduce_sum<uint64_t>(c, od, ndraw));
+          HIPCHK(c, hipMemcpyAsync(drawn, od, ndraw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        for (int i = 0; i < ndraw; ++i) drawn[i] = drawn[i] ? drawn[i] - 1 : 0;
       }
-      for (int i = 0; i < ndraw; ++i) drawn[i] = drawn[i] ? drawn[i] - 1 : 0;
     }
     new_added = 0;
     std::vector<uint64_t> fresh;

@@ -379,6 +379,8 @@ int k_search(isle_ctx* c, const double* cum, uint64_t n, const double* dice_dev,
 int k_search_args(isle_ctx* c, const double* cum, uint64_t n, const double* dice_host, int nd /*<= 16*/, uint64_t* out_dev);
 int k_fetch_rows(isle_ctx* c, const float* P, int ldk, const uint64_t* local_ids /*~0: not on this rank*/, int n, float* dst);
 int k_pack2(isle_ctx* c, const double* a, const float* b /*nullable*/, double* out2);
+int k_search_frac(isle_ctx* c, const double* cum, uint64_t n, const float* last /*nullable*/, const double* frac_host, int nd /*<= 40*/,
+                  uint64_t* out_dev /*42 x 8 bytes: positions, then {cum[n], last[0]} as doubles*/);
 int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
                   float* ub = nullptr, float* lb = nullptr);
 int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, int ldk, const float* C, const float* cn,

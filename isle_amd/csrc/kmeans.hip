@@ -251,6 +251,38 @@ int k_search_args(isle_ctx* c, const double* cum, uint64_t n, const double* dice
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// One launch for everything a single-rank k-means++ round needs from the device: dice[t] = total * frac[t] (the host's
+// `grand * rng.fraction()` of src/sparseMatrix.cpp:2184 — the same IEEE double product, taken where the total lives), its
+// position in the prefix sums, and the two scalars {total, last min-distance}: one copy and one round trip per round instead of two.
+struct KmFrac {
+  double f[40];
+};
+__global__ void search_frac_k(const double* __restrict__ cum, uint64_t n, const float* __restrict__ last, KmFrac frac, int nd,
+                              uint64_t* __restrict__ out /*40 positions, then the 2 scalars as doubles*/) {
+  const int t = threadIdx.x;
+  const double total = cum[n];
+  if (t == 0) {
+    double* o2 = reinterpret_cast<double*>(out + 40);
+    o2[0] = total;
+    o2[1] = last ? (double)last[0] : 0.0;
+  }
+  if (t >= nd) return;
+  const double x = fmin(fmax(total * frac.f[t], 0.0), total);
+  uint64_t lo = 0, hi = n + 1;  // first index with cum[idx] > x
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (cum[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  out[t] = lo - 1;
+}
+int k_search_frac(isle_ctx* c, const double* cum, uint64_t n, const float* last, const double* frac_host, int nd, uint64_t* out_dev) {
+  if (nd > 40) return isle_fail(c, ISLE_E_ARG, "k_search_frac: %d > 40 dice", nd);
+  KmFrac ff;
+  for (int i = 0; i < 40; ++i) ff.f[i] = i < nd ? frac_host[i] : 0.0;
+  hipLaunchKernelGGL(search_frac_k, dim3(1), dim3(64), 0, c->stream, cum, n, last, ff, nd, out_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 struct KmIds {
   uint64_t id[16];  // local row, or ~0 for "not on this rank" (destination row zeroed)
 };
