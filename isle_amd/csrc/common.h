@@ -184,6 +184,9 @@ struct isle_ctx {
   DevBuf<double> pq_part, pq_R1;  // panel QR: partial Gram matrices, first triangular factor
   DevBuf<float> pq_T;             // panel QR: T (32 x 32) and R (32 x 32)
   DevBuf<int> pq_meta;            // panel QR: rank, status, pivots
+  DevBuf<unsigned int> pq_bar;    // persistent panel QR: [grid-barrier counter | abort flag]
+  unsigned int pq_bar_count = 0;  // arrivals counted so far (the next launch's base)
+  bool pq_fused_failed = false;   // the persistent form lost residency once: five-kernel form from then on
   DevBuf<float> small;     // misc small device scratch
   DevBuf<double> jacW, jacV;  // n x n each
   DevBuf<double> jacS;        // per-pair Gram / rotation scratch
@@ -361,6 +364,7 @@ int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, 
 // dense.hip
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/, uint64_t ld = 0);
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef, uint64_t ld = 0);
+int k_panel_qr_fused_lost(isle_ctx* c);
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
 int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, int* meta_dev /*2 + 32*/, float* Rout_dev /*w*w*/);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gridbar.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -292,15 +293,31 @@ __global__ __launch_bounds__(256) void pqr_gram_k(const float* __restrict__ F, u
   }
 }
 
-// meta: [0] rank, [1] status (0 ok, 1 second Gram matrix not positive definite), [2..2+PQ_W) pivots
-__global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ part, int nparts, int wmax, int pass, double* __restrict__ R1g /*PQ_W*PQ_W*/,
-                                                     int* __restrict__ meta, float* __restrict__ T /*PQ_W*PQ_W*/, float* __restrict__ Rout) {
-  __shared__ double G[PQ_W][PQ_W + 1];
-  __shared__ double Rm[PQ_W][PQ_W + 1];  // Rm[r][col]: row r of the triangular factor
-  __shared__ double X[PQ_W][PQ_W + 1];
-  __shared__ int piv[PQ_W];
-  __shared__ int sh_rk, sh_bad;
-  __shared__ double sh_nrm;
+// meta: [0] rank, [1] status (0 ok, 1 second Gram matrix not positive definite, 2 the persistent form lost residency), [2..2+PQ_W) pivots
+struct PqFactorLds {
+  double G[PQ_W][PQ_W + 1];
+  double Rm[PQ_W][PQ_W + 1];  // Rm[r][col]: row r of the triangular factor
+  double X[PQ_W][PQ_W + 1];
+  int piv[PQ_W];
+  int sh_rk, sh_bad;
+  double sh_nrm;
+};
+// The factor step of one CholQR pass for a workgroup of 256 threads.  R1g, meta, T, Rout may live in global memory (pqr_factor_k)
+// or in the workgroup's LDS (pqr_fused_k, where every workgroup repeats the step): the arithmetic is the same either way.
+template <bool COH>  // COH: the partial sums were stored by other workgroups of this launch (agent-scope loads, see gridbar.h)
+__device__ inline double pq_ld(const double* p) {
+  return COH ? gb_ld(p) : *p;
+}
+template <bool COH>
+__device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts, int wmax, int pass, double* R1g /*PQ_W*PQ_W*/, int* meta,
+                                 float* T /*PQ_W*PQ_W*/, float* Rout) {
+  auto& G = L.G;
+  auto& Rm = L.Rm;
+  auto& X = L.X;
+  auto& piv = L.piv;
+  int& sh_rk = L.sh_rk;
+  int& sh_bad = L.sh_bad;
+  double& sh_nrm = L.sh_nrm;
   const int t = threadIdx.x;
   const int w = (pass == 1) ? wmax : meta[0];
   {
@@ -315,18 +332,18 @@ __global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ p
       for (; p + 16 <= p1; p += 16) {  // sixteen loads in flight, summed in index order
         double v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
+        for (int q = 0; q < 16; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += v[q];
       }
       for (; p + 4 <= p1; p += 4) {
         double v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = part[(size_t)(p + q) * (PQ_W * PQ_W) + u];
+        for (int q = 0; q < 4; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += v[q];
       }
-      for (; p < p1; ++p) s += part[(size_t)p * (PQ_W * PQ_W) + u];
+      for (; p < p1; ++p) s += pq_ld<COH>(&part[(size_t)p * (PQ_W * PQ_W) + u]);
       if (half) X[i][j] = s;  // X is free until the inverse below
       else G[i][j] = s;
     }
@@ -413,6 +430,11 @@ __global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ p
     if (t == 0) meta[1] = sh_bad;
   }
 }
+__global__ __launch_bounds__(256) void pqr_factor_k(const double* __restrict__ part, int nparts, int wmax, int pass, double* __restrict__ R1g /*PQ_W*PQ_W*/,
+                                                     int* __restrict__ meta, float* __restrict__ T /*PQ_W*PQ_W*/, float* __restrict__ Rout) {
+  __shared__ PqFactorLds L;
+  pq_factor<false>(L, part, nparts, wmax, pass, R1g, meta, T, Rout);
+}
 
 // Q[r, 0:rk] = F[r, 0:b] * T (b x rk col-major), rk (and b in pass 2) read from device memory.  Q may alias F.
 __global__ __launch_bounds__(256) void pqr_apply_k(const float* F, uint64_t n, int bmax, int pass, const float* __restrict__ T, const int* __restrict__ meta,
@@ -492,6 +514,131 @@ __global__ __launch_bounds__(256) void pqr_apply_gram_k(const float* F, uint64_t
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole CholQR2 of a panel in ONE launch (n <= 512 x number of CUs rows; opt-in, see k_panel_qr_kernels).  One workgroup per 512 rows keeps its rows in LDS from the first read to the last write;
+// the two all-to-all dependencies (the summed Gram matrices) are grid barriers (gridbar.h), after which EVERY workgroup repeats the
+// small factor step on the same partial sums in the same order — cheaper than a third barrier to broadcast it.  Slab partition,
+// summation orders and formulas are those of the kernels above, so both forms give the same bits (the ranks of a multi-GPU job
+// may fall back independently).  Workgroup 0 also writes the side outputs (rank, status, pivots, T, R).
+// ------------------------------------------------------------------------------------------
+struct PqFusedLds {
+  float Ft[PQ_SUB][PQ_W][PQ_ROWS + 1];
+  PqFactorLds fac;
+  double R1[PQ_W * PQ_W];
+  float T[PQ_W * PQ_W];
+  float Rout[PQ_W * PQ_W];
+  int meta[2 + PQ_W];
+};
+__device__ inline void pq_gram_slab(const float (*Ft)[PQ_ROWS + 1], int w, double acc[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = threadIdx.x + 256 * q;
+    if (o >= w * w) break;
+    const int i = o / w, j = o - i * w;
+    if (j < i) continue;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains, combined in a fixed order (as pqr_gram_k)
+#pragma unroll 4
+    for (int r = 0; r < PQ_ROWS; r += 4) {
+      s0 = fma((double)Ft[i][r], (double)Ft[j][r], s0);
+      s1 = fma((double)Ft[i][r + 1], (double)Ft[j][r + 1], s1);
+      s2 = fma((double)Ft[i][r + 2], (double)Ft[j][r + 2], s2);
+      s3 = fma((double)Ft[i][r + 3], (double)Ft[j][r + 3], s3);
+    }
+    acc[q] += (s0 + s1) + (s2 + s3);
+  }
+}
+__device__ inline void pq_store_part(double* out, int w, const double acc[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = threadIdx.x + 256 * q;
+    if (o >= w * w) break;
+    const int i = o / w, j = o - i * w;
+    if (j >= i) __hip_atomic_store(&out[j * w + i], acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by other workgroups after the barrier
+  }
+}
+__global__ __launch_bounds__(256) void pqr_fused_k(const float* __restrict__ F, uint64_t n, int w, float* __restrict__ Q,
+                                                    double* part /*2 x nparts x PQ_W*PQ_W*/, int nparts, double* __restrict__ R1g,
+                                                    int* __restrict__ meta_g, float* __restrict__ Tg, float* __restrict__ Rout_g,
+                                                    unsigned int* __restrict__ bar, unsigned int bar_base, unsigned int* __restrict__ abort) {
+  extern __shared__ __align__(16) unsigned char pqf_raw[];
+  PqFusedLds& L = *reinterpret_cast<PqFusedLds*>(pqf_raw);
+  const int t = threadIdx.x;
+  const unsigned int G = gridDim.x;
+  // ---- pass 1: this workgroup's slabs into LDS, their partial Gram matrix
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int sub = 0; sub < PQ_SUB; ++sub) {
+    const uint64_t r0 = ((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS;
+    const int rc = r0 < n ? (int)min((uint64_t)PQ_ROWS, n - r0) : 0;
+    for (int idx = t; idx < w * PQ_ROWS; idx += 256) {
+      const int j = idx / PQ_ROWS, r = idx - j * PQ_ROWS;
+      L.Ft[sub][j][r] = (r < rc) ? F[(uint64_t)j * n + r0 + r] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int sub = 0; sub < PQ_SUB; ++sub)
+    if (((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS < n) pq_gram_slab(L.Ft[sub], w, acc);
+  pq_store_part(part + (size_t)blockIdx.x * (PQ_W * PQ_W), w, acc);
+  if (!gb_barrier(bar, bar_base + G, abort)) {
+    if (blockIdx.x == 0 && t == 0) meta_g[1] = 2;
+    return;
+  }
+  pq_factor<true>(L.fac, part, nparts, w, 1, L.R1, L.meta, L.T, L.Rout);
+  __syncthreads();
+  const int rk = L.meta[0];
+  // ---- Q1 = F T in place (a thread owns one row of each slab), partial Gram matrix of Q1
+  acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+  for (int sub = 0; sub < PQ_SUB; ++sub) {
+    if (((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS >= n) break;
+    float f[PQ_W];
+#pragma unroll
+    for (int j = 0; j < PQ_W; ++j) f[j] = (j < w) ? L.Ft[sub][j][t] : 0.f;
+    for (int cc = 0; cc < rk; ++cc) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < PQ_W; ++j)
+        if (j < w) sacc = fmaf(f[j], L.T[cc * w + j], sacc);
+      L.Ft[sub][cc][t] = sacc;  // rows beyond n were zero and stay zero
+    }
+  }
+  __syncthreads();
+  for (int sub = 0; sub < PQ_SUB; ++sub)
+    if (((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS < n) pq_gram_slab(L.Ft[sub], rk, acc);
+  double* part2 = part + (size_t)nparts * (PQ_W * PQ_W);
+  pq_store_part(part2 + (size_t)blockIdx.x * (PQ_W * PQ_W), rk, acc);
+  if (blockIdx.x == 0) {  // side outputs of pass 1 (the unfused form leaves them in global memory too)
+    for (int o = t; o < PQ_W * PQ_W; o += 256) R1g[o] = L.R1[o];
+    if (t < 2 + PQ_W) meta_g[t] = L.meta[t];
+  }
+  if (!gb_barrier(bar, bar_base + 2 * G, abort)) {
+    if (blockIdx.x == 0 && t == 0) meta_g[1] = 2;
+    return;
+  }
+  // ---- pass 2
+  pq_factor<true>(L.fac, part2, nparts, w, 2, L.R1, L.meta, L.T, L.Rout);
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int o = t; o < PQ_W * PQ_W; o += 256) {
+      Tg[o] = L.T[o];
+      if (o < rk * w) Rout_g[o] = L.Rout[o];
+    }
+    if (t == 0) meta_g[1] = L.meta[1];
+  }
+  for (int sub = 0; sub < PQ_SUB; ++sub) {
+    const uint64_t r = ((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS + t;
+    if (r >= n) break;
+    float f[PQ_W];
+#pragma unroll
+    for (int j = 0; j < PQ_W; ++j) f[j] = (j < rk) ? L.Ft[sub][j][t] : 0.f;
+    for (int cc = 0; cc < rk; ++cc) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < PQ_W; ++j)
+        if (j < rk) sacc = fmaf(f[j], L.T[cc * rk + j], sacc);
+      Q[(uint64_t)cc * n + r] = sacc;
+    }
+  }
+}
+
 // F: n x w (device, destroyed).  Q: n x rank at Qdst.  R_host: room for w*w floats, rank x w as [j*rank + r].
 // Kernels only.  meta_dev (2 + PQ_W ints: rank, status, pivots) and Rout_dev (rank x w, leading dimension rank) are device
 // buffers of the caller's choice, so that a pipelined caller can fetch them, together with whatever else it needs from the
@@ -500,9 +647,28 @@ int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, in
   TimeScope ts(c, ISLE_T_QR);
   if (w < 1 || w > PQ_W) return isle_fail(c, ISLE_E_ARG, "panel QR: width %d not in [1, %d]", w, PQ_W);
   const int nparts = cdiv((long)n, PQ_ROWS * PQ_SUB);
-  HIPCHK(c, c->pq_part.reserve((size_t)nparts * PQ_W * PQ_W));
+  HIPCHK(c, c->pq_part.reserve((size_t)2 * nparts * PQ_W * PQ_W));
   HIPCHK(c, c->pq_R1.reserve(PQ_W * PQ_W));
   HIPCHK(c, c->pq_T.reserve(2 * PQ_W * PQ_W));
+  // Opt-in (ISLE_QR_FUSED=1): measured at C2 / C3 shard the one launch takes as long as the five (79 against 75 us of kernel time plus
+  // four 5-us gaps) — the chain is not launch latency but the two serial factor steps (15 us each: a 98- to 196-way sum of partial
+  // Gram matrices and a 10-step fp64 Cholesky), which every workgroup now repeats behind agent-scope loads.  It saves 240 launches per
+  // C2 step and no time, so the form without grid barriers stays the default.  Read per call: the parity test switches forms.
+  const char* fq = getenv("ISLE_QR_FUSED");
+  const bool fused_on = fq && atoi(fq) != 0;
+  if (fused_on && !c->pq_fused_failed && nparts <= c->num_cus) {  // every workgroup resident: one per CU
+    if (!c->pq_bar.p) {
+      HIPCHK(c, c->pq_bar.reserve(2));
+      HIPCHK(c, hipMemsetAsync(c->pq_bar.p, 0, 2 * sizeof(unsigned int), c->stream));
+      c->pq_bar_count = 0;
+    }
+    ISLECHK(isle_max_lds(c, (const void*)pqr_fused_k, (int)sizeof(PqFusedLds)));
+    hipLaunchKernelGGL(pqr_fused_k, dim3(nparts), dim3(256), sizeof(PqFusedLds), c->stream, F, n, w, Qdst, c->pq_part.p, nparts, c->pq_R1.p, meta_dev,
+                       c->pq_T.p, Rout_dev, c->pq_bar.p, c->pq_bar_count, c->pq_bar.p + 1);
+    HIPCHK(c, hipGetLastError());
+    c->pq_bar_count += 2u * (unsigned int)nparts;  // the counter only grows (wraps with the kernel's signed comparison)
+    return 0;
+  }
   const dim3 rows(cdiv((long)n, 256));
   hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, F, n, w, (const int*)nullptr, c->pq_part.p);
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 1, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
@@ -510,6 +676,13 @@ int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, in
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
   hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, meta_dev, Qdst);
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+// The persistent form gave up at a grid barrier (a workgroup not resident within the spin limit): nothing was written but the status.
+// Clears the abort flag and switches this context to the five-kernel form.
+int k_panel_qr_fused_lost(isle_ctx* c) {
+  c->pq_fused_failed = true;
+  if (c->pq_bar.p) HIPCHK(c, hipMemsetAsync(c->pq_bar.p + 1, 0, sizeof(unsigned int), c->stream));
   return 0;
 }
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* rank_out) {
@@ -521,6 +694,13 @@ int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_h
   HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (meta[1] == 2) {  // F is untouched: once more with the five kernels
+    ISLECHK(k_panel_qr_fused_lost(c));
+    ISLECHK(k_panel_qr_kernels(c, F, n, w, Qdst, c->pq_meta.p, Rout));
+    HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
   *rank_out = meta[0];
   return 0;
