@@ -1415,7 +1415,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     int ndraw = 0;
     for (int cc = 0; cc < 1 + std::sqrt((double)(s - 5 > 0 ? s - 5 : 0)); ++cc) ndraw++;  // :2183 (upper bound on draws)
     ndraw = std::min(ndraw, maxdraw);
-    if (!multi && !inject && ndraw <= 40) {
+    if (!multi && !inject && ndraw <= 40 && !getenv("ISLE_KMPP_HOST_DICE")) {  // the switch: for the test that holds both forms to the same seeds
       // one rank: the dice are products of the total with host-drawn fractions, so the device can throw them itself — the totals, the
       // dice and their search come back in one copy (search_frac_k), one host round trip per round
       for (int i = 0; i < ndraw; ++i) dice[i] = rng.fraction();  // :2184

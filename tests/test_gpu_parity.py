@@ -560,3 +560,17 @@ def test_persistent_panel_qr_gives_the_bits_of_the_five_kernel_form(hp, small50,
     assert r0["napplies"] == r1["napplies"] and r0["restarts"] == r1["restarts"]
     assert np.array_equal(r0["evals"].view(np.uint32), r1["evals"].view(np.uint32))
     assert np.array_equal(U0.view(np.uint32), U1.view(np.uint32))
+
+
+def test_kmeanspp_dice_thrown_on_the_device_pick_the_hosts_seeds(hp, small50, monkeypatch):
+    """One rank: a round's dice are total x (host-drawn fraction); search_frac_k forms that product on the device, where the total
+    lives, and searches it in the same launch (one host round trip per round).  The IEEE double product is the same on both sides,
+    so the seeds, the round count and the residual equal those of the two-trip form (which several ranks still use)."""
+    B, k = small50, 50
+    _kmeans_setup(hp, B, k)
+    g1 = hp.kmeans_init_on_projected_space(k, rng_seed=17)
+    monkeypatch.setenv("ISLE_KMPP_HOST_DICE", "1")
+    g0 = hp.kmeans_init_on_projected_space(k, rng_seed=17)
+    assert (g0["seeds"] == g1["seeds"]).all() and g0["rounds"] == g1["rounds"]
+    assert g0["residual"] == g1["residual"]
+    assert np.array_equal(g0["C_lowd"], g1["C_lowd"])
