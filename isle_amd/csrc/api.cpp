@@ -1792,10 +1792,14 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   HamTop* top_dev = reinterpret_cast<HamTop*>(c->Csum.p + 2 * k + 12);
   StopRule stop(c, k);
   // first assignment through the projection: only for centres that came from isle_hip_lift_centers with the current U and P, and
-  // while the dense product (2 D k^2 flop) is cheaper than the sparse one (ISLE_FIRST_ASSIGN=sparse keeps the sparse product)
+  // while the dense product is cheaper than the sparse one: always up to k = 384; beyond, by the measured rates — the D x k x k
+  // product runs at ~65 TFLOP/s, a panel pass of the sparse product takes ~2.8 ps per nonzero (C3 shard, k = 1000: 38 against
+  // 44 ms, Lloyd on B 206 -> 196 ms per step) — and while its D x k scratch stays under 8 GB (ISLE_FIRST_ASSIGN=sparse|projection forces)
   const char* fa = getenv("ISLE_FIRST_ASSIGN");
+  const double t_dense = 2.0 * (double)D * k * k / 65e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
+  const bool dense_pays = k <= 384 || (t_dense < t_sparse && (double)D * k * sizeof(float) <= 8e9);
   const bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
-                              D > 0 && k <= 384 && !(fa && !strcmp(fa, "sparse"));
+                              D > 0 && (dense_pays || (fa && !strcmp(fa, "projection"))) && !(fa && !strcmp(fa, "sparse"));
   c->lift_valid = false;  // the centres move below
   int it = 0;
   isle_host_mark("lloyds_sparse: loop starts");
