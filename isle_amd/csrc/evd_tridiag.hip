@@ -217,7 +217,7 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
 // then runs the launch chain instead.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TD_P_GSMALL = 32;   // workgroups for n <= 512 (more only add barrier latency)
-constexpr int TD_P_T = 256;
+constexpr int TD_P_T = 1024;  // 16 waves: the length-n vector phases every workgroup repeats per column are latency chains (256 threads: 35 -> 28 ms at n = 2010)
 constexpr int TD_P_MAXPT = TD_NMAX_BACK / TD_P_T;  // column entries per thread
 constexpr size_t TD_P_LDS = 160 * 1024 - 512;  // dynamic part: the kernel also has a few static words
 
