@@ -468,12 +468,14 @@ __global__ __launch_bounds__(64) void td_vectors_k(const double* __restrict__ d,
 
 // Z (n x nvec row-major, fp64) <- Q Z, Q = H_0 ... H_{n-3} (reflector j: v = A[j+1:, j], tau[j]); result as fp32 col-major n x nvec.
 // One workgroup per 8 eigenvectors, tile in LDS.
+constexpr int TD_B_T = 1024;  // threads: per reflector every thread walks (n - j) / (TD_B_T / NC) rows twice, a latency chain (256 threads: 9.6 ms per call at n = 2010)
 template <int NC>  // eigenvectors per workgroup: 8, or 4 when there are too few of them to give every CU a workgroup
-__global__ __launch_bounds__(256) void td_back_k(const double* __restrict__ A, const double* __restrict__ tau, int n, const double* __restrict__ Z, int nvec,
-                                                  float* __restrict__ out) {
+__global__ __launch_bounds__(TD_B_T) void td_back_k(const double* __restrict__ A, const double* __restrict__ tau, int n, const double* __restrict__ Z, int nvec,
+                                                    float* __restrict__ out) {
   extern __shared__ double zs[];  // n x NC
-  __shared__ double red[4][NC];
-  constexpr int RL = 256 / NC;  // row lanes
+  constexpr int NWV = TD_B_T / 64;
+  __shared__ double red[NWV][NC];
+  constexpr int RL = TD_B_T / NC;  // row lanes
   const int c0 = blockIdx.x * NC;
   const int t = threadIdx.x, c = t & (NC - 1), rl = t / NC, lane = t & 63, wave = t >> 6;
   const bool live = c0 + c < nvec;
@@ -485,12 +487,15 @@ __global__ __launch_bounds__(256) void td_back_k(const double* __restrict__ A, c
     const double* vj = A + (size_t)j * n;
     double s = 0.0;
     for (int i = j + 1 + rl; i < n; i += RL) s = fma(vj[i], zs[i * NC + c], s);
-    // the row lanes of a column inside the wave by butterflies, the four waves in LDS: a fixed order
+    // the row lanes of a column inside the wave by butterflies, the waves in LDS: a fixed order
 #pragma unroll
     for (int off = NC; off < 64; off <<= 1) s += __shfl_xor(s, off);
     if (lane < NC) red[wave][lane] = s;
     __syncthreads();
-    const double tot = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) * tj;
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; w += 4) tot += (red[w][c] + red[w + 1][c]) + (red[w + 2][c] + red[w + 3][c]);
+    tot *= tj;
     for (int i = j + 1 + rl; i < n; i += RL) zs[i * NC + c] = fma(-tot, vj[i], zs[i * NC + c]);
     __syncthreads();
   }
@@ -638,9 +643,9 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   hipLaunchKernelGGL(td_bisect_k, dim3((n + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
   hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
   if ((nvec + 7) / 8 > c->num_cus / 2)
-    hipLaunchKernelGGL(td_back_k<8>, dim3((nvec + 7) / 8), dim3(256), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
-  else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread
-    hipLaunchKernelGGL(td_back_k<4>, dim3((nvec + 3) / 4), dim3(256), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
+    hipLaunchKernelGGL(td_back_k<8>, dim3((nvec + 7) / 8), dim3(TD_B_T), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
+  else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread (two per workgroup measured no better)
+    hipLaunchKernelGGL(td_back_k<4>, dim3((nvec + 3) / 4), dim3(TD_B_T), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
   hipLaunchKernelGGL(td_check_k, dim3(nvec), dim3(256), 0, c->stream, vecs_dev, n, nvec, worst);
   HIPCHK(c, hipGetLastError());
   std::vector<double> ev(n);
