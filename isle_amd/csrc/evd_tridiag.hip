@@ -410,59 +410,111 @@ __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d,
 __global__ __launch_bounds__(64) void td_vectors_k(const double* __restrict__ d, const double* __restrict__ e, int n, const double* __restrict__ lam_desc,
                                                     int nvec, double* __restrict__ Dp /*n x nvec*/, double* __restrict__ Lf /*n x nvec*/,
                                                     double* __restrict__ Z /*n x nvec; also holds U factors during the backward sweep*/) {
-  const int v = blockIdx.x * 64 + threadIdx.x;
-  if (v >= nvec) return;
+  // One lane per eigenvector; every sweep is a recurrence over the rows.  The operands of a step (d, e, and what an earlier sweep parked
+  // in Dp / Lf / Z) do not depend on the recurrence, so they are fetched U rows ahead: fetched inside the step, each row paid a
+  // memory latency on top of its division (2.8 ms per call at n = 2010, one wave per CU on 16 CUs).
+  constexpr int U = 8;
+  const int v = min(blockIdx.x * 64 + (int)threadIdx.x, nvec - 1);  // lanes beyond the last vector repeat it (the wave max below needs them)
+  const bool live = blockIdx.x * 64 + (int)threadIdx.x < nvec;
   const double lam = lam_desc[v];
   double tnorm = 0.0;
-  for (int i = 0; i < n; ++i) tnorm = fmax(tnorm, fabs(d[i]) + (i < n - 1 ? fabs(e[i]) : 0.0) + (i > 0 ? fabs(e[i - 1]) : 0.0));
+  for (int i = threadIdx.x; i < n; i += 64) tnorm = fmax(tnorm, fabs(d[i]) + (i < n - 1 ? fabs(e[i]) : 0.0) + (i > 0 ? fabs(e[i - 1]) : 0.0));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tnorm = fmax(tnorm, __shfl_xor(tnorm, off));
+  if (!live) return;
   const double piv = fmax(2.3e-16 * tnorm, 1e-300);
   auto IDX = [&](int i) { return (size_t)i * nvec + v; };
   // forward: T - lam I = L D L^T
   double D = d[0] - lam;
   if (fabs(D) < piv) D = -piv;
   Dp[IDX(0)] = D;
-  for (int i = 0; i < n - 1; ++i) {
-    const double ei = e[i];
-    const double l = ei / D;
-    Lf[IDX(i)] = l;
-    D = (d[i + 1] - lam) - l * ei;
-    if (fabs(D) < piv) D = -piv;
-    Dp[IDX(i + 1)] = D;
+  for (int i0 = 0; i0 < n - 1; i0 += U) {
+    double ev[U], dv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u, n - 2);
+      ev[u] = e[i];
+      dv[u] = d[i + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u;
+      if (i < n - 1) {
+        const double l = ev[u] / D;
+        Lf[IDX(i)] = l;
+        D = (dv[u] - lam) - l * ev[u];
+        if (fabs(D) < piv) D = -piv;
+        Dp[IDX(i + 1)] = D;
+      }
+    }
   }
   // backward: T - lam I = U Dm U^T; gamma_i = Dp_i + Dm_i - (d_i - lam)
   double Dm = d[n - 1] - lam;
   if (fabs(Dm) < piv) Dm = -piv;
   double gbest = fabs(Dp[IDX(n - 1)] + Dm - (d[n - 1] - lam));
   int r = n - 1;
-  for (int i = n - 2; i >= 0; --i) {
-    const double ei = e[i];
-    const double u = ei / Dm;
-    Z[IDX(i)] = u;  // U factor of row i (used for z_{i+1} = -u_i z_i)
-    Dm = (d[i] - lam) - u * ei;
-    if (fabs(Dm) < piv) Dm = -piv;
-    const double g = fabs(Dp[IDX(i)] + Dm - (d[i] - lam));
-    if (g < gbest) {
-      gbest = g;
-      r = i;
+  for (int i0 = n - 2; i0 >= 0; i0 -= U) {
+    double ev[U], dv[U], pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = max(i0 - u, 0);
+      ev[u] = e[i];
+      dv[u] = d[i];
+      pv[u] = Dp[IDX(i)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 - u;
+      if (i >= 0) {
+        const double uu = ev[u] / Dm;
+        Z[IDX(i)] = uu;  // U factor of row i (used for z_{i+1} = -u_i z_i)
+        Dm = (dv[u] - lam) - uu * ev[u];
+        if (fabs(Dm) < piv) Dm = -piv;
+        const double g = fabs(pv[u] + Dm - (dv[u] - lam));
+        if (g < gbest) {
+          gbest = g;
+          r = i;
+        }
+      }
     }
   }
   // substitution from the twist
   double nrm = 1.0;
   double z = 1.0;
-  for (int i = r - 1; i >= 0; --i) {
-    z = -Lf[IDX(i)] * z;
-    Dp[IDX(i)] = z;  // Dp is free below the twist: park z there
-    nrm = fma(z, z, nrm);
+  for (int i0 = r - 1; i0 >= 0; i0 -= U) {
+    double lv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) lv[u] = Lf[IDX(max(i0 - u, 0))];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 - u;
+      if (i >= 0) {
+        z = -lv[u] * z;
+        Dp[IDX(i)] = z;  // Dp is free below the twist: park z there
+        nrm = fma(z, z, nrm);
+      }
+    }
   }
   z = 1.0;
-  for (int i = r; i < n - 1; ++i) {
-    z = -Z[IDX(i)] * z;  // reads u_i, then row i+1 of Z is written below (u_{i+1} is read in the next iteration first)
-    Lf[IDX(i + 1)] = z;  // park in Lf (free above the twist)
-    nrm = fma(z, z, nrm);
+  for (int i0 = r; i0 < n - 1; i0 += U) {
+    double uv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) uv[u] = Z[IDX(min(i0 + u, n - 2))];  // the u factors of rows i0 .. i0 + U - 1
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u;
+      if (i < n - 1) {
+        z = -uv[u] * z;
+        Lf[IDX(i + 1)] = z;  // park in Lf (free above the twist)
+        nrm = fma(z, z, nrm);
+      }
+    }
   }
   const double s = 1.0 / sqrt(nrm);
+#pragma unroll 8
   for (int i = 0; i < r; ++i) Z[IDX(i)] = Dp[IDX(i)] * s;
   Z[IDX(r)] = s;
+#pragma unroll 8
   for (int i = r + 1; i < n; ++i) Z[IDX(i)] = Lf[IDX(i)] * s;
 }
 
