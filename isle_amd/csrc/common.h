@@ -371,7 +371,7 @@ int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family = ISLE_T_ROTATE);  // col-major, lda = ldc = M
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl
 int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x n col-major*/);
-int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec);  // evd_tridiag.hip; 1 = use another solver
+int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec);  // evd_tridiag.hip; 1 = use another solver; evals_host[nvec..n) = 0
 int k_eig_small(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x nvec col-major*/, int nvec);
 int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, float* out, const float* Sub = nullptr);
 int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, const int* counts);

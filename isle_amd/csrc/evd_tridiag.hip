@@ -343,7 +343,9 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
 // Eigenvalue number idx (ascending) of the tridiagonal (d, e) by multisection on the Sturm count: one wave per eigenvalue, the
 // 64 lanes count at 64 interior points of the current interval, which shrinks 65-fold per pass (ten passes instead of
 // fifty-odd dependent bisection steps of n divisions each).  Output descending.
-__global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d, const double* __restrict__ e, int n, double* __restrict__ lam_desc) {
+// only the nvec largest eigenvalues (lam_desc[0 .. nvec)) are located; the rest of lam_desc is set to 0
+__global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d, const double* __restrict__ e, int n, int nvec,
+                                                    double* __restrict__ lam_desc) {
   extern __shared__ double sm[];  // d[n], e2[n]
   double* sd = sm;
   double* se2 = sm + n;
@@ -377,7 +379,9 @@ __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d,
   hi += 2.0 * 2.3e-16 * span * n + 1e-300;
   const double pivmin = fmax(2.3e-308 * fmax(1.0, emax), 1e-300);
   const int lane = threadIdx.x & 63;
-  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {  // wave-uniform
+  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n - nvec; idx += gridDim.x * 4)
+    if (lane == 0) lam_desc[n - 1 - idx] = 0.0;
+  for (int idx = n - nvec + blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {  // wave-uniform; idx-th smallest
     double a = lo, b = hi;  // invariant: count(a) <= idx < count(b)
     for (int it = 0; it < 16; ++it) {
       const double h = (b - a) * (1.0 / 65.0);
@@ -692,7 +696,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     break;
   }
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
-  hipLaunchKernelGGL(td_bisect_k, dim3((n + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, lam);
+  hipLaunchKernelGGL(td_bisect_k, dim3((nvec + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, nvec, lam);
   hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
   if ((nvec + 7) / 8 > c->num_cus / 2)
     hipLaunchKernelGGL(td_back_k<8>, dim3((nvec + 7) / 8), dim3(TD_B_T), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
