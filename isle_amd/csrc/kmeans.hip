@@ -257,29 +257,49 @@ int k_search_args(isle_ctx* c, const double* cum, uint64_t n, const double* dice
 struct KmFrac {
   double f[40];
 };
-__global__ void search_frac_k(const double* __restrict__ cum, uint64_t n, const float* __restrict__ last, KmFrac frac, int nd,
-                              uint64_t* __restrict__ out /*40 positions, then the 2 scalars as doubles*/) {
-  const int t = threadIdx.x;
+// One wave per die: the 64 lanes probe 64 evenly spaced positions of the bracket at once (a binary search by one lane is 21 dependent
+// loads at D = 1M, ~20 us per round; this is 4).  The answer is the same: the first index whose prefix sum exceeds the die.
+__global__ __launch_bounds__(64) void search_frac_k(const double* __restrict__ cum, uint64_t n, const float* __restrict__ last, KmFrac frac, int nd,
+                                                     uint64_t* __restrict__ out /*40 positions, then the 2 scalars as doubles*/) {
+  const int lane = threadIdx.x, t = blockIdx.x;
   const double total = cum[n];
-  if (t == 0) {
+  if (t == 0 && lane == 0) {
     double* o2 = reinterpret_cast<double*>(out + 40);
     o2[0] = total;
     o2[1] = last ? (double)last[0] : 0.0;
   }
   if (t >= nd) return;
-  const double x = fmin(fmax(total * frac.f[t], 0.0), total);
-  uint64_t lo = 0, hi = n + 1;  // first index with cum[idx] > x
+  double fr = 0.0;
+#pragma unroll
+  for (int i = 0; i < 40; ++i)  // frac lives in kernel-argument registers: a run-time index would spill it
+    if (i == t) fr = frac.f[i];
+  const double x = fmin(fmax(total * fr, 0.0), total);
+  uint64_t lo = 0, hi = n + 1;  // the first index with cum[idx] > x lies in [lo, hi]; cum[idx] > x for all idx >= hi
   while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (cum[mid] > x) hi = mid; else lo = mid + 1;
+    const uint64_t len = hi - lo;  // candidates lo .. hi - 1, and hi itself if none of them qualifies
+    const uint64_t step = (len + 63) / 64;
+    const uint64_t idx = lo + (uint64_t)lane * step;  // lanes probe lo, lo + step, ...
+    const bool in = idx < hi;
+    const bool gt = in && cum[idx] > x;
+    const unsigned long long m = __ballot(gt);
+    if (m) {  // the first probing lane that exceeds x: the answer is in (previous probe, that probe]
+      const int f = __ffsll((long long)m) - 1;
+      hi = lo + (uint64_t)f * step;
+      lo = f ? lo + (uint64_t)(f - 1) * step + 1 : lo;
+      if (f == 0) hi = lo;  // cum[lo] > x already
+    } else {  // no probe exceeds x: the answer lies behind the last probe
+      const unsigned long long inm = __ballot(in);
+      const int lastl = 63 - __builtin_clzll(inm);
+      lo = lo + (uint64_t)lastl * step + 1;
+    }
   }
-  out[t] = lo - 1;
+  if (lane == 0) out[t] = lo - 1;
 }
 int k_search_frac(isle_ctx* c, const double* cum, uint64_t n, const float* last, const double* frac_host, int nd, uint64_t* out_dev) {
   if (nd > 40) return isle_fail(c, ISLE_E_ARG, "k_search_frac: %d > 40 dice", nd);
   KmFrac ff;
   for (int i = 0; i < 40; ++i) ff.f[i] = i < nd ? frac_host[i] : 0.0;
-  hipLaunchKernelGGL(search_frac_k, dim3(1), dim3(64), 0, c->stream, cum, n, last, ff, nd, out_dev);
+  hipLaunchKernelGGL(search_frac_k, dim3(nd > 0 ? nd : 1), dim3(64), 0, c->stream, cum, n, last, ff, nd, out_dev);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
