@@ -324,7 +324,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
                                                               const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ sbase,
                                                               uint16_t* __restrict__ ids16, const uint16_t* __restrict__ cellpre /*null: unmerged*/) {
   extern __shared__ uint32_t hist[];
-  constexpr int NU = 8;  // entries in flight per lane
+  constexpr int NU = 16;  // entries in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t band = blockIdx.x;
   const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
