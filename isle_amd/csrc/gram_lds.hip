@@ -334,8 +334,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
   for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
     const uint32_t d = dperm[p];
     const int64_t iend = offs[d + 1];
-    // eight entries per lane and pass (four in round 1): the chain row id -> cursor -> word position -> slice base -> store is five dependent
-    // round trips, so independent entries are kept in flight together
+    // sixteen entries per lane and pass — a whole document per batch of its GL_SUB lanes (four in round 1, then eight: operator build 6.3 ->
+    // 5.5 -> 5.1 ms at C2): the chain row id -> cursor -> word position -> slice base -> store is five dependent round trips, so
+    // independent entries are kept in flight together
     for (int64_t i = offs[d] + sl; i < iend; i += NU * GL_SUB) {
       uint32_t w[NU], q[NU];
       bool in[NU];
