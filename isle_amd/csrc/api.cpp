@@ -1419,10 +1419,16 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
       // one rank: the dice are products of the total with host-drawn fractions, so the device can throw them itself — the totals, the
       // dice and their search come back in one copy (search_frac_k), one host round trip per round
       for (int i = 0; i < ndraw; ++i) dice[i] = rng.fraction();  // :2184
-      uint64_t* od = (uint64_t*)(c->gram.p + 128);
-      ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, od));
       uint64_t* res = drawn + maxdraw;  // page-locked, 42 entries
-      HIPCHK(c, hipMemcpyAsync(res, od, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      if (getenv("ISLE_KMPP_COPY")) {
+        uint64_t* od = (uint64_t*)(c->gram.p + 128);
+        ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, od));
+        HIPCHK(c, hipMemcpyAsync(res, od, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      } else {
+        // the kernel writes its 42 words straight into the page-locked area (host memory mapped into the device's address space): no
+        // copy kernel, and one gap less, between the search and the host's wake-up
+        ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, res));
+      }
       HIPCHK(c, hipStreamSynchronize(c->stream));
       memcpy(my, res + 40, 2 * sizeof(double));
       grand = my[0];
