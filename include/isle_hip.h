@@ -193,6 +193,10 @@ int isle_hip_eig_sym(isle_ctx* ctx, const float* S_colmajor, int n, float* evals
 int isle_hip_kmeanspp_projected(isle_ctx* ctx, int k, const uint64_t* inject_seeds, uint64_t rng_seed,
                                 uint64_t* seeds_out, float* C_lowd, float* residual, int* rounds);
 
+/* Test hook, no context needed: the first n values of the host generator that stands in for the reference's rand() calls
+ * (src/sparseMatrix.cpp:2150, include/matUtils.h:473-477) — glibc's rand() after srand(seed); seed 1 = never seeded. */
+int isle_hip_host_rand(uint64_t seed, int n, uint32_t* out);
+
 /* Optional test hook: copies the current min-distance array (local docs) after kmeanspp. */
 int isle_hip_get_min_dist(isle_ctx* ctx, float* min_dist);
 

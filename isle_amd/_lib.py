@@ -38,6 +38,7 @@ SYMBOLS = {
     "isle_hip_eig_sym": (_I, [_P, _P, _I, _P, _P]),
     "isle_hip_kmeanspp_projected": (_I, [_P, _I, _P, _U64, _P, _P, _P, _P]),
     "isle_hip_get_min_dist": (_I, [_P, _P]),
+    "isle_hip_host_rand": (_I, [_U64, _I, _P]),
     "isle_hip_lloyds_projected": (_I, [_P, _I, _P, _I, _P, _P]),
     "isle_hip_lift_centers": (_I, [_P, _P, _I, _I, _P]),
     "isle_hip_lloyds_sparse": (_I, [_P, _I, _P, _P, _P, _I, _P]),

@@ -181,16 +181,35 @@ __global__ void ks_agree_pack_k(int* meta) {
 // host RNG (rand() stand-in)
 // ------------------------------------------------------------------------------------------
 namespace {
+// glibc's rand() (the TYPE_3 additive feedback generator of random_r.c: r[i] = r[i - 31] + r[i - 3], 31 state words seeded by the
+// Lehmer generator 16807 mod 2^31 - 1, the first 310 outputs discarded, results shifted right by one).  The reference calls rand()
+// without ever calling srand(), i.e. with seed 1: rng_seed = 1 therefore draws the numbers a reference binary linked against glibc
+// draws (tests/test_abi_cpu.py checks the sequence against this machine's libc).  What still separates un-injected seeds from a
+// reference run is the prefix sum they index (fp32 and sequential there, :2170-2172; fp64 and parallel here).
 struct HostRng {
-  uint64_t s;
-  explicit HostRng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
-  uint64_t next64() {
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+  uint32_t r[34];
+  int k = 0;  // next output is the k-th
+  explicit HostRng(uint64_t seed64) {
+    uint32_t seed = (uint32_t)seed64;
+    if (seed == 0) seed = 1;
+    int32_t w[34];
+    w[0] = (int32_t)seed;
+    for (int i = 1; i < 31; ++i) {
+      int64_t v = (16807LL * w[i - 1]) % 2147483647LL;
+      if (v < 0) v += 2147483647LL;
+      w[i] = (int32_t)v;
+    }
+    for (int i = 31; i < 34; ++i) w[i] = w[i - 31];
+    for (int i = 0; i < 34; ++i) r[i] = (uint32_t)w[i];
+    for (int i = 34; i < 344; ++i) step();  // discarded
   }
-  uint32_t next31() { return (uint32_t)(next64() >> 33); }
+  uint32_t step() {  // the ring holds the last 34 words; word i lives at i % 34
+    const uint32_t v = r[(k + 34 - 31) % 34] + r[(k + 34 - 3) % 34];
+    r[k % 34] = v;
+    k = (k + 1) % 34;
+    return v;
+  }
+  uint32_t next31() { return step() >> 1; }  // rand(): 0 .. RAND_MAX = 2^31 - 1
   double fraction() {  // include/matUtils.h:473-477
     const double R1 = 2147483648.0;
     const double lo = (double)next31();
@@ -198,6 +217,14 @@ struct HostRng {
     return (lo + hi * R1) / (R1 * R1);
   }
 };
+}  // namespace
+extern "C" int isle_hip_host_rand(uint64_t seed, int n, uint32_t* out) {
+  if (!out || n < 0) return ISLE_E_ARG;
+  HostRng g(seed);
+  for (int i = 0; i < n; ++i) out[i] = g.next31();
+  return 0;
+}
+namespace {
 
 struct HMat {  // small col-major float matrix on the host (the projected matrix H)
   size_t r = 0, c = 0, ld = 0, cap_c = 0;  // r x c in use inside an ld x cap_c allocation (zero outside what was written)

@@ -69,3 +69,25 @@ def test_id_ring_registers_are_left_alone_by_the_compiler():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_id_ring.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("0 foreign uses") == 12
+
+
+def test_host_generator_is_glibc_rand():
+    """The reference draws its first seed and its k-means++ dice with rand() and never calls srand() (src/sparseMatrix.cpp:2150,
+    include/matUtils.h:473-477).  The library's host generator restates glibc's TYPE_3 generator; this holds it to the rand() of the
+    C library this process runs on — a known-answer test against the reference's actual dependency — for several seeds, seed 1
+    being the unseeded sequence (whose first value, 1804289383, every glibc user has seen)."""
+    import ctypes
+    import isle_amd
+    lib = isle_amd.load_library()
+    libc = ctypes.CDLL("libc.so.6")
+    libc.rand.restype = ctypes.c_int
+    for seed in (1, 2, 7, 12345, 2 ** 31 - 1):
+        n = 2000
+        out = np.empty(n, np.uint32)
+        assert lib.isle_hip_host_rand(ctypes.c_uint64(seed), n, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        libc.srand(ctypes.c_uint(seed))
+        ref = np.array([libc.rand() for _ in range(n)], np.uint32)
+        assert np.array_equal(out, ref), seed
+    one = np.empty(1, np.uint32)
+    lib.isle_hip_host_rand(ctypes.c_uint64(1), 1, one.ctypes.data_as(ctypes.c_void_p))
+    assert int(one[0]) == 1804289383
