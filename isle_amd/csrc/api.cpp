@@ -315,6 +315,7 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  isle_rocblas_release(c);
   for (auto& e : c->ks_ev)
     if (e) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(c->stream);

@@ -237,6 +237,7 @@ struct isle_ctx {
 
   // block Krylov-Schur, pipelined expand loop: device mailbox [rank, status, pivots | R | coefficients] of a step, fetched by
   // one copy; the events that mark its arrival
+  void* rocblas = nullptr;  // rocblas_handle, created by the first large plain GEMM (dense.hip)
   hipEvent_t ks_ev[2] = {nullptr, nullptr};
   DevBuf<float> ks_mail;
   DevBuf<float> ks_top;     // truncation: the locked rows of H next to the rotated block, and their product with the Ritz rotation
@@ -259,6 +260,7 @@ struct isle_ctx {
 int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
+void isle_rocblas_release(isle_ctx* c);
 // ISLE_HOST_TRACE=1: host wall time since the previous mark, to stderr (marks that follow within 0.2 ms stay silent).  Finds GPU-idle
 // stretches that are host work, which no kernel profile shows.
 void isle_host_mark(const char* what);

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <rocblas/rocblas.h>
+
 #include "common.h"
 #include "gridbar.h"
 
@@ -775,9 +777,34 @@ __global__ __launch_bounds__(256) void gemm_nn_k(const float* __restrict__ A, ui
     }
   }
 }
+// Large plain products (Ritz rotation, lift, the D x k x k first assignment of Lloyd on B) go to rocBLAS: its sgemm runs the same fp32
+// matrix-core arithmetic at 135 - 139 TFLOP/s on these shapes against 69 - 75 for gemm_nn_k (tools/microbench/rocblas_sgemm_probe.cpp),
+// with atomics (split-K accumulation) switched off so that the result is a function of the operands alone.  Skinny products (the dense
+// test operator's n x n x 10, the k-means++ thin products) and everything small keep gemm_nn_k; the handle is created on first use.
+static int gemm_rocblas(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C) {
+  if (!c->rocblas) {
+    rocblas_handle h = nullptr;
+    if (rocblas_create_handle(&h) != rocblas_status_success) return isle_fail(c, ISLE_E_HIP, "rocblas_create_handle failed");
+    if (rocblas_set_stream(h, c->stream) != rocblas_status_success || rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed) != rocblas_status_success) {
+      rocblas_destroy_handle(h);
+      return isle_fail(c, ISLE_E_HIP, "rocBLAS: cannot bind the stream / switch atomics off");
+    }
+    c->rocblas = h;
+  }
+  const float one = 1.f, zero = 0.f;
+  const rocblas_status st = rocblas_sgemm((rocblas_handle)c->rocblas, rocblas_operation_none, rocblas_operation_none, (int)M, N, K, &one, A, (int)M, B, ldb,
+                                          &zero, C, (int)M);
+  if (st != rocblas_status_success) return isle_fail(c, ISLE_E_HIP, "rocblas_sgemm(%llu x %d x %d) -> status %d", (unsigned long long)M, N, K, (int)st);
+  return 0;
+}
+void isle_rocblas_release(isle_ctx* c) {
+  if (c->rocblas) rocblas_destroy_handle((rocblas_handle)c->rocblas);
+  c->rocblas = nullptr;
+}
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family) {
   TimeScope ts(c, family);
   if (M == 0 || N == 0) return 0;
+  if (N >= 64 && K >= 64 && M < (1ull << 31) && (double)M * N * K >= 1e9 && !getenv("ISLE_GEMM_OWN")) return gemm_rocblas(c, A, M, K, B, ldb, N, C);
   dim3 g(cdiv(M, GM), cdiv(N, GN)), blk(256);
   hipLaunchKernelGGL(gemm_nn_k, g, blk, 0, c->stream, A, M, K, B, ldb, N, C);
   HIPCHK(c, hipGetLastError());
