@@ -391,6 +391,7 @@ int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
                   float* ub = nullptr, float* lb = nullptr);
 int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, int ldk, const float* C, const float* cn,
                          const uint32_t* active, uint32_t n, float* Pa, float* pna, uint32_t* assign, float* ub, float* lb);
+bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k);  // the full tile-bound pass goes through the library GEMM (kmeans.hip)
 int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
                         float* ub, float* tlb, int TL, const uint32_t* active, uint32_t n, const uint32_t* need, float* Pa, float* pna);
 int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* tlb, int T, int TL, const float* delta_dev,

@@ -747,11 +747,81 @@ int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, in
 // Tile bounds (pt_filter_k, spmm.hip): full assignment that also leaves, per document, an upper bound on the distance to its
 // centre and one lower bound per tile of 32 centres (row stride TL); need == null examines every tile, otherwise the n documents
 // of `active` (compacted into Pa) examine the tiles their masks name.
+// Epilogue of the full tile-bound assignment when the D x k dot products come from one plain GEMM (k_proj_assign_tiles): one thread per
+// document walks its row of the coordinate-major dot matrix (column j = centre j, so a wave reads consecutive documents of one centre)
+// and forms exactly what the PR_TILES epilogue of proj_assign_reg_k forms — per tile of 32 centres the smallest distance, its first index
+// and the runner-up; the bound of every tile; the assignment; the upper bound; the runner-up bound for the assigned centre's tile.
+__global__ __launch_bounds__(256) void proj_dots_tiles_k(const float* __restrict__ dotsT, uint32_t D, int k, const float* __restrict__ pn,
+                                                          const float* __restrict__ cn, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                          float* __restrict__ lb, int TL) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float nd = pn[d];
+  float best = 3.4e38f, second = 3.4e38f, btc = 0.f, cmax = 0.f;
+  uint32_t bidx = 0xffffffffu, btile = 0;
+  for (int c0 = 0; c0 < k; c0 += 32) {
+    float m1 = 3.4e38f, m2 = 3.4e38f, tc = 0.f;
+    uint32_t i1 = 0xffffffffu;
+    float dot[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dot[j] = dotsT[(size_t)min(c0 + j, k - 1) * D + d];  // thirty-two loads in flight
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int cc = c0 + j;
+      if (cc < k) {
+        const float cnj = cn[cc];
+        tc = fmaxf(tc, cnj);
+        const float dist = fabsf((-2.0f * dot[j] + cnj) + nd);
+        if (dist < m1) {  // ascending index: a tie keeps the earlier centre
+          m2 = m1;
+          m1 = dist;
+          i1 = (uint32_t)cc;
+        } else {
+          m2 = fminf(m2, dist);
+        }
+      }
+    }
+    const uint32_t T = (uint32_t)(c0 >> 5);
+    if (m1 < best) {
+      best = m1;
+      bidx = i1;
+      second = m2;
+      btile = T;
+      btc = tc;
+    }
+    cmax = fmaxf(cmax, tc);
+    float uu, ll;
+    hamerly_store_bounds(m1, m1, nd + tc, &uu, &ll);
+    lb[(size_t)d * TL + T] = ll;
+  }
+  assign[d] = bidx;
+  float uu, ll, l2;
+  hamerly_store_bounds(best, second, nd + btc, &uu, &l2);
+  hamerly_store_bounds(best, best, nd + cmax, &uu, &ll);
+  ub[d] = uu;
+  lb[(size_t)d * TL + btile] = l2;  // the assigned centre's tile: closest OTHER centre in it
+}
+
+bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k) {
+  const char* pf = getenv("ISLE_PROJ_FULL");
+  return c->Pt_ready && D > 0 && k >= 64 && (double)D * k * sizeof(float) <= 8e9 &&
+         ((2.0 * (double)D * k * k >= 2e10 && !(pf && !strcmp(pf, "fused"))) || (pf && !strcmp(pf, "gemm")));
+}
 int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
                         float* ub, float* tlb, int TL, const uint32_t* active, uint32_t n, const uint32_t* need, float* Pa, float* pna) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   bool done = false;
   if (!active) {
+    // The full pass is 2 D k^2 flop of plain matrix product: above ~20 GFLOP it goes through the library GEMM (135 TFLOP/s against the
+    // 69 of the fused kernel's full pass, k_gemm_nn) on the coordinate-major copy of P, followed by the epilogue above over the D x k
+    // dot products (5 GB at a C3 shard: 18 + 2 ms instead of 36).  ISLE_PROJ_FULL=gemm|fused forces a route.
+    if (k_proj_full_by_gemm(c, D, k)) {
+      HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+      ISLECHK(k_gemm_nn(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));
+      hipLaunchKernelGGL(proj_dots_tiles_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, (uint32_t)D, k, pn, cn, assign, ub, tlb, TL);
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    }
     ISLECHK(launch_proj_reg<PR_TILES>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done, nullptr, nullptr, ub, tlb, nullptr, TL));
   } else {
     if (n == 0) return 0;
