@@ -9,7 +9,7 @@ int main() {
   rocblas_create_handle(&h);
   struct S { long M, N, K; const char* what; } shapes[] = {{100000, 1000, 2010, "rotation, C3"}, {1250000, 1000, 1000, "first assignment, C3 shard"},
                                                             {50000, 200, 410, "rotation, C2"}, {1000000, 200, 200, "first assignment, C2"},
-                                                            {100000, 1000, 1000, "lift, C3"}};
+                                                            {100000, 1000, 1000, "lift, C3"}, {1250000, 33, 1000, "k-means++ round, 33 seeds, C3 shard"}, {1250000, 16, 1000, "k-means++ round, 16 seeds"}, {1000000, 15, 200, "k-means++ round, 15 seeds, C2"}};
   for (auto& s : shapes) {
     float *A, *B, *C;
     hipMalloc(&A, s.M * s.K * 4); hipMalloc(&B, s.K * s.N * 4); hipMalloc(&C, s.M * s.N * 4);
