@@ -30,6 +30,15 @@ int isle_fail(isle_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
+// May the optional D x k scratch of the GEMM routes be taken?  Always up to 8 GB; beyond (all of config 3 on one GPU: 40 GB), when it
+// is there already or the device still has 32 GB to spare after it.
+bool isle_scratch_ok(isle_ctx* c, size_t have_elems, double bytes) {
+  if (bytes <= 8e9 || (double)have_elems * sizeof(float) >= bytes) return true;
+  size_t fr = 0, tot = 0;
+  if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+  return (double)fr >= bytes + 32e9;
+}
+
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes) {
   for (auto& e : c->lds_attr)
     if (e.first == fn) {
@@ -1831,11 +1840,11 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   StopRule stop(c, k);
   // first assignment through the projection: only for centres that came from isle_hip_lift_centers with the current U and P, and
   // while the dense product is cheaper than the sparse one: always up to k = 384; beyond, by the measured rates — the D x k x k
-  // product runs at ~65 TFLOP/s, a panel pass of the sparse product takes ~2.8 ps per nonzero (C3 shard, k = 1000: 38 against
-  // 44 ms, Lloyd on B 206 -> 196 ms per step) — and while its D x k scratch stays under 8 GB (ISLE_FIRST_ASSIGN=sparse|projection forces)
+  // product runs at ~130 TFLOP/s (rocBLAS), a panel pass of the sparse product takes ~2.8 ps per nonzero (C3 shard, k = 1000: 19 against
+  // 44 ms) — and while its D x k scratch can be had (isle_scratch_ok) (ISLE_FIRST_ASSIGN=sparse|projection forces)
   const char* fa = getenv("ISLE_FIRST_ASSIGN");
-  const double t_dense = 2.0 * (double)D * k * k / 65e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
-  const bool dense_pays = k <= 384 || (t_dense < t_sparse && (double)D * k * sizeof(float) <= 8e9);
+  const double t_dense = 2.0 * (double)D * k * k / 130e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
+  const bool dense_pays = k <= 384 || (t_dense < t_sparse && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)));
   const bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
                               D > 0 && (dense_pays || (fa && !strcmp(fa, "projection"))) && !(fa && !strcmp(fa, "sparse"));
   c->lift_valid = false;  // the centres move below

@@ -260,6 +260,7 @@ struct isle_ctx {
 int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
+bool isle_scratch_ok(isle_ctx* c, size_t have_elems, double bytes);
 void isle_rocblas_release(isle_ctx* c);
 // ISLE_HOST_TRACE=1: host wall time since the previous mark, to stderr (marks that follow within 0.2 ms stay silent).  Finds GPU-idle
 // stretches that are host work, which no kernel profile shows.

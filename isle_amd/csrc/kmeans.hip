@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void proj_dots_tiles_k(const float* __restrict
 
 bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k) {
   const char* pf = getenv("ISLE_PROJ_FULL");
-  return c->Pt_ready && D > 0 && k >= 64 && (double)D * k * sizeof(float) <= 8e9 &&
+  return c->Pt_ready && D > 0 && k >= 64 && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)) &&
          ((2.0 * (double)D * k * k >= 2e10 && !(pf && !strcmp(pf, "fused"))) || (pf && !strcmp(pf, "gemm")));
 }
 int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
