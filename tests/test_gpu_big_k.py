@@ -151,6 +151,30 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         assert np.array_equal(res[mode][2], res["yinyang"][2])
 
 
+def test_full_tile_pass_by_library_gemm_equals_the_fused_kernel(hp, monkeypatch):
+    """At large k the full passes of the projected Lloyd (iteration 0, and later iterations with more than half the documents
+    active) are one library GEMM over the coordinate-major projection plus proj_dots_tiles_k; the fused matrix-core kernel
+    (ISLE_PROJ_FULL=fused) forms the same distances in another summation order.  Both routes must give the same partition, the
+    same iteration count and centres equal to rounding, here and in the sparse loop's first assignment (ISLE_FIRST_ASSIGN)."""
+    f, B, k = load_case("c3k1000")
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+    out = {}
+    for route in ("gemm", "fused"):
+        monkeypatch.setenv("ISLE_PROJ_FULL", route)
+        monkeypatch.setenv("ISLE_FIRST_ASSIGN", "projection" if route == "gemm" else "sparse")
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = hp.run_lloyds(k, fetch_centers=False)
+        out[route] = (lp, ls)
+    (lg, sg), (lf, sf) = out["gemm"], out["fused"]
+    assert lg["iters"] == lf["iters"] and sg["iters"] == sf["iters"]
+    assert (lg["assign"] == lf["assign"]).mean() >= 0.9999
+    assert (sg["assign"] == sf["assign"]).mean() >= 0.9995
+    assert np.abs(lg["C_lowd"] - lf["C_lowd"]).max() <= 1e-3 * np.abs(lf["C_lowd"]).max()
+
+
 def test_config5_edge_topics_at_k1000(hp):
     """BASELINE.json configs[4]: edge_topics = 1, max_edge_topics = 5000 at k = 1000 — catchwords, topic model and edge topics
     on the device from the fixture's partition, against the CPU restatement (src/trainer.cpp:577-654, :1116-1167)."""
