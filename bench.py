@@ -8,11 +8,12 @@ A *step* is one pass of the hot path of ISLETrainer::train() (reference src/trai
 device-resident thresholded matrix B: compute_block_ks -> kmeans_init_on_projected_space ->
 run_lloyds_on_projected_space -> left_multiply_by_U -> run_lloyds, with the reference's hyper-parameters
 (include/hyperparams.h).  Metric = docs/sec = (documents of all ranks) * steps / wall time, inputs already in
-HBM when the timed region starts.  Workload at N = 1: BASELINE.json configs[1] (vocab 50k, 1M docs,
-~100M nnz, k = 200, sample = 0).  At N > 1: BASELINE.json configs[2] — ONE corpus of vocab 100k x 10M docs x ~1B nnz,
-k = 1000, column-sharded N ways (strong scaling: rank r holds documents [r D/N, (r+1) D/N); Gram / centroid sums are
-all-reduced with RCCL inside libisle_hip.so).  `--workload c2` at N > 1 keeps the earlier weak-scaling run (1M documents of
-the C2 shape per rank).
+HBM when the timed region starts.  Workload for every N: BASELINE.json configs[2], the configuration the metric is quoted on —
+ONE corpus of vocab 100k x 10M docs x ~1B nnz, k = 1000 (ncv = 2010, include/hyperparams.h:38-40).  It fits one MI355X (~110 GB of
+288 GB), so N = 1 runs all of it on one GPU; at N > 1 it is column-sharded N ways (strong scaling: rank r holds documents
+[r D/N, (r+1) D/N); Gram / centroid sums are all-reduced with RCCL inside libisle_hip.so).  `--workload c2` runs BASELINE
+configs[1] (vocab 50k, 1M docs, ~100M nnz, k = 200; weak scaling at N > 1: 1M documents per rank); at N = 1 the default run also
+reports C2's ms_per_step as a secondary key ("secondary_c2", a short separate run after the main one, --no-secondary skips it).
 
 Inside the timed region only the Gram-apply launches are bracketed by HIP events (the `roofline` object needs their average
 duration over exactly those steps); the per-family breakdown `device_ms_per_step` comes from one more, untimed pass.
@@ -31,20 +32,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (vocab, docs per GPU, topics, generator seed)          BASELINE.json configs
+    # name: (vocab, docs, topics, generator seed)          BASELINE.json configs
     "c1": (10_000, 50_000, 50, 12345),     # configs[0] (reference's CPU-runnable case)
-    "c2": (50_000, 1_000_000, 200, 2024),  # configs[1]  <- bench default
-    "c3": (100_000, 10_000_000, 1000, 31337),      # configs[2], column-sharded over all ranks (strong scaling)  <- default at N > 1
-    "c3shard": (100_000, 1_250_000, 1000, 31337),  # one GPU's share of configs[2]
-    "c3full": (100_000, 10_000_000, 1000, 31337),  # ALL of configs[2] on one GPU (fits: ~110 GB of 288 GB)
+    "c2": (50_000, 1_000_000, 200, 2024),  # configs[1] (per rank: weak scaling at N > 1)
+    "c3": (100_000, 10_000_000, 1000, 31337),      # configs[2], column-sharded over all ranks (strong scaling)  <- bench default, every N
+    "c3shard": (100_000, 1_250_000, 1000, 31337),  # one GPU's share of configs[2] at N = 8
+    "c3full": (100_000, 10_000_000, 1000, 31337),  # = c3 (the name earlier rounds' profiles use for the one-GPU run)
     "tiny": (2_000, 5_000, 10, 0),
 }
+CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c3full": 2, "c3shard": 2}
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+BIG_NNZ = 400_000_000  # above this the CPU legs (accuracy, k-means sample, cpu_baseline) run on bounded samples
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def csc_columns(B, cols):
+    """The CSC sub-matrix of B's columns `cols` (in that order)."""
+    offs = B["offs"]
+    lens = (offs[cols + 1] - offs[cols]).astype(np.int64)
+    so = np.zeros(len(cols) + 1, np.int64)
+    np.cumsum(lens, out=so[1:])
+    idx = np.repeat(offs[cols] - so[:-1], lens) + np.arange(so[-1], dtype=np.int64)
+    return dict(vals=B["vals"][idx], rows=B["rows"][idx], offs=so)
 
 
 def main():
@@ -58,10 +71,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2 on one GPU, c3 (one 10M-document corpus sharded over the ranks) on several")
+                    help="default: c3 = BASELINE.json configs[2] (one 10M-document corpus, k = 1000; sharded over the ranks at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 run behind the default N = 1 run")
     ap.add_argument("--fetch-centers", action="store_true", help="also copy the final V x k centres to the host inside the timed step")
-    ap.add_argument("--no-upstream", action="store_true", help="skip the (untimed-region) device thresholding check")
+    ap.add_argument("--no-upstream", action="store_true", help="skip the (untimed-region) stages either side of the path")
     ap.add_argument("--blk", type=int, default=0, help="experiment: block size of the eigensolver (0 = the reference's 10)")
     args = ap.parse_args()
 
@@ -73,9 +87,9 @@ def main():
     if world > 1 and "OMP_NUM_THREADS" not in os.environ:  # the ranks share the node's cores (corpus generation, thresholding)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // max(local_world, 1)))
-    if args.workload is None:
-        args.workload = "c2" if world == 1 else "c3"
-    strong = args.workload == "c3"
+    defaulted = args.workload is None
+    if defaulted:
+        args.workload = "c3"
     import torch
     dist = None
     if world > 1:
@@ -84,10 +98,29 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)  # host control plane only
 
+    out = run(args, args.workload, rank, world, local_rank, dist, torch, args.steps, args.warmup, full=True)
+    if out is not None and defaulted and world == 1 and not args.no_secondary:
+        # BASELINE configs[1] beside the headline, so that rounds stay comparable: a short run, hot path only
+        try:
+            sec = run(args, "c2", rank, world, local_rank, dist, torch, 3, 1, full=False)
+            out["secondary_c2"] = {"workload": sec["config"]["workload"], "ms_per_step": sec["ms_per_step"], "value": sec["value"],
+                                   "unit": "docs/sec", "steps": 3, "warmup": 1, "roofline_frac": sec["roofline"]["frac"],
+                                   "avg_gram_apply_ms": sec["roofline"]["avg_launch_ms"]}
+        except Exception as e:  # the headline line must not depend on the secondary run
+            out["secondary_c2"] = {"error": repr(e)[:300]}
+    if out is not None:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+
+
+def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, full):
+    """One workload: generate, upload, warm up, time `steps` steps; with full=True also the accuracy / CPU / side-stage legs.
+    Returns the result object on rank 0, None elsewhere."""
     from isle_amd import HotPath
     from tools.synth import Corpus, effective_cpus
 
-    V, D_per, k, seed = WORKLOADS[args.workload]
+    V, D_per, k, seed = WORKLOADS[workload]
+    strong = workload in ("c3", "c3full")
     doc_base = rank * D_per
     if strong:  # one corpus, documents [doc_base, doc_base + D_per) on this rank (the generator seeds every document by its global id)
         D_total = D_per
@@ -104,7 +137,10 @@ def main():
     t0 = time.time()
     corp = Corpus(V, D_per, k, seed, doc_base=doc_base)
     nnz_A = corp.nnz_A
-    upstream = world == 1 and not args.no_upstream
+    big = nnz_A > BIG_NNZ
+    # stages either side of the path: run (outside the timed region) where the tdf text of the corpus is a sensible object — a
+    # 1 B-line file is 15 GB of text (SURVEY §8d generates C3-C5 directly as CSC)
+    upstream = full and world == 1 and not args.no_upstream and not big
     A_host = corp.A() if upstream else None
     tdf_text = corp.tdf_bytes() if upstream else None
     t_thr0 = time.time()
@@ -123,8 +159,8 @@ def main():
     tot = np.array([nnz_loc, nnz_A], np.int64)
     allreduce_np(tot)
     nnz_glob = int(tot[0])
-    log("[rank %d] corpus: V=%d docs=%d (global %d) nnz(A)=%d nnz(B)=%d  generated in %.1fs" %
-        (rank, V, D_loc, D_glob, nnz_A, nnz_loc, t_gen))
+    log("[rank %d] %s corpus: V=%d docs=%d (global %d) nnz(A)=%d nnz(B)=%d  generated in %.1fs" %
+        (rank, workload, V, D_loc, D_glob, nnz_A, nnz_loc, t_gen))
 
     # ISLE_BENCH_REHEARSE=1: all ranks on GPU 0 with the host-staged test transport (RCCL refuses two ranks on one device).
     # For checking this script's N > 1 control flow on a one-GPU box only: the line it prints is marked and is not a measurement.
@@ -170,22 +206,26 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
+        tw = time.perf_counter()
         step(-1 - i, wall=False)
+        log("[rank %d] warm-up step %d: %.2f s" % (rank, i, time.perf_counter() - tw))
     hp.timing_enable(2)  # events around the Gram-apply launches only (roofline); everything else runs as in production
     hp.timing_reset()
     fence()
     t0 = time.perf_counter()
     last = None
-    for i in range(args.steps):
+    for i in range(steps):
         last = step(i)
+        if big:
+            log("[rank %d] step %d of %d done at %.1f s" % (rank, i + 1, steps, time.perf_counter() - t0))  # a line a minute for the watchdog
     fence()
     dt = time.perf_counter() - t0
     tm_gram = hp.timing_get()
     # per-family breakdown: one more pass, untimed, with events around every launch
     hp.timing_enable(1)
     hp.timing_reset()
-    step(args.steps - 1, wall=False)  # the last timed step again (same seeds), so that the per-family device times describe a timed step
+    step(steps - 1, wall=False)  # the last timed step again (same seeds), so that the per-family device times describe a timed step
     fence()
     tm = hp.timing_get()
     hp.timing_enable(0)
@@ -194,42 +234,6 @@ def main():
         t = torch.from_numpy(dtt)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(dtt[0])
-
-    # ---------------- accuracy (outside the timed region) -----------------------------------------------------------------
-    # sigma: |lambda_i - lambda_true| <= ||A u_i - lambda_i u_i||  =>  sigma rel-err <= resid_i / (2 lambda_i), with A u_i computed by the
-    # CPU oracle's operator (an independent implementation: a self-consistent but wrong HIP operator would not pass).  One GPU: all k
-    # Ritz pairs; several ranks: 32 pairs spread over the spectrum (each rank applies its shard on the CPU, partial products are summed).
-    from oracle.oracle import OracleCsc
-    ev = last["ks"]["evals"].astype(np.float64)
-    U = hp.get_U(k)
-    t_acc0 = time.time()
-    o_full = OracleCsc(V, D_loc, B["vals"], B["rows"], B["offs"])
-    pick = np.arange(k) if world == 1 else np.unique(np.concatenate([np.arange(min(16, k)), np.linspace(0, k - 1, 16).astype(np.int64)]))
-    resid = np.empty(len(pick))
-    for j0 in range(0, len(pick), 50):
-        cols = pick[j0:j0 + 50]
-        AU = o_full.gram_apply(np.asfortranarray(U[:, cols])).astype(np.float64)
-        if dist is not None:
-            AU = np.ascontiguousarray(AU)
-            allreduce_np(AU)
-        resid[j0:j0 + len(cols)] = np.linalg.norm(AU - U[:, cols].astype(np.float64) * ev[cols], axis=0) / ev[cols]
-    ortho = float(np.abs(U[:, :min(k, 200)].astype(np.float64).T @ U[:, :min(k, 200)] - np.eye(min(k, 200))).max())
-    t_acc = time.time() - t_acc0
-    sizes = np.bincount(last["assign"], minlength=k).astype(np.int64)
-    allreduce_np(sizes)
-    # k-means quality of the timed run's partition: agreement with the planted dominant topics (majority label per cluster; the
-    # reference itself reaches 0.81-0.87 on this kind of corpus, BASELINE.md)
-    maj = np.zeros((k, k), np.int64)
-    np.add.at(maj, (last["assign"].astype(np.int64), planted.astype(np.int64) % k), 1)
-    allreduce_np(maj)
-    purity = float(maj.max(1).sum() / max(D_glob, 1))
-
-    if rank != 0:
-        return
-    if rank != 0:
-        return
-
-    steps = args.steps
     ms_per_step = 1e3 * dt / steps
     value = D_glob * steps / dt
 
@@ -240,27 +244,113 @@ def main():
     # bytes per application = 8*nnz + 8*(D+1) + 2*4*V*b   (this rank's shard)
     alg_bytes = 8.0 * nnz_loc + 8.0 * (D_loc + 1) + 8.0 * V * b
     achieved = alg_bytes / (t_apply_ms * 1e-3) / 1e9 if n_apply else 0.0
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(args.workload, {}).get("gram_apply_hbm_bytes_per_launch")
-    except Exception:
-        pass
+    form = hp.operator_form()
+    form_kernels = ("LDS-banded form: gl_pack_scale_k + gl_apply_k (pass 1) + gl_apply_k + gl_reduce_cm_k (pass 2)" if form == 1
+                    else "gather form: seg_gather_k<3,false> (pass 1) + seg_gather_k<3,true> + reduce_chunks_k (pass 2)")
+    # HBM bytes per application from the PMC counters: a committed measurement of this workload on this kernel form
+    # (profiles/pmc_traffic.json, collected by tools/pmc_probe.py under rocprofv3 --pmc in passes of their own), or null with the reason
+    traffic, traffic_note = None, None
+    pmc_key = {"c3": "c3full"}.get(workload, workload)
+    if world > 1:
+        traffic_note = "no counter pass exists for a %d-rank shard" % world
+    elif form != 1:
+        traffic_note = "profiles/pmc_traffic.json holds the LDS-banded form's counters; this run used the gather form"
+    else:
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(pmc_key, {}).get("gram_apply_hbm_bytes_per_launch")
+        except Exception:
+            pass
+        traffic_note = ("profiles/pmc_traffic.json['%s']: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py at this size"
+                        % pmc_key if traffic is not None else "no counter pass committed for workload '%s'" % pmc_key)
+    roofline = {"bound": "hbm", "kernel": "gram_apply (Z = B(B^T X), b=%d) = %s" % (b, form_kernels),
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply}
     device_ms = {f: round(v[0], 3) for f, v in tm.items() if v[1]}  # the one untimed pass with events around every launch
     scopes_per_step = int(sum(v[1] for v in tm.values()))  # event-bracketed scopes (a scope may hold several launches; rocprof has the launch count)
-    form = hp.operator_form()
-    form_kernels = ("LDS-banded form: gl_pack_scale_k + gl_apply_k<3,true,0> (pass 1) + gl_apply_k<3,true,0> + gl_reduce_cm_k (pass 2)" if form == 1
-                    else "gather form: seg_gather_k<3,false> (pass 1) + seg_gather_k<3,true> + reduce_chunks_k (pass 2)")
-    if form != 1:
-        traffic = None  # profiles/pmc_traffic.json holds the LDS-banded form's counters
+
+    sizes = np.bincount(last["assign"], minlength=k).astype(np.int64)
+    allreduce_np(sizes)
+    cfg = {
+        "workload": "synthetic planted-topic Zipf corpus (%s = BASELINE.json configs[%d]%s): vocab=%d, docs=%d (%d on rank 0), nnz(A)=%d, "
+                    "nnz(B)=%d, num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
+                    % (workload, CONFIG_INDEX.get(workload, -1), ", all of it on one GPU" if strong and world == 1 else "", V, D_glob,
+                       D_loc, int(tot[1]), nnz_glob, k),
+        "block_ks": {"nev": k, "ncv": 2 * k + 10, "blk": b, "tol": 1e-4, "maxit": 100,
+                     "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"],
+                     "converged": bool(last["ks"]["rc"] == 0 and last["ks"]["nconv"] == k)},
+        "kmeans": {"kmpp_rounds": last["kmpp_rounds"], "lloyd_projected_iters": last["lp_iters"],
+                   "lloyd_sparse_iters": last["ls_iters"], "nonempty_clusters": int((sizes > 0).sum())},
+        "parallelism": ("REHEARSAL (not a measurement): %d ranks sharing GPU 0, host-staged collectives" % world if rehearse
+                        else "docs column-sharded x%d, RCCL all-reduce" % world if world > 1 else "single GPU"),
+        "centers_fetched": bool(args.fetch_centers),
+    }
+    out = {
+        "metric": "docs/sec end-to-end ISLETrain (SVD+k-means), k=%d; top-k σ rel-err" % k,
+        "value": round(value, 1),
+        "unit": "docs/sec",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong" if strong and world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": cfg,
+        "roofline": roofline,
+        "device_ms_per_step": device_ms,
+        "timed_scopes_per_step": scopes_per_step,
+        "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
+    }
+    if not full:
+        hp.close()
+        return out if rank == 0 else None
+
+    # ---------------- accuracy (outside the timed region) -----------------------------------------------------------------
+    # sigma: |lambda_i - lambda_true| <= ||A u_i - lambda_i u_i||  =>  sigma rel-err <= resid_i / (2 lambda_i), with A u_i computed by the
+    # CPU oracle's operator (an independent implementation: a self-consistent but wrong HIP operator would not pass).  Small inputs on
+    # one GPU: all k Ritz pairs; otherwise 48 pairs spread over the spectrum (the leading 16, the trailing 8 — the last to converge —
+    # and 24 in between); several ranks: each rank applies its shard on the CPU, partial products are summed.
+    from oracle.oracle import OracleCsc
+    ev = last["ks"]["evals"].astype(np.float64)
+    U = hp.get_U(k)
+    t_acc0 = time.time()
+    o_full = OracleCsc(V, D_loc, B["vals"], B["rows"], B["offs"])
+    if world == 1 and not big:
+        pick = np.arange(k)
+    else:
+        pick = np.unique(np.concatenate([np.arange(min(16, k)), np.arange(max(k - 8, 0), k), np.linspace(0, k - 1, 24).astype(np.int64)]))
+    resid = np.empty(len(pick))
+    for j0 in range(0, len(pick), 50):
+        cols = pick[j0:j0 + 50]
+        AU = o_full.gram_apply(np.asfortranarray(U[:, cols])).astype(np.float64)
+        if dist is not None:
+            AU = np.ascontiguousarray(AU)
+            allreduce_np(AU)
+        resid[j0:j0 + len(cols)] = np.linalg.norm(AU - U[:, cols].astype(np.float64) * ev[cols], axis=0) / ev[cols]
+    ortho = float(np.abs(U[:, :min(k, 200)].astype(np.float64).T @ U[:, :min(k, 200)] - np.eye(min(k, 200))).max())
+    t_acc = time.time() - t_acc0
+    log("[rank %d] accuracy leg: %.1f s" % (rank, t_acc))
+    # k-means quality of the timed run's partition: agreement with the planted dominant topics (majority label per cluster; the
+    # reference itself reaches 0.81-0.87 on this kind of corpus, BASELINE.md)
+    maj = np.zeros((k, k), np.int64)
+    np.add.at(maj, (last["assign"].astype(np.int64), planted.astype(np.int64) % k), 1)
+    allreduce_np(maj)
+    purity = float(maj.max(1).sum() / max(D_glob, 1))
+
+    if rank != 0:
+        return None
 
     # ---------------- k-means parity on a sub-sample: the HIP path and the CPU oracle from the same U and the same injected seeds ------
     km = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import lift
-        n_sub = min(D_loc, 50_000)
-        e_sub = int(B["offs"][n_sub])
-        Bs = dict(vals=B["vals"][:e_sub], rows=B["rows"][:e_sub], offs=B["offs"][:n_sub + 1])
+        n_sub = min(D_loc, 50_000 if k <= 200 else 30_000)
+        cols = np.sort(np.random.default_rng(7).choice(D_loc, n_sub, replace=False)) if n_sub < D_loc else np.arange(D_loc)
+        Bs = csc_columns(B, cols)
         o_sub = OracleCsc(V, n_sub, Bs["vals"], Bs["rows"], Bs["offs"])
         t1 = time.time()
         ko = o_sub.kmeanspp(U, k, seed=11)
@@ -289,27 +379,40 @@ def main():
                 tot_ += float(d2.sum())
             return tot_
 
-        pl = planted[:n_sub].astype(np.int64) % k
+        pl = planted[cols].astype(np.int64) % k
 
         def purity_of(a):
             m = np.zeros((k, k), np.int64)
             np.add.at(m, (a.astype(np.int64), pl), 1)
             return float(m.max(1).sum() / n_sub)
 
-        km = {"sample": "first %d documents of B, U of the timed run, seeds drawn by the oracle's k-means++ and injected into the HIP path" % n_sub,
+        km = {"sample": "%d documents of B drawn at random (seed 7), U of the timed run, seeds drawn by the oracle's k-means++ and injected "
+                        "into the HIP path" % n_sub,
               "partition_agreement_projected": round(float((lp2["assign"] == lo["assign"]).mean()), 5),
               "partition_agreement_word_space": round(float((ls2["assign"] == so["assign"]).mean()), 5),
               "iterations_hip": [lp2["iters"], ls2["iters"]], "iterations_oracle": [lo["iters"], so["iters"]],
               "objective_hip": objective(ls2["assign"], ls2["centers"]), "objective_oracle": objective(so["assign"], so["centers"]),
               "planted_topic_agreement_hip": round(purity_of(ls2["assign"]), 4), "planted_topic_agreement_oracle": round(purity_of(so["assign"]), 4),
               "oracle_seconds": round(t_cpu_km, 1)}
+        log("k-means sample leg: oracle %.1f s" % t_cpu_km)
+        del o_sub, Bs
 
     # ---------------- CPU baseline: the oracle ("port") on a bounded sample of the same work --------------
+    # Unit costs (one Gram application, one k-means++ round, one iteration of each Lloyd loop) are measured and scaled by the counts the
+    # GPU run executed.  Small inputs: measured on the full matrix.  Big inputs (config 3): measured on the first 1/32 of the columns
+    # and scaled by 32 — every unit cost is linear in the number of documents / nonzeros at fixed V and k.
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cores = effective_cpus()
         tc0 = time.time()
-        o = o_full
+        frac = 32 if big else 1
+        if frac == 1:
+            o, n_o = o_full, D_loc
+        else:
+            n_o = D_loc // frac
+            e_o = int(B["offs"][n_o])
+            del o_full
+            o = OracleCsc(V, n_o, B["vals"][:e_o], B["rows"][:e_o], B["offs"][:n_o + 1])
         X = np.random.default_rng(0).standard_normal((V, b)).astype(np.float32)
         o.gram_apply(X)
         t1 = time.time()
@@ -336,20 +439,23 @@ def main():
         o.lloyds_sparse(cen, max_reps=2)
         t_ls_cpu = max(time.time() - t1 - ta, 1e-9)
         n_app = last["ks"]["napplies"]
-        est = (n_app * t_apply_cpu + last["kmpp_rounds"] * t_round_cpu + last["lp_iters"] * t_lp_cpu +
-               last["ls_iters"] * t_ls_cpu)
+        est = frac * (n_app * t_apply_cpu + last["kmpp_rounds"] * t_round_cpu + last["lp_iters"] * t_lp_cpu +
+                      last["ls_iters"] * t_ls_cpu)
         cpu = {
             "value": round(D_loc / est, 1), "unit": "docs/sec", "cores": cores, "kind": "port",
-            "sample": ("same-work extrapolation on the full-size matrix: measured 1 Gram-apply (%.3fs), 1 k-means++ round "
+            "sample": ("same-work extrapolation on %s: measured 1 Gram-apply (%.3fs), 1 k-means++ round "
                        "(%.3fs), 1 projected-Lloyd iteration (%.3fs), 1 sparse-Lloyd iteration (%.3fs) of oracle/ "
                        "(OpenMP, %d threads), scaled by the counts the GPU run executed (%d applies, %d rounds, %d+%d "
-                       "iterations); orthogonalisation/QR/EVD time of the CPU eigensolver NOT included (upper bound on CPU "
+                       "iterations)%s; orthogonalisation/QR/EVD time of the CPU eigensolver NOT included (upper bound on CPU "
                        "docs/s); sampling took %.0fs" %
-                       (t_apply_cpu, t_round_cpu, t_lp_cpu, t_ls_cpu, cores, n_app, last["kmpp_rounds"], last["lp_iters"],
-                        last["ls_iters"], time.time() - tc0)),
+                       ("the full-size matrix" if frac == 1 else "the first 1/%d of the columns (%d documents, all %d words, k = %d)" % (frac, n_o, V, k),
+                        t_apply_cpu, t_round_cpu, t_lp_cpu, t_ls_cpu, cores, n_app, last["kmpp_rounds"], last["lp_iters"],
+                        last["ls_iters"], "" if frac == 1 else " and by %d for the size" % frac, time.time() - tc0)),
         }
+        log("cpu_baseline leg: %.1f s" % (time.time() - tc0))
+        del o
 
-    # ---------------- upstream stage (outside the timed region): A -> B on the device, checked against the CPU B --------
+    # ---------------- stages either side of the path (outside the timed region), each checked at full size --------
     up = None
     if upstream:
         cntA, rowsA, offsA = A_host
@@ -423,49 +529,20 @@ def main():
         up = {"note": "stages either side of the hot path, run OUTSIDE the timed region at the same size, each checked at full size",
               "ingest": ingest, "threshold": up, "downstream": down, "inference": infer_stage}
         del A_host
+    elif full and world == 1 and big and not args.no_upstream:
+        up = {"note": "not run at this size: the corpus is generated directly as CSC (a 1.1 B-line tdf file is 15 GB of text, SURVEY §8d); "
+                      "`--workload c2` runs ingest, thresholding, catchwords + topic model and inference at 1 M documents, each checked at "
+                      "full size"}
+    hp.close()
 
-    out = {
-        "metric": "docs/sec end-to-end ISLETrain hot path (SVD+k-means)",
-        "value": round(value, 1),
-        "unit": "docs/sec",
-        "n_gpus": world,
-        "steps": steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True,
-        "scaling": "strong" if strong else "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": "synthetic planted-topic Zipf corpus (%s = BASELINE.json configs[%d]): vocab=%d, docs=%d (%d on rank 0), nnz(A)=%d, "
-                        "nnz(B)=%d, num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
-                        % (args.workload, {"c1": 0, "c2": 1}.get(args.workload, 2), V, D_glob, D_loc, int(tot[1]), nnz_glob, k),
-            "block_ks": {"nev": k, "ncv": 2 * k + 10, "blk": b, "tol": 1e-4, "maxit": 100,
-                         "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"],
-                         "converged": bool(last["ks"]["rc"] == 0 and last["ks"]["nconv"] == k)},
-            "kmeans": {"kmpp_rounds": last["kmpp_rounds"], "lloyd_projected_iters": last["lp_iters"],
-                       "lloyd_sparse_iters": last["ls_iters"], "nonempty_clusters": int((sizes > 0).sum())},
-            "parallelism": ("REHEARSAL (not a measurement): %d ranks sharing GPU 0, host-staged collectives" % world if rehearse
-                            else "docs column-sharded x%d, RCCL all-reduce" % world if world > 1 else "single GPU"),
-        },
-        "accuracy": {"sigma_rel_err_bound": float(np.max(resid) / 2.0), "checked_pairs": int(len(pick)), "of": k,
-                     "U_orthonormality_defect": ortho, "seconds": round(t_acc, 1),
-                     "note": "|sigma-sigma_true|/sigma <= ||A u - lambda u|| / (2 lambda); A u computed by the CPU ORACLE's operator "
-                             "(oracle/isle_oracle.cpp, fp32 OpenMP), not by the library under test",
-                     "planted_topic_agreement": round(purity, 4), "kmeans_vs_oracle": km},
-        "roofline": {"bound": "hbm", "kernel": "gram_apply (Z = B(B^T X), b=%d) = %s" % (b, form_kernels),
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply},
-        "device_ms_per_step": device_ms,
-        "timed_scopes_per_step": scopes_per_step,
-        "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
-        "cpu_baseline": cpu,
-        "other_stages": up,
-    }
-    sys.stdout.flush()
-    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    out["accuracy"] = {"sigma_rel_err_bound": float(np.max(resid) / 2.0), "checked_pairs": int(len(pick)), "of": k,
+                       "U_orthonormality_defect": ortho, "seconds": round(t_acc, 1),
+                       "note": "|sigma-sigma_true|/sigma <= ||A u - lambda u|| / (2 lambda); A u computed by the CPU ORACLE's operator "
+                               "(oracle/isle_oracle.cpp, fp32 OpenMP), not by the library under test",
+                       "planted_topic_agreement": round(purity, 4), "kmeans_vs_oracle": km}
+    out["cpu_baseline"] = cpu
+    out["other_stages"] = up
+    return out
 
 
 if __name__ == "__main__":
