@@ -324,7 +324,6 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
-  isle_rocblas_release(c);
   for (auto& e : c->ks_ev)
     if (e) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(c->stream);
@@ -1882,11 +1881,21 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       }
       uint32_t* nact = c->active.p + D;
       ISLECHK(k_yy_filter(c, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
-      ISLECHK(k_yy_scan(c, c->centers_rm.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p));
-      if (getenv("ISLE_DEBUG_HAMERLY")) {
+      const bool dbg = getenv("ISLE_DEBUG_HAMERLY") != nullptr;
+      unsigned long long* dbg_dev = nullptr;
+      if (dbg) {  // diagnostic only: group scans and gathered nonzeros of this iteration (behind the partial norms nobody reads here)
+        HIPCHK(c, c->dbg_cnt.reserve(2));
+        HIPCHK(c, hipMemsetAsync(c->dbg_cnt.p, 0, 16, c->stream));
+        dbg_dev = c->dbg_cnt.p;
+      }
+      ISLECHK(k_yy_scan(c, c->centers_rm.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, dbg_dev));
+      if (dbg) {
         uint32_t na = 0;
+        unsigned long long cnt[2] = {0, 0};
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[yinyang] iter %d active %u of %llu\n", it, na, (unsigned long long)D);
+        HIPCHK(c, hipMemcpy(cnt, dbg_dev, 16, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[yinyang] iter %d active %u of %llu; group scans %llu (%.1f per active document, of %d), gathered nonzeros %llu\n", it, na,
+                (unsigned long long)D, cnt[0], na ? (double)cnt[0] / na : 0.0, G, cnt[1]);
       }
     } else {
       uint32_t* nact = c->active.p + D;

@@ -232,12 +232,12 @@ struct isle_ctx {
   DevBuf<int> seg_desc;    // projected centroid sums: chunk descriptors (beg, end) and the centres' first chunks
   DevBuf<float> seg_part;  // one partial row per chunk
   DevBuf<uint32_t> active; // D + 1 (last = count)
+  DevBuf<unsigned long long> dbg_cnt;  // diagnostics (ISLE_DEBUG_HAMERLY)
   DevBuf<float> centers_old;  // V x ldk
   DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
 
   // block Krylov-Schur, pipelined expand loop: device mailbox [rank, status, pivots | R | coefficients] of a step, fetched by
   // one copy; the events that mark its arrival
-  void* rocblas = nullptr;  // rocblas_handle, created by the first large plain GEMM (dense.hip)
   hipEvent_t ks_ev[2] = {nullptr, nullptr};
   DevBuf<float> ks_mail;
   DevBuf<float> ks_top;     // truncation: the locked rows of H next to the rotated block, and their product with the Ritz rotation
@@ -261,7 +261,6 @@ int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
 bool isle_scratch_ok(isle_ctx* c, size_t have_elems, double bytes);
-void isle_rocblas_release(isle_ctx* c);
 // ISLE_HOST_TRACE=1: host wall time since the previous mark, to stderr (marks that follow within 0.2 ms stay silent).  Finds GPU-idle
 // stretches that are host work, which no kernel profile shows.
 void isle_host_mark(const char* what);
@@ -321,7 +320,7 @@ int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const floa
 int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev, uint32_t* active,
                 uint32_t* nactive);
 int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
-              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb);
+              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr);
 struct HamTop {  // largest and second largest centre movement of an iteration (Hamerly's bound update), device resident
   uint32_t amax;
   float d1, d2, pad;

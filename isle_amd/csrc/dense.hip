@@ -10,7 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include <rocblas/rocblas.h>
+#include "gemm_f32.h"
 
 #include "common.h"
 #include "gridbar.h"
@@ -725,89 +725,36 @@ int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed) {
 }
 
 // ------------------------------------------------------------------------------------------
-// C (M x N) = A (M x K, lda = M) * B (K x N, ldb), col-major, exact f32 on the matrix cores.
-// Tile 128 (M) x 64 (N) x 16 (K); wave w owns rows [32w, 32w+32) x all 64 columns (2 MFMA tiles).
-// The MFMA is issued "transposed" (its row index = n, its column index = m) so that a lane owns one
-// row m of C and the col-major stores of a wave are 128-B contiguous.
+// C (M x N) = A (M x K, lda = M) * B (K x N, ldb), col-major, exact f32 on the matrix cores: gemm_f32.h (v_mfma_f32_32x32x2_f32,
+// 16-byte LDS operand units, two-stage LDS ring, XCD-aware tile order).  Every plain product of the path goes through it — the Ritz
+// rotation, the lift, the D x k x k products of the projected / first word-space assignment, the thin k-means++ products, the dense
+// test operator.  The tile shape is a function of the problem's shape alone (so the result is a function of the operands alone):
+//   N <= 32: 256 x 32, N <= 64: 256 x 64 (thin products);  >= 1024 tiles of 256 x 256: that shape with 16 waves;
+//   >= 512 tiles of 256 x 128: 8 waves;  else 128 x 128 with 4 waves.
+// tools/microbench/gemm_probe.hip (random operands, one MI355X): 123 TFLOP/s at 1.25 M x 1000 x 1000, 105 - 109 at 100 000 x 1000 x 2000,
+// 97 - 101 at 100 000 x 1000 x 1000, 44 at 1.25 M x 33 x 1000; rocBLAS sgemm on the same operands 121 / 116 / 105 / 33.
 // ------------------------------------------------------------------------------------------
-constexpr int GM = 128, GN = 64, GK = 16;
-__global__ __launch_bounds__(256) void gemm_nn_k(const float* __restrict__ A, uint64_t M, int K, const float* __restrict__ B, int ldb,
-                                                  int N, float* __restrict__ C) {
-  __shared__ float As[GK][GM];
-  __shared__ float Bs[GK][GN + 1];
-  const uint64_t m0 = (uint64_t)blockIdx.x * GM;
-  const int n0 = blockIdx.y * GN;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  floatx16 acc0 = {0}, acc1 = {0};
-  for (int k0 = 0; k0 < K; k0 += GK) {
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < (GK * GM) / 256; ++u) {
-      const int idx = threadIdx.x + 256 * u;
-      const int kk = idx / GM, mm = idx - kk * GM;
-      const uint64_t gm = m0 + mm;
-      const float va = A[(uint64_t)min(k0 + kk, K - 1) * M + min(gm, M - 1)];  // clamped + masked: loads stay unconditional
-      As[kk][mm] = va * ((gm < M && k0 + kk < K) ? 1.f : 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < (GK * GN) / 256; ++u) {
-      const int idx = threadIdx.x + 256 * u;
-      const int kk = idx % GK, nn = idx / GK;
-      const float vb = B[(size_t)min(n0 + nn, N - 1) * ldb + min(k0 + kk, K - 1)];
-      Bs[kk][nn] = vb * ((n0 + nn < N && k0 + kk < K) ? 1.f : 0.f);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < GK; kk += 2) {
-      const float bm = As[kk + h][32 * wave + l31];
-      const float a0 = Bs[kk + h][l31];
-      const float a1 = Bs[kk + h][32 + l31];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bm, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bm, acc1, 0, 0, 0);
-    }
-  }
-  const uint64_t gm = m0 + 32 * wave + l31;
-  if (gm < M) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int nn = (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (n0 + nn < N) C[(uint64_t)(n0 + nn) * M + gm] = acc0[r];
-      if (n0 + 32 + nn < N) C[(uint64_t)(n0 + 32 + nn) * M + gm] = acc1[r];
-    }
-  }
+using GemmHuge = isle_gemm::Cfg<2, 2, 4, 4, 16, 4>;   // 256 x 256 x 16, 1024 threads
+using GemmBig = isle_gemm::Cfg<2, 2, 4, 2, 16, 2>;    // 256 x 128 x 16, 512 threads
+using GemmSmall = isle_gemm::Cfg<2, 2, 2, 2, 16, 2>;  // 128 x 128 x 16, 256 threads
+using GemmThin64 = isle_gemm::Cfg<2, 2, 4, 1, 16, 2>;  // 256 x 64 x 16, 256 threads
+using GemmThin32 = isle_gemm::Cfg<2, 1, 4, 1, 16, 2>;  // 256 x 32 x 16, 256 threads
+
+template <class Epi>
+static hipError_t gemm_dispatch(hipStream_t st, const float* A, uint64_t M, int K, const float* B, int ldb, int N, Epi epi) {
+  const uint64_t mb256 = (M + 255) / 256;
+  if (N <= 32) return isle_gemm::launch<GemmThin32>(st, A, M, K, B, ldb, N, epi);
+  if (N <= 64) return isle_gemm::launch<GemmThin64>(st, A, M, K, B, ldb, N, epi);
+  if (mb256 * (uint64_t)((N + 255) / 256) >= 1024) return isle_gemm::launch<GemmHuge>(st, A, M, K, B, ldb, N, epi);
+  if (mb256 * (uint64_t)((N + 127) / 128) >= 512) return isle_gemm::launch<GemmBig>(st, A, M, K, B, ldb, N, epi);
+  return isle_gemm::launch<GemmSmall>(st, A, M, K, B, ldb, N, epi);
 }
-// Large plain products (Ritz rotation, lift, the D x k x k first assignment of Lloyd on B) go to rocBLAS: its sgemm runs the same fp32
-// matrix-core arithmetic at 135 - 139 TFLOP/s on these shapes against 69 - 75 for gemm_nn_k (tools/microbench/rocblas_sgemm_probe.cpp),
-// with atomics (split-K accumulation) switched off so that the result is a function of the operands alone.  Skinny products (the dense
-// test operator's n x n x 10, the k-means++ thin products) and everything small keep gemm_nn_k; the handle is created on first use.
-static int gemm_rocblas(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C) {
-  if (!c->rocblas) {
-    rocblas_handle h = nullptr;
-    if (rocblas_create_handle(&h) != rocblas_status_success) return isle_fail(c, ISLE_E_HIP, "rocblas_create_handle failed");
-    if (rocblas_set_stream(h, c->stream) != rocblas_status_success || rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed) != rocblas_status_success) {
-      rocblas_destroy_handle(h);
-      return isle_fail(c, ISLE_E_HIP, "rocBLAS: cannot bind the stream / switch atomics off");
-    }
-    c->rocblas = h;
-  }
-  const float one = 1.f, zero = 0.f;
-  const rocblas_status st = rocblas_sgemm((rocblas_handle)c->rocblas, rocblas_operation_none, rocblas_operation_none, (int)M, N, K, &one, A, (int)M, B, ldb,
-                                          &zero, C, (int)M);
-  if (st != rocblas_status_success) return isle_fail(c, ISLE_E_HIP, "rocblas_sgemm(%llu x %d x %d) -> status %d", (unsigned long long)M, N, K, (int)st);
-  return 0;
-}
-void isle_rocblas_release(isle_ctx* c) {
-  if (c->rocblas) rocblas_destroy_handle((rocblas_handle)c->rocblas);
-  c->rocblas = nullptr;
-}
+
 int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family) {
   TimeScope ts(c, family);
   if (M == 0 || N == 0) return 0;
-  if (N >= 64 && K >= 64 && M < (1ull << 31) && (double)M * N * K >= 1e9 && !getenv("ISLE_GEMM_OWN")) return gemm_rocblas(c, A, M, K, B, ldb, N, C);
-  dim3 g(cdiv(M, GM), cdiv(N, GN)), blk(256);
-  hipLaunchKernelGGL(gemm_nn_k, g, blk, 0, c->stream, A, M, K, B, ldb, N, C);
-  HIPCHK(c, hipGetLastError());
+  if (M >= (1ull << 32) || (uint64_t)N * (uint64_t)ldb >= (1ull << 32)) return isle_fail(c, ISLE_E_ARG, "gemm: operand too large for 32-bit row / column offsets");
+  HIPCHK(c, gemm_dispatch(c->stream, A, M, K, B, ldb, N, isle_gemm::StoreC{C, M}));
   return 0;
 }
 

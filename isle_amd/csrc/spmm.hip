@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
                                                   const float* __restrict__ C /*V x ld row-major*/, int ld, int k, int G, const float* __restrict__ cn,
                                                   const float* __restrict__ dn, const float* __restrict__ cn_max_p, const uint32_t* __restrict__ active,
                                                   const uint32_t* __restrict__ nactive, uint32_t* __restrict__ assign, float* __restrict__ ub,
-                                                  float* __restrict__ glb) {
+                                                  float* __restrict__ glb, unsigned long long* __restrict__ dbg /*nullable: [0] group scans, [1] their nonzeros*/) {
   const int lane = threadIdx.x & 63;
   uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   slot = __builtin_amdgcn_readfirstlane(slot);
@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
     }
   };
   float dist[4];
+  int nscan = 1;
   scan_group(ga, dist);                                   // tighten: exact distance to the assigned centre (and its group)
   absorb(ga, yy_group_top2(dist, YY_GROUP * ga + 4 * q, k));
   for (int g = 0; g < G; ++g) {
@@ -1043,9 +1044,14 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
     const float uhi = u + fminf(sE, E / fmaxf(u, 1e-30f));
     const float lg = gl[g];                               // already lowered by this update's movement (yy_filter_k)
     if (lg <= uhi) {                                      // wave-uniform
+      ++nscan;
       scan_group(g, dist);
       absorb(g, yy_group_top2(dist, YY_GROUP * g + 4 * q, k));
     }
+  }
+  if (dbg && lane == 0) {
+    atomicAdd(dbg, (unsigned long long)nscan);
+    atomicAdd(dbg + 1, (unsigned long long)nscan * (unsigned long long)len);
   }
   if (lane == 0) {
     const float u = sqrtf(best);
@@ -1070,12 +1076,12 @@ int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int 
   return 0;
 }
 int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
-              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb) {
+              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
   hipLaunchKernelGGL(yy_scan_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, Crm, ld, k, G, cn, dn, cn_max, active,
-                     nactive, assign, ub, glb);
+                     nactive, assign, ub, glb, dbg);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

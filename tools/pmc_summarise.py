@@ -13,7 +13,7 @@ with open(path, newline="") as f:
     for r in csv.DictReader(f):
         if want and r.get("Counter_Name") != want:
             continue
-        name = r["Kernel_Name"].split("(")[0][:90]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
         key = (name, r.get("Counter_Name"))
         acc[key][1] += float(r["Counter_Value"])
         disp[key].add(r["Dispatch_Id"])
