@@ -54,7 +54,8 @@ class IsleHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libisle_hip.so")
+    # ISLE_HIP_LIB: developer override for A/B runs of differently compiled builds of the same sources (tools/*_probe.py)
+    return os.environ.get("ISLE_HIP_LIB") or os.path.join(_HERE, "libisle_hip.so")
 
 
 def load_library():

@@ -48,9 +48,10 @@ struct GlDesc {  // one workgroup: 16 waves wave0 + i*wstride (i < nw), source b
 };
 struct GlSide {
   uint32_t n_out = 0, n_src = 0, NB = 0, nslice = 0, nwv = 0, ndesc = 0;
-  DevBuf<uint32_t> slice_of;  // nwv x 4: slice (64 consecutive output positions) of (wave, group), 0xffffffff = none
+  int G = 4;                  // groups of a wave = output items per lane (4 ... 8)
+  DevBuf<uint32_t> slice_of;  // nwv x G: slice (64 consecutive output positions) of (wave, group), 0xffffffff = none
   DevBuf<int64_t> roff;       // nwv x NB + 1: first super-round of (wave, band)
-  DevBuf<uint16_t> cnt;       // nwv x NB x 4: super-rounds (4 nonzeros per lane) of (wave, band, group)
+  DevBuf<uint16_t> cnt;       // nwv x NB x 8: super-rounds (4 nonzeros per lane) of (wave, band, group), zero beyond G
   DevBuf<uint2> ids;          // super-rounds x 64 lanes: four u16 band-local source ids per lane (+ prefetch slack)
   DevBuf<GlDesc> desc;
   int64_t total_sr = 0;
@@ -156,8 +157,6 @@ struct isle_ctx {
   DevBuf<uint32_t> gl_val_a, gl_val_b;
   DevBuf<uint32_t> gl_bst;   // D x (NB1 + 1): first entry of each word band inside a document's column
   DevBuf<uint16_t> gl_cellcnt;   // V x NB2: entries of (word, document band)
-  DevBuf<uint16_t> gl_cellpre;   // V x NB2 (merged streams): entries of the lane's earlier items in the merged group | item tag << 14
-  int gl_merge = 0;              // stream form of both passes: 0 one item per group, 1 four items merged (item changes on super-round boundaries), 2 merged entry by entry
   DevBuf<uint32_t> gl_srsum, gl_sbase;
   DevBuf<uint32_t> gl_biglist;   // [count | (wave, band, group) triples whose pass-2 cells are too long for the register sort]
   DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)

@@ -13,8 +13,9 @@
 // (0.24 ms for a 99 M-nonzero pass against 0.75 ms for the gather kernel).
 //
 // Geometry.  Output items (documents in pass 1, words in pass 2) are ordered by decreasing nonzero count and cut into
-// slices of 64 consecutive positions; a wave owns GL_G = 4 slices (one output item per lane and group), a workgroup is
-// 16 waves.  Per (wave, source band, group) the stream holds cnt super-rounds = ceil(max lane count / 4); padding ids
+// slices of 64 consecutive positions; a wave owns G slices (one output item per lane and group; G = 4 ... 8 per side, chosen by the
+// build so that the workgroups fill whole rounds of the CUs: every workgroup stages every band it walks, so fewer, fatter workgroups
+// stage less), a workgroup is 16 waves.  Per (wave, source band, group) the stream holds cnt super-rounds = ceil(max lane count / 4); padding ids
 // point at a zero row kept behind the band in LDS.  Pass 1: a workgroup walks all word bands for its 4096 documents;
 // slices are dealt to waves in serpentine order over four quantile ranges so that all waves carry the same load.
 // Pass 2: a word block (64 consecutive slices) is split over document-band chunks in proportion to its work; chunk
@@ -40,7 +41,7 @@ namespace {
 
 constexpr int GL_WAVES = 16;
 constexpr int GL_THREADS = GL_WAVES * 64;
-constexpr int GL_G = 4;
+constexpr int GL_GMAX = 8;  // groups (output items per lane) of a wave: 4 ... 8, GlSide::G; count records are GL_GMAX wide
 constexpr uint32_t GL_RB = 3412;  // source rows per band: (3412 + 1 zero row) * 48 B = 163 824 B <= 160 KiB
 constexpr uint32_t GL_LDS = 163840;  // all of it: the last 1-KiB DMA piece of a band ends 16 bytes behind the padding row
 constexpr int GL_PF = 4;  // super-rounds in flight per wave (4 x 512 B)
@@ -109,24 +110,18 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
-// cnt[(wv * NB + band) * 4 + g] = super-rounds of (wave, band, group); srsum[wv * NB + band] = their sum.
-// One workgroup of 4 waves per wave wv (wave g of the workgroup = group g).  PASS 1: lane count = bst differences;
+// cnt[(wv * NB + band) * GL_GMAX + g] = super-rounds of (wave, band, group); srsum[wv * NB + band] = their sum.
+// One workgroup of G waves per wave wv (wave g of the workgroup = group g).  PASS 1: lane count = bst differences;
 // PASS 2: lane count = size of cell (word wperm[q], band).
-// Merged streams (merge = 1, 2): the four items of a lane form ONE stream per band (item 0's entries, then item 1's, ...), so
-// the wave pays the maximum over lanes of the SUM of four counts instead of the sum of four maxima; group 0 carries all the
-// super-rounds, groups 1-3 none.  merge = 1 starts every item on a super-round boundary (counts rounded up to 4), merge = 2
-// packs entry by entry.  PASS 2 also stores where an item's entries start inside the lane's stream (cellpre, with the item's
-// tag), for the placement by cursors in gl_hist_fill_k.
 template <int PASS>
-__global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ slice_of, uint32_t n_out, uint32_t NB,
-                                                 const uint32_t* __restrict__ bst, const uint16_t* __restrict__ cellcnt,
-                                                 const uint32_t* __restrict__ wperm, uint16_t* __restrict__ cnt, uint32_t* __restrict__ srsum,
-                                                 int* __restrict__ overflow, int merge, uint16_t* __restrict__ cellpre) {
-  __shared__ uint32_t sh[4];
-  __shared__ uint32_t shn[4][64];
+__global__ __launch_bounds__(64 * GL_GMAX) void gl_cnt_k(const uint32_t* __restrict__ slice_of, int G, uint32_t n_out, uint32_t NB,
+                                                          const uint32_t* __restrict__ bst, const uint16_t* __restrict__ cellcnt,
+                                                          const uint32_t* __restrict__ wperm, uint16_t* __restrict__ cnt, uint32_t* __restrict__ srsum,
+                                                          int* __restrict__ overflow) {
+  __shared__ uint32_t sh[GL_GMAX];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t wv = blockIdx.x;
-  const uint32_t sl = slice_of[wv * 4 + g];
+  const uint32_t sl = slice_of[wv * G + g];
   const uint64_t pos = (uint64_t)sl * 64 + lane;
   const bool live = sl != GL_NONE && pos < n_out;
   size_t base = 0;
@@ -134,44 +129,38 @@ __global__ __launch_bounds__(256) void gl_cnt_k(const uint32_t* __restrict__ sli
   for (uint32_t band = 0; band < NB; ++band) {
     uint32_t n = 0;
     if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[base + band];
-    uint32_t sr;
-    if (merge) {
-      shn[g][lane] = merge == 1 ? ((n + 3u) & ~3u) : n;
-      __syncthreads();
-      uint32_t pre = 0;
-      for (int j = 0; j < g; ++j) pre += shn[j][lane];
-      if (PASS == 2 && live) cellpre[base + band] = (uint16_t)(pre | ((uint32_t)g << 14));  // pre <= 3 * 3412 < 2^14
-      sr = g == 0 ? (wave_max_u32(shn[0][lane] + shn[1][lane] + shn[2][lane] + shn[3][lane]) + 3) >> 2 : 0u;
-      sr = (sr + 3u) & ~3u;  // the apply kernel's id ring is static: whole turns of four super-rounds
-    } else {
-      sr = (wave_max_u32(n) + 3) >> 2;
-    }
+    const uint32_t sr = (wave_max_u32(n) + 3) >> 2;
     if (lane == 0) {
       if (sr > 0xffffu) *overflow = 1;
-      cnt[(wv * NB + band) * 4 + g] = (uint16_t)sr;
+      cnt[(wv * NB + band) * GL_GMAX + g] = (uint16_t)sr;
       sh[g] = sr;
     }
     __syncthreads();
-    if (threadIdx.x == 0) srsum[wv * NB + band] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int j = 0; j < G; ++j) t += sh[j];
+      srsum[wv * NB + band] = t;
+      for (int j = G; j < GL_GMAX; ++j) cnt[(wv * NB + band) * GL_GMAX + j] = 0;
+    }
     __syncthreads();
   }
 }
 
-// ids of pass 1: one workgroup of 4 waves per (wave wv, band); wave g writes group g's super-rounds.
-__global__ __launch_bounds__(256) void gl_fill1_k(const uint32_t* __restrict__ slice_of, uint32_t D, uint32_t NB,
-                                                   const uint32_t* __restrict__ bst, const uint32_t* __restrict__ dperm,
-                                                   const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint64_t nnz,
-                                                   const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
+// ids of pass 1: one workgroup of G waves per (wave wv, band); wave g writes group g's super-rounds.
+__global__ __launch_bounds__(64 * GL_GMAX) void gl_fill1_k(const uint32_t* __restrict__ slice_of, int G, uint32_t D, uint32_t NB,
+                                                            const uint32_t* __restrict__ bst, const uint32_t* __restrict__ dperm,
+                                                            const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint64_t nnz,
+                                                            const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t wb = blockIdx.x;  // wv * NB + band
   const size_t wv = wb / NB;
   const uint32_t band = (uint32_t)(wb - wv * NB);
-  const uint16_t* cc = cnt + wb * 4;
+  const uint16_t* cc = cnt + wb * GL_GMAX;
   const uint32_t n = cc[g];
   if (n == 0) return;
   int64_t sr0 = roff[wb];
   for (int j = 0; j < g; ++j) sr0 += cc[j];
-  const uint32_t sl = slice_of[wv * 4 + g];
+  const uint32_t sl = slice_of[wv * G + g];
   const uint64_t pos = (uint64_t)sl * 64 + lane;
   int64_t base = 0;
   uint32_t len = 0;
@@ -190,60 +179,6 @@ __global__ __launch_bounds__(256) void gl_fill1_k(const uint32_t* __restrict__ s
       if (at > (int64_t)nnz - 1) at = (int64_t)nnz - 1;
       const uint32_t row = rows[at];
       id[t] = j < len ? row - r0 : GL_RB;
-    }
-    ids[(size_t)(sr0 + r) * 64 + lane] = make_uint2(id[0] | (id[1] << 16), id[2] | (id[3] << 16));
-  }
-}
-
-// ids of pass 1, merged streams: one wave per (wave wv, band) writes the lanes' merged streams (ids carry the item's tag in
-// bits 12-13; padding = the zero row with tag 0)
-__global__ __launch_bounds__(64) void gl_fill1m_k(const uint32_t* __restrict__ slice_of, uint32_t D, uint32_t NB,
-                                                   const uint32_t* __restrict__ bst, const uint32_t* __restrict__ dperm,
-                                                   const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint64_t nnz,
-                                                   const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids,
-                                                   int merge) {
-  const int lane = threadIdx.x;
-  const size_t wb = blockIdx.x;  // wv * NB + band
-  const size_t wv = wb / NB;
-  const uint32_t band = (uint32_t)(wb - wv * NB);
-  const uint32_t n = cnt[wb * 4];
-  if (n == 0) return;
-  const int64_t sr0 = roff[wb];
-  int64_t base[4];
-  uint32_t len[4], start[4];  // start: first stream position of the item's entries
-  uint32_t at0 = 0;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const uint32_t sl = slice_of[wv * 4 + g];
-    const uint64_t pos = (uint64_t)sl * 64 + lane;
-    base[g] = 0;
-    len[g] = 0;
-    if (sl != GL_NONE && pos < D) {
-      const uint32_t b0 = bst[pos * (NB + 1) + band], b1 = bst[pos * (NB + 1) + band + 1];
-      base[g] = offs[dperm[pos]] + b0;
-      len[g] = b1 - b0;
-    }
-    start[g] = at0;
-    at0 += merge == 1 ? ((len[g] + 3u) & ~3u) : len[g];
-  }
-  const uint32_t r0 = band * GL_RB;
-  for (uint32_t r = 0; r < n; ++r) {
-    uint32_t id[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t e = 4 * r + t;
-      int sel = 0;
-#pragma unroll
-      for (int g = 1; g < 4; ++g)
-        if (e >= start[g]) sel = g;
-      const uint32_t st = sel == 0 ? start[0] : sel == 1 ? start[1] : sel == 2 ? start[2] : start[3];
-      const uint32_t ln = sel == 0 ? len[0] : sel == 1 ? len[1] : sel == 2 ? len[2] : len[3];
-      const int64_t bs = sel == 0 ? base[0] : sel == 1 ? base[1] : sel == 2 ? base[2] : base[3];
-      const uint32_t j = e - st;
-      int64_t at = bs + j;
-      if (at > (int64_t)nnz - 1) at = (int64_t)nnz - 1;
-      const uint32_t row = rows[at];
-      id[t] = j < ln ? ((row - r0) | ((uint32_t)sel << 12)) : GL_RB;
     }
     ids[(size_t)(sr0 + r) * 64 + lane] = make_uint2(id[0] | (id[1] << 16), id[2] | (id[3] << 16));
   }
@@ -303,18 +238,17 @@ __global__ __launch_bounds__(256) void gl_rowlen_key_k(const uint16_t* __restric
 }
 
 // sbase[slice * NB + band] = first super-round of (slice, band) in the stream
-__global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ slice_of, const uint16_t* __restrict__ cnt,
-                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase,
-                                                   int merge) {
+__global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ slice_of, int G, const uint16_t* __restrict__ cnt,
+                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase) {
   const size_t wb = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (wb >= nwb) return;
   const size_t wv = wb / NB;
   const uint32_t band = (uint32_t)(wb - wv * NB);
   uint32_t base = (uint32_t)roff[wb];
-  for (int g = 0; g < GL_G; ++g) {
-    const uint32_t sl = slice_of[wv * 4 + g];
-    if (sl != GL_NONE) sbase[(size_t)sl * NB + band] = base;  // merged streams: all four slices share the wave's stream
-    if (!merge) base += cnt[wb * 4 + g];
+  for (int g = 0; g < G; ++g) {
+    const uint32_t sl = slice_of[wv * G + g];
+    if (sl != GL_NONE) sbase[(size_t)sl * NB + band] = base;
+    base += cnt[wb * GL_GMAX + g];
   }
 }
 
@@ -322,7 +256,7 @@ __global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ s
 __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                               const uint32_t* __restrict__ dperm, uint32_t D, uint32_t V, uint32_t NB,
                                                               const uint32_t* __restrict__ wpos, const uint32_t* __restrict__ sbase,
-                                                              uint16_t* __restrict__ ids16, const uint16_t* __restrict__ cellpre /*null: unmerged*/) {
+                                                              uint16_t* __restrict__ ids16) {
   extern __shared__ uint32_t hist[];
   constexpr int NU = 16;  // entries in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
@@ -349,18 +283,16 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u) q[u] = in[u] ? wpos[w[u]] : 0u;
-      uint32_t sb[NU], pre[NU];
+      uint32_t sb[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) sb[u] = in[u] ? sbase[(size_t)(q[u] >> 6) * NB + band] : 0u;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) pre[u] = (cellpre && in[u]) ? (uint32_t)cellpre[(size_t)w[u] * NB + band] : 0u;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         if (in[u]) {
           const uint32_t odd = (w[u] - w0) & 1u;
           const uint32_t cur = atomicAdd(&hist[(w[u] - w0) >> 1], odd ? 0x10000u : 1u);
-          const uint32_t j = (odd ? (cur >> 16) : (cur & 0xffffu)) + (pre[u] & 0x3fffu);
-          ids16[((size_t)(sb[u] + (j >> 2)) * 64 + (q[u] & 63u)) * 4 + (j & 3u)] = (uint16_t)((p - p0) | ((pre[u] >> 14) << 12));
+          const uint32_t j = odd ? (cur >> 16) : (cur & 0xffffu);
+          ids16[((size_t)(sb[u] + (j >> 2)) * 64 + (q[u] & 63u)) * 4 + (j & 3u)] = (uint16_t)(p - p0);
         }
       }
     }
@@ -408,12 +340,12 @@ __device__ inline void gl_sort_regs(uint2* __restrict__ s, uint32_t n) {  // n <
     if ((uint32_t)r < n) s[(size_t)r * 64] = make_uint2(v[4 * r] | (v[4 * r + 1] << 16), v[4 * r + 2] | (v[4 * r + 3] << 16));
 }
 
-// one workgroup of 4 waves per (wave wv, band); wave g sorts group g's slots.  big[0] = number of entries that follow.
-__global__ __launch_bounds__(256) void gl_sort2_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
-                                                   uint2* __restrict__ ids, uint32_t* __restrict__ big) {
+// one workgroup of G waves per (wave wv, band); wave g sorts group g's slots.  big[0] = number of entries that follow.
+__global__ __launch_bounds__(64 * GL_GMAX) void gl_sort2_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
+                                                            uint2* __restrict__ ids, uint32_t* __restrict__ big) {
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t wb = blockIdx.x;  // wv * NB + band
-  const uint16_t* cc = cnt + wb * 4;
+  const uint16_t* cc = cnt + wb * GL_GMAX;
   const uint32_t n = cc[g];
   if (n == 0) return;
   int64_t sr0 = roff[wb];
@@ -423,7 +355,7 @@ __global__ __launch_bounds__(256) void gl_sort2_k(uint32_t NB, const uint16_t* _
   else if (n <= 4) gl_sort_regs<16>(s, n);
   else if (n <= 8) gl_sort_regs<32>(s, n);
   else if (n <= 16) gl_sort_regs<64>(s, n);
-  else if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = (uint32_t)(wb * 4 + g);  // the list's order does not matter
+  else if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = (uint32_t)(wb * GL_GMAX + g);  // the list's order does not matter
 }
 
 constexpr int GL_BMW = ((GL_RB + 31) / 32 + 3) & ~3;  // bitmap words per lane, a multiple of 4
@@ -434,9 +366,9 @@ __global__ __launch_bounds__(128) void gl_sort2_big_k(uint32_t NB, const uint16_
   const uint32_t nbig = big[0];
   for (uint32_t it = blockIdx.x * 2 + wave; it < nbig; it += gridDim.x * 2) {
     const uint32_t e = big[1 + it];
-    const size_t wb = e >> 2;
-    const int g = (int)(e & 3u);
-    const uint16_t* cc = cnt + wb * 4;
+    const size_t wb = e / GL_GMAX;
+    const int g = (int)(e % GL_GMAX);
+    const uint16_t* cc = cnt + wb * GL_GMAX;
     const uint32_t n = cc[g];
     int64_t sr0 = roff[wb];
     for (int j = 0; j < g; ++j) sr0 += cc[j];
@@ -502,26 +434,13 @@ __device__ inline void add4(float4& a, const float4 b) {
   a.w += b.w;
 }
 
-// id ring of the merged-stream forms of gl_apply_k (see the comment in the kernel)
-#define GL_LOAD(Q, PTR) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(Q) : "v"(PTR) : "memory")  // tied: the register a round reads is the one it reloads
-
-typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ inline void fma4(float4& a, const float4 b, const f2v m) {  // a += m * b as two v_pk_fma_f32
-  f2v lo = {a.x, a.y}, hi = {a.z, a.w};
-  const f2v blo = {b.x, b.y}, bhi = {b.z, b.w};
-  lo = __builtin_elementwise_fma(blo, m, lo);
-  hi = __builtin_elementwise_fma(bhi, m, hi);
-  a = make_float4(lo.x, lo.y, hi.x, hi.y);
-}
-
 // LPE float4 per panel row; HALF: the panel's last two columns are padding (b = 4 LPE - 2 or 4 LPE - 3), so only the low
-// half of the last float4 is read and accumulated (b = 10: 40 of 48 bytes per gathered row).
-// MERGE (the stream form, gl_cnt_k): 0 = one item per (lane, group): the rows of a group's super-rounds add into acc[g].
-// 1, 2 = the lane's four items share one stream; bits 12-13 of an id name the item.  The accumulator cannot be indexed per
-// lane, so the row is added into all four with multipliers 1, 0, 0, 0 (exact: x * 1 + a, x * 0 + a).  MERGE 1: an item changes
-// only between super-rounds, so the four rows of a super-round are summed first (3 + 4 operations per float and super-round
-// instead of 4 before); MERGE 2: entry by entry (16 per super-round), no rounding-up of the items' counts.
-template <int LPE, bool HALF, int MERGE>
+// half of the last float4 is read and accumulated (b = 10: 40 of 48 bytes per gathered row).  G: output items per lane (the groups
+// of a wave; GlSide::G): the rows of a group's super-rounds add into acc[g].
+// (Rounds 1-2 also carried "merged stream" forms — a lane's items sharing one stream per band, ids tagged with the item, a static
+// four-register id ring loaded by inline asm — built to cut the padded slots (2.17x -> 1.52x) and the id latency; measured no faster in
+// either pass, twice, and removed in round 3.)
+template <int LPE, bool HALF, int G>
 __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restrict__ In, uint32_t n_src, const uint2* __restrict__ ids,
                                                           const int64_t* __restrict__ roff, const uint16_t* __restrict__ cnt,
                                                           const uint32_t* __restrict__ slice_of, const GlDesc* __restrict__ desc, uint32_t NB,
@@ -531,38 +450,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   extern __shared__ float4 xs[];  // (GL_RB + 1) rows of LPE float4
   constexpr int NF = HALF ? LPE - 1 : LPE;  // whole float4 per row
   constexpr int NFA = NF > 0 ? NF : 1;
+  // entries of a super-round whose LDS rows are in flight together: all four while the accumulators leave room (a wave has 128
+  // registers at 16 waves per workgroup), two beyond — measured at a C3 shard, pass 1 with 10 columns: 5 items per lane 0.313 ms with
+  // four in flight against 0.322 with two; 8 items per lane 0.50 ms (spills inside the loop) against 0.38
+  constexpr int GL_INFLIGHT = G * (4 * NF + (HALF ? 2 : 0)) <= 56 ? 4 : 2;
   const GlDesc ds = desc[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool wvalid = (uint32_t)w < ds.nw;  // wave-uniform
   const size_t wv = wvalid ? (size_t)ds.wave0 + (size_t)w * ds.wstride : (size_t)ds.wave0;
-  float4 acc[GL_G][NFA];
-  float2 acch[GL_G];
+  float4 acc[G][NFA];
+  float2 acch[G];
 #pragma unroll
-  for (int g = 0; g < GL_G; ++g) {
+  for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int l = 0; l < NF; ++l) acc[g][l] = make_float4(0.f, 0.f, 0.f, 0.f);
     acch[g] = make_float2(0.f, 0.f);
   }
-  // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
+  // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array).  The ring is
+  // rotated in C++ (q0 = q1; ... q3 = *p): hipcc turns that into register moves behind a vmcnt(0), one or two loads in flight — a static
+  // ring with hand-placed waits was measured in round 2 and lost to its filler rounds (this form is bound by LDS issue).
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
-  // MERGE 0: the ring is rotated in C++ (q0 = q1; ... q3 = *p).  (Round 2 measured the static ring below for this form too —
-  // segments padded to whole turns, the group of a round chosen by scalar branches: 0.496 -> 0.520 ms per apply at C2, the 9 %
-  // filler rounds cost more than the deeper prefetch gains, because this form is bound by LDS issue, not by id latency.)
-  //  hipcc turns that into register moves that read the newest
-  // load's destination and therefore waits vmcnt(0) in every round: one or two loads in flight, the pass runs at memory latency.
-  // Merged forms: four 64-bit registers that never move — a (wave, band) segment is a multiple of four super-rounds
-  // (gl_cnt_k), round i's ids sit in register i & 3, which is reloaded as soon as it has been read.  The loads are inline asm
-  // with a hand-placed s_waitcnt vmcnt(3): the three younger loads stay in flight.
-  uint2 q0, q1, q2, q3;
-  unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-  if (MERGE == 0) {
-    q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
-  } else {
-    GL_LOAD(r0, p);
-    GL_LOAD(r1, p + 64);
-    GL_LOAD(r2, p + 128);
-    GL_LOAD(r3, p + 192);
-  }
+  uint2 q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
   p += 256;
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
     __syncthreads();  // every wave is done with the previous band
@@ -572,8 +480,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
       const uint32_t nrow = min(GL_RB, n_src - r0);
       const float4* src = In + (size_t)r0 * LPE;
       const uint32_t n4 = nrow * LPE;  // <= 10 * 1024
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
+#pragma nounroll
+      for (int j = 0; j < 10; ++j) {  // rolled: unrolled, the ten address pairs stayed live beside the accumulators and the 10-column form spilled
         const uint32_t i0 = (uint32_t)(j * GL_WAVES + w) * 64;  // wave-uniform LDS base, lane l lands at i0 + l
         if (i0 + lane < n4) {  // lanes past the band's end stay masked: they must not land on the padding row
           const float4* gp = src + i0 + lane;
@@ -585,116 +493,50 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
       if (threadIdx.x < LPE) xs[GL_RB * LPE + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding row
     }
     __syncthreads();
-    const uint2 cc = *reinterpret_cast<const uint2*>(cnt + (wv * NB + band) * 4);
-    uint32_t c01 = __builtin_amdgcn_readfirstlane(cc.x), c23 = __builtin_amdgcn_readfirstlane(cc.y);
-    if (!wvalid) c01 = c23 = 0;
-    if (MERGE == 0) {
+    const uint4 cc = *reinterpret_cast<const uint4*>(cnt + (wv * NB + band) * GL_GMAX);  // GL_GMAX u16 counts
+    uint32_t cw[4] = {(uint32_t)__builtin_amdgcn_readfirstlane(cc.x), (uint32_t)__builtin_amdgcn_readfirstlane(cc.y),
+                      (uint32_t)__builtin_amdgcn_readfirstlane(cc.z), (uint32_t)__builtin_amdgcn_readfirstlane(cc.w)};
+    if (!wvalid) cw[0] = cw[1] = cw[2] = cw[3] = 0;
 #pragma unroll
-      for (int g = 0; g < GL_G; ++g) {
-        const uint32_t n = ((g < 2 ? c01 : c23) >> (16 * (g & 1))) & 0xffffu;
-        for (uint32_t r = 0; r < n; ++r) {
-          const uint2 u = q0;
-          q0 = q1;
-          q1 = q2;
-          q2 = q3;
-          q3 = *p;
-          p += 64;
-          const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
+    for (int g = 0; g < G; ++g) {
+      const uint32_t n = (cw[g >> 1] >> (16 * (g & 1))) & 0xffffu;
+      for (uint32_t r = 0; r < n; ++r) {
+        const uint2 u = q0;
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
+        q3 = *p;
+        p += 64;
+        const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+        for (int t2 = 0; t2 < 4; t2 += GL_INFLIGHT) {
+          float4 v[GL_INFLIGHT][NFA];
+          float2 h[GL_INFLIGHT];
 #pragma unroll
-            for (int l = 0; l < NF; ++l) add4(acc[g][l], xs[a[t] + l]);
+          for (int t = 0; t < GL_INFLIGHT; ++t) {
+#pragma unroll
+            for (int l = 0; l < NF; ++l) v[t][l] = xs[a[t2 + t] + l];
+            if (HALF) h[t] = *reinterpret_cast<const float2*>(&xs[a[t2 + t] + NF]);
+          }
+#pragma unroll
+          for (int t = 0; t < GL_INFLIGHT; ++t) {
+#pragma unroll
+            for (int l = 0; l < NF; ++l) add4(acc[g][l], v[t][l]);
             if (HALF) {
-              const float2 h = *reinterpret_cast<const float2*>(&xs[a[t] + NF]);
-              acch[g].x += h.x;
-              acch[g].y += h.y;
+              acch[g].x += h[t].x;
+              acch[g].y += h[t].y;
             }
           }
+          if (GL_INFLIGHT < 4) __builtin_amdgcn_sched_barrier(0);
         }
       }
-    } else {
-      const uint32_t n = c01 & 0xffffu;  // group 0 carries the merged stream: a multiple of 4 super-rounds
-      auto round = [&](const unsigned long long qq) {
-        const uint32_t ux = (uint32_t)qq, uy = (uint32_t)(qq >> 32);
-        const uint32_t e[4] = {ux & 0xffffu, ux >> 16, uy & 0xffffu, uy >> 16};
-        if (MERGE == 1) {
-          float4 sum[NFA];
-          float2 sumh = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int l = 0; l < NF; ++l) sum[l] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const uint32_t a = (e[t] & 0xfffu) * LPE;
-#pragma unroll
-            for (int l = 0; l < NF; ++l) add4(sum[l], xs[a + l]);
-            if (HALF) {
-              const float2 h = *reinterpret_cast<const float2*>(&xs[a + NF]);
-              sumh.x += h.x;
-              sumh.y += h.y;
-            }
-          }
-          const uint32_t tag = e[0] >> 12;  // the same for the four entries of a super-round (or padding behind the item's last entry)
-#pragma unroll
-          for (int g = 0; g < GL_G; ++g) {
-            const float m = tag == (uint32_t)g ? 1.f : 0.f;
-            const f2v m2 = {m, m};
-#pragma unroll
-            for (int l = 0; l < NF; ++l) fma4(acc[g][l], sum[l], m2);
-            if (HALF) {
-              f2v ah = {acch[g].x, acch[g].y};
-              const f2v sh2 = {sumh.x, sumh.y};
-              ah = __builtin_elementwise_fma(sh2, m2, ah);
-              acch[g] = make_float2(ah.x, ah.y);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const uint32_t a = (e[t] & 0xfffu) * LPE;
-            const uint32_t tag = e[t] >> 12;
-            float4 v[NFA];
-            float2 h = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int l = 0; l < NF; ++l) v[l] = xs[a + l];
-            if (HALF) h = *reinterpret_cast<const float2*>(&xs[a + NF]);
-#pragma unroll
-            for (int g = 0; g < GL_G; ++g) {
-              const float m = tag == (uint32_t)g ? 1.f : 0.f;
-              const f2v m2 = {m, m};
-#pragma unroll
-              for (int l = 0; l < NF; ++l) fma4(acc[g][l], v[l], m2);
-              if (HALF) {
-                f2v ah = {acch[g].x, acch[g].y};
-                const f2v h2 = {h.x, h.y};
-                ah = __builtin_elementwise_fma(h2, m2, ah);
-                acch[g] = make_float2(ah.x, ah.y);
-              }
-            }
-          }
-        }
-      };
-#define GL_ROUND(Q)                                                                                                     \
-  {                                                                                                                     \
-    unsigned long long u_; /* the copy is made by the asm itself, after the wait: a C++ copy would share Q's register */ \
-    asm volatile("s_waitcnt vmcnt(3)\n\tv_mov_b64 %0, %1" : "=&v"(u_) : "v"(Q) : "memory");                              \
-    GL_LOAD(Q, p);                                                                                                      \
-    p += 64;                                                                                                            \
-    round(u_);                                                                                                          \
-  }
-      for (uint32_t r = 0; r < n; r += 4) {
-        GL_ROUND(r0)
-        GL_ROUND(r1)
-        GL_ROUND(r2)
-        GL_ROUND(r3)
-      }
-#undef GL_ROUND
     }
   }
   if (!wvalid) return;
   float4* out = Out + (size_t)ds.slab * slab_stride;
 #pragma unroll
-  for (int g = 0; g < GL_G; ++g) {
-    const uint32_t sl = slice_of[wv * 4 + g];
+  for (int g = 0; g < G; ++g) {
+    const uint32_t sl = slice_of[wv * G + g];
     const uint64_t pos = (uint64_t)sl * 64 + lane;
     if (sl != GL_NONE && pos < n_out) {
       const size_t row = rowmap ? (size_t)rowmap[pos] : (size_t)(pos - ds.pos_base);
@@ -871,16 +713,14 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   HIPCHK(c, s.slice_of.reserve(slice_of_host.size()));
   HIPCHK(c, hipMemcpyAsync(s.slice_of.p, slice_of_host.data(), slice_of_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   const size_t nwb = (size_t)s.nwv * s.NB;
-  HIPCHK(c, s.cnt.reserve(nwb * 4));
+  HIPCHK(c, s.cnt.reserve(nwb * GL_GMAX));
   HIPCHK(c, s.roff.reserve(nwb + 1));
   HIPCHK(c, c->gl_srsum.reserve(nwb));
   HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(nwb) + 8));
   HIPCHK(c, c->gl_flag.reserve(4));
   HIPCHK(c, hipMemsetAsync(c->gl_flag.p, 0, sizeof(int), c->stream));
-  const int merge = c->gl_merge;
-  if (PASS == 2 && merge) HIPCHK(c, c->gl_cellpre.reserve((size_t)s.n_out * s.NB));
-  hipLaunchKernelGGL((gl_cnt_k<PASS>), dim3(s.nwv), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->gl_cellcnt.p,
-                     c->wperm.p, s.cnt.p, c->gl_srsum.p, c->gl_flag.p, merge, c->gl_cellpre.p);
+  hipLaunchKernelGGL((gl_cnt_k<PASS>), dim3(s.nwv), dim3(64 * s.G), 0, c->stream, s.slice_of.p, s.G, s.n_out, s.NB, c->gl_bst.p, c->gl_cellcnt.p,
+                     c->wperm.p, s.cnt.p, c->gl_srsum.p, c->gl_flag.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, c->gl_srsum.p, nwb, s.roff.p, c->gl_scan.p)));
   int overflow = 0;
@@ -896,27 +736,24 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   uint16_t* ids16 = reinterpret_cast<uint16_t*>(s.ids.p);
   if (PASS == 1) {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)GL_RB, n16_all - n16_body, c->stream));
-    if (nwb && !merge)
-      hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
+    if (nwb)
+      hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(64 * s.G), 0, c->stream, s.slice_of.p, s.G, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
                          c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
-    if (nwb && merge)
-      hipLaunchKernelGGL(gl_fill1m_k, dim3((unsigned)nwb), dim3(64), 0, c->stream, s.slice_of.p, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
-                         c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p, merge);
     HIPCHK(c, hipGetLastError());
   } else {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
     HIPCHK(c, c->gl_sbase.reserve((size_t)s.nslice * s.NB));
-    if (nwb) hipLaunchKernelGGL(gl_sbase_k, dim3(cdiv((long)nwb, 256)), dim3(256), 0, c->stream, s.slice_of.p, s.cnt.p, s.roff.p, nwb, s.NB,
-                                c->gl_sbase.p, merge);
+    if (nwb) hipLaunchKernelGGL(gl_sbase_k, dim3(cdiv((long)nwb, 256)), dim3(256), 0, c->stream, s.slice_of.p, s.G, s.cnt.p, s.roff.p, nwb, s.NB,
+                                c->gl_sbase.p);
     HIPCHK(c, hipGetLastError());
     const uint32_t nvp = (s.n_out + GL_VP - 1) / GL_VP;
     hipLaunchKernelGGL(gl_hist_fill_k, dim3(s.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, s.n_out,
-                       s.NB, c->wpos.p, c->gl_sbase.p, ids16, merge ? c->gl_cellpre.p : nullptr);
+                       s.NB, c->wpos.p, c->gl_sbase.p, ids16);
     HIPCHK(c, hipGetLastError());
-    if (nwb && !merge && !getenv("ISLE_GL_NOSORT")) {  // merged streams (experiments) keep the arrival order
-      HIPCHK(c, c->gl_biglist.reserve(nwb * 4 + 1));
+    if (nwb) {
+      HIPCHK(c, c->gl_biglist.reserve(nwb * GL_GMAX + 1));
       HIPCHK(c, hipMemsetAsync(c->gl_biglist.p, 0, sizeof(uint32_t), c->stream));
-      hipLaunchKernelGGL(gl_sort2_k, dim3((unsigned)nwb), dim3(256), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p, c->gl_biglist.p);
+      hipLaunchKernelGGL(gl_sort2_k, dim3((unsigned)nwb), dim3(64 * s.G), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p, c->gl_biglist.p);
       hipLaunchKernelGGL(gl_sort2_big_k, dim3(2 * c->num_cus), dim3(128), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p, c->gl_biglist.p);
       HIPCHK(c, hipGetLastError());
     }
@@ -924,10 +761,10 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   return 0;
 }
 
-template <int LPE, bool HALF, int MERGE>
-int launch_apply_m(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4) {
-  ISLECHK(isle_max_lds(c, (const void*)gl_apply_k<LPE, HALF, MERGE>, GL_LDS));
-  hipLaunchKernelGGL((gl_apply_k<LPE, HALF, MERGE>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
+template <int LPE, bool HALF, int G>
+int launch_apply_g(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4) {
+  ISLECHK(isle_max_lds(c, (const void*)gl_apply_k<LPE, HALF, G>, GL_LDS));
+  hipLaunchKernelGGL((gl_apply_k<LPE, HALF, G>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
                      s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -935,9 +772,14 @@ int launch_apply_m(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, 
 template <int LPE, bool HALF>
 int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap = nullptr,
                  uint32_t out_ld4 = 0) {
-  if (c->gl_merge == 1) return launch_apply_m<LPE, HALF, 1>(c, s, In, Out, slab_stride, rowmap, out_ld4);
-  if (c->gl_merge == 2) return launch_apply_m<LPE, HALF, 2>(c, s, In, Out, slab_stride, rowmap, out_ld4);
-  return launch_apply_m<LPE, HALF, 0>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+  switch (s.G) {
+    case 4: return launch_apply_g<LPE, HALF, 4>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+    case 5: return launch_apply_g<LPE, HALF, 5>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+    case 6: return launch_apply_g<LPE, HALF, 6>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+    case 7: return launch_apply_g<LPE, HALF, 7>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+    case 8: return launch_apply_g<LPE, HALF, 8>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+  }
+  return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: %d items per lane", s.G);
 }
 int launch_apply_any(isle_ctx* c, int LPE, bool half, const GlSide& s, const float4* In, float4* Out, size_t slab_stride) {
   if (LPE == 1) return half ? launch_apply<1, true>(c, s, In, Out, slab_stride) : launch_apply<1, false>(c, s, In, Out, slab_stride);
@@ -984,10 +826,6 @@ int k_gl_detect(isle_ctx* c) {
 
 int k_gl_build(isle_ctx* c) {
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
-  {
-    const char* e = getenv("ISLE_GL_MERGE");  // stream form (gl_cnt_k): 0, 1 or 2
-    c->gl_merge = e ? std::max(0, std::min(2, atoi(e))) : 0;
-  }
   GlSide& s1 = c->gl1;
   GlSide& s2 = c->gl2;
   ISLECHK(isle_max_lds(c, (const void*)gl_hist_count_k, GL_HLDS));
@@ -1008,15 +846,45 @@ int k_gl_build(isle_ctx* c) {
   s1.n_src = V;
   s1.NB = (V + GL_RB - 1) / GL_RB;
   s1.nslice = (D + 63) / 64;
-  s1.nwv = (s1.nslice + GL_G - 1) / GL_G;
+  // items per lane G and waves per workgroup: the makespan model  rounds x (waves x G x LDS time of a slice + staging of all bands)
+  // over G = 4..8 and 1..16 waves.  Every workgroup stages every word band, so a shard whose documents need more than one round of
+  // workgroups at G = 4 (a C3 shard: 306 workgroups on 256 CUs, 0.44 ms per pass) runs one fuller round at G = 5 (245 workgroups,
+  // 0.31 ms), and all of config 3 on one GPU five rounds at G = 8 instead of ten (2.69 -> 2.34 ms); small matrices keep G = 4 and
+  // take fewer waves per workgroup so that all CUs stay busy.  The model's figures against the measured ones, pass 1 with 10 columns:
+  // C3 shard G = 5: 312 / 313 us; config 3 on one GPU G = 4 / 6 / 8: 2610 / 2530 / 2310 against 2690 / 2490 / 2336 us.
+  // ISLE_GL_G1 = 4..8 forces G.
+  uint32_t wpw = GL_WAVES;
   {
-    // serpentine over four quantile ranges of the length-ordered slices: every wave gets one long, two middle, one short slice
-    std::vector<uint32_t> so((size_t)s1.nwv * 4);
-    const uint64_t n = s1.nwv;
-    for (uint64_t wv = 0; wv < n; ++wv) {
-      const uint64_t cand[4] = {wv, 2 * n - 1 - wv, 2 * n + wv, 4 * n - 1 - wv};
-      for (int g = 0; g < 4; ++g) so[wv * 4 + g] = cand[g] < s1.nslice ? (uint32_t)cand[g] : GL_NONE;
+    const double t_slice = 0.05 * 2.5 * (double)c->nnz / 256.0 / std::max<uint32_t>(1u, s1.nslice);  // us: ~50 ns per super-round, ~2.5x padded
+    const double t_stage = 2.0 * s1.NB;                                                               // us: ~2 us per band from L2
+    const char* e_g = getenv("ISLE_GL_G1");
+    const int g_lo = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4, g_hi = e_g ? g_lo : GL_GMAX;
+    double best = 1e300;
+    for (int G = g_lo; G <= g_hi; ++G) {
+      const uint32_t nwv = (s1.nslice + G - 1) / G;
+      for (uint32_t cand = GL_WAVES; cand >= 1; --cand) {
+        const uint32_t wgs = (nwv + cand - 1) / cand;
+        const double fewer = 1.0 + 0.25 * (double)(GL_WAVES - cand) / GL_WAVES;  // fewer waves hide less of the id-stream latency
+        const double cost = (double)((wgs + c->num_cus - 1) / c->num_cus) * (cand * G * t_slice * fewer + t_stage);
+        if (cost < best * 0.97) {  // prefer fewer items per lane and more waves per workgroup unless clearly worse
+          best = cost;
+          wpw = cand;
+          s1.G = G;
+        }
+      }
     }
+  }
+  s1.nwv = (s1.nslice + s1.G - 1) / s1.G;
+  {
+    // serpentine over G quantile ranges of the length-ordered slices: every wave gets long, middle and short slices alike
+    const int G = s1.G;
+    std::vector<uint32_t> so((size_t)s1.nwv * G);
+    const uint64_t n = s1.nwv;
+    for (uint64_t wv = 0; wv < n; ++wv)
+      for (int g = 0; g < G; ++g) {
+        const uint64_t cand = (g & 1) ? (uint64_t)(g + 1) * n - 1 - wv : (uint64_t)g * n + wv;
+        so[wv * G + g] = cand < s1.nslice ? (uint32_t)cand : GL_NONE;
+      }
     HIPCHK(c, c->gl_bst.reserve((size_t)D * (s1.NB + 1)));
     const uint64_t nb = (uint64_t)D * (s1.NB + 1);
     hipLaunchKernelGGL(gl_bst_k, dim3(cdiv((long)nb, 256)), dim3(256), 0, c->stream, c->rows.p, c->offs.p, c->dperm.p, (uint64_t)D, s1.NB,
@@ -1024,23 +892,6 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipGetLastError());
     ISLECHK(build_side<1>(c, s1, so));
     // workgroup j = waves j, j + nwg, j + 2 nwg, ... : equal totals, one slab (Y itself)
-    // small matrices: fewer (valid) waves per workgroup, so that there is still about one workgroup per CU
-    // waves per workgroup: the makespan model  rounds x (waves x LDS time of a wave + staging of all bands)  over 1..16 waves
-    // (small matrices: fewer valid waves per workgroup keep all CUs busy; large ones: avoid a nearly empty last round)
-    uint32_t wpw = GL_WAVES;
-    {
-      const double t_wave = 0.05 * (double)s1.total_sr / std::max<uint32_t>(1u, s1.nwv);  // us: ~50 ns of LDS time per super-round
-      const double t_stage = 2.0 * s1.NB;                                                  // us: ~2 us per band from L2
-      double best = 1e300;
-      for (uint32_t cand = GL_WAVES; cand >= 1; --cand) {
-        const uint32_t wgs = (s1.nwv + cand - 1) / cand;
-        const double cost = (double)((wgs + c->num_cus - 1) / c->num_cus) * (cand * t_wave + t_stage);
-        if (cost < best * 0.97) {  // prefer more waves per workgroup unless clearly worse
-          best = cost;
-          wpw = cand;
-        }
-      }
-    }
     const uint32_t nwg = (s1.nwv + wpw - 1) / wpw;
     std::vector<GlDesc> ds(nwg);
     for (uint32_t j = 0; j < nwg; ++j) {
@@ -1079,23 +930,27 @@ int k_gl_build(isle_ctx* c) {
   s2.nslice = (V + 63) / 64;
   // a word block = wpb waves = 4 wpb consecutive slices; 16 waves unless the vocabulary is so small that blocks x bands would
   // leave CUs idle
+  {
+    const char* e_g = getenv("ISLE_GL_G2");  // items per lane in pass 2 (4 ... 8)
+    s2.G = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4;
+  }
+  const uint32_t G2 = (uint32_t)s2.G;
   uint32_t wpb = GL_WAVES;
-  while (wpb > 1 && (uint64_t)((s2.nslice + 4 * wpb - 1) / (4 * wpb)) * s2.NB < 2ull * c->num_cus) wpb /= 2;
-  const uint32_t bslices = 4 * wpb, bitems = 64 * bslices;
+  while (wpb > 1 && (uint64_t)((s2.nslice + G2 * wpb - 1) / (G2 * wpb)) * s2.NB < 2ull * c->num_cus) wpb /= 2;
+  const uint32_t bslices = G2 * wpb, bitems = 64 * bslices;
   const uint32_t nblk = (s2.nslice + bslices - 1) / bslices;
   s2.nwv = nblk * wpb;
   c->gl_block_items = bitems;
   {
     // serpentine inside the block keeps its waves level
-    std::vector<uint32_t> so((size_t)s2.nwv * 4);
+    std::vector<uint32_t> so((size_t)s2.nwv * G2);
     for (uint32_t ob = 0; ob < nblk; ++ob)
-      for (uint32_t w = 0; w < wpb; ++w) {
-        const uint32_t cand[4] = {w, 2 * wpb - 1 - w, 2 * wpb + w, 4 * wpb - 1 - w};
-        for (int g = 0; g < 4; ++g) {
-          const uint64_t sl = (uint64_t)ob * bslices + cand[g];
-          so[((size_t)ob * wpb + w) * 4 + g] = sl < s2.nslice ? (uint32_t)sl : GL_NONE;
+      for (uint32_t w = 0; w < wpb; ++w)
+        for (uint32_t g = 0; g < G2; ++g) {
+          const uint32_t cand = (g & 1u) ? (g + 1) * wpb - 1 - w : g * wpb + w;
+          const uint64_t sl = (uint64_t)ob * bslices + cand;
+          so[((size_t)ob * wpb + w) * G2 + g] = sl < s2.nslice ? (uint32_t)sl : GL_NONE;
         }
-      }
     ISLECHK(build_side<2>(c, s2, so));
     const char* e_bc = getenv("ISLE_GL_BAND_COST");   // tuning knobs (defaults measured at C2)
     const char* e_wg = getenv("ISLE_GL_WGS_PER_CU");
@@ -1237,9 +1092,9 @@ int k_gl_build(isle_ctx* c) {
     }
     if (getenv("ISLE_GL_VERBOSE"))
       fprintf(stderr,
-              "[gram_lds] V=%u D=%u nnz=%llu | pass1: bands=%u waves=%u wgs=%u padded=%.2fx | pass2: bands=%u blocks=%u wgs=%u slabs=%u "
+              "[gram_lds] V=%u D=%u nnz=%llu | pass1: bands=%u items/lane=%d waves=%u wgs=%u padded=%.2fx | pass2: bands=%u items/lane=%d blocks=%u wgs=%u slabs=%u "
               "padded=%.2fx\n",
-              V, D, (unsigned long long)c->nnz, s1.NB, s1.nwv, s1.ndesc, (double)s1.total_sr * 256.0 / (double)c->nnz, s2.NB, nblk, s2.ndesc,
+              V, D, (unsigned long long)c->nnz, s1.NB, s1.G, s1.nwv, s1.ndesc, (double)s1.total_sr * 256.0 / (double)c->nnz, s2.NB, s2.G, nblk, s2.ndesc,
               nslab, (double)s2.total_sr * 256.0 / (double)c->nnz);
   }
   return 0;

@@ -61,16 +61,6 @@ def test_plan_shards_is_nnz_balanced_and_contiguous():
         assert nn.max() - nn.min() <= 2 * lens.max()
 
 
-def test_id_ring_registers_are_left_alone_by_the_compiler():
-    """tools/check_id_ring.py: the merged-stream forms of gl_apply_k load their id ring by inline asm; no compiler-generated
-    instruction may name a ring register while loads can be in flight (cross-compiles gram_lds.hip for gfx950, no GPU)."""
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_id_ring.py")], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("0 foreign uses") == 12
-
-
 def test_host_generator_is_glibc_rand():
     """The reference draws its first seed and its k-means++ dice with rand() and never calls srand() (src/sparseMatrix.cpp:2150,
     include/matUtils.h:473-477).  The library's host generator restates glibc's TYPE_3 generator; this holds it to the rand() of the

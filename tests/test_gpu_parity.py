@@ -109,13 +109,14 @@ def test_gram_apply_lds_form_ragged(hp, V, D, b):
     assert relerr(Z, Zo) <= 1e-5 + eo
 
 
-@pytest.mark.parametrize("merge", ["1", "2"])
-def test_merged_id_streams_agree_with_the_plain_form(hp, small50, monkeypatch, merge):
-    """ISLE_GL_MERGE=1/2 (gram_lds.hip): the four items of a lane share one id stream per band (tagged ids, accumulators chosen by
-    0/1 multipliers, static id ring with hand-placed waits).  Same operator, same k-wide products: Gram apply on ragged matrices
-    (band and block boundaries, dense and empty columns) against the oracle, and the k-means chain against the plain form."""
+@pytest.mark.parametrize("items", [("6", "4"), ("8", "8"), ("5", "7")])
+def test_items_per_lane_of_the_id_streams_do_not_change_the_operator(hp, small50, monkeypatch, items):
+    """ISLE_GL_G1 / ISLE_GL_G2 (gram_lds.hip): 4 ... 8 output items per lane of a wave (the build picks 4 ... 7 for pass 1 by its
+    makespan model, 4 for pass 2).  Same operator, same k-wide products: Gram apply on ragged matrices (band and block boundaries,
+    dense and empty columns) against the oracle, and the k-means chain against the form with four items."""
     from oracle.oracle import OracleCsc
-    monkeypatch.setenv("ISLE_GL_MERGE", merge)
+    monkeypatch.setenv("ISLE_GL_G1", items[0])
+    monkeypatch.setenv("ISLE_GL_G2", items[1])
     for V, D in [(4500, 300), (3413, 65), (6825, 3411), (7000, 9000), (90000, 300)]:
         vals, rows, offs = _ragged(V, D, 11, True)
         o = OracleCsc(V, D, vals, rows, offs)
@@ -129,8 +130,9 @@ def test_merged_id_streams_agree_with_the_plain_form(hp, small50, monkeypatch, m
     U = B["oracle"].block_ks(k)["U"]
     seeds = np.random.default_rng(3).choice(B["D"], size=k, replace=False).astype(np.uint64)
     res = {}
-    for form in (merge, "0"):
-        monkeypatch.setenv("ISLE_GL_MERGE", form)
+    for form in (items, ("4", "4")):
+        monkeypatch.setenv("ISLE_GL_G1", form[0])
+        monkeypatch.setenv("ISLE_GL_G2", form[1])
         upload(hp, B)
         r = hp.compute_block_ks(k, allow_noconv=True)
         hp.set_U(U)
@@ -139,7 +141,7 @@ def test_merged_id_streams_agree_with_the_plain_form(hp, small50, monkeypatch, m
         hp.left_multiply_by_U(lg["C_lowd"], fetch=False)
         sg = hp.run_lloyds(k)
         res[form] = (r["evals"], g["C_lowd"], lg["assign"], sg["assign"])
-    a, b = res[merge], res["0"]
+    a, b = res[items], res[("4", "4")]
     assert np.max(np.abs(a[0] - b[0]) / b[0]) <= 1e-5 and relerr(a[1], b[1]) <= 1e-5
     assert (a[2] == b[2]).mean() >= 0.999 and (a[3] == b[3]).mean() >= 0.999
 

@@ -15,6 +15,8 @@ from tools.synth import Corpus  # noqa: E402
 V, D, k, seed = 50_000, 1_000_000, 200, 2024
 if os.environ.get("GRAM_PROBE_WORKLOAD") == "c3shard":  # one GPU's share of BASELINE config 3
     V, D, k, seed = 100_000, 1_250_000, 1000, 31337
+if os.environ.get("GRAM_PROBE_WORKLOAD") == "c3full":  # all of BASELINE config 3
+    V, D, k, seed = 100_000, 10_000_000, 1000, 31337
 B = Corpus(V, D, k, seed).threshold(k, free_A=True)
 hp = HotPath(0)
 X = np.random.default_rng(0).standard_normal((V, 10)).astype(np.float32)
@@ -29,11 +31,12 @@ for setting in (sys.argv[1:] or [""]):
         ref = Z
     hp.timing_enable(True)
     hp.timing_reset()
-    for _ in range(20):
+    reps = 20 if D < 5_000_000 else 6
+    for _ in range(reps):
         hp.gram_apply(X)
     t = hp.timing_get()
     err = float(np.linalg.norm(Z - ref) / np.linalg.norm(ref))
-    print("%-40s form=%d pass1 %.4f ms  pass2 %.4f ms  (relerr vs first %.1e)" % (setting or "(default)", hp.operator_form(),
-          t["gram_pass1"][0] / 20, t["gram_pass2"][0] / 20, err), flush=True)
+    print("%-40s form=%d pass1 %.4f ms  pass2 %.4f ms  op_build %.1f ms (relerr vs first %.1e)" % (setting or "(default)", hp.operator_form(),
+          t["gram_pass1"][0] / reps, t["gram_pass2"][0] / reps, t["op_build"][0] if "op_build" in t else -1.0, err), flush=True)
     for a, b in kv:
         del os.environ[a]
