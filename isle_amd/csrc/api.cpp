@@ -1826,6 +1826,8 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   const bool hamerly = !nobounds;                                   // any bound-based mode
   const bool yinyang = hamerly && !(bmode && !strcmp(bmode, "hamerly"));
   const int G = (k + 7) / 8;
+  int yy_mode_env = -1;  // form of the Yinyang iteration: 0 = by document over the row-major centres, 1 = by document over the group-major copy, 2 = by group
+  if (const char* e = getenv("ISLE_YY_MODE")) yy_mode_env = !strcmp(e, "doc") ? 0 : !strcmp(e, "docg") ? 1 : !strcmp(e, "group") ? 2 : -1;
   if (yinyang) HIPCHK(c, c->yglb.reserve((size_t)(D ? D : 1) * G + 64));
   float* gmax_dev = nullptr;
   HIPCHK(c, c->hub.reserve(D ? D : 1));
@@ -1880,22 +1882,39 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
         ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
       }
       uint32_t* nact = c->active.p + D;
-      ISLECHK(k_yy_filter(c, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
+      // large k: the centres also group-major (one 32-byte-row table per group) and the active documents grouped by their own group
+      // (the member lists), so that waves running together gather from one table in L2; ISLE_YY_MODE = doc | docg | group picks the form
+      // (measured, Lloyd on B per step: C3 shard 176 ms by document -> 112 ms by group, all of config 3 on one GPU 825 -> 588 ms; at C2,
+      // G = 25 and a 40 MB table, the three forms are within 10 % of each other and the plain one stays)
+      const int yy_mode = yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
+      const uint32_t* order = yy_mode && c->members_valid ? c->members.p : nullptr;
+      if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
+      ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
       const bool dbg = getenv("ISLE_DEBUG_HAMERLY") != nullptr;
       unsigned long long* dbg_dev = nullptr;
-      if (dbg) {  // diagnostic only: group scans and gathered nonzeros of this iteration (behind the partial norms nobody reads here)
+      if (dbg) {  // diagnostic only: group scans and gathered nonzeros of this iteration
         HIPCHK(c, c->dbg_cnt.reserve(2));
         HIPCHK(c, hipMemsetAsync(c->dbg_cnt.p, 0, 16, c->stream));
         dbg_dev = c->dbg_cnt.p;
       }
-      ISLECHK(k_yy_scan(c, c->centers_rm.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, dbg_dev));
+      bool done = false;
+      unsigned long long npairs = 0;
+      if (yy_mode == 2)
+        ISLECHK(k_yy2_assign(c, c->yy_cg.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, &done, &npairs));
+      if (!done)
+        ISLECHK(k_yy_scan(c, c->centers_rm.p, yy_mode ? c->yy_cg.p : nullptr, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p,
+                          c->hub.p, c->yglb.p, dbg_dev));
       if (dbg) {
         uint32_t na = 0;
         unsigned long long cnt[2] = {0, 0};
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(cnt, dbg_dev, 16, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[yinyang] iter %d active %u of %llu; group scans %llu (%.1f per active document, of %d), gathered nonzeros %llu\n", it, na,
-                (unsigned long long)D, cnt[0], na ? (double)cnt[0] / na : 0.0, G, cnt[1]);
+        if (done)
+          fprintf(stderr, "[yinyang] iter %d active %u of %llu; by group: %llu pairs beside the own-group scans (%.1f per active document, of %d)\n", it, na,
+                  (unsigned long long)D, npairs, na ? (double)npairs / na : 0.0, G);
+        else
+          fprintf(stderr, "[yinyang] iter %d active %u of %llu; group scans %llu (%.1f per active document, of %d), gathered nonzeros %llu\n", it, na,
+                  (unsigned long long)D, cnt[0], na ? (double)cnt[0] / na : 0.0, G, cnt[1]);
       }
     } else {
       uint32_t* nact = c->active.p + D;

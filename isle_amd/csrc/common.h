@@ -232,6 +232,12 @@ struct isle_ctx {
   DevBuf<float> seg_part;  // one partial row per chunk
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<unsigned long long> dbg_cnt;  // diagnostics (ISLE_DEBUG_HAMERLY)
+  // Yinyang iteration ordered by group (spmm.hip, k_yy2_assign)
+  DevBuf<float> yy_cg;                 // centres group-major: G tables of V x 8 floats
+  DevBuf<uint32_t> yy_own, yy_res;     // YyRes (3 words) per active slot / per pair
+  DevBuf<unsigned long long> yy_need;  // per active slot: bit mask of the groups to scan
+  DevBuf<uint32_t> yy_cnt, yy_off;     // pairs per active slot, their exclusive scan
+  DevBuf<uint8_t> yy_pgrp;             // group of every pair (slot-major order)
   DevBuf<float> centers_old;  // V x ldk
   DevBuf<float> Pa, pna, Cold; // compacted active rows (ldk x n), their norms, previous projected centres
 
@@ -316,10 +322,13 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
                        const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
                        float* ub = nullptr, float* lb = nullptr, int G = 0 /*> 0: lb holds G Yinyang group bounds per document*/);
-int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev, uint32_t* active,
-                uint32_t* nactive);
-int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
-              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr);
+int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
+                uint32_t* active, uint32_t* nactive);
+int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G);  // c->yy_cg = the centres group-major (V x 8 floats per group)
+int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg /*nullable*/, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev,
+              const uint32_t* active, const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr);
+int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
+                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out = nullptr);
 struct HamTop {  // largest and second largest centre movement of an iteration (Hamerly's bound update), device resident
   uint32_t amax;
   float d1, d2, pad;

@@ -862,29 +862,43 @@ int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
 // overlaps its upper bound.  A group is 32 bytes of a centre row, so a group scan gathers one 32-byte piece per nonzero
 // of the document instead of the whole k-wide row.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb, int G,
+__global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* __restrict__ order /*nullable: visiting order*/,
+                                                    const uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb, int G,
                                                     const float* __restrict__ delta, const float* __restrict__ gmax, uint32_t* __restrict__ active,
                                                     uint32_t* __restrict__ nactive, int docs_per_block) {
-  // The group bounds of a block of documents are one contiguous run of docs x G floats: lowered by the group movements and
-  // written back with coalesced accesses through an LDS tile (a thread walking its own document's G floats touches a
-  // different cache line per lane: 0.30 ms per call at C2), then one thread per document takes the minimum from the tile
-  // (stride G words: conflict-free for odd G, 2-way at worst).
+  // The group bounds of a block of documents are lowered by the group movements and written back through an LDS tile with
+  // coalesced accesses (a thread walking its own document's G floats touches a different cache line per lane: 0.30 ms per call at
+  // C2), then one thread per document takes the minimum from the tile (stride G words: conflict-free for odd G, 2-way at worst).
+  // Without `order` the block's bounds are one contiguous run of docs x G floats; with it (documents grouped by their centre, so that
+  // the active list comes out grouped by Yinyang group: k_yy2_assign) every document's G floats are a run of their own.
   extern __shared__ float tile[];  // docs_per_block x G
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
   const uint32_t nd = min((uint32_t)docs_per_block, D - d0);
   const uint32_t nel = nd * (uint32_t)G;
-  float* src = glb + (size_t)d0 * G;
-  for (uint32_t i = threadIdx.x; i < nel; i += 256) {
-    float l = src[i] - gmax[i % (uint32_t)G] * 1.000001f;
-    l = l > 0.f ? l * 0.999999f : l;
-    src[i] = l;
-    tile[i] = l;
+  {
+    // (document j, group g) of element i = threadIdx.x + 256 t, stepped without a division per element
+    uint32_t j = threadIdx.x / (uint32_t)G, g = threadIdx.x - j * (uint32_t)G;
+    const uint32_t sj = 256u / (uint32_t)G, sg = 256u - sj * (uint32_t)G;
+    for (uint32_t i = threadIdx.x; i < nel; i += 256) {
+      float* src = glb + (size_t)(order ? order[d0 + j] : d0 + j) * G + g;
+      float l = *src - gmax[g] * 1.000001f;
+      l = l > 0.f ? l * 0.999999f : l;
+      *src = l;
+      tile[i] = l;
+      j += sj;
+      g += sg;
+      if (g >= (uint32_t)G) {
+        g -= (uint32_t)G;
+        ++j;
+      }
+    }
   }
   __syncthreads();
   for (uint32_t j0 = 0; j0 < (uint32_t)docs_per_block; j0 += 256) {  // the same trip count for every thread: block_append_slot synchronises
     const uint32_t j = j0 + threadIdx.x;
     const bool in = j < nd;
-    const uint32_t d = d0 + (in ? j : 0u);
+    uint32_t d = d0 + (in ? j : 0u);
+    if (order) d = order[d];
     float u = 0.f, lmin = 3.4e38f;
     if (in) {
       u = (ub[d] + delta[assign[d]]) * 1.000001f;
@@ -939,64 +953,57 @@ __device__ inline float yy_parity_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
-                                                  const float* __restrict__ C /*V x ld row-major*/, int ld, int k, int G, const float* __restrict__ cn,
-                                                  const float* __restrict__ dn, const float* __restrict__ cn_max_p, const uint32_t* __restrict__ active,
-                                                  const uint32_t* __restrict__ nactive, uint32_t* __restrict__ assign, float* __restrict__ ub,
-                                                  float* __restrict__ glb, unsigned long long* __restrict__ dbg /*nullable: [0] group scans, [1] their nonzeros*/) {
-  const int lane = threadIdx.x & 63;
-  uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  slot = __builtin_amdgcn_readfirstlane(slot);
-  if (slot >= *nactive) return;
-  const uint32_t d = __builtin_amdgcn_readfirstlane(active[slot]);
-  const int64_t beg = offs[d], end = offs[d + 1];
-  const float dnd = dn[d];
-  const uint32_t a = assign[d];
-  const int ga = (int)(a / YY_GROUP);
-  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
-  const int q = lane & 1, e = lane >> 1;
-  float* gl = glb + (size_t)d * G;
-
-  // the document's entries, fetched once (not once per scanned group) while it has at most 64 * YY_NCH of them
-  constexpr int YY_NCH = 4;
-  const int len = (int)(end - beg);
-  const bool small = len <= 64 * YY_NCH;  // wave-uniform
+// a document's entries held by the wave (fetched once, not once per scanned group, while it has at most 64 * YY_NCH of them)
+constexpr int YY_NCH = 4;
+struct YyDoc {
+  int64_t beg, end;
+  int len;
+  bool small;  // wave-uniform
   uint32_t rrow[YY_NCH];
   float rval[YY_NCH];
+};
+__device__ inline YyDoc yy_load_doc(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint32_t d,
+                                    int lane) {
+  YyDoc dc;
+  dc.beg = offs[d];
+  dc.end = offs[d + 1];
+  dc.len = (int)(dc.end - dc.beg);
+  dc.small = dc.len <= 64 * YY_NCH;
 #pragma unroll
   for (int ch = 0; ch < YY_NCH; ++ch) {
-    const bool in = small && 64 * ch + lane < len;
-    rrow[ch] = in ? rows[beg + 64 * ch + lane] : 0u;
-    rval[ch] = in ? vals[beg + 64 * ch + lane] : 0.f;
+    const bool in = dc.small && 64 * ch + lane < dc.len;
+    dc.rrow[ch] = in ? rows[dc.beg + 64 * ch + lane] : 0u;
+    dc.rval[ch] = in ? vals[dc.beg + 64 * ch + lane] : 0.f;
   }
-  // distances of the document to the YY_GROUP centres of group g; lane parity q holds centres 8g+4q .. 8g+4q+3
-  auto scan_group = [&](int g, float dist[4]) {
-    const int col = YY_GROUP * g + 4 * q;
-    const float live = (col < ld) ? 1.f : 0.f;
-    const float4* base = reinterpret_cast<const float4*>(C + min(col, ld - 4));
-    const size_t rstride = (size_t)ld / 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (small) {
-      // all gathers of the group in flight together (the loop below keeps two): same products, same order of accumulation
-      float4 gv[2 * YY_NCH];
+  return dc;
+}
+// distances of the document to the YY_GROUP centres of one group; lane parity q holds centres 8g + 4q .. 8g + 4q + 3.  `base` = the
+// group's float4 of row 0 for this parity, `rstride` = row stride in float4 (the row-major centres: ld / 4; the group-major copy: 2)
+__device__ inline void yy_group_dists(const YyDoc& dc, const float* __restrict__ vals, const uint32_t* __restrict__ rows, const float4* __restrict__ base,
+                                      size_t rstride, float live, int lane, int col, int k, const float* __restrict__ cn, float dnd, float dist[4]) {
+  const int e = lane >> 1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dc.small) {
+    // all gathers of the group in flight together (the loop below keeps two): same products, same order of accumulation
+    float4 gv[2 * YY_NCH];
 #pragma unroll
-      for (int s2 = 0; s2 < 2 * YY_NCH; ++s2) {
-        gv[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (32 * s2 < len) {  // wave-uniform
-          const uint32_t r = __shfl(rrow[s2 >> 1], (s2 & 1) * 32 + e);
-          gv[s2] = base[(size_t)r * rstride];
-        }
+    for (int s2 = 0; s2 < 2 * YY_NCH; ++s2) {
+      gv[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (32 * s2 < dc.len) {  // wave-uniform
+        const uint32_t r = __shfl(dc.rrow[s2 >> 1], (s2 & 1) * 32 + e);
+        gv[s2] = base[(size_t)r * rstride];
       }
+    }
 #pragma unroll
-      for (int s2 = 0; s2 < 2 * YY_NCH; ++s2) {
-        if (32 * s2 < len) {
-          const float v = __shfl(rval[s2 >> 1], (s2 & 1) * 32 + e) * live;  // 0 beyond the document's end
-          acc = f4_fma(v, gv[s2], acc);
-        }
+    for (int s2 = 0; s2 < 2 * YY_NCH; ++s2) {
+      if (32 * s2 < dc.len) {
+        const float v = __shfl(dc.rval[s2 >> 1], (s2 & 1) * 32 + e) * live;  // 0 beyond the document's end
+        acc = f4_fma(v, gv[s2], acc);
       }
-    } else
-    for (int64_t b0 = beg; b0 < end; b0 += 64) {
-      const int cnt = (int)min((int64_t)64, end - b0);
+    }
+  } else {
+    for (int64_t b0 = dc.beg; b0 < dc.end; b0 += 64) {
+      const int cnt = (int)min((int64_t)64, dc.end - b0);
       const uint32_t myrow = (lane < cnt) ? rows[b0 + lane] : 0u;
       const float myval = (lane < cnt) ? vals[b0 + lane] : 0.f;
 #pragma unroll
@@ -1008,26 +1015,55 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
         }
       }
     }
-    // sum over the 32 lanes of equal parity: inside a DPP row by data-parallel moves that keep the parity (swap quad halves,
-    // rotate by 4, rotate by 8), across the four rows by two ds_bpermute steps (five of those per value before)
-    acc.x = yy_parity_sum(acc.x);
-    acc.y = yy_parity_sum(acc.y);
-    acc.z = yy_parity_sum(acc.z);
-    acc.w = yy_parity_sum(acc.w);
-    const float aa[4] = {acc.x, acc.y, acc.z, acc.w};
+  }
+  // sum over the 32 lanes of equal parity: inside a DPP row by data-parallel moves that keep the parity (swap quad halves,
+  // rotate by 4, rotate by 8), across the four rows by two ds_bpermute steps (five of those per value before)
+  acc.x = yy_parity_sum(acc.x);
+  acc.y = yy_parity_sum(acc.y);
+  acc.z = yy_parity_sum(acc.z);
+  acc.w = yy_parity_sum(acc.w);
+  const float aa[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cc = min(col + j, k - 1);
-      dist[j] = fabsf((-2.0f * aa[j] + cn[cc]) + dnd);
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int cc = min(col + j, k - 1);
+    dist[j] = fabsf((-2.0f * aa[j] + cn[cc]) + dnd);
+  }
+}
+__device__ inline float yy_slack_down(float m, float E, float sE) {  // lower bound from a squared distance
+  const float l = sqrtf(m);
+  return fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+}
+
+__global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                  const float* __restrict__ C /*V x ld row-major*/, const float4* __restrict__ Cg /*nullable: group-major copy*/,
+                                                  uint32_t V, int ld, int k, int G, const float* __restrict__ cn,
+                                                  const float* __restrict__ dn, const float* __restrict__ cn_max_p, const uint32_t* __restrict__ active,
+                                                  const uint32_t* __restrict__ nactive, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                  float* __restrict__ glb, unsigned long long* __restrict__ dbg /*nullable: [0] group scans, [1] their nonzeros*/) {
+  const int lane = threadIdx.x & 63;
+  uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (slot >= *nactive) return;
+  const uint32_t d = __builtin_amdgcn_readfirstlane(active[slot]);
+  const float dnd = dn[d];
+  const uint32_t a = assign[d];
+  const int ga = (int)(a / YY_GROUP);
+  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+  const int q = lane & 1;
+  float* gl = glb + (size_t)d * G;
+  const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
+  auto scan_group = [&](int g, float dist[4]) {
+    const int col = YY_GROUP * g + 4 * q;
+    const float live = (col < ld) ? 1.f : 0.f;
+    if (Cg) yy_group_dists(dc, vals, rows, Cg + (size_t)g * V * 2 + q, 2, live, lane, col, k, cn, dnd, dist);  // one 32-byte-row table per group
+    else yy_group_dists(dc, vals, rows, reinterpret_cast<const float4*>(C + min(col, ld - 4)), (size_t)ld / 4, live, lane, col, k, cn, dnd, dist);
   };
 
   float best = 3.4e38f, best_group_second = 3.4e38f;
   uint32_t bidx = 0xffffffffu;
   auto absorb = [&](int g, const YyTop2& t) {
     // provisional bound of the group: its closest centre; the group of the final assignment is fixed up at the end
-    const float l = sqrtf(t.m1);
-    if (lane == 0) gl[g] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+    if (lane == 0) gl[g] = yy_slack_down(t.m1, E, sE);
     if (t.m1 < best || (t.m1 == best && t.i1 < bidx)) {
       best = t.m1;
       bidx = t.i1;
@@ -1051,37 +1087,239 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
   }
   if (dbg && lane == 0) {
     atomicAdd(dbg, (unsigned long long)nscan);
-    atomicAdd(dbg + 1, (unsigned long long)nscan * (unsigned long long)len);
+    atomicAdd(dbg + 1, (unsigned long long)nscan * (unsigned long long)dc.len);
   }
   if (lane == 0) {
     const float u = sqrtf(best);
     ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
     assign[d] = bidx;
-    const float l = sqrtf(best_group_second);             // the assigned centre does not bound its own group
-    gl[bidx / YY_GROUP] = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+    gl[bidx / YY_GROUP] = yy_slack_down(best_group_second, E, sE);  // the assigned centre does not bound its own group
   }
 }
 
-int k_yy_filter(isle_ctx* c, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev, uint32_t* active,
-                uint32_t* nactive) {
+// ------------------------------------------------------------------------------------------
+// The same Yinyang iteration ordered by GROUP instead of by document (large k).  yy_scan_k walks a document's groups one after the
+// other, each scan a gather of 32-byte pieces of 4 KB centre rows: at k = 1000 the 400 MB of centres sit in HBM, every piece costs a
+// DRAM access and every scan of a document waits for the one before it.  Here
+//   (1) the centres are copied group-major (Cg[g][w][8]: one 32-byte-row table of V x 32 bytes per group, 3.2 MB at V = 100k);
+//   (2) the active documents arrive grouped by their own group (yy_filter_k over the member lists) and every one scans its OWN group
+//       (the tightening step): waves running together gather from one table, which stays in L2;
+//   (3) with the upper bound that step leaves, the other groups whose lower bound it reaches become (group, document) pairs — the
+//       test Ding et al. make, not narrowed group by group as yy_scan_k does (a superset: exact either way);
+//   (4) the pairs are sorted by group (one radix pass) and scanned in that order: again one table at a time in L2;
+//   (5) a last pass folds a document's scans together in ascending group order — the assignment (first index among equal minima),
+//       the upper bound and the bounds of the scanned groups exactly as yy_scan_k leaves them.
+// Per (document, group) the distances are the same sums in the same order as yy_scan_k's (yy_group_dists).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void yy2_pack_k(const float* __restrict__ Crm, uint32_t V, int ld, int G, float4* __restrict__ Cg) {
+  // Cg[(g * V + w) * 2 + q] = Crm[w * ld + 8 g + 4 q .. + 3] (zero beyond ld); consecutive threads read consecutive float4 of a row
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nq = 2 * G;
+  if (i >= (size_t)V * nq) return;
+  const uint32_t w = (uint32_t)(i / nq);
+  const int gq = (int)(i - (size_t)w * nq);
+  const int col = 4 * gq;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < ld) v = *reinterpret_cast<const float4*>(Crm + (size_t)w * ld + col);
+  Cg[((size_t)(gq >> 1) * V + w) * 2 + (gq & 1)] = v;
+}
+
+struct YyRes {  // top two of one group scan
+  float m1, m2;
+  uint32_t i1;
+};
+
+// (2) + (3): wave per active slot.  own[e] = the scan of the document's own group; need[e * NW + j] = bit mask of the other groups to
+// scan; cnt[e] = their number
+__global__ __launch_bounds__(256) void yy2_tighten_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                      const float4* __restrict__ Cg, uint32_t V, int ld, int k, int G, int NW, const float* __restrict__ cn,
+                                                      const float* __restrict__ dn, const float* __restrict__ cn_max_p,
+                                                      const uint32_t* __restrict__ active, const uint32_t* __restrict__ nactive,
+                                                      const uint32_t* __restrict__ assign, const float* __restrict__ glb, YyRes* __restrict__ own,
+                                                      unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (slot >= *nactive) return;
+  const uint32_t d = __builtin_amdgcn_readfirstlane(active[slot]);
+  const float dnd = dn[d];
+  const int ga = (int)(assign[d] / YY_GROUP);
+  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+  const int q = lane & 1;
+  const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
+  const int col = YY_GROUP * ga + 4 * q;
+  float dist[4];
+  yy_group_dists(dc, vals, rows, Cg + (size_t)ga * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
+  const YyTop2 t = yy_group_top2(dist, col, k);
+  const float u = sqrtf(t.m1);
+  const float uhi = u + fminf(sE, E / fmaxf(u, 1e-30f));
+  const float* gl = glb + (size_t)d * G;
+  uint32_t total = 0;
+  for (int j = 0; j < NW; ++j) {
+    const int g = 64 * j + lane;
+    const bool nd = g < G && g != ga && gl[g] <= uhi;
+    const unsigned long long m = __ballot(nd);
+    total += (uint32_t)__popcll(m);
+    if (lane == 0) need[(size_t)slot * NW + j] = m;
+  }
+  if (lane == 0) {
+    own[slot] = YyRes{t.m1, t.m2, t.i1};
+    cnt[slot] = total;
+  }
+}
+
+// pairs of slot e at off[e] ..: key = document << 8 | group (sorted on the low 8 bits only: stable, so a group's pairs keep the slot order),
+// val = pair index, pgrp = group (ascending inside a slot)
+__global__ __launch_bounds__(256) void yy2_emit_k(const uint32_t* __restrict__ nactive, const uint32_t* __restrict__ active,
+                                                   const unsigned long long* __restrict__ need, int NW,
+                                                   const uint32_t* __restrict__ off, uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                   uint8_t* __restrict__ pgrp) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= *nactive) return;
+  const uint64_t d = active[e];
+  uint32_t p = off[e];
+  for (int j = 0; j < NW; ++j) {
+    unsigned long long m = need[(size_t)e * NW + j];
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      key[p] = (d << 8) | (uint64_t)(64 * j + b);
+      val[p] = p;
+      pgrp[p] = (uint8_t)(64 * j + b);
+      ++p;
+    }
+  }
+}
+
+// (4): wave per pair, in group order
+__global__ __launch_bounds__(256) void yy2_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                   const float4* __restrict__ Cg, uint32_t V, int ld, int k, const float* __restrict__ cn,
+                                                   const float* __restrict__ dn, uint32_t npairs, const uint64_t* __restrict__ key,
+                                                   const uint32_t* __restrict__ val, YyRes* __restrict__ res) {
+  const int lane = threadIdx.x & 63;
+  uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  i = __builtin_amdgcn_readfirstlane(i);
+  if (i >= npairs) return;
+  const uint64_t kd = key[i];
+  const int g = (int)__builtin_amdgcn_readfirstlane((uint32_t)(kd & 0xffu));
+  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(kd >> 8));
+  const uint32_t p = __builtin_amdgcn_readfirstlane(val[i]);
+  const float dnd = dn[d];
+  const int q = lane & 1;
+  const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
+  const int col = YY_GROUP * g + 4 * q;
+  float dist[4];
+  yy_group_dists(dc, vals, rows, Cg + (size_t)g * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
+  const YyTop2 t = yy_group_top2(dist, col, k);
+  if (lane == 0) res[p] = YyRes{t.m1, t.m2, t.i1};
+}
+
+// (5): thread per active slot
+__global__ __launch_bounds__(256) void yy2_combine_k(const uint32_t* __restrict__ nactive, const uint32_t* __restrict__ active, const YyRes* __restrict__ own,
+                                                      const uint32_t* __restrict__ off, const uint8_t* __restrict__ pgrp,
+                                                      const YyRes* __restrict__ res, const float* __restrict__ dn, const float* __restrict__ cn_max_p, int G,
+                                                      uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= *nactive) return;
+  const uint32_t d = active[e];
+  const float E = 1e-4f * (dn[d] + *cn_max_p), sE = sqrtf(E);
+  float* gl = glb + (size_t)d * G;
+  const int ga = (int)(assign[d] / YY_GROUP);
+  float best = 3.4e38f, best_group_second = 3.4e38f;
+  uint32_t bidx = 0xffffffffu;
+  auto absorb = [&](int g, const YyRes& t) {
+    gl[g] = yy_slack_down(t.m1, E, sE);
+    if (t.m1 < best || (t.m1 == best && t.i1 < bidx)) {
+      best = t.m1;
+      bidx = t.i1;
+      best_group_second = t.m2;
+    }
+  };
+  absorb(ga, own[e]);
+  for (uint32_t p = off[e]; p < off[e + 1]; ++p) absorb((int)pgrp[p], res[p]);
+  const float u = sqrtf(best);
+  ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+  assign[d] = bidx;
+  gl[bidx / YY_GROUP] = yy_slack_down(best_group_second, E, sE);  // the assigned centre does not bound its own group
+}
+
+int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
+                uint32_t* active, uint32_t* nactive) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D;
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
   int dpb = 256;
   while (dpb > 32 && (size_t)dpb * G * sizeof(float) > 64 * 1024) dpb /= 2;  // LDS tile of at most 64 KB
-  hipLaunchKernelGGL(yy_filter_k, dim3(cdiv(D, dpb)), dim3(256), (size_t)dpb * G * sizeof(float), c->stream, D, assign, ub, glb, G, delta_dev,
+  hipLaunchKernelGGL(yy_filter_k, dim3(cdiv(D, dpb)), dim3(256), (size_t)dpb * G * sizeof(float), c->stream, D, order, assign, ub, glb, G, delta_dev,
                      gmax_dev, active, nactive, dpb);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-int k_yy_scan(isle_ctx* c, const float* Crm, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
+int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  const uint32_t V = (uint32_t)c->V;
+  HIPCHK(c, c->yy_cg.reserve((size_t)V * 8 * G));
+  const size_t n = (size_t)V * 2 * G;
+  hipLaunchKernelGGL(yy2_pack_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, Crm, V, ld, G, (float4*)c->yy_cg.p);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
               const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
-  hipLaunchKernelGGL(yy_scan_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, Crm, ld, k, G, cn, dn, cn_max, active,
-                     nactive, assign, ub, glb, dbg);
+  hipLaunchKernelGGL(yy_scan_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, Crm, (const float4*)Cg, (uint32_t)c->V, ld, k, G,
+                     cn, dn, cn_max, active, nactive, assign, ub, glb, dbg);
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// The Yinyang iteration ordered by group (see the kernels): active -> assign / ub / glb.  *done = false if the pair list would be too
+// long (more than 48 pairs per document) — nothing has been changed then and the caller runs yy_scan_k instead.
+int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
+                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  *done = false;
+  const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
+  if (D == 0 || G > 256) return 0;
+  const int NW = cdiv(G, 64);
+  HIPCHK(c, c->yy_own.reserve((size_t)D * 3));
+  HIPCHK(c, c->yy_need.reserve((size_t)D * NW));
+  HIPCHK(c, c->yy_cnt.reserve((size_t)D + 1));
+  HIPCHK(c, c->yy_off.reserve((size_t)D + 2));
+  HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(D) + 8));
+  HIPCHK(c, hipMemsetAsync(c->yy_cnt.p, 0, ((size_t)D + 1) * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(yy2_tighten_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, G, NW, cn, dn,
+                     cn_max, active, nactive, assign, glb, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p, c->yy_cnt.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, uint32_t>(c->stream, c->yy_cnt.p, D, c->yy_off.p, reinterpret_cast<uint32_t*>(c->gl_scan.p))));
+  uint32_t npairs = 0;
+  HIPCHK(c, hipMemcpyAsync(&npairs, c->yy_off.p + D, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (pairs_out) *pairs_out = npairs;
+  if ((uint64_t)npairs > 48ull * D) return 0;
+  if (npairs) {
+    const size_t np = npairs;
+    HIPCHK(c, c->gl_key_a.reserve(np));
+    HIPCHK(c, c->gl_key_b.reserve(np));
+    HIPCHK(c, c->gl_val_a.reserve(np));
+    HIPCHK(c, c->gl_val_b.reserve(np));
+    HIPCHK(c, c->yy_pgrp.reserve(np));
+    HIPCHK(c, c->yy_res.reserve(np * 3));
+    hipLaunchKernelGGL(yy2_emit_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, nactive, active, (const unsigned long long*)c->yy_need.p, NW, c->yy_off.p,
+                       c->gl_key_a.p, c->gl_val_a.p, c->yy_pgrp.p);
+    HIPCHK(c, hipGetLastError());
+    bool in_a = true;
+    ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, np, 8, &in_a));
+    hipLaunchKernelGGL(yy2_scan_k, dim3(cdiv((long)np, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, cn, dn,
+                       npairs, in_a ? c->gl_key_a.p : c->gl_key_b.p, in_a ? c->gl_val_a.p : c->gl_val_b.p, (YyRes*)c->yy_res.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(yy2_combine_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, nactive, active, (const YyRes*)c->yy_own.p, c->yy_off.p, c->yy_pgrp.p,
+                     (const YyRes*)c->yy_res.p, dn, cn_max, G, assign, ub, glb);
+  HIPCHK(c, hipGetLastError());
+  *done = true;
   return 0;
 }
