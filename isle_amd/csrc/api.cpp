@@ -30,13 +30,65 @@ int isle_fail(isle_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
-// May the optional D x k scratch of the GEMM routes be taken?  Always up to 8 GB; beyond (all of config 3 on one GPU: 40 GB), when it
-// is there already or the device still has 32 GB to spare after it.
+// every environment switch of the library (common.h IsleKnob); DESIGN.md tables them with the measurements behind the defaults
+const IsleKnobInfo isle_knob_table[KN_COUNT] = {
+    {"ISLE_GRAM_LDS", "form", "0: Gram apply and k-wide products by the row-gather kernels (any CSC matrix) instead of the LDS-banded form (row-constant B)"},
+    {"ISLE_GL_G1", "tuning", "4..8: output items per lane in pass 1 of the LDS-banded form (default: makespan model, gram_lds.hip)"},
+    {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4)"},
+    {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
+    {"ISLE_GL_PANEL", "tuning", "12: twelve columns per pass of the k-wide / thin products instead of eight"},
+    {"ISLE_WIDE_GATHER", "form", "k-wide products (projection, first word-space assignment) by the row-gather kernel"},
+    {"ISLE_WIDE_LDS", "form", "k-wide products through the LDS-banded pass-1 stream whatever the vocabulary size"},
+    {"ISLE_KS_ROWSHARD", "form", "1: several ranks orthogonalise row slices of the Krylov block (all-reduced coefficients, all-gathered block); default 0 = replicated"},
+    {"ISLE_KS_SYNC", "form", "expand loop without the speculative pipeline (one host synchronisation per step)"},
+    {"ISLE_KS_ORTHO_PASSES", "form", "3: the reference's three Gram-Schmidt passes per Krylov step instead of two"},
+    {"ISLE_QR_FUSED", "form", "1: panel QR as one persistent launch (bitwise equal to the kernel chain, no faster)"},
+    {"ISLE_EVD_JACOBI", "form", "small symmetric EVD by block Jacobi instead of tridiagonalisation"},
+    {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},
+    {"ISLE_KMPP_HOST_DICE", "form", "k-means++ dice scaled and searched through the host round trip (the multi-rank form) on one rank too"},
+    {"ISLE_KMPP_SPARSE", "form", "0 / 1: k-means++ rounds on the projection / through thin products of B (default: by cost)"},
+    {"ISLE_NO_HAMERLY", "form", "both Lloyd loops without distance bounds (every document re-examined every iteration)"},
+    {"ISLE_KMEANS_BOUNDS", "form", "hamerly | none: bounds of Lloyd on B (default Yinyang group bounds)"},
+    {"ISLE_PROJ_BOUNDS", "form", "hamerly: single lower bound in the projected Lloyd loop at k > 224 instead of tile bounds"},
+    {"ISLE_PROJ_FULL", "form", "gemm | fused: full passes of the projected Lloyd loop as GEMM + epilogue or as the fused register kernel"},
+    {"ISLE_FIRST_ASSIGN", "form", "sparse | projection: first assignment of Lloyd on B through the sparse product or through the projection"},
+    {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
+    {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
+    {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},
+    {"ISLE_CHUNK_COLS", "tuning", "gather form: rows per chunk of the chunked-CSR copy"},
+    {"ISLE_FORCE_COMM", "test hook", "create a 1-rank RCCL communicator so that every collective call site runs on one GPU"},
+    {"ISLE_HOST_TRACE", "diagnostic", "print host wall time between marks of the control loops"},
+    {"ISLE_DEBUG_HAMERLY", "diagnostic", "print active documents / group scans per Lloyd iteration"},
+    {"ISLE_DEBUG_EVD", "diagnostic", "print sweeps / orthogonality defect of the small EVD"},
+    {"ISLE_GL_VERBOSE", "diagnostic", "print the geometry of the LDS-banded operator build"},
+    {"ISLE_TD_FORCE_BAIL_RANK", "test hook", "this rank behaves as if the grid barrier of its persistent EVD had timed out"},
+};
+void isle_refresh_knobs(isle_ctx* c) {
+  for (int i = 0; i < KN_COUNT; ++i) {
+    const char* e = getenv(isle_knob_table[i].name);
+    c->knob_set[i] = e != nullptr;
+    if (e) c->knob_val[i] = e;
+    else c->knob_val[i].clear();
+  }
+}
+int isle_enter(isle_ctx* c) {
+  ISLECHK(isle_enter(c));
+  isle_refresh_knobs(c);
+  return 0;
+}
+
+// May the optional D x k scratch of the GEMM routes be taken?  A function of the problem's size and the device's TOTAL memory only —
+// never of what happens to be free — so that the route, and with it every rounding of the first assignment, is the same run after run
+// and rank after rank: always up to 8 GB; beyond (all of config 3 on one GPU: 40 GB), up to a fifth of the device (57 GB on an MI355X).
 bool isle_scratch_ok(isle_ctx* c, size_t have_elems, double bytes) {
-  if (bytes <= 8e9 || (double)have_elems * sizeof(float) >= bytes) return true;
-  size_t fr = 0, tot = 0;
-  if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
-  return (double)fr >= bytes + 32e9;
+  (void)have_elems;
+  if (bytes <= 8e9) return true;
+  if (c->total_mem == 0) {
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    c->total_mem = tot;
+  }
+  return bytes <= 0.2 * (double)c->total_mem;
 }
 
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes) {
@@ -219,7 +271,12 @@ struct HostRng {
     return v;
   }
   uint32_t next31() { return step() >> 1; }  // rand(): 0 .. RAND_MAX = 2^31 - 1
-  double fraction() {  // include/matUtils.h:473-477
+  // include/matUtils.h:473-477: (double)rand() + (double)rand() * (RAND_MAX + 1), over (RAND_MAX + 1)^2.  The two rand() calls of that
+  // expression are UNSEQUENCED in C++: which of them supplies the low word is the reference compiler's choice.  Assumed here: the left
+  // operand is evaluated first (what g++ does for this expression at -O3 — the only arrangement under which rng_seed = 1 reproduces an
+  // unseeded reference binary's dice); with the other order the low and high words swap.  Un-injected seeds are not promised equal to
+  // a reference run's in any case, which is why the parity tests inject them.
+  double fraction() {
     const double R1 = 2147483648.0;
     const double lo = (double)next31();
     const double hi = (double)next31();
@@ -255,10 +312,6 @@ HMat hsub(const HMat& m, size_t r0, size_t c0, size_t r1, size_t c1) {  // inclu
 }  // namespace
 
 static int round4(int k) { return (k + 3) & ~3; }
-static bool getenv_is_zero(const char* name) {
-  const char* e = getenv(name);
-  return e && atoi(e) == 0;
-}
 
 // rows [r0, r0 + nl) of a column-major n x w matrix <-> a packed nloc x w block (rows beyond nl zero)
 __global__ void slice_rows_k(float* __restrict__ M, uint64_t n, int w, uint64_t r0, uint64_t nl, uint64_t nloc, float* __restrict__ blk, int pack) {
@@ -299,8 +352,8 @@ extern "C" isle_ctx* isle_hip_create(int device_id) {
     delete c;
     return nullptr;
   }
-  const char* br = getenv("ISLE_CHUNK_COLS");
-  if (br) c->band_rows = (uint32_t)atoi(br);
+  isle_refresh_knobs(c);
+  if (const char* br = c->knob(KN_CHUNK_COLS)) c->band_rows = (uint32_t)atoi(br);
   if (hipHostMalloc((void**)&c->pin, isle_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -347,8 +400,9 @@ extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* 
   c->rank = rank;
   // world == 1 needs no communicator; ISLE_FORCE_COMM=1 creates a 1-rank one anyway so that every RCCL call site
   // of the sharded path can be exercised on a single GPU (tests/test_gpu_comm_selftest.py)
-  if (world == 1 && !getenv("ISLE_FORCE_COMM")) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  isle_refresh_knobs(c);
+  if (world == 1 && !c->knob_on(KN_FORCE_COMM)) return 0;
+  ISLECHK(isle_enter(c));
   ncclUniqueId id;
   memcpy(&id, uid, sizeof id);
   NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
@@ -387,7 +441,7 @@ extern "C" int isle_hip_plan_shards(uint64_t num_docs, const int64_t* offs, int 
 static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* vals, const uint32_t* rows32,
                          const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (V == 0 || V > 0xfffffff0ull || D > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "vocab/doc count out of range");
   if (offs[0] != 0 || (uint64_t)offs[D] != nnz) return isle_fail(c, ISLE_E_ARG, "offsets[0] != 0 or offsets[D] != nnz");
   for (uint64_t d = 0; d < D; ++d) {
@@ -447,7 +501,7 @@ extern "C" int isle_hip_upload_csc_u64(isle_ctx* c, uint64_t V, uint64_t D, uint
 extern "C" int isle_hip_upload_counts_u32(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* counts, const uint32_t* rows,
                                           const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (V == 0 || V > 0xfffffff0ull || D > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "vocab/doc count out of range");
   if (offs[0] != 0 || (uint64_t)offs[D] != nnz) return isle_fail(c, ISLE_E_ARG, "offsets[0] != 0 or offsets[D] != nnz");
   for (uint64_t d = 0; d < D; ++d) {
@@ -482,7 +536,7 @@ extern "C" int isle_hip_upload_counts_u32(isle_ctx* c, uint64_t V, uint64_t D, u
 extern "C" int isle_hip_ingest_tdf(isle_ctx* c, const char* text, uint64_t nbytes, uint64_t V, uint64_t D, uint64_t max_entries,
                                    uint64_t* entries_read, uint64_t* nnz) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (c->world > 1) return isle_fail(c, ISLE_E_ARG, "ingest_tdf: single-rank only");
   if (V == 0 || V > 0xfffffff0ull || D == 0 || D > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "ingest_tdf: vocab/doc count out of range");
   if (nbytes && !text) return isle_fail(c, ISLE_E_ARG, "ingest_tdf: null text");
@@ -517,7 +571,7 @@ extern "C" int isle_hip_ingest_tdf(isle_ctx* c, const char* text, uint64_t nbyte
 
 extern "C" int isle_hip_get_A(isle_ctx* c, float* counts, uint32_t* rows, int64_t* offs) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (!c->a_ready) return isle_fail(c, ISLE_E_ARG, "get_A: no count matrix");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (counts && c->a_nnz) HIPCHK(c, hipMemcpy(counts, c->a_cnt.p, c->a_nnz * sizeof(float), hipMemcpyDeviceToHost));
@@ -529,7 +583,7 @@ extern "C" int isle_hip_get_A(isle_ctx* c, float* counts, uint32_t* rows, int64_
 extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sample_rate, uint64_t sample_seed, uint64_t* docs_kept,
                                   uint64_t* nnz_kept, uint64_t* entries_above, float* avg_out) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (!c->a_ready) return isle_fail(c, ISLE_E_ARG, "threshold: no count matrix uploaded");
   if (num_topics == 0) return isle_fail(c, ISLE_E_ARG, "threshold: num_topics == 0");
   const bool sampling = sample_rate > 0.0 && sample_rate < 1.0;
@@ -682,7 +736,7 @@ extern "C" int isle_hip_shape(isle_ctx* c, uint64_t* V, uint64_t* D, uint64_t* n
 
 extern "C" int isle_hip_get_B(isle_ctx* c, float* vals, uint32_t* rows, int64_t* offs, uint64_t* original_cols, float* zetas) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "get_B: no matrix");
   if ((original_cols || zetas) && !c->b_from_threshold)
     return isle_fail(c, ISLE_E_ARG, "get_B: original_cols / zetas exist only after isle_hip_threshold");
@@ -707,7 +761,7 @@ static int post_prepare(isle_ctx* c, const char* who) {
 extern "C" int isle_hip_catchwords(isle_ctx* c, int num_topics, const uint32_t* assign, uint64_t r, double rho, float* thresholds,
                                    int32_t* catch_topic, uint64_t* num_catchwords) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   ISLECHK(post_prepare(c, "catchwords"));
   if (num_topics < 1) return isle_fail(c, ISLE_E_ARG, "catchwords: num_topics < 1");
   if (r < 1 || r > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "catchwords: rank r = %llu out of range (too few documents per topic?)",
@@ -757,7 +811,7 @@ extern "C" int isle_hip_catchwords(isle_ctx* c, int num_topics, const uint32_t* 
 extern "C" int isle_hip_topic_model(isle_ctx* c, int num_topics, uint64_t rank_threshold, float* model, float* model_threshold, int32_t* top1,
                                     int32_t* top2, uint64_t* doc_topic_sums) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   ISLECHK(post_prepare(c, "topic_model"));
   if (!c->p_catch_ready || c->p_k != num_topics) return isle_fail(c, ISLE_E_ARG, "topic_model: run isle_hip_catchwords(num_topics = %d) first", num_topics);
   if (rank_threshold < 1 || rank_threshold > 0xfffffff0ull) return isle_fail(c, ISLE_E_ARG, "topic_model: rank_threshold out of range");  // :721
@@ -777,7 +831,7 @@ extern "C" int isle_hip_topic_model(isle_ctx* c, int num_topics, uint64_t rank_t
 
 extern "C" int isle_hip_get_doc_topic_sums(isle_ctx* c, int64_t* doc_offsets, uint32_t* topic, float* val) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (!c->p_model_ready) return isle_fail(c, ISLE_E_ARG, "get_doc_topic_sums: run isle_hip_topic_model first");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (doc_offsets) HIPCHK(c, hipMemcpy(doc_offsets, c->p_dts_off.p, (c->a_D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -788,7 +842,7 @@ extern "C" int isle_hip_get_doc_topic_sums(isle_ctx* c, int64_t* doc_offsets, ui
 
 extern "C" int isle_hip_edge_topics(isle_ctx* c, const int64_t* pairs, int n, float primary_ratio, float* edge) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (!c->p_model_ready) return isle_fail(c, ISLE_E_ARG, "edge_topics: run isle_hip_topic_model first");
   if (n < 0 || (n && (!pairs || !edge))) return isle_fail(c, ISLE_E_ARG, "edge_topics: bad arguments");
   if (n == 0) return 0;
@@ -820,13 +874,13 @@ extern "C" int isle_hip_infer(isle_ctx* c, uint64_t V, int k, const float* model
   if (!c || !model_by_word || !offs || (nnz && (!counts || !rows))) return ISLE_E_ARG;
   if (iters < 1 || !(Lf > 0.f)) return isle_fail(c, ISLE_E_ARG, "infer: iters = %d, Lf = %g", iters, (double)Lf);
   if (offs[0] != 0 || (uint64_t)offs[D] != nnz) return isle_fail(c, ISLE_E_ARG, "infer: offsets do not span the %llu entries", (unsigned long long)nnz);
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   return k_infer(c, V, k, model_by_word, D, nnz, counts, rows, offs, iters, Lf, avg_doc_sz, weights, top_topic, top_weight, llh, nconverged);
 }
 
 extern "C" int isle_hip_frobenius(isle_ctx* c, float* out) {
   if (!c || !out) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   double s = 0.0;
   ISLECHK(k_frobenius(c, &s));
   if (c->multi()) {
@@ -874,7 +928,7 @@ static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
 extern "C" int isle_hip_gram_apply(isle_ctx* c, const float* X, int b, float* Z) {
   if (!c || !X || !Z) return ISLE_E_ARG;
   if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   const size_t n = (size_t)c->V * b;
   HIPCHK(c, c->Xcm.reserve(n));
   HIPCHK(c, c->Zcm.reserve(n));
@@ -939,7 +993,7 @@ struct Ks {
     // and at the end the slices of F are all-gathered (4 MB at V = 100k), so every rank again holds the whole, bitwise equal F for
     // the replicated panel QR.  The step is HBM-bound on reading the basis (0.15 s of a 1.15 s C3-shard step): it now divides by
     // the number of ranks at the price of passes + 1 small collectives per step.  ISLE_KS_ROWSHARD=0 keeps it replicated.
-    const bool shard = c->multi() && !dense_A && !getenv_is_zero("ISLE_KS_ROWSHARD");
+    const bool shard = c->multi() && !dense_A && c->knob_on(KN_KS_ROWSHARD) && !c->knob_zero(KN_KS_ROWSHARD);
     if (!shard) {
       for (int p = 0; p < passes; ++p) {
         float* cf = base + (size_t)p * m * w;
@@ -1047,12 +1101,12 @@ struct Ks {
     // R, the three coefficient blocks — is written into one device mailbox and comes back as ONE copy (every small copy
     // costs ~20 us of queue time).  A rank-deficient panel (never seen on thresholded matrices) discards the speculative
     // work and repairs, as the synchronous form (ISLE_KS_SYNC=1) does.
-    const bool pipelined = !getenv("ISLE_KS_SYNC");
+    const bool pipelined = !c->knob_on(KN_KS_SYNC);
     // Passes of block Gram-Schmidt against the basis per step.  The reference makes three (CGS + 2 DGKS, :83-91); the second
     // already leaves coefficients at rounding level ("twice is enough"), so two are made here and the third
     // block of coefficients that the reference adds into H is zero.  ISLE_KS_ORTHO_PASSES=3 restores the reference's count.
     int npass = 2;
-    if (const char* e = getenv("ISLE_KS_ORTHO_PASSES")) npass = std::max(2, std::min(3, atoi(e)));
+    if (const char* e = c->knob(KN_KS_ORTHO_PASSES)) npass = std::max(2, std::min(3, atoi(e)));
     constexpr size_t MB_R = 64, MB_COEF = 64 + 32 * 32;  // mailbox offsets (floats): [meta ints | R | coefficients]
     const size_t mb_floats = MB_COEF + 3 * cap_r * blk;
     HIPCHK(c, c->ks_mail.reserve(mb_floats));
@@ -1303,7 +1357,7 @@ extern "C" int isle_hip_block_ks(isle_ctx* c, int nev, int ncv, int maxit, int b
                                  int* restarts, int* napplies) {
   if (!c || !evals) return ISLE_E_ARG;
   if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   Ks ks;
   ks.dim = c->V;
   c->band_ready = false;  // the operator (CSR copy) is rebuilt per solve, as in src/sparseMatrix.cpp:1199
@@ -1322,7 +1376,7 @@ extern "C" int isle_hip_block_ks_dense(isle_ctx* c, const float* A, uint64_t n, 
                                        uint64_t seed, const float* start_block, float* evals, float* U, int* nconv, int* nconv_ref_rule,
                                        int* restarts, int* napplies) {
   if (!c || !A || !evals || n < 2 || n > 46340) return isle_fail(c, ISLE_E_ARG, "block_ks_dense: bad arguments (2 <= n <= 46340)");
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (c->multi()) return isle_fail(c, ISLE_E_ARG, "block_ks_dense: the dense operator is not sharded (single rank only)");
   const int b_eff = (blk < nev) ? blk : 1;
   DevBuf<float> Adev, Sdev;
@@ -1349,14 +1403,14 @@ extern "C" int isle_hip_block_ks_dense(isle_ctx* c, const float* A, uint64_t n, 
 
 extern "C" int isle_hip_get_U(isle_ctx* c, float* U) {
   if (!c || !U || c->U_k == 0) return isle_fail(c, ISLE_E_ARG, "no U available");
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   HIPCHK(c, hipMemcpyAsync(U, c->Ucm.p, (size_t)c->V * c->U_k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 extern "C" int isle_hip_set_U(isle_ctx* c, const float* U, int k) {
   if (!c || !U || k < 1 || c->V == 0) return isle_fail(c, ISLE_E_ARG, "set_U: bad arguments");
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   HIPCHK(c, c->Ucm.reserve((size_t)c->V * k));
   HIPCHK(c, hipMemcpy(c->Ucm.p, U, (size_t)c->V * k * sizeof(float), hipMemcpyHostToDevice));
   ISLECHK(install_U(c, c->Ucm.p, k));
@@ -1366,7 +1420,7 @@ extern "C" int isle_hip_set_U(isle_ctx* c, const float* U, int k) {
 
 extern "C" int isle_hip_eig_sym(isle_ctx* c, const float* S, int n, float* evals, float* vecs) {
   if (!c || !S || !evals || !vecs || n < 1) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   HIPCHK(c, c->Wf.reserve((size_t)n * n));
   ISLECHK(k_eig_small(c, S, n, evals, c->Wf.p, n));
   HIPCHK(c, hipMemcpy(vecs, c->Wf.p, (size_t)n * n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1412,7 +1466,7 @@ static int fetch_rows(isle_ctx* c, const uint64_t* ids, int n, float* dst) {
 extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* inject, uint64_t rng_seed, uint64_t* seeds_out,
                                            float* C_lowd, float* residual, int* rounds_out) {
   if (!c || !seeds_out || !C_lowd || k < 1) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if ((uint64_t)k > c->D_global) return isle_fail(c, ISLE_E_ARG, "k > number of documents");
   isle_host_mark("kmeanspp: entry");
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2144
@@ -1451,20 +1505,14 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     int ndraw = 0;
     for (int cc = 0; cc < 1 + std::sqrt((double)(s - 5 > 0 ? s - 5 : 0)); ++cc) ndraw++;  // :2183 (upper bound on draws)
     ndraw = std::min(ndraw, maxdraw);
-    if (!multi && !inject && ndraw <= 40 && !getenv("ISLE_KMPP_HOST_DICE")) {  // the switch: for the test that holds both forms to the same seeds
+    if (!multi && !inject && ndraw <= 40 && !c->knob_on(KN_KMPP_HOST_DICE)) {  // the switch: for the test that holds both forms to the same seeds
       // one rank: the dice are products of the total with host-drawn fractions, so the device can throw them itself — the totals, the
       // dice and their search come back in one copy (search_frac_k), one host round trip per round
       for (int i = 0; i < ndraw; ++i) dice[i] = rng.fraction();  // :2184
       uint64_t* res = drawn + maxdraw;  // page-locked, 42 entries
-      if (getenv("ISLE_KMPP_COPY")) {
-        uint64_t* od = (uint64_t*)(c->gram.p + 128);
-        ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, od));
-        HIPCHK(c, hipMemcpyAsync(res, od, 42 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      } else {
-        // the kernel writes its 42 words straight into the page-locked area (host memory mapped into the device's address space): no
-        // copy kernel, and one gap less, between the search and the host's wake-up
-        ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, res));
-      }
+      // the kernel writes its 42 words straight into the page-locked area (host memory mapped into the device's address space): no
+      // copy kernel, and one gap less, between the search and the host's wake-up
+      ISLECHK(k_search_frac(c, c->cum.p, D, D > 0 ? c->min_dist.p + (D - 1) : nullptr, dice.data(), ndraw, res));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       memcpy(my, res + 40, 2 * sizeof(double));
       grand = my[0];
@@ -1561,7 +1609,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
 
 extern "C" int isle_hip_get_min_dist(isle_ctx* c, float* out) {
   if (!c || !out) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (c->D) HIPCHK(c, hipMemcpy(out, c->min_dist.p, c->D * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1620,7 +1668,7 @@ static int fetch_sizes(isle_ctx* c, int k, std::vector<long long>& sizes) {
 
 extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int max_reps, int* iters_run, uint32_t* assign_out) {
   if (!c || !C_lowd || k < 1) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   isle_host_mark("lloyds_projected: entry");
   ISLECHK(ensure_P(c, k));  // compute_projected_docs_l2sq :2032
   const uint64_t D = c->D;
@@ -1640,7 +1688,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is written again at the end of this call
   isle_host_mark("lloyds_projected: centres uploaded");
   // Hamerly bounds (exact skip of documents whose closest centre provably did not change), as in the sparse Lloyd
-  const bool hamerly = !getenv("ISLE_NO_HAMERLY") && c->Pt_ready;
+  const bool hamerly = !c->knob_on(KN_NO_HAMERLY) && c->Pt_ready;
   if (hamerly) {
     HIPCHK(c, c->hub.reserve(D ? D : 1));
     HIPCHK(c, c->hlb.reserve(D ? D : 1));
@@ -1654,7 +1702,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   // k > 224 (more than 7 tiles of 32 centres): one lower bound per tile instead of Hamerly's single one, which prunes nothing at
   // k = 1000 (kmeans.hip PR_TILES, spmm.hip pt_filter_k).  ISLE_PROJ_BOUNDS=hamerly keeps the single bound.
   const int T = (k + 31) / 32, TL = (T + 3) & ~3;
-  const char* pbm = getenv("ISLE_PROJ_BOUNDS");
+  const char* pbm = c->knob(KN_PROJ_BOUNDS);
   const bool tiles = hamerly && k > 224 && T <= 32 && !(pbm && !strcmp(pbm, "hamerly"));
   float* tmove_dev = nullptr;
   if (tiles) {
@@ -1677,10 +1725,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
         uint32_t* nact = c->active.p + D;
         // documents are taken grouped by their centre (member lists of the previous iteration): a workgroup of the re-examination
         // then holds neighbours, whose needed tiles coincide
-        if (getenv("ISLE_PROJ_NOTIGHTEN")) {
-          ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
-                              c->pneed.p, c->active.p, nact));
-        } else {  // candidates by the grown upper bounds, then the exact distance to the own centre for those (pt_tighten_k)
+        {  // candidates by the grown upper bounds, then the exact distance to the own centre for those (pt_tighten_k)
           uint32_t* ncand = c->pcand.p + D;
           ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
                               c->pneed.p, c->pcand.p, ncand));
@@ -1691,7 +1736,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
         HIPCHK(c, hipMemcpyAsync(na_pin, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t na = *na_pin;
-        if (getenv("ISLE_DEBUG_HAMERLY")) {  // debug only: how many tiles the active documents ask for
+        if (c->knob_on(KN_DEBUG_HAMERLY)) {  // debug only: how many tiles the active documents ask for
           std::vector<uint32_t> act(na), need(D);
           if (na) HIPCHK(c, hipMemcpy(act.data(), c->active.p, na * sizeof(uint32_t), hipMemcpyDeviceToHost));
           if (D) HIPCHK(c, hipMemcpy(need.data(), c->pneed.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1724,7 +1769,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
       HIPCHK(c, hipMemcpyAsync(na_pin, nact, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       const uint32_t na = *na_pin;
-      if (getenv("ISLE_DEBUG_HAMERLY")) fprintf(stderr, "[hamerly, projected] iter %d active %u of %llu\n", it, na, (unsigned long long)D);
+      if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[hamerly, projected] iter %d active %u of %llu\n", it, na, (unsigned long long)D);
       ISLECHK(k_proj_assign_active(c, c->P.p, c->pnorm.p, k, ldk, c->Cdev.p, c->cnorm.p, c->active.p, na, c->Pa.p, c->pna.p, c->assign.p,
                                    c->hub.p, c->hlb.p));
     }
@@ -1772,7 +1817,7 @@ static int install_centers(isle_ctx* c, int ncols) {  // centers_cm (V x ncols) 
 
 extern "C" int isle_hip_lift_centers(isle_ctx* c, const float* in, int ld_in, int ncols, float* centers) {
   if (!c || !in || ncols < 1) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   if (c->U_k == 0 || ld_in < c->U_k) return isle_fail(c, ISLE_E_ARG, "lift: need U and ld_in >= k");
   isle_host_mark("lift: entry");
   HIPCHK(c, c->Csum.reserve((size_t)ld_in * ncols));
@@ -1801,7 +1846,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
                                       int* iters_run) {
   if (!c || k < 1) return ISLE_E_ARG;
   if (c->V == 0) return isle_fail(c, ISLE_E_ARG, "no matrix uploaded");
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   isle_host_mark("lloyds_sparse: entry");
   const uint64_t D = c->D, V = c->V;
   const int ld = round4(k);
@@ -1821,13 +1866,13 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   ISLECHK(k_doc_norms(c, c->dnorm.p));  // :1680-1687
   // Distance bounds: exact accelerations of the assignment step (documents whose bounds prove "unchanged" are skipped).
   // Default: Yinyang group bounds (groups of 8 centres); ISLE_KMEANS_BOUNDS=hamerly|none selects the others.
-  const char* bmode = getenv("ISLE_KMEANS_BOUNDS");
-  const bool nobounds = getenv("ISLE_NO_HAMERLY") || (bmode && !strcmp(bmode, "none"));
+  const char* bmode = c->knob(KN_KMEANS_BOUNDS);
+  const bool nobounds = c->knob_on(KN_NO_HAMERLY) || (bmode && !strcmp(bmode, "none"));
   const bool hamerly = !nobounds;                                   // any bound-based mode
   const bool yinyang = hamerly && !(bmode && !strcmp(bmode, "hamerly"));
   const int G = (k + 7) / 8;
   int yy_mode_env = -1;  // form of the Yinyang iteration: 0 = by document over the row-major centres, 1 = by document over the group-major copy, 2 = by group
-  if (const char* e = getenv("ISLE_YY_MODE")) yy_mode_env = !strcmp(e, "doc") ? 0 : !strcmp(e, "docg") ? 1 : !strcmp(e, "group") ? 2 : -1;
+  if (const char* e = c->knob(KN_YY_MODE)) yy_mode_env = !strcmp(e, "doc") ? 0 : !strcmp(e, "docg") ? 1 : !strcmp(e, "group") ? 2 : -1;
   if (yinyang) HIPCHK(c, c->yglb.reserve((size_t)(D ? D : 1) * G + 64));
   float* gmax_dev = nullptr;
   HIPCHK(c, c->hub.reserve(D ? D : 1));
@@ -1843,7 +1888,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   // while the dense product is cheaper than the sparse one: always up to k = 384; beyond, by the measured rates — the D x k x k
   // product runs at ~130 TFLOP/s (rocBLAS), a panel pass of the sparse product takes ~2.8 ps per nonzero (C3 shard, k = 1000: 19 against
   // 44 ms) — and while its D x k scratch can be had (isle_scratch_ok) (ISLE_FIRST_ASSIGN=sparse|projection forces)
-  const char* fa = getenv("ISLE_FIRST_ASSIGN");
+  const char* fa = c->knob(KN_FIRST_ASSIGN);
   const double t_dense = 2.0 * (double)D * k * k / 130e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
   const bool dense_pays = k <= 384 || (t_dense < t_sparse && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)));
   const bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
@@ -1890,7 +1935,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       const uint32_t* order = yy_mode && c->members_valid ? c->members.p : nullptr;
       if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
       ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
-      const bool dbg = getenv("ISLE_DEBUG_HAMERLY") != nullptr;
+      const bool dbg = c->knob_on(KN_DEBUG_HAMERLY);
       unsigned long long* dbg_dev = nullptr;
       if (dbg) {  // diagnostic only: group scans and gathered nonzeros of this iteration
         HIPCHK(c, c->dbg_cnt.reserve(2));
@@ -1921,7 +1966,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       ISLECHK(k_hamerly_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->hlb.p, delta_dev, top_dev, c->active.p,
                                nact));
       ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->active.p, nact, c->hub.p, c->hlb.p));
-      if (getenv("ISLE_DEBUG_HAMERLY")) {
+      if (c->knob_on(KN_DEBUG_HAMERLY)) {
         uint32_t na = 0;
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
         fprintf(stderr, "[hamerly] iter %d active %u of %llu\n", it, na, (unsigned long long)D);
@@ -1977,7 +2022,7 @@ extern "C" int isle_hip_timing_enable(isle_ctx* c, int on) {
 }
 extern "C" int isle_hip_timing_reset(isle_ctx* c) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   ISLECHK(drain_events(c));
   for (int i = 0; i < ISLE_T_COUNT; ++i) {
     c->t_ms[i] = 0.0;
@@ -1987,7 +2032,7 @@ extern "C" int isle_hip_timing_reset(isle_ctx* c) {
 }
 extern "C" int isle_hip_timing_get(isle_ctx* c, double* ms, uint64_t* launches) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   ISLECHK(drain_events(c));
   for (int i = 0; i < ISLE_T_COUNT; ++i) {
     if (ms) ms[i] = c->t_ms[i];
@@ -1997,7 +2042,7 @@ extern "C" int isle_hip_timing_get(isle_ctx* c, double* ms, uint64_t* launches) 
 }
 extern "C" int isle_hip_synchronize(isle_ctx* c) {
   if (!c) return ISLE_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ISLECHK(isle_enter(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -43,6 +43,26 @@ struct DevBuf {
 };
 
 // One side of the LDS-banded Gram apply (gram_lds.hip): a sliced-ELL stream of band-local u16 source ids.
+// ------------------------------------------------------------------------------------------
+// Environment switches.  Every switch the library honours is in this table; they are read into the context when it is created and
+// again at the entry of every C-ABI call (isle_enter, api.cpp) — never inside a loop or a launch path — and the code asks the context
+// (isle_ctx::knob).  DESIGN.md section "Environment switches" is this table with the measurements behind the defaults.
+// ------------------------------------------------------------------------------------------
+enum IsleKnob {
+  KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
+  KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_YY_MODE, KN_CENTERS_FRESH,
+  KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
+  KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK,
+  KN_COUNT
+};
+struct IsleKnobInfo {
+  const char* name;
+  const char* kind;  // "form" (selects between exact forms of a computation), "tuning", "diagnostic", "test hook"
+  const char* what;
+};
+extern const IsleKnobInfo isle_knob_table[KN_COUNT];
+
 struct GlDesc {  // one workgroup: 16 waves wave0 + i*wstride (i < nw), source bands [b0, b1), output slab
   uint32_t wave0, wstride, nw, b0, b1, slab, pos_base, pad;
 };
@@ -58,7 +78,15 @@ struct GlSide {
 };
 
 struct isle_ctx {
+  // environment switches as read at the last C-ABI entry (isle_refresh_knobs)
+  std::string knob_val[KN_COUNT];
+  bool knob_set[KN_COUNT] = {};
+  const char* knob(int id) const { return knob_set[id] ? knob_val[id].c_str() : nullptr; }
+  bool knob_on(int id) const { return knob_set[id]; }                                         // set at all (any value)
+  bool knob_is(int id, const char* v) const { return knob_set[id] && knob_val[id] == v; }
+  bool knob_zero(int id) const { return knob_set[id] && atoi(knob_val[id].c_str()) == 0; }
   int device = 0;
+  size_t total_mem = 0;  // bytes of device memory (isle_scratch_ok)
   hipStream_t stream = nullptr;
   std::string err;
   int num_cus = 256;
@@ -266,6 +294,8 @@ int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
 bool isle_scratch_ok(isle_ctx* c, size_t have_elems, double bytes);
+void isle_refresh_knobs(isle_ctx* c);
+int isle_enter(isle_ctx* c);  // entry of a C-ABI call: the context's device becomes current, the environment switches are read
 // ISLE_HOST_TRACE=1: host wall time since the previous mark, to stderr (marks that follow within 0.2 ms stay silent).  Finds GPU-idle
 // stretches that are host work, which no kernel profile shows.
 void isle_host_mark(const char* what);

@@ -162,7 +162,7 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
     HIPCHK(c, hipMemsetAsync(coef, 0, (size_t)m * b * sizeof(float), c->stream));
     return 0;
   }
-  if (b <= 16 && m >= 64 && !getenv("ISLE_VTF_VALU")) {  // matrix-core path (enough columns to fill the chip)
+  if (b <= 16 && m >= 64) {  // matrix-core path (enough columns to fill the chip)
     const int BT = bt_of(b);
     const int nch = cdiv(n, VM_RC);
     HIPCHK(c, c->part.reserve((size_t)nch * m * BT));
@@ -656,7 +656,7 @@ int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, in
   // four 5-us gaps) — the chain is not launch latency but the two serial factor steps (15 us each: a 98- to 196-way sum of partial
   // Gram matrices and a 10-step fp64 Cholesky), which every workgroup now repeats behind agent-scope loads.  It saves 240 launches per
   // C2 step and no time, so the form without grid barriers stays the default.  Read per call: the parity test switches forms.
-  const char* fq = getenv("ISLE_QR_FUSED");
+  const char* fq = c->knob(KN_QR_FUSED);
   const bool fused_on = fq && atoi(fq) != 0;
   if (fused_on && !c->pq_fused_failed && nparts <= c->num_cus) {  // every workgroup resident: one per CU
     if (!c->pq_bar.p) {
@@ -1106,7 +1106,7 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
     for (int round = 0; round < nblk - 1; ++round) {
       hipLaunchKernelGGL(bj_gram_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, np, nblk, round, gpart);
       hipLaunchKernelGGL(bj_inner_k, dim3(npairs), dim3(256), 0, c->stream, np, nblk, round, tol, abs_tol, gpart, nrowch, c->jacS.p, rot,
-                         (round > 0 && !getenv("ISLE_EVD_FULL_TOURNAMENT")) ? 1 : 0);
+                         round > 0 ? 1 : 0);
       hipLaunchKernelGGL(bj_apply_k, dim3(npairs, nrowch), dim3(256), 0, c->stream, c->jacW.p, c->jacV.p, np, nblk, round, c->jacS.p,
                          2);
     }
@@ -1114,7 +1114,7 @@ int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, flo
     unsigned int nrot = 0;
     HIPCHK(c, hipMemcpyAsync(&nrot, rot, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (getenv("ISLE_DEBUG_EVD")) fprintf(stderr, "[evd n=%d] sweep %d rotations %u\n", n, sweep, nrot);
+    if (c->knob_on(KN_DEBUG_EVD)) fprintf(stderr, "[evd n=%d] sweep %d rotations %u\n", n, sweep, nrot);
     if (nrot == 0) converged = true;
   }
   if (!converged) return isle_fail(c, ISLE_E_NUMERIC, "Jacobi EVD (n=%d) did not converge in 60 sweeps", n);
@@ -1229,7 +1229,7 @@ int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, cons
 // solver above is the fallback for sizes it does not take and for spectra whose eigenvectors fail its orthogonality check
 // (clusters far tighter than Ritz matrices show).  ISLE_EVD_JACOBI=1 forces the Jacobi solver.
 int k_eig_small(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec) {
-  if (n >= 16 && !getenv("ISLE_EVD_JACOBI")) {
+  if (n >= 16 && !c->knob_on(KN_EVD_JACOBI)) {
     int rc;
     {
       TimeScope ts(c, ISLE_T_EVD);

@@ -601,7 +601,6 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   HIPCHK(c, hipMemcpyAsync(c->evd_in.p, S_host, nn * sizeof(float), hipMemcpyHostToDevice, c->stream));
   int CB = 16;
   while (CB < 64 && (n + CB - 1) / CB > 32) CB *= 2;
-  if (const char* e = getenv("ISLE_TD_CB")) CB = std::max(8, std::min(128, atoi(e)));  // tuning knob
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
   const int nrb_max = TD_NRB;
@@ -628,7 +627,6 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   const bool small = n <= TD_ROWS * 4;
   // persistent form: G workgroups, each with its columns (ncl of them) plus v and w in LDS
   int pG = TD_P_GSMALL;
-  if (const char* eg = getenv("ISLE_TD_G")) pG = std::max(1, atoi(eg));  // tuning knob
   {
     const int ncl_max = (int)(TD_P_LDS / sizeof(double) / (size_t)n) - 2;
     if (ncl_max >= 1) pG = std::max(pG, (n + ncl_max - 1) / ncl_max);  // what the LDS needs
@@ -636,7 +634,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   }
   // one workgroup per CU at most: all must be resident.  A time-out at the grid barrier (the GPU is shared with other work) is
   // remembered: later solves of this context go straight to the launch chain instead of paying the time-out again.
-  bool persist = pG <= c->num_cus && n <= TD_NMAX_BACK && !getenv("ISLE_TD_CHAIN") && !c->td_persist_failed;
+  bool persist = pG <= c->num_cus && n <= TD_NMAX_BACK && !c->knob_on(KN_TD_CHAIN) && !c->td_persist_failed;
   if (c->multi()) {  // every rank must take the same form (their roundings differ): the form is agreed, like the bail-out below
     unsigned int no = persist ? 0u : 1u;
     HIPCHK(c, hipMemcpyAsync(tickets + 1, &no, sizeof no, hipMemcpyHostToDevice, c->stream));
@@ -658,7 +656,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
       ISLECHK(isle_max_lds(c, (const void*)td_persist_k, (int)TD_P_LDS));
       hipLaunchKernelGGL(td_persist_k, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, tickets, tickets + 1);
       HIPCHK(c, hipGetLastError());
-      if (const char* fb = getenv("ISLE_TD_FORCE_BAIL_RANK")) {  // test hook: this rank behaves as if its barrier had timed out
+      if (const char* fb = c->knob(KN_TD_FORCE_BAIL_RANK)) {  // test hook: this rank behaves as if its barrier had timed out
         if (atoi(fb) == c->rank) {
           const unsigned int one = 1u;
           HIPCHK(c, hipMemcpyAsync(tickets + 1, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
@@ -712,7 +710,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   float dev;
   static_assert(sizeof(dev) == sizeof(wbits), "");
   memcpy(&dev, &wbits, sizeof dev);
-  if (getenv("ISLE_DEBUG_EVD")) fprintf(stderr, "[evd n=%d] tridiagonal solver: nvec %d, worst orthogonality defect %.3g\n", n, nvec, (double)dev);
+  if (c->knob_on(KN_DEBUG_EVD)) fprintf(stderr, "[evd n=%d] tridiagonal solver: nvec %d, worst orthogonality defect %.3g\n", n, nvec, (double)dev);
   if (!(dev <= 1e-6f)) return 1;
   for (int i = 0; i < n; ++i) evals_host[i] = (float)ev[i];
   return 0;

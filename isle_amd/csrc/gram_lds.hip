@@ -795,7 +795,7 @@ int launch_apply_any(isle_ctx* c, int LPE, bool half, const GlSide& s, const flo
 int k_gl_detect(isle_ctx* c) {
   if (c->gl_mode >= 0) return 0;  // decided for this B (reset by every upload / thresholding)
   c->gl_mode = 0;
-  const char* e = getenv("ISLE_GRAM_LDS");
+  const char* e = c->knob(KN_GRAM_LDS);
   // every rank takes part in the agreement below, whatever its own shard looks like
   bool eligible = !(e && atoi(e) == 0) && c->nnz > 0 && c->D > 0 && c->V > 0 && c->D < 0xfffffff0ull && c->V < 0xfffffff0ull;
   HIPCHK(c, c->gl_flag.reserve(4));
@@ -857,7 +857,7 @@ int k_gl_build(isle_ctx* c) {
   {
     const double t_slice = 0.05 * 2.5 * (double)c->nnz / 256.0 / std::max<uint32_t>(1u, s1.nslice);  // us: ~50 ns per super-round, ~2.5x padded
     const double t_stage = 2.0 * s1.NB;                                                               // us: ~2 us per band from L2
-    const char* e_g = getenv("ISLE_GL_G1");
+    const char* e_g = c->knob(KN_GL_G1);
     const int g_lo = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4, g_hi = e_g ? g_lo : GL_GMAX;
     double best = 1e300;
     for (int G = g_lo; G <= g_hi; ++G) {
@@ -931,7 +931,7 @@ int k_gl_build(isle_ctx* c) {
   // a word block = wpb waves = 4 wpb consecutive slices; 16 waves unless the vocabulary is so small that blocks x bands would
   // leave CUs idle
   {
-    const char* e_g = getenv("ISLE_GL_G2");  // items per lane in pass 2 (4 ... 8)
+    const char* e_g = c->knob(KN_GL_G2);  // items per lane in pass 2 (4 ... 8)
     s2.G = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4;
   }
   const uint32_t G2 = (uint32_t)s2.G;
@@ -952,14 +952,11 @@ int k_gl_build(isle_ctx* c) {
           so[((size_t)ob * wpb + w) * G2 + g] = sl < s2.nslice ? (uint32_t)sl : GL_NONE;
         }
     ISLECHK(build_side<2>(c, s2, so));
-    const char* e_bc = getenv("ISLE_GL_BAND_COST");   // tuning knobs (defaults measured at C2)
-    const char* e_wg = getenv("ISLE_GL_WGS_PER_CU");
-    const double bc = e_bc ? atof(e_bc) : GL_BAND_COST;
-    const double wgs_per_cu = e_wg ? atof(e_wg) : 2.0;
+    const double bc = GL_BAND_COST, wgs_per_cu = 2.0;  // measured by sweeps at C2
     std::vector<uint32_t> slab0(nblk), nch(nblk, 0);
     std::vector<GlDesc> ds;
     uint32_t nslab = 0;
-    const char* e_col = getenv("ISLE_GL_COLUMNS");
+    const char* e_col = c->knob(KN_GL_COLUMNS);
     const bool columns = !(e_col && atoi(e_col) == 0) && s2.NB >= 16;  // ISLE_GL_COLUMNS=0: per-block chunking only
     std::vector<unsigned long long> tot;
     if (columns) {
@@ -984,10 +981,9 @@ int k_gl_build(isle_ctx* c) {
         for (uint32_t ob = 0; ob < nblk; ++ob) bcost[bnd] += (double)tot[(size_t)ob * NB + bnd] + bc;
         all += bcost[bnd];
       }
-      const char* e_cb = getenv("ISLE_GL_COL_BANDS");
       // <= 12 bands (1.9 MB of Y) per column: measured at C2 / C3 shard, pass 2 in ms — per-block chunks 0.291 / 0.474, columns of
       // <= 8 bands 0.294 / 0.459, <= 12 bands 0.283 / 0.436, <= 16 bands 0.282 / 0.464
-      const uint32_t colbands = e_cb ? (uint32_t)std::max(1, atoi(e_cb)) : 12u;
+      const uint32_t colbands = 12u;
       const double W = wgs_per_cu * c->num_cus;
       uint32_t NC = 8u * (uint32_t)std::ceil(std::max(W / (1.25 * nblk), (double)NB / colbands) / 8.0);
       NC = std::max(8u, std::min(NC, (NB / 8u) * 8u));
@@ -1080,7 +1076,7 @@ int k_gl_build(isle_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->gl_nch.p, nch.data(), nblk * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->gl_part.reserve((size_t)nslab * bitems * 12));  // sized for the widest panel (BP = 12)
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (getenv("ISLE_GL_VERBOSE")) {
+    if (c->knob_on(KN_GL_VERBOSE)) {
       fprintf(stderr, "[gram_lds] pass-2 %s, word blocks (super-rounds, chunks):", columns ? "band columns shared per XCD" : "per-block band chunks");
       const size_t per = columns ? s2.NB : 1;
       for (uint32_t ob = 0; ob < nblk; ++ob) {
@@ -1090,7 +1086,7 @@ int k_gl_build(isle_ctx* c) {
       }
       fprintf(stderr, "\n");
     }
-    if (getenv("ISLE_GL_VERBOSE"))
+    if (c->knob_on(KN_GL_VERBOSE))
       fprintf(stderr,
               "[gram_lds] V=%u D=%u nnz=%llu | pass1: bands=%u items/lane=%d waves=%u wgs=%u padded=%.2fx | pass2: bands=%u items/lane=%d blocks=%u wgs=%u slabs=%u "
               "padded=%.2fx\n",
@@ -1163,8 +1159,8 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
 // Columns per pass of the k-wide / thin products through the pass-1 stream.  A 12-column panel (three ds_read_b128 per slot, 48
 // accumulator registers) runs 2.2x as long as an 8-column one (two reads, 32 registers) — 0.77 against 0.35 ms per pass at the
 // C3-shard shape, 324 against ~150 us at C2 — so 8 columns per pass move more columns per second.  ISLE_GL_PANEL=12 restores 12.
-static int gl_panel_width() {
-  const char* e = getenv("ISLE_GL_PANEL");
+static int gl_panel_width(const isle_ctx* c) {
+  const char* e = c->knob(KN_GL_PANEL);
   return (e && atoi(e) == 12) ? 12 : 8;
 }
 
@@ -1177,7 +1173,7 @@ int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out) {
   if (ld % 4 || nc > ld) return isle_fail(c, ISLE_E_ARG, "k_gl_thin: bad leading dimension");
   const uint32_t V = (uint32_t)c->V;
   HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
-  const int PW = gl_panel_width();
+  const int PW = gl_panel_width(c);
   for (int j0 = 0; j0 < nc; j0 += PW) {
     const int ncol = std::min(PW, nc - j0);
     const int LPE = (ncol + 3) / 4;
@@ -1204,7 +1200,7 @@ int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
   if (ld % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: leading dimension %d not a multiple of 4", ld);
   const uint32_t V = (uint32_t)c->V;
   HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
-  const int PW = gl_panel_width();
+  const int PW = gl_panel_width(c);
   for (int j0 = 0; j0 < k; j0 += PW) {
     const int ncol = std::min(PW, k - j0);
     const int LPE = (ncol + 3) / 4;

@@ -591,7 +591,7 @@ int k_infer(isle_ctx* c, uint64_t V, int k, const float* model_by_word, uint64_t
     if (D) hipLaunchKernelGGL(inf_prep_k, dim3(cdiv((long)D, 4)), dim3(256), 0, c->stream, dcounts.p, drows.p, doffs.p, D, dok.p, dfw.p, dfa.p, dnk.p);
     HIPCHK(c, hipGetLastError());
     // LDS: cap_rows model rows + 4 partial gradients + the weights + cap_rows values of a
-    const bool lanes16 = nq <= 64 && !getenv("ISLE_INFER_WAVE_ROWS");  // k <= 256: sixteen lanes per row
+    const bool lanes16 = nq <= 64;  // k <= 256: sixteen lanes per row
     const size_t fixed = (lanes16 ? 17 : 5) * (size_t)ld * sizeof(float);
     uint32_t cap_rows = (uint32_t)((INF_LDS - fixed) / ((size_t)ld * sizeof(float) + sizeof(float)));
     // Measured at C2 size (50k x 200 model, ~108 kept words per document): staging a document's slice in LDS (one workgroup per
@@ -599,7 +599,7 @@ int k_infer(isle_ctx* c, uint64_t V, int k, const float* model_by_word, uint64_t
     // CU 5.3 M docs/s (6.9 TB/s of row gathers) — occupancy beats locality, so no rows are staged unless
     // ISLE_INFER_CAP_ROWS asks for it.
     {
-      const char* e = getenv("ISLE_INFER_CAP_ROWS");
+      const char* e = c->knob(KN_INFER_CAP_ROWS);
       cap_rows = std::min<uint32_t>(cap_rows, e ? (uint32_t)atoi(e) : 0u);
     }
     const size_t lds = (size_t)cap_rows * ld * sizeof(float) + fixed + (size_t)cap_rows * sizeof(float);

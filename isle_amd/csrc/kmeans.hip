@@ -176,7 +176,7 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
   // measured rates: a pass of the pass-1 stream costs ~2.8 ps per nonzero (= 15.4 bytes of streaming at 5.5 TB/s), the materialised
   // projection streams at 5.5 TB/s for <= 16 new seeds (kmpp_min_pt_k) and 2.3x slower through the matrix-core tile beyond.
   {
-    const char* e = getenv("ISLE_KMPP_SPARSE");
+    const char* e = c->knob(KN_KMPP_SPARSE);
     const int passes = (nc + 7) / 8;  // 8 columns per pass of the pass-1 stream (gram_lds.hip gl_panel_width)
     bool sparse = c->gl_mode == 1 && c->band_ready && nc <= 32 && c->U_k == k &&
                   15.4 * (double)c->nnz * passes < 4.0 * (double)ldk * (double)D * (nc <= 16 ? 1.0 : 2.3);
@@ -192,7 +192,7 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
       return 0;
     }
   }
-  if (nc <= 16 && c->Pt_ready && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024 && !getenv("ISLE_KMPP_MFMA")) {
+  if (nc <= 16 && c->Pt_ready && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024) {
     // streaming pass over the coordinate-major copy (the centres fit the default 64 KB of dynamic LDS)
     const int nq = (nc + 3) / 4;
     const dim3 g(cdiv(D, 256)), b(256);
@@ -687,7 +687,6 @@ static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float*
   } while (0)
   if (MODE == PR_TILES) {  // only the shape that needs it: more than 7 tiles or slabs (k > 224), at most 32 tiles
     if (ct > 32) return 0;
-    if (const char* e = getenv("ISLE_PT_DBG")) TL |= atoi(e) << 16;
     LR(8, 8);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -803,7 +802,7 @@ __global__ __launch_bounds__(256) void proj_dots_tiles_k(const float* __restrict
 }
 
 bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k) {
-  const char* pf = getenv("ISLE_PROJ_FULL");
+  const char* pf = c->knob(KN_PROJ_FULL);
   return c->Pt_ready && D > 0 && k >= 64 && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)) &&
          ((2.0 * (double)D * k * k >= 2e10 && !(pf && !strcmp(pf, "fused"))) || (pf && !strcmp(pf, "gemm")));
 }
@@ -835,7 +834,7 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
 
 int k_proj_assign(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn,
                   uint32_t* assign, float* ub, float* lb) {
-  if (!getenv("ISLE_PROJ_ASSIGN_GENERIC")) {
+  {
     TimeScope ts(c, ISLE_T_LLOYD_PROJ);
     bool done = false;
     ISLECHK(launch_proj_reg<PR_ARGMIN>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done, nullptr, nullptr, ub, lb));

@@ -496,8 +496,8 @@ static int launch_wide(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, 
 // win while the vocabulary spans few bands (C2: 15 bands, 5.8 vs 7.0 ms), a loss at 30 bands (C3 shard: 68 vs 52 ms).
 // ISLE_WIDE_GATHER=1 / ISLE_WIDE_LDS=1 force either form.
 static bool wide_through_lds(const isle_ctx* c) {
-  if (getenv("ISLE_WIDE_GATHER")) return false;
-  if (getenv("ISLE_WIDE_LDS")) return true;
+  if (c->knob_on(KN_WIDE_GATHER)) return false;
+  if (c->knob_on(KN_WIDE_LDS)) return true;
   return c->V <= 32 * 3412;  // 8-column panels (gram_lds.hip gl_panel_width): measured 46.7 against 51.7 ms at 30 word bands (V = 100k, k = 1000)
 }
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void centers_from_rows_k(const float* __restri
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool first_of_run) {
   ISLECHK(k_gl_detect(c));
   if (c->gl_mode == 1)  // row-constant B: integer counting, no transposed copy
-    return k_centers_counts(c, assign, k, ldk, Crm, first_of_run || getenv("ISLE_CENTERS_FRESH") != nullptr);
+    return k_centers_counts(c, assign, k, ldk, Crm, first_of_run || c->knob_on(KN_CENTERS_FRESH));
   ISLECHK(k_band_build(c));
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
   const uint32_t V = (uint32_t)c->V;
