@@ -72,7 +72,7 @@ void isle_refresh_knobs(isle_ctx* c) {
   }
 }
 int isle_enter(isle_ctx* c) {
-  ISLECHK(isle_enter(c));
+  HIPCHK(c, hipSetDevice(c->device));
   isle_refresh_knobs(c);
   return 0;
 }

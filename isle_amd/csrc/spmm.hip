@@ -875,12 +875,44 @@ __global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* _
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
   const uint32_t nd = min((uint32_t)docs_per_block, D - d0);
   const uint32_t nel = nd * (uint32_t)G;
-  {
+  if (order) {
+    // a wave per document: its G floats are one contiguous run (500 bytes at k = 1000), four documents in flight per wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t j0 = (uint32_t)w * 4; j0 < nd; j0 += 16) {
+      float* src[4];
+      float v[4][4];  // up to 256 groups: four per lane
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = min(j0 + u, nd - 1);
+        src[u] = glb + (size_t)order[d0 + j] * G;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int g = lane + 64 * t;
+          v[u][t] = g < G ? src[u][g] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + u < nd) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int g = lane + 64 * t;
+            if (g < G) {
+              float l = v[u][t] - gmax[g] * 1.000001f;
+              l = l > 0.f ? l * 0.999999f : l;
+              src[u][g] = l;
+              tile[(j0 + u) * (uint32_t)G + g] = l;
+            }
+          }
+        }
+      }
+    }
+  } else {
     // (document j, group g) of element i = threadIdx.x + 256 t, stepped without a division per element
     uint32_t j = threadIdx.x / (uint32_t)G, g = threadIdx.x - j * (uint32_t)G;
     const uint32_t sj = 256u / (uint32_t)G, sg = 256u - sj * (uint32_t)G;
     for (uint32_t i = threadIdx.x; i < nel; i += 256) {
-      float* src = glb + (size_t)(order ? order[d0 + j] : d0 + j) * G + g;
+      float* src = glb + (size_t)(d0 + j) * G + g;
       float l = *src - gmax[g] * 1.000001f;
       l = l > 0.f ? l * 0.999999f : l;
       *src = l;
