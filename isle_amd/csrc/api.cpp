@@ -36,7 +36,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_G1", "tuning", "4..8: output items per lane in pass 1 of the LDS-banded form (default: makespan model, gram_lds.hip)"},
     {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4)"},
     {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
-    {"ISLE_GL_PANEL", "tuning", "12: twelve columns per pass of the k-wide / thin products instead of eight"},
+    {"ISLE_GL_PANEL", "tuning", "8 | 12: columns per pass of the k-wide / thin products (default 12 up to 6 items per lane in pass 1, else 8)"},
     {"ISLE_WIDE_GATHER", "form", "k-wide products (projection, first word-space assignment) by the row-gather kernel"},
     {"ISLE_WIDE_LDS", "form", "k-wide products through the LDS-banded pass-1 stream whatever the vocabulary size"},
     {"ISLE_KS_ROWSHARD", "form", "1: several ranks orthogonalise row slices of the Krylov block (all-reduced coefficients, all-gathered block); default 0 = replicated"},
@@ -1908,11 +1908,17 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
       ISLECHK(k_gemm_nn(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
-      c->P_ready = false;  // P now holds the dot products (as with the LDS-banded wide product)
-      c->Pt_ready = false;
-      if (ld != k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, (size_t)D * ld * sizeof(float), c->stream));
-      ISLECHK(k_transpose(c, c->dotsT.p, D, (uint64_t)k, D, c->P.p, (uint64_t)ld));
-      ISLECHK(k_dots_assign(c, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->hub.p, yinyang ? c->yglb.p : c->hlb.p, yinyang ? G : 0));
+      if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
+        float* cn_max_dev = c->Csum.p + 2 * k + 8;
+        ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
+        ISLECHK(k_dots_assign_cm(c, c->dotsT.p, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p, c->hub.p, c->yglb.p));
+      } else {
+        c->P_ready = false;  // P now holds the dot products (as with the LDS-banded wide product)
+        c->Pt_ready = false;
+        if (ld != k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, (size_t)D * ld * sizeof(float), c->stream));
+        ISLECHK(k_transpose(c, c->dotsT.p, D, (uint64_t)k, D, c->P.p, (uint64_t)ld));
+        ISLECHK(k_dots_assign(c, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->hub.p, c->hlb.p, 0));
+      }
     } else if (it == 0 || !hamerly) {
       // documents are visited grouped by their previous centre (cache locality of the centre rows); results are order-independent
       ISLECHK(k_spmm_wide_assign(c, c->centers_rm.p, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p,

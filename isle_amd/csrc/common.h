@@ -339,6 +339,8 @@ enum { ISLE_DT_F32 = 0, ISLE_DT_F64 = 1, ISLE_DT_I32 = 2, ISLE_DT_U32 = 3, ISLE_
 int isle_allreduce(isle_ctx* c, void* buf, size_t count, int dtype, bool max_op = false);  // in place
 int isle_allgather(isle_ctx* c, const void* send, void* recv, size_t count_per_rank, int dtype);  // recv: world * count_per_rank
 int k_dots_assign(isle_ctx* c, int k, int ldk, const float* cn, const float* dn, uint32_t* assign, float* ub, float* lb, int G);
+int k_dots_assign_cm(isle_ctx* c, const float* dotsT, int k, int G, const float* cn, const float* dn, const float* cn_max_dev, uint32_t* assign, float* ub,
+                     float* lb);  // the same from column-major dot products, Yinyang bounds
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);

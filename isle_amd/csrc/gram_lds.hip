@@ -1156,12 +1156,16 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
   return 0;
 }
 
-// Columns per pass of the k-wide / thin products through the pass-1 stream.  A 12-column panel (three ds_read_b128 per slot, 48
-// accumulator registers) runs 2.2x as long as an 8-column one (two reads, 32 registers) — 0.77 against 0.35 ms per pass at the
-// C3-shard shape, 324 against ~150 us at C2 — so 8 columns per pass move more columns per second.  ISLE_GL_PANEL=12 restores 12.
+// Columns per pass of the k-wide / thin products through the pass-1 stream: 12 while the 12-column kernel fits its registers (up to 6
+// output items per lane: 72 accumulator registers of a wave's 128), 8 beyond (at 8 items per lane the 12-column form spills 76
+// registers).  Measured at a C3 shard (5 items per lane): projection 38.9 ms in 8-column passes, 33.0 ms in 12-column ones, k-means++
+// 62.2 -> 55.9 ms.  (Rounds 1-2 found the 12-column pass 2.2x as slow as the 8-column one — it spilled inside its loop; the rolled band
+// staging and the bounded number of LDS rows in flight of round 3 removed that.)  ISLE_GL_PANEL = 8 | 12 forces a width.
 static int gl_panel_width(const isle_ctx* c) {
   const char* e = c->knob(KN_GL_PANEL);
-  return (e && atoi(e) == 12) ? 12 : 8;
+  if (e && atoi(e) == 12) return 12;
+  if (e && atoi(e) == 8) return 8;
+  return c->gl1.G <= 6 ? 12 : 8;
 }
 
 // Out (D x ld row-major, natural document order, ld = 4 ceil(nc / 4)) = B^T W for a THIN column-major operand W (V x nc, nc <= 32):

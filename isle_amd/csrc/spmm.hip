@@ -327,6 +327,10 @@ int k_frobenius(isle_ctx* c, double* out_host) {
 enum { WIDE_PROJECT = 0, WIDE_ASSIGN = 1 };
 #include "hamerly.h"
 constexpr int YY_GROUP = 8;  // centres per Yinyang group: two float4 of a centre row, never straddling a 64-byte line
+__device__ inline float yy_slack_down_sq(float m, float E, float sE) {  // lower bound from a squared distance
+  const float l = sqrtf(m);
+  return fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+}
 
 // The assignment epilogue shared by the fused k-wide SpMM (spmm_wide_k) and the dots-from-memory variant (dots_assign_k):
 // lane `lane` holds the dot products of document d with centres 4 (lane + 64 it) .. + 3.
@@ -516,6 +520,75 @@ __global__ __launch_bounds__(256) void dots_assign_k(const float4* __restrict__ 
     acc[it] = cidx < nq ? dots[(size_t)d * nq + cidx] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   wide_assign_epilogue<NIT>(acc, lane, d, nq, k, cn, dn, assign, ub, lb, G);
+}
+
+// The same assignment + Yinyang group bounds straight from the COLUMN-major dot products a GEMM leaves (dotsT[c * D + d], the first
+// assignment of Lloyd on B through the projection): one thread per document walks its row — consecutive threads read consecutive
+// documents of one centre, 128 coalesced bytes per half wave — so the D x k matrix is read once where the doc-major form needed a
+// transposition into c->P first (40 GB written and read again for all of config 3: 50 + 24 ms per step).  Per group of YY_GROUP
+// centres the smallest distance, its first index and the runner-up are final when the group's last column has been seen; the
+// group that holds the assignment gets its runner-up as bound (wide_assign_epilogue's "closest member other than the assigned
+// centre"), which is known once the row is done: the bounds go through an LDS tile [document][group] and leave it as whole rows.
+__global__ __launch_bounds__(128) void dots_assign_cm_k(const float* __restrict__ dotsT, uint32_t D, int k, int G, const float* __restrict__ cn,
+                                                        const float* __restrict__ dn, const float* __restrict__ cn_max_p, uint32_t* __restrict__ assign,
+                                                        float* __restrict__ ub, float* __restrict__ lb, int dpb) {
+  extern __shared__ float tile[];  // dpb x G
+  const uint32_t d0 = blockIdx.x * (uint32_t)dpb;
+  const uint32_t j = threadIdx.x;
+  const uint32_t nd = min((uint32_t)dpb, D - d0);
+  if (j < nd) {
+    const uint32_t d = d0 + j;
+    const float dnd = dn[d];
+    const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+    float best = 3.4e38f, bg_m2 = 3.4e38f;
+    uint32_t bidx = 0xffffffffu;
+    int bg = 0;
+    for (int g = 0; g < G; ++g) {
+      float dot[YY_GROUP];
+#pragma unroll
+      for (int t = 0; t < YY_GROUP; ++t) dot[t] = dotsT[(size_t)min(YY_GROUP * g + t, k - 1) * D + d];  // eight loads in flight
+      float m1 = 3.4e38f, m2 = 3.4e38f;
+      uint32_t i1 = 0xffffffffu;
+#pragma unroll
+      for (int t = 0; t < YY_GROUP; ++t) {
+        const int cc = YY_GROUP * g + t;
+        if (cc < k) {
+          const float dist = fabsf((-2.0f * dot[t] + cn[cc]) + dnd);
+          if (dist < m1) {  // ascending index: a tie keeps the earlier centre
+            m2 = m1;
+            m1 = dist;
+            i1 = (uint32_t)cc;
+          } else {
+            m2 = fminf(m2, dist);
+          }
+        }
+      }
+      tile[j * (uint32_t)G + g] = yy_slack_down_sq(m1, E, sE);
+      if (m1 < best) {
+        best = m1;
+        bidx = i1;
+        bg = g;
+        bg_m2 = m2;
+      }
+    }
+    tile[j * (uint32_t)G + bg] = yy_slack_down_sq(bg_m2, E, sE);
+    const float u = sqrtf(best);
+    ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+    assign[d] = bidx;
+  }
+  __syncthreads();
+  float* out = lb + (size_t)d0 * G;
+  for (uint32_t i = threadIdx.x; i < nd * (uint32_t)G; i += 128) out[i] = tile[i];
+}
+int k_dots_assign_cm(isle_ctx* c, const float* dotsT, int k, int G, const float* cn, const float* dn, const float* cn_max_dev, uint32_t* assign, float* ub,
+                     float* lb) {
+  const uint32_t D = (uint32_t)c->D;
+  if (D == 0) return 0;
+  const int dpb = G <= 128 ? 128 : 64;
+  hipLaunchKernelGGL(dots_assign_cm_k, dim3(cdiv(D, dpb)), dim3(128), (size_t)dpb * G * sizeof(float), c->stream, dotsT, D, k, G, cn, dn, cn_max_dev, assign,
+                     ub, lb, dpb);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 
 // Assignment (and bounds) from dot products held doc-major in c->P (D x ldk): dist = (-2 dot + |C_c|^2) + |b_d|^2
@@ -1061,10 +1134,7 @@ __device__ inline void yy_group_dists(const YyDoc& dc, const float* __restrict__
     dist[j] = fabsf((-2.0f * aa[j] + cn[cc]) + dnd);
   }
 }
-__device__ inline float yy_slack_down(float m, float E, float sE) {  // lower bound from a squared distance
-  const float l = sqrtf(m);
-  return fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
-}
+__device__ inline float yy_slack_down(float m, float E, float sE) { return yy_slack_down_sq(m, E, sE); }
 
 __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                   const float* __restrict__ C /*V x ld row-major*/, const float4* __restrict__ Cg /*nullable: group-major copy*/,
