@@ -25,6 +25,7 @@ typedef uint64_t word_id_t;
 typedef uint64_t doc_id_t;
 typedef int64_t offset_t;
 typedef float FPTYPE;
+typedef uint32_t count_t;  // include/types.h:29
 
 // include/hyperparams.h
 #define ISLE_BLOCK_KS_MAX_ITERS 100

@@ -89,3 +89,39 @@ def test_isletrain_cli(tmp_path, sample):
         t, w, x = ln.split("\t")
         E[int(w) - 1, int(t) - 1] = float(x)
     assert pairs.shape[0] == 30 and np.abs(E - edge * (edge > 1e-8)).max() <= 2e-6
+
+
+def test_trainer_class_fed_document_by_document_equals_the_file_load(tmp_path):
+    """ISLE::ISLETrainer (isle_amd/host/trainer_hip.h) in ITERATIVE_DATA_LOAD mode — feed_data per document (shuffled documents, words in
+    reverse order), finalize_data, train, get_basic_model: the call sequence of the reference's export layer
+    (drivers/trainer_export.cpp:31-98) — must leave the model the file-loading CLI leaves for the same corpus: same A, same B, and the
+    path is deterministic."""
+    V, D, k = 1500, 4000, 20
+    c = Corpus(V, D, k, seed=6)
+    counts, rows, offs = c.A()
+    tdf = str(tmp_path / "corpus.tdf")
+    n = write_tdf(tdf, counts, rows, offs)
+    vocab = str(tmp_path / "vocab.txt")
+    open(vocab, "w").write("\n".join("w%d" % i for i in range(V)))
+    out_a, out_b = str(tmp_path / "a"), str(tmp_path / "b")
+    os.mkdir(out_a)
+    os.mkdir(out_b)
+    r = subprocess.run([os.path.join(ROOT, "isle_amd", "host", "ISLETrain"), tdf, vocab, out_a, str(V), str(D), str(n), str(k), "0", "0", "0", "0", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    model_b = str(tmp_path / "model_b.txt")
+    r = subprocess.run([os.path.join(ROOT, "isle_amd", "host", "trainer_feed_main"), tdf, out_b, str(V), str(D), str(k), model_b],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sub = "log_t_%d_eps1_0.016667_eps2_0.333333_eps3_5.000000_kMppReps_1_kMLowDReps_10_kMReps_10_sample_0_tfidf_0" % k
+    A = np.zeros((V, k))
+    for ln in open(os.path.join(out_a, sub, "M_hat_catch_sparse")).read().splitlines():
+        t, w, x = ln.split("\t")
+        A[int(w) - 1, int(t) - 1] = float(x)
+    Bm = np.zeros((V, k))
+    for ln in open(model_b).read().splitlines():
+        w, t, x = ln.split()
+        Bm[int(w), int(t)] = float(x)
+    assert np.array_equal(np.loadtxt(os.path.join(out_a, sub, "HotPathClusters.tsv"), dtype=np.int64),
+                          np.loadtxt(os.path.join(out_b, sub, "HotPathClusters.tsv"), dtype=np.int64))
+    assert np.abs(A - np.floor(Bm * 1e6) / 1e6 * (Bm > 1e-8)).max() <= 1.01e-6  # the file holds six truncated decimals
