@@ -420,6 +420,7 @@ int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, cons
 
 // kmeans.hip
 int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc, float* min_dist);
+int k_gl_panel_width(const isle_ctx* c);  // columns per pass of the k-wide / thin products through the pass-1 stream (gram_lds.hip)
 int k_scan_f2d(isle_ctx* c, const float* in, uint64_t n, double* cum /*n+1*/);
 int k_search(isle_ctx* c, const double* cum, uint64_t n, const double* dice_dev, int nd, uint64_t* out_dev);
 int k_search_args(isle_ctx* c, const double* cum, uint64_t n, const double* dice_host, int nd /*<= 16*/, uint64_t* out_dev);

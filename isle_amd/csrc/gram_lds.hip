@@ -1168,6 +1168,8 @@ static int gl_panel_width(const isle_ctx* c) {
   return c->gl1.G <= 6 ? 12 : 8;
 }
 
+int k_gl_panel_width(const isle_ctx* c) { return gl_panel_width(c); }
+
 // Out (D x ld row-major, natural document order, ld = 4 ceil(nc / 4)) = B^T W for a THIN column-major operand W (V x nc, nc <= 32):
 // ceil(nc / 12) passes of the pass-1 stream.  The k-means++ round of a large shard: against the nc newest seeds the reference
 // itself forms B^T (U C_new^T) (SURVEY §8d "sparse form"): 8 nnz bytes per 12 columns instead of re-reading the D x k projection.

@@ -15,3 +15,24 @@ __device__ inline void hamerly_store_bounds(float best_sq, float second_sq, floa
   *ub = u + fminf(sE, E / fmaxf(u, 1e-30f));
   *lb = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
 }
+
+// slot of this thread's element in a list all workgroups append to (valid only where act): ONE atomic per workgroup.  Every thread of
+// the workgroup must call it (it synchronises); order inside the list is arbitrary.
+__device__ inline uint32_t block_append_slot(bool act, uint32_t* __restrict__ counter) {
+  __shared__ uint32_t wcnt[16], wbase[17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  const unsigned long long m = __ballot(act);
+  __syncthreads();  // the previous call's readers are done
+  if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < nw; ++w) {
+      wbase[w] = t;
+      t += wcnt[w];
+    }
+    wbase[16] = t ? atomicAdd(counter, t) : 0u;
+  }
+  __syncthreads();
+  return wbase[16] + wbase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}

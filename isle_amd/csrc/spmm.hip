@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "hamerly.h"
 #include "scan.h"
 
 // ------------------------------------------------------------------------------------------
@@ -700,24 +701,6 @@ int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, flo
 // counts, thread 0 claims the workgroup's range).  One atomic per wave put 15 600 atomics per pass on a single address at
 // D = 1M — they serialise in L2 at ~10 ns each, 150 us of a 177 us kernel whose memory traffic needs 10.  Every thread of the
 // workgroup must call it (it synchronises); order inside the list is arbitrary anyway.
-__device__ inline uint32_t block_append_slot(bool act, uint32_t* __restrict__ counter) {
-  __shared__ uint32_t wcnt[16], wbase[17];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-  const unsigned long long m = __ballot(act);
-  __syncthreads();  // the previous call's readers are done
-  if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < nw; ++w) {
-      wbase[w] = t;
-      t += wcnt[w];
-    }
-    wbase[16] = t ? atomicAdd(counter, t) : 0u;
-  }
-  __syncthreads();
-  return wbase[16] + wbase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
 
 // Hamerly's bounds for Lloyd on the sparse matrix (an EXACT acceleration: a document is skipped only when its bounds
 // prove that its closest centre cannot have changed).  ub >= distance to the assigned centre, lb <= distance to the
