@@ -1960,6 +1960,23 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
         unsigned long long cnt[2] = {0, 0};
         HIPCHK(c, hipMemcpy(&na, nact, 4, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(cnt, dbg_dev, 16, hipMemcpyDeviceToHost));
+        {
+          std::vector<float> dl(k), gm(G), cn(k);
+          float cm = 0.f;
+          HIPCHK(c, hipMemcpy(dl.data(), delta_dev, k * sizeof(float), hipMemcpyDeviceToHost));
+          HIPCHK(c, hipMemcpy(gm.data(), gmax_dev, G * sizeof(float), hipMemcpyDeviceToHost));
+          HIPCHK(c, hipMemcpy(cn.data(), c->cnorm.p, k * sizeof(float), hipMemcpyDeviceToHost));
+          HIPCHK(c, hipMemcpy(&cm, cn_max_dev, sizeof(float), hipMemcpyDeviceToHost));
+          std::vector<float> sd(dl), sc(cn);
+          std::sort(sd.begin(), sd.end());
+          std::sort(sc.begin(), sc.end());
+          std::vector<long long> szs;
+          ISLECHK(fetch_sizes(c, k, szs));
+          long long smin = szs[0], smax = szs[0], empty = 0;
+          for (auto v : szs) { smin = std::min(smin, v); smax = std::max(smax, v); empty += v == 0; }
+          fprintf(stderr, "[yinyang] iter %d: movement median %.3g max %.3g; |c|^2 median %.3g max %.3g (cn_max %.3g); cluster sizes %lld..%lld, %lld empty\n", it,
+                  sd[k / 2], sd[k - 1], sc[k / 2], sc[k - 1], cm, smin, smax, empty);
+        }
         if (done)
           fprintf(stderr, "[yinyang] iter %d active %u of %llu; by group: %llu pairs beside the own-group scans (%.1f per active document, of %d)\n", it, na,
                   (unsigned long long)D, npairs, na ? (double)npairs / na : 0.0, G);

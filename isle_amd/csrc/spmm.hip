@@ -1282,21 +1282,22 @@ __global__ __launch_bounds__(256) void yy2_scan_k(const float* __restrict__ vals
                                                    const float* __restrict__ dn, uint32_t npairs, const uint64_t* __restrict__ key,
                                                    const uint32_t* __restrict__ val, YyRes* __restrict__ res) {
   const int lane = threadIdx.x & 63;
-  uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  i = __builtin_amdgcn_readfirstlane(i);
-  if (i >= npairs) return;
-  const uint64_t kd = key[i];
-  const int g = (int)__builtin_amdgcn_readfirstlane((uint32_t)(kd & 0xffu));
-  const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(kd >> 8));
-  const uint32_t p = __builtin_amdgcn_readfirstlane(val[i]);
-  const float dnd = dn[d];
-  const int q = lane & 1;
-  const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
-  const int col = YY_GROUP * g + 4 * q;
-  float dist[4];
-  yy_group_dists(dc, vals, rows, Cg + (size_t)g * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
-  const YyTop2 t = yy_group_top2(dist, col, k);
-  if (lane == 0) res[p] = YyRes{t.m1, t.m2, t.i1};
+  // the grid is capped (a launch of more than 2^32 threads does not run: 2^26 pairs at four per workgroup): waves stride over the pairs
+  for (uint64_t i64 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i64 < npairs; i64 += (uint64_t)gridDim.x * 4) {
+    const uint32_t i = __builtin_amdgcn_readfirstlane((uint32_t)i64);
+    const uint64_t kd = key[i];
+    const int g = (int)__builtin_amdgcn_readfirstlane((uint32_t)(kd & 0xffu));
+    const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(kd >> 8));
+    const uint32_t p = __builtin_amdgcn_readfirstlane(val[i]);
+    const float dnd = dn[d];
+    const int q = lane & 1;
+    const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
+    const int col = YY_GROUP * g + 4 * q;
+    float dist[4];
+    yy_group_dists(dc, vals, rows, Cg + (size_t)g * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
+    const YyTop2 t = yy_group_top2(dist, col, k);
+    if (lane == 0) res[p] = YyRes{t.m1, t.m2, t.i1};
+  }
 }
 
 // (5): thread per active slot
@@ -1398,7 +1399,7 @@ int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float
     HIPCHK(c, hipGetLastError());
     bool in_a = true;
     ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, np, 8, &in_a));
-    hipLaunchKernelGGL(yy2_scan_k, dim3(cdiv((long)np, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, cn, dn,
+    hipLaunchKernelGGL(yy2_scan_k, dim3((unsigned)std::min<size_t>(cdiv((long)np, 4), (size_t)1 << 22)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, cn, dn,
                        npairs, in_a ? c->gl_key_a.p : c->gl_key_b.p, in_a ? c->gl_val_a.p : c->gl_val_b.p, (YyRes*)c->yy_res.p);
     HIPCHK(c, hipGetLastError());
   }

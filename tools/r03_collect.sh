@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for st in "$@"; do
 case $st in
 bench) echo "== bench default (c3 on one GPU), 3 steps"; timeout -k 10 900 python bench.py --steps 3 --warmup 1 > $O/c3full_bench.json 2> $O/c3full_bench.err; echo rc=$?; tail -c 600 $O/c3full_bench.err;;
-benchfull) echo "== bench: the driver's command"; /usr/bin/time -v timeout -k 10 1100 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/c3full_bench_driver_cmd.json 2> $O/c3full_bench_driver_cmd.err; echo rc=$?; tail -c 900 $O/c3full_bench_driver_cmd.err;;
+benchfull) echo "== bench: the driver's command"; T0=$(date +%s); timeout -k 10 1100 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/c3full_bench_driver_cmd.json 2> $O/c3full_bench_driver_cmd.err; echo rc=$? wall_s=$(( $(date +%s) - T0 )); tail -c 900 $O/c3full_bench_driver_cmd.err;;
 prof) echo "== rocprof stats c3 (1 step)"; timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3full -o c3full -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/c3full_bench_under_rocprof.json 2> $O/c3full_rocprof.err; echo rc=$?;;
 pmc) echo "== pmc FETCH_SIZE c3full"; timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 tools/pmc_probe.py c3full > $O/pmc_fetch.log 2>&1; echo rc=$?
      echo "== pmc WRITE_SIZE c3full"; timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 tools/pmc_probe.py c3full > $O/pmc_write.log 2>&1; echo rc=$?
