@@ -215,12 +215,25 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     fence()
     t0 = time.perf_counter()
     last = None
+    step_assigns, step_wall = [], []
     for i in range(steps):
+        ts = time.perf_counter()
         last = step(i)
+        step_assigns.append(last["assign"])  # looked at behind the timed region
+        step_wall.append(time.perf_counter() - ts)
         if big:
             log("[rank %d] step %d of %d done at %.1f s" % (rank, i + 1, steps, time.perf_counter() - t0))  # a line a minute for the watchdog
     fence()
     dt = time.perf_counter() - t0
+    # every timed step must have produced a usable partition (the steps differ in their seeds): a run in which some seed's k-means
+    # collapsed must not pass as a measurement
+    step_nonempty, step_largest = [], []
+    for a in step_assigns:
+        sz = np.bincount(a, minlength=k).astype(np.int64)
+        allreduce_np(sz)
+        step_nonempty.append(int((sz > 0).sum()))
+        step_largest.append(int(sz.max()))
+    del step_assigns
     tm_gram = hp.timing_get()
     # per-family breakdown: one more pass, untimed, with events around every launch
     hp.timing_enable(1)
@@ -272,6 +285,9 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
 
     sizes = np.bincount(last["assign"], minlength=k).astype(np.int64)
     allreduce_np(sizes)
+    if min(step_nonempty) < 0.5 * min(k, D_glob) or max(step_largest) > 0.5 * D_glob:
+        raise SystemExit("bench.py: a timed step left a degenerate partition (fewest non-empty clusters %d of %d, largest cluster %d of %d documents)"
+                         % (min(step_nonempty), k, max(step_largest), D_glob))
     cfg = {
         "workload": "synthetic planted-topic Zipf corpus (%s = BASELINE.json configs[%d]%s): vocab=%d, docs=%d (%d on rank 0), nnz(A)=%d, "
                     "nnz(B)=%d, num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
@@ -281,7 +297,9 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
                      "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"],
                      "converged": bool(last["ks"]["rc"] == 0 and last["ks"]["nconv"] == k)},
         "kmeans": {"kmpp_rounds": last["kmpp_rounds"], "lloyd_projected_iters": last["lp_iters"],
-                   "lloyd_sparse_iters": last["ls_iters"], "nonempty_clusters": int((sizes > 0).sum())},
+                   "lloyd_sparse_iters": last["ls_iters"], "nonempty_clusters": int((sizes > 0).sum()),
+                   "over_all_timed_steps": {"fewest_nonempty_clusters": min(step_nonempty), "largest_cluster": max(step_largest),
+                                            "slowest_step_ms": round(1e3 * max(step_wall), 1), "fastest_step_ms": round(1e3 * min(step_wall), 1)}},
         "parallelism": ("REHEARSAL (not a measurement): %d ranks sharing GPU 0, host-staged collectives" % world if rehearse
                         else "docs column-sharded x%d, RCCL all-reduce" % world if world > 1 else "single GPU"),
         "centers_fetched": bool(args.fetch_centers),
