@@ -530,21 +530,27 @@ __global__ __launch_bounds__(256) void dots_assign_k(const float4* __restrict__ 
 // centres the smallest distance, its first index and the runner-up are final when the group's last column has been seen; the
 // group that holds the assignment gets its runner-up as bound (wide_assign_epilogue's "closest member other than the assigned
 // centre"), which is known once the row is done: the bounds go through an LDS tile [document][group] and leave it as whole rows.
-__global__ __launch_bounds__(128) void dots_assign_cm_k(const float* __restrict__ dotsT, uint32_t D, int k, int G, const float* __restrict__ cn,
+__global__ __launch_bounds__(256) void dots_assign_cm_k(const float* __restrict__ dotsT, uint32_t D, int k, int G, const float* __restrict__ cn,
                                                         const float* __restrict__ dn, const float* __restrict__ cn_max_p, uint32_t* __restrict__ assign,
-                                                        float* __restrict__ ub, float* __restrict__ lb, int dpb) {
-  extern __shared__ float tile[];  // dpb x G
-  const uint32_t d0 = blockIdx.x * (uint32_t)dpb;
+                                                        float* __restrict__ ub, float* __restrict__ lb) {
+  // bounds leave through an LDS tile of DA_GCH groups per document at a time (64 contiguous bytes of a document's row per flush): a
+  // tile of all 125 groups (64 KB for 128 documents) left two workgroups per CU and the kernel at 1.7 TB/s
+  constexpr int DA_GCH = 16;
+  __shared__ float tile[256][DA_GCH + 1];
+  const uint32_t d0 = blockIdx.x * 256u;
   const uint32_t j = threadIdx.x;
-  const uint32_t nd = min((uint32_t)dpb, D - d0);
-  if (j < nd) {
-    const uint32_t d = d0 + j;
-    const float dnd = dn[d];
-    const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
-    float best = 3.4e38f, bg_m2 = 3.4e38f;
-    uint32_t bidx = 0xffffffffu;
-    int bg = 0;
-    for (int g = 0; g < G; ++g) {
+  const uint32_t nd = min(256u, D - d0);
+  const bool live = j < nd;
+  const uint32_t d = d0 + (live ? j : 0u);
+  const float dnd = dn[d];
+  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+  float best = 3.4e38f, bg_m2 = 3.4e38f;
+  uint32_t bidx = 0xffffffffu;
+  int bg = 0;
+  for (int g0 = 0; g0 < G; g0 += DA_GCH) {
+    const int ng = min(DA_GCH, G - g0);
+    for (int gg = 0; gg < ng; ++gg) {
+      const int g = g0 + gg;
       float dot[YY_GROUP];
 #pragma unroll
       for (int t = 0; t < YY_GROUP; ++t) dot[t] = dotsT[(size_t)min(YY_GROUP * g + t, k - 1) * D + d];  // eight loads in flight
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(128) void dots_assign_cm_k(const float* __restrict_
           }
         }
       }
-      tile[j * (uint32_t)G + g] = yy_slack_down_sq(m1, E, sE);
+      tile[j][gg] = yy_slack_down_sq(m1, E, sE);
       if (m1 < best) {
         best = m1;
         bidx = i1;
@@ -572,22 +578,25 @@ __global__ __launch_bounds__(128) void dots_assign_cm_k(const float* __restrict_
         bg_m2 = m2;
       }
     }
-    tile[j * (uint32_t)G + bg] = yy_slack_down_sq(bg_m2, E, sE);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nd * (uint32_t)ng; i += 256) {
+      const uint32_t jj = i / (uint32_t)ng, gg = i - jj * (uint32_t)ng;
+      lb[(size_t)(d0 + jj) * G + g0 + gg] = tile[jj][gg];
+    }
+    __syncthreads();
+  }
+  if (live) {
+    lb[(size_t)d * G + bg] = yy_slack_down_sq(bg_m2, E, sE);  // the assigned centre's group: its closest OTHER member
     const float u = sqrtf(best);
     ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
     assign[d] = bidx;
   }
-  __syncthreads();
-  float* out = lb + (size_t)d0 * G;
-  for (uint32_t i = threadIdx.x; i < nd * (uint32_t)G; i += 128) out[i] = tile[i];
 }
 int k_dots_assign_cm(isle_ctx* c, const float* dotsT, int k, int G, const float* cn, const float* dn, const float* cn_max_dev, uint32_t* assign, float* ub,
                      float* lb) {
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
-  const int dpb = G <= 128 ? 128 : 64;
-  hipLaunchKernelGGL(dots_assign_cm_k, dim3(cdiv(D, dpb)), dim3(128), (size_t)dpb * G * sizeof(float), c->stream, dotsT, D, k, G, cn, dn, cn_max_dev, assign,
-                     ub, lb, dpb);
+  hipLaunchKernelGGL(dots_assign_cm_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, dotsT, D, k, G, cn, dn, cn_max_dev, assign, ub, lb);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
