@@ -47,6 +47,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},
     {"ISLE_KMPP_HOST_DICE", "form", "k-means++ dice scaled and searched through the host round trip (the multi-rank form) on one rank too"},
     {"ISLE_KMPP_SPARSE", "form", "0 / 1: k-means++ rounds on the projection / through thin products of B (default: by cost)"},
+    {"ISLE_KMPP_TRACK", "form", "0: Lloyd in span(U) always starts with a full assignment pass (default at k > 224 on a large shard: it starts from the nearest seeds and tile minima the k-means++ rounds kept)"},
     {"ISLE_NO_HAMERLY", "form", "both Lloyd loops without distance bounds (every document re-examined every iteration)"},
     {"ISLE_KMEANS_BOUNDS", "form", "hamerly | none: bounds of Lloyd on B (default Yinyang group bounds)"},
     {"ISLE_PROJ_BOUNDS", "form", "hamerly: single lower bound in the projected Lloyd loop at k > 224 instead of tile bounds"},
@@ -1438,6 +1439,7 @@ static int ensure_P(isle_ctx* c, int k) {
   HIPCHK(c, c->pnorm.reserve(D));
   ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p));
   c->P_ready = true;
+  c->P_gen++;
   c->Pt_ready = false;
   if (c->D) {  // coordinate-major copy for the register-resident MFMA distance kernels
     HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
@@ -1487,6 +1489,10 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   ISLECHK(fetch_rows(c, &first, 1, c->Cdev.p));
   int new_added = 1, rounds = 0;
   double grand = 0.0, last_md = 0.0;
+  // k > 224 (Lloyd in span(U) keeps tile bounds): the rounds also keep every document's nearest seed and tile minima, so that Lloyd's
+  // first assignment — a D x k x k pass against exactly these seeds — need not be computed again (kmeans.hip kmpp_min_dots_track_k)
+  const bool track = k > 224 && (k + 31) / 32 <= 32 && !c->knob_zero(KN_KMPP_TRACK);
+  c->kmpp_track_k = 0;
   const int maxdraw = 2 + (int)std::ceil(std::sqrt((double)k));
   std::vector<double> dice(maxdraw);
   // page-locked staging for the per-round scalars: [my 2 | tot 2 * world | local maxdraw] doubles, then drawn maxdraw u64
@@ -1499,7 +1505,7 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   while ((int)centers.size() < k) {
     rounds++;
     ISLECHK(k_kmpp_update(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p + (centers.size() - new_added) * (size_t)ldk, new_added,
-                          c->min_dist.p));
+                          c->min_dist.p, (int)(centers.size() - new_added), track));
     ISLECHK(k_scan_f2d(c, c->min_dist.p, D, c->cum.p));  // :2170-2172 (double, parallel; the reference's is fp32 sequential)
     const int s = (int)centers.size();
     int ndraw = 0;
@@ -1591,6 +1597,13 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
     if (rounds > 100 * k) return isle_fail(c, ISLE_E_NUMERIC, "k-means++ cannot find %d distinct seeds", k);
   }
   isle_host_mark("kmeanspp: rounds done");
+  // the last batch of seeds is never folded into min_dist (the loop ends when the k-th seed is drawn, :2163-2207); for Lloyd's first
+  // assignment it is folded into a COPY of the distances
+  if (track && c->kmpp_track && new_added > 0 && c->kmpp_track_seeds == k - new_added && D > 0) {
+    HIPCHK(c, c->kmpp_best.reserve(D));
+    HIPCHK(c, hipMemcpyAsync(c->kmpp_best.p, c->min_dist.p, D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    ISLECHK(k_kmpp_update(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p + (size_t)(k - new_added) * ldk, new_added, c->kmpp_best.p, k - new_added, true));
+  }
   // best_centers_coords[c] = U^T b_seed[c]  (:2232-2234)
   const size_t ch_bytes = (size_t)k * ldk * sizeof(float);
   HIPCHK(c, c->pin_stage_reserve(ch_bytes));
@@ -1603,6 +1616,11 @@ extern "C" int isle_hip_kmeanspp_projected(isle_ctx* c, int k, const uint64_t* i
   }
   if (residual) *residual = (float)(grand - last_md);  // dist_cumul[num_docs - 1]  (:2208; App. C #9)
   if (rounds_out) *rounds_out = rounds;
+  if (track && c->kmpp_track && c->kmpp_track_seeds == k) {  // complete: Lloyd may start from it if it is handed exactly these centres
+    c->kmpp_C_host.assign(C_lowd, C_lowd + (size_t)k * k);
+    c->kmpp_P_gen = c->P_gen;
+    c->kmpp_track_k = k;
+  }
   isle_host_mark("kmeanspp: exit");
   return 0;
 }
@@ -1712,13 +1730,21 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
     HIPCHK(c, c->small.reserve(4096));
     tmove_dev = c->small.p;  // T floats
   }
+  const bool from_kmpp = tiles && c->kmpp_track_k == k && c->kmpp_P_gen == c->P_gen && c->P_ready && !c->knob_zero(KN_KMPP_TRACK) &&
+                         c->kmpp_C_host.size() == (size_t)k * k && memcmp(c->kmpp_C_host.data(), C_lowd, (size_t)k * k * sizeof(float)) == 0;
+  c->kmpp_track_k = 0;  // used (the tile minima become bounds in place) or stale
+  if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[projected Lloyd] first assignment %s\n", from_kmpp ? "taken from the k-means++ rounds" : "computed");
   StopRule stop(c, k);
   int it = 0;
   isle_host_mark("lloyds_projected: loop starts");
   for (; it < max_reps; ++it) {
     ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
     if (tiles) {
-      if (it == 0) {
+      if (it == 0 && from_kmpp) {
+        // the centres are the k-means++ seeds and the rounds kept every document's nearest seed, its tile's runner-up and the minimum of
+        // every other tile: exactly this assignment (up to the rounding of the two distance evaluations, inside the bounds' slack)
+        ISLECHK(k_kmpp_to_tiles(c, D, k, c->pnorm.p, c->cnorm.p, c->kmpp_best.p, c->assign.p, c->hub.p, TL));
+      } else if (it == 0) {
         ISLECHK(k_proj_assign_tiles(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->hub.p, c->ptlb.p, TL, nullptr, 0,
                                     nullptr, nullptr, nullptr));                                           // :1947
       } else {

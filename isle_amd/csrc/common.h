@@ -51,7 +51,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_YY_MODE, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_YY_MODE, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK,
   KN_COUNT
@@ -260,6 +260,16 @@ struct isle_ctx {
   DevBuf<float> seg_part;  // one partial row per chunk
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<unsigned long long> dbg_cnt;  // diagnostics (ISLE_DEBUG_HAMERLY)
+  // what the k-means++ rounds keep for Lloyd's first assignment in span(U) (kmeans.hip kmpp_min_dots_track_k)
+  DevBuf<uint32_t> kmpp_arg;   // nearest seed so far
+  DevBuf<float> kmpp_m2a;      // smallest distance to the other seeds of its tile
+  DevBuf<float> kmpp_tmin;     // smallest distance per tile of 32 seeds, tile-major [tile][document]
+  DevBuf<float> kmpp_best;     // distances to the nearest of ALL k seeds (min_dist does not include the last batch)
+  bool kmpp_track = false;     // every round so far went through the tracking kernel
+  int kmpp_track_seeds = 0;    // seeds folded in
+  int kmpp_track_k = 0;        // 0: nothing to start from; k: state complete for the k seeds in kmpp_C_host, projection generation kmpp_P_gen
+  uint64_t P_gen = 0, kmpp_P_gen = 0;
+  std::vector<float> kmpp_C_host;  // the seeds' coordinates as handed to the caller (k x k)
   // Yinyang iteration ordered by group (spmm.hip, k_yy2_assign)
   DevBuf<float> yy_cg;                 // centres group-major: G tables of V x 8 floats
   DevBuf<uint32_t> yy_own, yy_res;     // YyRes (3 words) per active slot / per pair
@@ -419,7 +429,10 @@ int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, 
 int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, const int* counts);
 
 // kmeans.hip
-int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc, float* min_dist);
+// s_old = seeds before the nc new ones; track: also keep the nearest seed and the tile minima where the route allows (c->kmpp_track)
+int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc, float* min_dist, int s_old = -1,
+                  bool track = false);
+int k_kmpp_to_tiles(isle_ctx* c, uint64_t D, int k, const float* pn, const float* cn, const float* best, uint32_t* assign, float* ub, int TL);
 int k_gl_panel_width(const isle_ctx* c);  // columns per pass of the k-wide / thin products through the pass-1 stream (gram_lds.hip)
 int k_scan_f2d(isle_ctx* c, const float* in, uint64_t n, double* cum /*n+1*/);
 int k_search(isle_ctx* c, const double* cum, uint64_t n, const double* dice_dev, int nd, uint64_t* out_dev);

@@ -164,10 +164,99 @@ __global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__
   min_dist[d] = m;
 }
 
+// The same update that also keeps what Lloyd's first assignment in span(U) needs (k > 224, tile bounds): the nearest seed so far
+// (arg; first index among equal distances), per tile of 32 seeds the smallest distance (tmin, TILE-major [tile][document]: a round touches
+// one or two floats per document, coalesced across documents — document-major rows cost a 128-byte line each) and, for the tile that
+// holds the nearest seed, the smallest distance to its OTHER seeds (m2a).  The seeds arrive in index order, so a round touches the two
+// or three tiles its seeds fall into.  After the last seed this is, document by document, what a full assignment against the k seeds
+// produces — nearest centre, runner-up of its tile, minimum of every other tile — and run_lloyds_on_projected_space can start from it
+// instead of a D x k x k pass (kmpp_to_tiles_k).  `best` = the running minimum (min_dist during the rounds; a copy for the last batch,
+// which the reference never folds into min_dist).
+__global__ __launch_bounds__(256) void kmpp_min_dots_track_k(const float* __restrict__ dots, int ld, const float* __restrict__ pn,
+                                                              const float* __restrict__ cn, int nc, uint32_t D, float* __restrict__ best,
+                                                              uint32_t* __restrict__ arg, float* __restrict__ m2a, float* __restrict__ tmin,
+                                                              uint32_t s_old) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float nd = pn[d];
+  float m = best[d], m2 = m2a[d];
+  uint32_t a = arg[d];  // meaningless while m is FP_MAX (no seed seen): the first seed replaces it
+  float* tm_col = tmin + d;  // tile T of this document at tm_col[T * D]
+  uint32_t curT = s_old >> 5;
+  float tm = tm_col[(size_t)curT * D];
+  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)d * ld);
+  for (int q = 0; q < ld / 4; ++q) {
+    const float4 v = row[q];
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * q + e;
+      if (j < nc) {
+        const uint32_t sj = s_old + (uint32_t)j, T = sj >> 5;
+        if (T != curT) {
+          tm_col[(size_t)curT * D] = tm;
+          curT = T;
+          tm = tm_col[(size_t)T * D];
+        }
+        const float x = fmaxf((-2.0f * xs[e] + cn[j]) + nd, 0.0f);
+        if (x < m) {  // strictly: the earlier seed keeps a tie
+          m2 = (T == (a >> 5) && m < 3.0e38f) ? m : tm;  // same tile: the old nearest becomes its runner-up; another tile: that tile's minimum so far
+          m = x;
+          a = sj;
+        } else if (T == (a >> 5)) {
+          m2 = fminf(m2, x);
+        }
+        tm = fminf(tm, x);
+      }
+    }
+  }
+  tm_col[(size_t)curT * D] = tm;
+  best[d] = m;
+  arg[d] = a;
+  m2a[d] = m2;
+}
+// tracked state -> the outputs of the full tile-bound assignment (proj_dots_tiles_k's tail): assign, ub, one lower bound per tile
+__global__ __launch_bounds__(256) void kmpp_to_tiles_k(uint32_t D, int k, const float* __restrict__ pn, const float* __restrict__ cn, const float* __restrict__ best,
+                                                        const uint32_t* __restrict__ arg, const float* __restrict__ m2a, const float* __restrict__ tmin,
+                                                        uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ tlb, int TL) {
+  __shared__ float tcn[33];  // largest |centre|^2 per tile, and over all
+  const int T = (k + 31) / 32;
+  if (threadIdx.x < 33) {
+    float m = 0.f;
+    if ((int)threadIdx.x < T)
+      for (int j = 32 * threadIdx.x; j < min(k, 32 * (int)threadIdx.x + 32); ++j) m = fmaxf(m, cn[j]);
+    tcn[threadIdx.x] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int t = 0; t < T; ++t) m = fmaxf(m, tcn[t]);
+    tcn[32] = m;
+  }
+  __syncthreads();
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float nd = pn[d], b = best[d];
+  const uint32_t a = arg[d], Ta = a >> 5;
+  float* row = tlb + (size_t)d * TL;
+  float uu, ll;
+  for (int t = 0; t < T; ++t) {
+    const float m1 = tmin[(size_t)t * D + d];
+    hamerly_store_bounds(m1, m1, nd + tcn[t], &uu, &ll);
+    row[t] = ll;
+  }
+  hamerly_store_bounds(b, m2a[d], nd + tcn[Ta], &uu, &ll);
+  row[Ta] = ll;  // the assigned centre's tile: closest OTHER centre in it
+  hamerly_store_bounds(b, b, nd + tcn[32], &uu, &ll);
+  ub[d] = uu;
+  assign[d] = a;
+}
+
 int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc,
-                  float* min_dist) {
+                  float* min_dist, int s_old, bool track) {
   TimeScope ts(c, ISLE_T_KMPP);
   if (D == 0 || nc == 0) return 0;
+  if (s_old == 0) c->kmpp_track = false;
   HIPCHK(c, c->cnorm.reserve((size_t)std::max(k, nc)));
   ISLECHK(k_rownorms(c, newC, nc, k, ldk, c->cnorm.p));
   // The reference's own formulation: P_d . P_c = b_d^T (U P_c), a thin product of B with the V x nc matrix U C_new^T —
@@ -194,12 +283,32 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
         HIPCHK(c, c->dotsT.reserve((size_t)D * 32));
         ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, k, newC + (size_t)j0 * ldk, ldk, ncj, c->Tmp.p, ISLE_T_KMPP));  // W = U C_new^T  (V x ncj col-major)
         ISLECHK(k_gl_thin(c, c->Tmp.p, ncj, ld, c->dotsT.p));
-        hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist);
+        if (track) {  // also the nearest seed and the tile minima (kmpp_min_dots_track_k)
+          const int T = (k + 31) / 32;
+          if (s_old == 0 && j0 == 0) {
+            HIPCHK(c, c->kmpp_arg.reserve(D));
+            HIPCHK(c, c->kmpp_m2a.reserve(D));
+            HIPCHK(c, c->kmpp_tmin.reserve((size_t)D * T));
+            ISLECHK(k_fill_f32(c, c->kmpp_tmin.p, (size_t)D * T, 3.402823466e+38f));
+            ISLECHK(k_fill_f32(c, c->kmpp_m2a.p, D, 3.402823466e+38f));
+            HIPCHK(c, hipMemsetAsync(c->kmpp_arg.p, 0, D * sizeof(uint32_t), c->stream));
+            c->kmpp_track = true;
+          }
+          if (c->kmpp_track)
+            hipLaunchKernelGGL(kmpp_min_dots_track_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist,
+                               c->kmpp_arg.p, c->kmpp_m2a.p, c->kmpp_tmin.p, (uint32_t)(s_old + j0));
+          else
+            hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist);
+        } else {
+          hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist);
+        }
         HIPCHK(c, hipGetLastError());
       }
+      if (track && c->kmpp_track) c->kmpp_track_seeds = s_old + nc;
       return 0;
     }
   }
+  c->kmpp_track = false;  // the routes below do not keep the nearest seed and the tile minima
   if (nc <= 16 && c->Pt_ready && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024) {
     // streaming pass over the coordinate-major copy (the centres fit the default 64 KB of dynamic LDS)
     const int nq = (nc + 3) / 4;
@@ -807,6 +916,17 @@ __global__ __launch_bounds__(256) void proj_dots_tiles_k(const float* __restrict
   hamerly_store_bounds(best, best, nd + cmax, &uu, &ll);
   ub[d] = uu;
   lb[(size_t)d * TL + btile] = l2;  // the assigned centre's tile: closest OTHER centre in it
+}
+
+// Lloyd's first assignment in span(U) from what the k-means++ rounds kept (kmpp_min_dots_track_k): best = distances to the nearest of all k
+// seeds; the tile minima (tile-major) become the tile bounds (document-major rows of c->ptlb).
+int k_kmpp_to_tiles(isle_ctx* c, uint64_t D, int k, const float* pn, const float* cn, const float* best, uint32_t* assign, float* ub, int TL) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  if (D == 0) return 0;
+  hipLaunchKernelGGL(kmpp_to_tiles_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, (uint32_t)D, k, pn, cn, best, c->kmpp_arg.p, c->kmpp_m2a.p, c->kmpp_tmin.p, assign,
+                     ub, c->ptlb.p, TL);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 
 bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k) {
