@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""CPU simulation (no GPU): padding of the sliced-ELL id stream of pass 1 (64 documents per slice, 30 word bands, 4 entries per super-round)
+under different document orders — by length (what the build does), by planted topic, by heaviest band(s), random.  Result of round 3:
+profiles/r03_padding_simulation.txt."""
 import numpy as np, sys, time
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.synth import make_B
 V,D,k=100_000,256_000,1000
 B=make_B(V,D,k,31337)
