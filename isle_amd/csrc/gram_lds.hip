@@ -42,7 +42,10 @@ namespace {
 constexpr int GL_WAVES = 16;
 constexpr int GL_THREADS = GL_WAVES * 64;
 constexpr int GL_GMAX = 8;  // groups (output items per lane) of a wave: 4 ... 8, GlSide::G; count records are GL_GMAX wide
-constexpr uint32_t GL_RB = 3412;  // source rows per band: (3412 + 1 zero row) * 48 B = 163 824 B <= 160 KiB
+constexpr uint32_t GL_RB = 3397;  // source rows per band: (3397 + 16 zero rows) * 48 B = 163 824 B <= 160 KiB
+constexpr uint32_t GL_NZ = 16;    // zero rows behind the band, one per residue class mod 16 (= per 16-byte bank group of a row's float4): a padding
+                                  // slot reads the zero row of a class no real lane of its ds_read_b128 lane group uses in that slot (gl_place_k)
+constexpr int GL_PLACE_MAXN = 8;  // slices of up to 8 super-rounds (32 slots per lane) are placed; longer ones keep their ascending order
 constexpr uint32_t GL_LDS = 163840;  // all of it: the last 1-KiB DMA piece of a band ends 16 bytes behind the padding row
 constexpr int GL_PF = 4;  // super-rounds in flight per wave (4 x 512 B)
 constexpr uint32_t GL_NONE = 0xffffffffu;
@@ -401,6 +404,116 @@ __global__ __launch_bounds__(128) void gl_sort2_big_k(uint32_t NB, const uint16_
   }
 }
 
+// Bank-aware placement of a slice's entries.  A gathered panel row is read as ds_read_b128 (+ a b64 for the 10-column panel): the LDS
+// serves a wave's b128 in four fixed groups of 16 lanes, one cycle per group when the 16 rows lie in 16 different bank groups — the bank
+// group of row r's float4 is (LPE r + l) mod 16, for 48-byte rows (LPE = 3) a bijection of r mod 16 — and one more cycle for every further
+// distinct row on a busy one.  With a lane's entries packed at the front of its slots in ascending order the LDS array spent 18.7 cycles
+// per wave-row at a C3 shard (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, 46 % of them SQ_LDS_BANK_CONFLICT) against 10 conflict-free.  The order of
+// a lane's entries inside a slice is free (a sum), and so is the slot a lane leaves empty: every (lane group, slot) is given rows of
+// DISTINCT classes mod 16 where the slice has room — an edge colouring of the bipartite multigraph lanes x classes with the slots as colours —
+// and the padding slots read the zero row of a class that is free in both lane groups of their half (the b64 is served per half).
+// Deterministic: a class of a lane group is claimed per step by its lowest pending lane (ds_min), which takes the first slot at or
+// behind its cursor that neither it nor the class uses; the result depends on the slice's ids alone.
+// One workgroup of G waves per (wave wv, band); wave g places group g's slice; no workgroup barrier (trip counts differ per wave).
+__device__ inline int gl_lane_group(int lane) {  // the four ds_read_b128 lane groups: {0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32
+  const int l = lane & 31;
+  const bool a = l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28);
+  return 2 * (lane >> 5) + (a ? 0 : 1);
+}
+__global__ __launch_bounds__(64 * GL_GMAX) void gl_place_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
+                                                            uint2* __restrict__ ids) {
+  constexpr int MS = 4 * GL_PLACE_MAXN;  // slots per lane
+  __shared__ uint16_t ent_s[GL_GMAX][MS][64], out_s[GL_GMAX][MS][64];
+  __shared__ uint32_t taken_s[GL_GMAX][4][16], owner_s[GL_GMAX][4][16], occ_s[GL_GMAX][4][MS];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const size_t wb = blockIdx.x;  // wv * NB + band
+  const uint16_t* cc = cnt + wb * GL_GMAX;
+  const uint32_t n = cc[g];
+  if (n == 0 || n > (uint32_t)GL_PLACE_MAXN) return;  // wave-uniform
+  int64_t sr0 = roff[wb];
+  for (int j = 0; j < g; ++j) sr0 += cc[j];
+  uint2* s = ids + (size_t)sr0 * 64 + lane;
+  const uint32_t S = 4 * n;
+  volatile uint16_t(*ent)[64] = ent_s[g];
+  volatile uint16_t(*out)[64] = out_s[g];
+  volatile uint32_t(*taken)[16] = taken_s[g];
+  volatile uint32_t(*owner)[16] = owner_s[g];
+  volatile uint32_t(*occ)[MS] = occ_s[g];
+  const int grp = gl_lane_group(lane);
+  uint32_t len = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    const uint2 u = s[(size_t)r * 64];
+    const uint32_t id[4] = {u.x & 0xffffu, u.x >> 16, u.y & 0xffffu, u.y >> 16};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ent[4 * r + t][lane] = (uint16_t)id[t];
+      len += id[t] < GL_RB ? 1u : 0u;
+    }
+  }
+  taken[lane >> 4][lane & 15] = 0u;
+  owner[lane >> 4][lane & 15] = 0xffffffffu;
+  for (uint32_t i = lane; i < 4 * S; i += 64) occ[i / S][i % S] = 0u;
+  const uint32_t maskS = S == 32 ? 0xffffffffu : (1u << S) - 1u;
+  uint32_t used = 0, j = 0, st = ((uint32_t)lane * 7u) % S;
+  while (true) {
+    const bool pending = j < len;
+    if (__ballot(pending) == 0ull) break;
+    uint32_t id = 0, rho = 0;
+    if (pending) {
+      id = ent[j][lane];
+      rho = id & 15u;
+      atomicMin(const_cast<uint32_t*>(&owner[grp][rho]), (uint32_t)lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool win = pending && owner[grp][rho] == (uint32_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    if (win) {
+      owner[grp][rho] = 0xffffffffu;
+      const uint32_t t = taken[grp][rho];
+      uint32_t cand = ~used & ~t & maskS;
+      if (!cand) cand = ~used & maskS;  // the class is in every free slot already: a conflict that cannot be avoided
+      const uint32_t hi = cand & ~((1u << st) - 1u);
+      const uint32_t sl = (uint32_t)__builtin_ctz(hi ? hi : cand);
+      taken[grp][rho] = t | (1u << sl);
+      used |= 1u << sl;
+      atomicOr(const_cast<uint32_t*>(&occ[grp][sl]), 1u << rho);
+      out[sl][lane] = (uint16_t)id;
+      ++j;
+      st = sl + 1 == S ? 0u : sl + 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // padding rows: slot = lane; per half one class that is free in both lane groups (else one per group)
+  uint32_t o[4] = {0, 0, 0, 0};
+  if ((uint32_t)lane < S) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = occ[q][lane] & 0xffffu;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if ((uint32_t)lane < S) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t both = ~(o[2 * h] | o[2 * h + 1]) & 0xffffu;
+#pragma unroll
+      for (int q = 2 * h; q < 2 * h + 2; ++q) {
+        const uint32_t own = ~o[q] & 0xffffu;
+        const uint32_t cl = both ? (uint32_t)__builtin_ctz(both) : own ? (uint32_t)__builtin_ctz(own) : 0u;
+        occ[q][lane] = GL_RB + ((cl + 16u - GL_RB % 16u) & 15u);  // the zero row of class cl
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t sl = 4 * r + t;
+      v[t] = (used >> sl) & 1u ? (uint32_t)out[sl][lane] : occ[grp][sl];
+    }
+    s[(size_t)r * 64] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+  }
+}
+
 // total super-rounds of every (word block, band zone): the weights used to size the band chunks.  grid = (blocks, zones)
 __global__ __launch_bounds__(256) void gl_blocktot_k(const uint32_t* __restrict__ srsum, uint32_t nwv, uint32_t wpb, uint32_t NB, uint32_t nzones,
                                                       unsigned long long* __restrict__ tot) {
@@ -490,7 +603,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
-      if (threadIdx.x < LPE) xs[GL_RB * LPE + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding row
+      if (threadIdx.x < GL_NZ * LPE) xs[GL_RB * LPE + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding rows
     }
     __syncthreads();
     const uint4 cc = *reinterpret_cast<const uint4*>(cnt + (wv * NB + band) * GL_GMAX);  // GL_GMAX u16 counts
@@ -757,6 +870,10 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
       hipLaunchKernelGGL(gl_sort2_big_k, dim3(2 * c->num_cus), dim3(128), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p, c->gl_biglist.p);
       HIPCHK(c, hipGetLastError());
     }
+  }
+  if (nwb && !c->knob_zero(KN_GL_PLACE)) {
+    hipLaunchKernelGGL(gl_place_k, dim3((unsigned)nwb), dim3(64 * s.G), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p);
+    HIPCHK(c, hipGetLastError());
   }
   return 0;
 }

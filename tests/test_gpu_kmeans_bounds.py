@@ -111,9 +111,21 @@ def test_tiny_and_degenerate_partitions(hp, D, k):
     ko = o.kmeanspp(U, k, inject=seeds)
     assert np.abs(g["C_lowd"] - ko["C_lowd"]).max() <= 1e-5 * max(1.0, np.abs(ko["C_lowd"]).max())
     lg, lo = hp.run_lloyds_on_projected_space(k, g["C_lowd"]), o.lloyds_projected(U, ko["C_lowd"])
-    assert lg["iters"] == lo["iters"] and np.array_equal(lg["assign"], lo["assign"])
-    assert np.abs(lg["C_lowd"] - lo["C_lowd"]).max() <= 1e-5 * max(1.0, np.abs(lo["C_lowd"]).max())
+    # Seeds that are copies of one document are centres at distance 0 of each other.  The oracle sums a document's entries in row order,
+    # so copies project to the same bits and the tie goes to the lower label; the LDS-banded products sum a document's entries in the
+    # order its slice's bank-aware placement gives them (gl_place_k), copies differ in the last bit and the tie can go either way: the
+    # PARTITION is the same, the labels of coincident centres may be exchanged.  Compared: the partition, and the centres cluster by cluster.
+    def same_partition(a, b, Ca, Cb):
+        first_a = {int(l): int(np.flatnonzero(a == l)[0]) for l in np.unique(a)}
+        first_b = {int(np.flatnonzero(b == l)[0]): int(l) for l in np.unique(b)}
+        assert sorted(first_a.values()) == sorted(first_b.keys())
+        for la, d0 in first_a.items():
+            lb = first_b[d0]
+            assert np.array_equal(a == la, b == lb)
+            assert np.abs(Ca[la] - Cb[lb]).max() <= 1e-5 * max(1.0, np.abs(Cb).max())
+    assert lg["iters"] == lo["iters"]
+    same_partition(lg["assign"], lo["assign"], lg["C_lowd"], lo["C_lowd"])
     hp.left_multiply_by_U(lo["C_lowd"], fetch=False)
     sg, so = hp.run_lloyds(k), o.lloyds_sparse(lift(U, lo["C_lowd"]))
-    assert sg["iters"] == so["iters"] and np.array_equal(sg["assign"], so["assign"])
-    assert np.abs(sg["centers"] - so["centers"]).max() <= 1e-5 * max(1.0, np.abs(so["centers"]).max())
+    assert sg["iters"] == so["iters"]
+    same_partition(sg["assign"], so["assign"], sg["centers"].T, so["centers"].T)  # (V, k): a column per centre

@@ -1,0 +1,23 @@
+#!/bin/bash
+# LDS / VALU counters of the Gram passes at a C3 shard
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r03_u
+mkdir -p $OUT
+for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  timeout -k 10 280 rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc_$tag -o x --output-format csv -- python3 tools/pmc_probe.py c3shard > $OUT/pmc_$tag.log 2>&1
+  echo "rc=$? $set"
+done
+python3 - <<'P'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/r03_u/pmc_*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"][:60], r["Counter_Name"])
+        agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+    print(f)
+    for (kn, cn), (n, v) in sorted(agg.items()):
+        if "gl_apply" in kn or "gl_reduce" in kn:
+            print("  %-62s %-26s calls %4d  per call %.4g" % (kn, cn, n, v / n))
+P
