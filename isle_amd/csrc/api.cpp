@@ -37,7 +37,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4)"},
     {"ISLE_GL_PLACE", "tuning", "0: a lane's entries stay packed at the front of its slots in ascending order instead of the bank-aware placement (gl_place_k)"},
     {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
-    {"ISLE_GL_PANEL", "tuning", "8 | 12: columns per pass of the k-wide / thin products (default 12 up to 6 items per lane in pass 1, else 8)"},
+    {"ISLE_GL_PANEL", "tuning", "8 | 10 | 12: columns per pass of the k-wide / thin products (default 12 up to 6 items per lane in pass 1, 10 at 7, 8 at 8)"},
     {"ISLE_WIDE_GATHER", "form", "k-wide products (projection, first word-space assignment) by the row-gather kernel"},
     {"ISLE_WIDE_LDS", "form", "k-wide products through the LDS-banded pass-1 stream whatever the vocabulary size"},
     {"ISLE_KS_ROWSHARD", "form", "1: several ranks orthogonalise row slices of the Krylov block (all-reduced coefficients, all-gathered block); default 0 = replicated"},

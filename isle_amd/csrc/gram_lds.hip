@@ -559,7 +559,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
                                                           const uint32_t* __restrict__ slice_of, const GlDesc* __restrict__ desc, uint32_t NB,
                                                           float4* __restrict__ Out, size_t slab_stride, uint32_t n_out,
                                                           const uint32_t* __restrict__ rowmap /*nullable: position -> output row*/,
-                                                          uint32_t out_ld4 /*output row stride in float4*/) {
+                                                          uint32_t out_ld4 /*output row stride in float4*/,
+                                                          uint32_t out_n2 /*0: whole float4 per row; else float2 per row to store (8-byte aligned rows)*/) {
   extern __shared__ float4 xs[];  // (GL_RB + 1) rows of LPE float4
   constexpr int NF = HALF ? LPE - 1 : LPE;  // whole float4 per row
   constexpr int NFA = NF > 0 ? NF : 1;
@@ -653,6 +654,16 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     const uint64_t pos = (uint64_t)sl * 64 + lane;
     if (sl != GL_NONE && pos < n_out) {
       const size_t row = rowmap ? (size_t)rowmap[pos] : (size_t)(pos - ds.pos_base);
+      if (out_n2) {  // a panel of 10-column steps inside a wider row: 8-byte aligned, exactly the panel's columns
+        float2* o2 = reinterpret_cast<float2*>(out) + row * (size_t)out_ld4 * 2;
+#pragma unroll
+        for (int l = 0; l < NF; ++l) {
+          if (2u * l < out_n2) o2[2 * l] = make_float2(acc[g][l].x, acc[g][l].y);
+          if (2u * l + 1 < out_n2) o2[2 * l + 1] = make_float2(acc[g][l].z, acc[g][l].w);
+        }
+        if (HALF && 2u * NF < out_n2) o2[2 * NF] = acch[g];
+        continue;
+      }
 #pragma unroll
       for (int l = 0; l < NF; ++l) out[row * out_ld4 + l] = acc[g][l];
       if (HALF) out[row * out_ld4 + NF] = make_float4(acch[g].x, acch[g].y, 0.f, 0.f);
@@ -879,22 +890,23 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
 }
 
 template <int LPE, bool HALF, int G>
-int launch_apply_g(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4) {
+int launch_apply_g(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4,
+                   uint32_t out_n2) {
   ISLECHK(isle_max_lds(c, (const void*)gl_apply_k<LPE, HALF, G>, GL_LDS));
   hipLaunchKernelGGL((gl_apply_k<LPE, HALF, G>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
-                     s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE);
+                     s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE, out_n2);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 template <int LPE, bool HALF>
 int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap = nullptr,
-                 uint32_t out_ld4 = 0) {
+                 uint32_t out_ld4 = 0, uint32_t out_n2 = 0) {
   switch (s.G) {
-    case 4: return launch_apply_g<LPE, HALF, 4>(c, s, In, Out, slab_stride, rowmap, out_ld4);
-    case 5: return launch_apply_g<LPE, HALF, 5>(c, s, In, Out, slab_stride, rowmap, out_ld4);
-    case 6: return launch_apply_g<LPE, HALF, 6>(c, s, In, Out, slab_stride, rowmap, out_ld4);
-    case 7: return launch_apply_g<LPE, HALF, 7>(c, s, In, Out, slab_stride, rowmap, out_ld4);
-    case 8: return launch_apply_g<LPE, HALF, 8>(c, s, In, Out, slab_stride, rowmap, out_ld4);
+    case 4: return launch_apply_g<LPE, HALF, 4>(c, s, In, Out, slab_stride, rowmap, out_ld4, out_n2);
+    case 5: return launch_apply_g<LPE, HALF, 5>(c, s, In, Out, slab_stride, rowmap, out_ld4, out_n2);
+    case 6: return launch_apply_g<LPE, HALF, 6>(c, s, In, Out, slab_stride, rowmap, out_ld4, out_n2);
+    case 7: return launch_apply_g<LPE, HALF, 7>(c, s, In, Out, slab_stride, rowmap, out_ld4, out_n2);
+    case 8: return launch_apply_g<LPE, HALF, 8>(c, s, In, Out, slab_stride, rowmap, out_ld4, out_n2);
   }
   return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: %d items per lane", s.G);
 }
@@ -1278,11 +1290,33 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
 // registers).  Measured at a C3 shard (5 items per lane): projection 38.9 ms in 8-column passes, 33.0 ms in 12-column ones, k-means++
 // 62.2 -> 55.9 ms.  (Rounds 1-2 found the 12-column pass 2.2x as slow as the 8-column one — it spilled inside its loop; the rolled band
 // staging and the bounded number of LDS rows in flight of round 3 removed that.)  ISLE_GL_PANEL = 8 | 12 forces a width.
+// 10 at 7 items per lane (the Gram apply's own 10-column form, 70 accumulator registers, no spill): a pass costs what it costs at 8 columns
+// (the slots, not the columns, set its time: 2.20 ms per 8-column pass against 2.29 per 10-column one at config 3 on one GPU), so k = 1000 is
+// walked in 100 passes instead of 125.  Steps of 10 columns leave the panels 8-byte aligned inside the output rows: they are stored as float2.
 static int gl_panel_width(const isle_ctx* c) {
   const char* e = c->knob(KN_GL_PANEL);
   if (e && atoi(e) == 12) return 12;
+  if (e && atoi(e) == 10) return 10;
   if (e && atoi(e) == 8) return 8;
-  return c->gl1.G <= 6 ? 12 : 8;
+  return c->gl1.G <= 6 ? 12 : c->gl1.G == 7 ? 10 : 8;
+}
+
+// Columns a panel pass stores: its own, and behind the last panel the padding columns of the row (ld = 4 ceil(k / 4); the consumers read
+// whole float4 of a row and rely on zeros there — the packed panel is zero beyond its columns, so the accumulators are).
+static inline int gl_panel_store_cols(int j0, int ncol, int k, int ld) { return j0 + ncol >= k ? ld - j0 : ncol; }
+
+// one pass of the pass-1 stream over a packed panel (LPE = ceil(wcols / 4) float4 per row) -> columns [j0, j0 + wcols) of Out
+// (D x ld row-major, document order)
+static int gl_panel_pass(isle_ctx* c, int wcols, int j0, int ld, float* Out) {
+  const int LPE = (wcols + 3) / 4;
+  const bool half = wcols <= 4 * LPE - 2;  // the last float4 holds at most two columns
+  const uint32_t ld4 = (uint32_t)(ld / 4);
+  float4* out = (float4*)(Out + j0);
+  const uint32_t n2 = (j0 % 4) || half ? (uint32_t)((wcols + 1) / 2) : 0u;  // float2 stores where float4 would be misaligned or too wide
+  const float4* in = (const float4*)c->gl_Xs.p;
+  if (LPE == 1) return half ? launch_apply<1, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<1, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
+  if (LPE == 2) return half ? launch_apply<2, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<2, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
+  return half ? launch_apply<3, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<3, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
 }
 
 int k_gl_panel_width(const isle_ctx* c) { return gl_panel_width(c); }
@@ -1299,16 +1333,13 @@ int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out) {
   const int PW = gl_panel_width(c);
   for (int j0 = 0; j0 < nc; j0 += PW) {
     const int ncol = std::min(PW, nc - j0);
-    const int LPE = (ncol + 3) / 4;
+    const int wcols = gl_panel_store_cols(j0, ncol, nc, ld);
+    const int LPE = (wcols + 3) / 4;
     const size_t n4 = (size_t)V * LPE;
     hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Wcm + (size_t)j0 * V, (size_t)V, ncol, LPE, c->rowval.p,
                        (float4*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
-    float4* out = (float4*)(Out + j0);  // 48-byte steps: 16-byte aligned
-    const uint32_t ld4 = (uint32_t)(ld / 4);
-    if (LPE == 1) ISLECHK((launch_apply<1, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
-    if (LPE == 2) ISLECHK((launch_apply<2, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
-    if (LPE == 3) ISLECHK((launch_apply<3, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+    ISLECHK(gl_panel_pass(c, wcols, j0, ld, Out));
   }
   return 0;
 }
@@ -1326,16 +1357,13 @@ int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
   const int PW = gl_panel_width(c);
   for (int j0 = 0; j0 < k; j0 += PW) {
     const int ncol = std::min(PW, k - j0);
-    const int LPE = (ncol + 3) / 4;
+    const int wcols = gl_panel_store_cols(j0, ncol, k, ld);
+    const int LPE = (wcols + 3) / 4;
     const size_t n4 = (size_t)V * LPE;
     hipLaunchKernelGGL(gl_pack_panel_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Mrm, ld, j0, ncol, LPE, c->rowval.p, n4,
                        (float4*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
-    float4* out = (float4*)(Out + j0);  // 48-byte steps: 16-byte aligned
-    const uint32_t ld4 = (uint32_t)(ld / 4);
-    if (LPE == 1) ISLECHK((launch_apply<1, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
-    if (LPE == 2) ISLECHK((launch_apply<2, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
-    if (LPE == 3) ISLECHK((launch_apply<3, false>(c, c->gl1, (const float4*)c->gl_Xs.p, out, 0, c->dperm.p, ld4)));
+    ISLECHK(gl_panel_pass(c, wcols, j0, ld, Out));
   }
   return 0;
 }
