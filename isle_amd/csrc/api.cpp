@@ -37,7 +37,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4)"},
     {"ISLE_GL_PLACE", "tuning", "0: a lane's entries stay packed at the front of its slots in ascending order instead of the bank-aware placement (gl_place_k)"},
     {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
-    {"ISLE_GL_PANEL", "tuning", "8 | 10 | 12: columns per pass of the k-wide / thin products (default 12 up to 6 items per lane in pass 1, 10 at 7, 8 at 8)"},
+    {"ISLE_GL_PANEL", "tuning", "8 | 10: columns per pass of the k-wide / thin products (default 10, 8 at 8 items per lane in pass 1)"},
     {"ISLE_WIDE_GATHER", "form", "k-wide products (projection, first word-space assignment) by the row-gather kernel"},
     {"ISLE_WIDE_LDS", "form", "k-wide products through the LDS-banded pass-1 stream whatever the vocabulary size"},
     {"ISLE_KS_ROWSHARD", "form", "1: several ranks orthogonalise row slices of the Krylov block (all-reduced coefficients, all-gathered block); default 0 = replicated"},
@@ -906,9 +906,10 @@ static int gram_apply_dev(isle_ctx* c, const float* Xcm, int b, float* Zcm) {
   if (b < 1 || b > 32) return isle_fail(c, ISLE_E_ARG, "gram_apply: b = %d not in [1, 32]", b);
   ISLECHK(k_band_build(c));  // first application of a solve: operator build (and the choice of the form)
   if (c->gl_mode == 1) {
-    // LDS-banded form (gram_lds.hip), panels of at most 12 columns; column groups of a col-major block are contiguous
-    for (int j0 = 0; j0 < b; j0 += 12) {
-      const int bg = std::min(12, b - j0);
+    // LDS-banded form (gram_lds.hip), panels of at most 10 columns (40-byte rows of a planar band); column groups of a col-major block
+    // are contiguous
+    for (int j0 = 0; j0 < b; j0 += 10) {
+      const int bg = std::min(10, b - j0);
       const int BPg = panel_width(bg);
       ISLECHK(k_gl_apply_cm(c, Xcm + (size_t)j0 * c->V, bg, BPg, Zcm + (size_t)j0 * c->V));
       ISLECHK(allreduce_sum<float>(c, Zcm + (size_t)j0 * c->V, (size_t)c->V * bg));

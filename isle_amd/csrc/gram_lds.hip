@@ -42,13 +42,29 @@ namespace {
 constexpr int GL_WAVES = 16;
 constexpr int GL_THREADS = GL_WAVES * 64;
 constexpr int GL_GMAX = 8;  // groups (output items per lane) of a wave: 4 ... 8, GlSide::G; count records are GL_GMAX wide
-constexpr uint32_t GL_RB = 3397;  // source rows per band: (3397 + 16 zero rows) * 48 B = 163 824 B <= 160 KiB
-constexpr uint32_t GL_NZ = 16;    // zero rows behind the band, one per residue class mod 16 (= per 16-byte bank group of a row's float4): a padding
-                                  // slot reads the zero row of a class no real lane of its ds_read_b128 lane group uses in that slot (gl_place_k)
+constexpr uint32_t GL_RB = 4078;  // source rows per band (even: the half plane is whole float4)
+constexpr uint32_t GL_NZ = 16;    // zero rows behind every plane of the band, one per residue class mod 16 (= per 16-byte bank group of the plane):
+                                  // a padding slot reads the zero row of a class no real lane of its ds_read_b128 lane group uses in that slot (gl_place_k)
+constexpr uint32_t GL_PS = GL_RB + GL_NZ;   // rows of a plane in LDS
+constexpr uint32_t GL_PSB = GL_PS * 16;     // 65 504 bytes: the plane stride still fits the 16-bit offset field of ds_read_b128
+// A band of a packed operand is PLANAR: plane l holds columns 4l .. 4l+3 of its rows as float4 (16-byte bank groups: row r lies on group
+// r mod 16), a panel of 4 LPE - 2 columns ends in a half plane of float2 (8-byte slots: r mod 32).  Ten columns are 40 bytes a row —
+// 4078 rows in 160 KiB where 48-byte rows held 3397 (25 word bands instead of 30 at V = 100 000: larger cells, less padding, fewer
+// staging rounds) — every read is a naturally aligned ds_read_b128 / b64 (rows of 40 bytes read as 8-byte pieces were measured in round 2:
+// slower than 48-byte rows), and the half plane is conflict-free where row-major 48-byte rows put all b64 reads on the even 8-byte slots.
+// In global memory a band image is the same planes without the zero rows: GL_RB * (16 NF + 8 HALF) bytes, bands back to back.
+__host__ __device__ constexpr uint32_t gl_img_bytes(int LPE, bool half) { return GL_RB * (16u * (uint32_t)(half ? LPE - 1 : LPE) + (half ? 8u : 0u)); }
+// byte offset of (row, plane l) in a packed operand; l == NF addresses the half plane (float2)
+__host__ __device__ inline size_t gl_planar_off(uint32_t row, int l, int LPE, bool half) {
+  const uint32_t band = row / GL_RB, r = row - band * GL_RB;
+  const int NF = half ? LPE - 1 : LPE;
+  return (size_t)band * gl_img_bytes(LPE, half) + (size_t)(l < NF ? l : NF) * GL_RB * 16u + (size_t)r * (l < NF ? 16u : 8u);
+}
 constexpr int GL_PLACE_MAXN = 8;  // slices of up to 8 super-rounds (32 slots per lane) are placed; longer ones keep their ascending order
-constexpr uint32_t GL_LDS = 163840;  // all of it: the last 1-KiB DMA piece of a band ends 16 bytes behind the padding row
+constexpr uint32_t GL_LDS = 163840;  // all of it (2 x 65 504 + 4094 x 8 = 163 760 bytes are used by the 10-column panel)
 constexpr int GL_PF = 4;  // super-rounds in flight per wave (4 x 512 B)
 constexpr uint32_t GL_NONE = 0xffffffffu;
+constexpr uint32_t GL_OUT_PLANAR = 0xffffffffu;  // gl_apply_k out_n2: the output is a packed (planar, banded) operand
 constexpr uint32_t GL_VP = 81920;  // words per vocabulary part of the LDS histograms (two u16 counters per dword: 160 KiB)
 constexpr uint32_t GL_HLDS = GL_VP / 2 * 4;
 constexpr int GL_SUB = 8;  // lanes per document in the histogram kernels
@@ -404,42 +420,51 @@ __global__ __launch_bounds__(128) void gl_sort2_big_k(uint32_t NB, const uint16_
   }
 }
 
-// Bank-aware placement of a slice's entries.  A gathered panel row is read as ds_read_b128 (+ a b64 for the 10-column panel): the LDS
-// serves a wave's b128 in four fixed groups of 16 lanes, one cycle per group when the 16 rows lie in 16 different bank groups — the bank
-// group of row r's float4 is (LPE r + l) mod 16, for 48-byte rows (LPE = 3) a bijection of r mod 16 — and one more cycle for every further
-// distinct row on a busy one.  With a lane's entries packed at the front of its slots in ascending order the LDS array spent 18.7 cycles
-// per wave-row at a C3 shard (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, 46 % of them SQ_LDS_BANK_CONFLICT) against 10 conflict-free.  The order of
-// a lane's entries inside a slice is free (a sum), and so is the slot a lane leaves empty: every (lane group, slot) is given rows of
-// DISTINCT classes mod 16 where the slice has room — an edge colouring of the bipartite multigraph lanes x classes with the slots as colours —
-// and the padding slots read the zero row of a class that is free in both lane groups of their half (the b64 is served per half).
-// Deterministic: a class of a lane group is claimed per step by its lowest pending lane (ds_min), which takes the first slot at or
-// behind its cursor that neither it nor the class uses; the result depends on the slice's ids alone.
-// One workgroup of G waves per (wave wv, band); wave g places group g's slice; no workgroup barrier (trip counts differ per wave).
+// Bank-aware placement of a slice's entries.  A gathered panel row is read as one ds_read_b128 per plane (+ a ds_read_b64 from the half
+// plane of the 10-column panel).  The LDS serves a wave's b128 in four fixed groups of 16 lanes, one cycle per group when the 16 rows lie
+// in 16 different 16-byte bank groups — row r of a plane lies on group r mod 16 — and one more cycle for every further distinct row on a
+// busy one; a b64 is served per 32-lane half, row r of the half plane on 8-byte slot r mod 32.  With a lane's entries packed at the front
+// of its slots in ascending order the LDS array spent 18.7 cycles per wave-row at a C3 shard (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, 46 % of
+// them SQ_LDS_BANK_CONFLICT) against 10 conflict-free.  The order of a lane's entries inside a slice is free (a sum), and so is the slot a
+// lane leaves empty: every (lane group, slot) is given rows of DISTINCT classes mod 16, every (half, slot) rows of distinct classes mod 32,
+// where the slice has room — an edge colouring of the bipartite multigraph lanes x classes with the slots as colours — and the padding
+// slots read the zero row of a class that is free in both lane groups of their half.
+// Deterministic: a class mod 16 of a half is claimed per step by its lowest pending lane (ds_min), which takes the first slot at or
+// behind its cursor that neither it nor the class (mod 16 in its lane group, mod 32 in its half) uses; the result depends on the
+// slice's ids alone.  One wave per slice, eight slices per workgroup; no workgroup barrier (trip counts differ per wave).
 __device__ inline int gl_lane_group(int lane) {  // the four ds_read_b128 lane groups: {0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32
   const int l = lane & 31;
   const bool a = l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28);
   return 2 * (lane >> 5) + (a ? 0 : 1);
 }
-__global__ __launch_bounds__(64 * GL_GMAX) void gl_place_k(uint32_t NB, const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff,
-                                                            uint2* __restrict__ ids) {
-  constexpr int MS = 4 * GL_PLACE_MAXN;  // slots per lane
-  __shared__ uint16_t ent_s[GL_GMAX][MS][64], out_s[GL_GMAX][MS][64];
-  __shared__ uint32_t taken_s[GL_GMAX][4][16], owner_s[GL_GMAX][4][16], occ_s[GL_GMAX][4][MS];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const size_t wb = blockIdx.x;  // wv * NB + band
+// MAXN: super-rounds of the slices this instantiation places (those of (MAXN / 2, MAXN] super-rounds, MAXN / 2 = 0 for the smallest): the
+// LDS of a wave is sized by it — 16 slots per lane for up to 4 super-rounds (most slices), 32 beyond — and eight slices share a workgroup
+// whatever the items per lane of the side are, so that the latency-bound claim loop runs at 16 ... 32 waves per CU.
+template <int MAXN, int MINN>
+__global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t nslices, const uint16_t* __restrict__ cnt,
+                                                   const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
+  constexpr int MS = 4 * MAXN;  // slots per lane
+  __shared__ uint16_t ent_s[8][MS][64], out_s[8][MS][64];
+  __shared__ uint32_t taken_s[8][4][16], taken32_s[8][2][32], owner_s[8][2][16], occ_s[8][4][MS];
+  const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  const size_t sid = (size_t)blockIdx.x * 8 + wq;  // slice = (wave wv, band, group g) = wb * G + g
+  if (sid >= nslices) return;
+  const size_t wb = sid / (size_t)G;
+  const int g = (int)(sid - wb * (size_t)G);
   const uint16_t* cc = cnt + wb * GL_GMAX;
   const uint32_t n = cc[g];
-  if (n == 0 || n > (uint32_t)GL_PLACE_MAXN) return;  // wave-uniform
+  if (n <= (uint32_t)MINN || n > (uint32_t)MAXN) return;  // wave-uniform
   int64_t sr0 = roff[wb];
   for (int j = 0; j < g; ++j) sr0 += cc[j];
   uint2* s = ids + (size_t)sr0 * 64 + lane;
   const uint32_t S = 4 * n;
-  volatile uint16_t(*ent)[64] = ent_s[g];
-  volatile uint16_t(*out)[64] = out_s[g];
-  volatile uint32_t(*taken)[16] = taken_s[g];
-  volatile uint32_t(*owner)[16] = owner_s[g];
-  volatile uint32_t(*occ)[MS] = occ_s[g];
-  const int grp = gl_lane_group(lane);
+  volatile uint16_t(*ent)[64] = ent_s[wq];
+  volatile uint16_t(*out)[64] = out_s[wq];
+  volatile uint32_t(*taken)[16] = taken_s[wq];
+  volatile uint32_t(*taken32)[32] = taken32_s[wq];
+  volatile uint32_t(*owner)[16] = owner_s[wq];
+  volatile uint32_t(*occ)[MS] = occ_s[wq];
+  const int grp = gl_lane_group(lane), half = lane >> 5;
   uint32_t len = 0;
   for (uint32_t r = 0; r < n; ++r) {
     const uint2 u = s[(size_t)r * 64];
@@ -451,7 +476,8 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_place_k(uint32_t NB, const ui
     }
   }
   taken[lane >> 4][lane & 15] = 0u;
-  owner[lane >> 4][lane & 15] = 0xffffffffu;
+  taken32[lane >> 5][lane & 31] = 0u;
+  if (lane < 32) owner[lane >> 4][lane & 15] = 0xffffffffu;
   for (uint32_t i = lane; i < 4 * S; i += 64) occ[i / S][i % S] = 0u;
   const uint32_t maskS = S == 32 ? 0xffffffffu : (1u << S) - 1u;
   uint32_t used = 0, j = 0, st = ((uint32_t)lane * 7u) % S;
@@ -462,19 +488,21 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_place_k(uint32_t NB, const ui
     if (pending) {
       id = ent[j][lane];
       rho = id & 15u;
-      atomicMin(const_cast<uint32_t*>(&owner[grp][rho]), (uint32_t)lane);
+      atomicMin(const_cast<uint32_t*>(&owner[half][rho]), (uint32_t)lane);
     }
     __builtin_amdgcn_wave_barrier();
-    const bool win = pending && owner[grp][rho] == (uint32_t)lane;
+    const bool win = pending && owner[half][rho] == (uint32_t)lane;
     __builtin_amdgcn_wave_barrier();
     if (win) {
-      owner[grp][rho] = 0xffffffffu;
-      const uint32_t t = taken[grp][rho];
-      uint32_t cand = ~used & ~t & maskS;
-      if (!cand) cand = ~used & maskS;  // the class is in every free slot already: a conflict that cannot be avoided
+      owner[half][rho] = 0xffffffffu;
+      const uint32_t t16 = taken[grp][rho], t32 = taken32[half][id & 31u];
+      uint32_t cand = ~used & ~t16 & ~t32 & maskS;
+      if (!cand) cand = ~used & ~t16 & maskS;  // no slot without a b64 conflict left
+      if (!cand) cand = ~used & maskS;         // the class is in every free slot already: a conflict that cannot be avoided
       const uint32_t hi = cand & ~((1u << st) - 1u);
       const uint32_t sl = (uint32_t)__builtin_ctz(hi ? hi : cand);
-      taken[grp][rho] = t | (1u << sl);
+      taken[grp][rho] = t16 | (1u << sl);
+      taken32[half][id & 31u] = t32 | (1u << sl);
       used |= 1u << sl;
       atomicOr(const_cast<uint32_t*>(&occ[grp][sl]), 1u << rho);
       out[sl][lane] = (uint16_t)id;
@@ -560,10 +588,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
                                                           float4* __restrict__ Out, size_t slab_stride, uint32_t n_out,
                                                           const uint32_t* __restrict__ rowmap /*nullable: position -> output row*/,
                                                           uint32_t out_ld4 /*output row stride in float4*/,
-                                                          uint32_t out_n2 /*0: whole float4 per row; else float2 per row to store (8-byte aligned rows)*/) {
-  extern __shared__ float4 xs[];  // (GL_RB + 1) rows of LPE float4
+                                                          uint32_t out_n2 /*0: whole float4 per row; GL_OUT_PLANAR: a packed operand (the input of
+                                                                            pass 2); else float2 per row to store (8-byte aligned rows)*/) {
+  extern __shared__ float4 xs[];  // NF planes of GL_PS float4 (+ a half plane of GL_PS float2)
   constexpr int NF = HALF ? LPE - 1 : LPE;  // whole float4 per row
   constexpr int NFA = NF > 0 ? NF : 1;
+  constexpr uint32_t IMG = gl_img_bytes(LPE, HALF);
+  constexpr int NPIECE = NF * 64 + (HALF ? 32 : 0);  // 1-KiB pieces of a band image: 64 per plane (the last one partial), 32 for the half plane
   // entries of a super-round whose LDS rows are in flight together: all four while the accumulators leave room (a wave has 128
   // registers at 16 waves per workgroup), two beyond — measured at a C3 shard, pass 1 with 10 columns: 5 items per lane 0.313 ms with
   // four in flight against 0.322 with two; 8 items per lane 0.50 ms (spills inside the loop) against 0.38
@@ -572,6 +603,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool wvalid = (uint32_t)w < ds.nw;  // wave-uniform
   const size_t wv = wvalid ? (size_t)ds.wave0 + (size_t)w * ds.wstride : (size_t)ds.wave0;
+  char* const lb = reinterpret_cast<char*>(xs);
+  // the zero rows behind every plane: the staging below never lands on them
+  if (threadIdx.x < GL_NZ * NF) reinterpret_cast<float4*>(lb + (threadIdx.x / GL_NZ) * GL_PSB)[GL_RB + threadIdx.x % GL_NZ] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (HALF && threadIdx.x < GL_NZ) reinterpret_cast<float2*>(lb + NF * GL_PSB)[GL_RB + threadIdx.x] = make_float2(0.f, 0.f);
   float4 acc[G][NFA];
   float2 acch[G];
 #pragma unroll
@@ -589,22 +624,25 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
     __syncthreads();  // every wave is done with the previous band
     {
-      // stage the band: ten 1-KiB LDS-DMA pieces per wave (global_load_lds_dwordx4: no VGPR round trip, all in flight at once)
-      const uint32_t r0 = band * GL_RB;
-      const uint32_t nrow = min(GL_RB, n_src - r0);
-      const float4* src = In + (size_t)r0 * LPE;
-      const uint32_t n4 = nrow * LPE;  // <= 10 * 1024
+      // stage the band: up to ten 1-KiB LDS-DMA pieces per wave (global_load_lds_dwordx4: no VGPR round trip, all in flight at once)
+      const uint32_t nrow = min(GL_RB, n_src - band * GL_RB);
+      const char* src = reinterpret_cast<const char*>(In) + (size_t)band * IMG;
 #pragma nounroll
-      for (int j = 0; j < 10; ++j) {  // rolled: unrolled, the ten address pairs stayed live beside the accumulators and the 10-column form spilled
-        const uint32_t i0 = (uint32_t)(j * GL_WAVES + w) * 64;  // wave-uniform LDS base, lane l lands at i0 + l
-        if (i0 + lane < n4) {  // lanes past the band's end stay masked: they must not land on the padding row
-          const float4* gp = src + i0 + lane;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)(xs + i0),
-                                           16, 0, 0);
+      for (int j = 0; j < (NPIECE + GL_WAVES - 1) / GL_WAVES; ++j) {  // rolled: unrolled, the address pairs stayed live beside the accumulators (spills)
+        const int q = j * GL_WAVES + w;  // wave-uniform piece
+        if (q < NPIECE) {
+          const bool hp = q >= NF * 64;  // a piece of the half plane
+          const int plane = hp ? NF : q >> 6;
+          const uint32_t i = (uint32_t)(hp ? q - NF * 64 : q & 63) * 64u + lane;  // float4 of the plane
+          // lanes past the band's rows stay masked: they must not land on the zero rows
+          if (i < (hp ? (nrow + 1) / 2 : nrow)) {
+            const char* gp = src + (size_t)plane * GL_RB * 16u + (size_t)i * 16u;
+            char* lp = lb + plane * GL_PSB + (i - lane) * 16u;  // wave-uniform LDS base, lane l lands 16 l behind it
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+          }
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
-      if (threadIdx.x < GL_NZ * LPE) xs[GL_RB * LPE + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the padding rows
     }
     __syncthreads();
     const uint4 cc = *reinterpret_cast<const uint4*>(cnt + (wv * NB + band) * GL_GMAX);  // GL_GMAX u16 counts
@@ -621,7 +659,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
         q2 = q3;
         q3 = *p;
         p += 64;
-        const uint32_t a[4] = {(u.x & 0xffffu) * LPE, (u.x >> 16) * LPE, (u.y & 0xffffu) * LPE, (u.y >> 16) * LPE};
+        const uint32_t a[4] = {(u.x & 0xffffu) << 4, (u.x >> 16) << 4, (u.y & 0xffffu) << 4, (u.y >> 16) << 4};  // byte offset in a plane
 #pragma unroll
         for (int t2 = 0; t2 < 4; t2 += GL_INFLIGHT) {
           float4 v[GL_INFLIGHT][NFA];
@@ -629,8 +667,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
 #pragma unroll
           for (int t = 0; t < GL_INFLIGHT; ++t) {
 #pragma unroll
-            for (int l = 0; l < NF; ++l) v[t][l] = xs[a[t2 + t] + l];
-            if (HALF) h[t] = *reinterpret_cast<const float2*>(&xs[a[t2 + t] + NF]);
+            for (int l = 0; l < NF; ++l) v[t][l] = *reinterpret_cast<const float4*>(lb + a[t2 + t] + l * GL_PSB);
+            if (HALF) h[t] = *reinterpret_cast<const float2*>(lb + (a[t2 + t] >> 1) + NF * GL_PSB);
           }
 #pragma unroll
           for (int t = 0; t < GL_INFLIGHT; ++t) {
@@ -653,6 +691,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     const uint32_t sl = slice_of[wv * G + g];
     const uint64_t pos = (uint64_t)sl * 64 + lane;
     if (sl != GL_NONE && pos < n_out) {
+      if (out_n2 == GL_OUT_PLANAR) {  // pass 1 of the Gram apply writes the operand of pass 2: planar, banded by output position
+        const uint32_t ob = (uint32_t)pos / GL_RB, orow = (uint32_t)pos - ob * GL_RB;
+        char* o = reinterpret_cast<char*>(Out) + (size_t)ob * IMG;
+#pragma unroll
+        for (int l = 0; l < NF; ++l) *reinterpret_cast<float4*>(o + (size_t)l * GL_RB * 16u + (size_t)orow * 16u) = acc[g][l];
+        if (HALF) *reinterpret_cast<float2*>(o + (size_t)NF * GL_RB * 16u + (size_t)orow * 8u) = acch[g];
+        continue;
+      }
       const size_t row = rowmap ? (size_t)rowmap[pos] : (size_t)(pos - ds.pos_base);
       if (out_n2) {  // a panel of 10-column steps inside a wider row: 8-byte aligned, exactly the panel's columns
         float2* o2 = reinterpret_cast<float2*>(out) + row * (size_t)out_ld4 * 2;
@@ -671,9 +717,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   }
 }
 
-// Xs[w, 0:4 LPE) = s_w * M[w, j0 : j0 + ncol)  (zero padded), M row-major with leading dimension ld: one panel of a wide operand
-__global__ __launch_bounds__(256) void gl_pack_panel_k(const float* __restrict__ M, int ld, int j0, int ncol, int LPE, const float* __restrict__ rowval,
-                                                        size_t n4, float4* __restrict__ Xs) {
+// packed panel (planar, banded: gl_planar_off) = s_w * M[w, j0 : j0 + ncol)  (zero padded), M row-major with leading dimension ld: one panel
+// of a wide operand.  One thread per (row, plane); with `half` the last plane holds two columns (float2).
+__global__ __launch_bounds__(256) void gl_pack_panel_k(const float* __restrict__ M, int ld, int j0, int ncol, int LPE, int half,
+                                                        const float* __restrict__ rowval, size_t n4, char* __restrict__ Xs) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const size_t w = i / LPE;
@@ -683,13 +730,15 @@ __global__ __launch_bounds__(256) void gl_pack_panel_k(const float* __restrict__
   float v[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) v[t] = (4 * l + t < ncol) ? s * src[t] : 0.f;
-  Xs[i] = make_float4(v[0], v[1], v[2], v[3]);
+  char* o = Xs + gl_planar_off((uint32_t)w, l, LPE, half != 0);
+  if (half && l == LPE - 1) *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+  else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// Xs[w, :] = s_w * X[w, :] straight from the eigensolver's column-major block (V x b, leading dimension V): the row-major
-// packing and the scaling in one pass (columns >= b of the panel are zero)
-__global__ __launch_bounds__(256) void gl_pack_scale_k(const float* __restrict__ Xcm, size_t V, int b, int LPE, const float* __restrict__ rowval,
-                                                        float4* __restrict__ Xs) {
+// packed panel = s_w * X[w, :] straight from the eigensolver's column-major block (V x b, leading dimension V): the packing and the
+// scaling in one pass (columns >= b of the panel are zero)
+__global__ __launch_bounds__(256) void gl_pack_scale_k(const float* __restrict__ Xcm, size_t V, int b, int LPE, int half,
+                                                        const float* __restrict__ rowval, char* __restrict__ Xs) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // i = l * V + w: consecutive threads read consecutive rows of a column
   if (i >= V * (size_t)LPE) return;
   const int l = (int)(i / V);
@@ -698,7 +747,9 @@ __global__ __launch_bounds__(256) void gl_pack_scale_k(const float* __restrict__
   float v[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) v[t] = (4 * l + t < b) ? s * Xcm[(size_t)(4 * l + t) * V + w] : 0.f;
-  Xs[w * LPE + l] = make_float4(v[0], v[1], v[2], v[3]);
+  char* o = Xs + gl_planar_off((uint32_t)w, l, LPE, half != 0);
+  if (half && l == LPE - 1) *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+  else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // gl_reduce_k writing the eigensolver's column-major block: Zcm[wperm[q] + j V] = s_w * sum over the slabs (fixed order), j < b
@@ -883,7 +934,10 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
     }
   }
   if (nwb && !c->knob_zero(KN_GL_PLACE)) {
-    hipLaunchKernelGGL(gl_place_k, dim3((unsigned)nwb), dim3(64 * s.G), 0, c->stream, s.NB, s.cnt.p, s.roff.p, s.ids.p);
+    const size_t nsl = nwb * (size_t)s.G;
+    hipLaunchKernelGGL((gl_place_k<4, 0>), dim3((unsigned)cdiv((long)nsl, 8)), dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p, s.ids.p);
+    hipLaunchKernelGGL((gl_place_k<GL_PLACE_MAXN, 4>), dim3((unsigned)cdiv((long)nsl, 8)), dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p,
+                       s.ids.p);
     HIPCHK(c, hipGetLastError());
   }
   return 0;
@@ -910,10 +964,12 @@ int launch_apply(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, si
   }
   return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: %d items per lane", s.G);
 }
-int launch_apply_any(isle_ctx* c, int LPE, bool half, const GlSide& s, const float4* In, float4* Out, size_t slab_stride) {
-  if (LPE == 1) return half ? launch_apply<1, true>(c, s, In, Out, slab_stride) : launch_apply<1, false>(c, s, In, Out, slab_stride);
-  if (LPE == 2) return half ? launch_apply<2, true>(c, s, In, Out, slab_stride) : launch_apply<2, false>(c, s, In, Out, slab_stride);
-  return half ? launch_apply<3, true>(c, s, In, Out, slab_stride) : launch_apply<3, false>(c, s, In, Out, slab_stride);
+// (twelve whole columns — three full planes — do not fit the LDS: the widest panel is <3, true>, ten columns)
+int launch_apply_any(isle_ctx* c, int LPE, bool half, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, uint32_t out_n2) {
+  if (LPE == 1) return half ? launch_apply<1, true>(c, s, In, Out, slab_stride, nullptr, 0, out_n2) : launch_apply<1, false>(c, s, In, Out, slab_stride, nullptr, 0, out_n2);
+  if (LPE == 2) return half ? launch_apply<2, true>(c, s, In, Out, slab_stride, nullptr, 0, out_n2) : launch_apply<2, false>(c, s, In, Out, slab_stride, nullptr, 0, out_n2);
+  if (LPE == 3 && half) return launch_apply<3, true>(c, s, In, Out, slab_stride, nullptr, 0, out_n2);
+  return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: a panel of %d columns", 4 * LPE);
 }
 
 }  // namespace
@@ -1225,29 +1281,36 @@ int k_gl_build(isle_ctx* c) {
   return 0;
 }
 
-// Zcm (V x b column-major) = B (B^T Xcm): the operator application on the eigensolver's own layout, panel of BP = 4, 8 or 12 columns
-// (the row-major packing of X is fused with its scaling, the slab reduction writes the column-major block)
+// floats of a packed operand of n rows (whole bands, + slack for the last float4 of a half plane)
+static size_t gl_packed_floats(size_t n_rows, int LPE, bool half) {
+  return ((n_rows + GL_RB - 1) / GL_RB) * (size_t)(gl_img_bytes(LPE, half) / 4) + 8;
+}
+
+// Zcm (V x b column-major) = B (B^T Xcm): the operator application on the eigensolver's own layout, b <= 10 columns in a panel of
+// BP = 4, 8 or 12 (the packing of X is fused with its scaling, the slab reduction writes the column-major block)
 int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm) {
   const int LPE = BP / 4;
-  if (LPE < 1 || LPE > 3 || b > BP || b <= BP - 4) return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: b = %d in a panel of %d", b, BP);
+  if (LPE < 1 || LPE > 3 || b > BP || b <= BP - 4 || b > 10) return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: b = %d in a panel of %d", b, BP);
   const bool half = b <= BP - 2;
   const uint32_t V = (uint32_t)c->V;
   const size_t nx4 = (size_t)V * LPE;
-  HIPCHK(c, c->gl_Xs.reserve((size_t)V * BP));
-  HIPCHK(c, c->Yrm.reserve((size_t)c->D * BP));
+  HIPCHK(c, c->gl_Xs.reserve(gl_packed_floats(V, LPE, half)));
+  HIPCHK(c, c->Yrm.reserve(gl_packed_floats(c->D, LPE, half)));
   // isle_hip_timing_enable(ctx, 2) — the bench's roofline figure, taken inside the timed region: ONE event pair around the whole
   // application (booked under pass 1) instead of one per pass; every event record sits in the queue between two kernels for ~5 us
   const bool one_pair = c->timing && c->timing_mask == ((1u << ISLE_T_GRAM_PASS1) | (1u << ISLE_T_GRAM_PASS2));
   TimeScope whole(c, one_pair ? ISLE_T_GRAM_PASS1 : -1);
   {
     TimeScope ts(c, one_pair ? -1 : ISLE_T_GRAM_PASS1);
-    hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, Xcm, (size_t)V, b, LPE, c->rowval.p, (float4*)c->gl_Xs.p);
+    hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, Xcm, (size_t)V, b, LPE, (int)half, c->rowval.p,
+                       (char*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
-    ISLECHK(launch_apply_any(c, LPE, half, c->gl1, (const float4*)c->gl_Xs.p, (float4*)c->Yrm.p, 0));
+    // Y = B^T X, written as the packed operand of pass 2 (banded by document position)
+    ISLECHK(launch_apply_any(c, LPE, half, c->gl1, (const float4*)c->gl_Xs.p, (float4*)c->Yrm.p, 0, GL_OUT_PLANAR));
   }
   {
     TimeScope ts(c, one_pair ? -1 : ISLE_T_GRAM_PASS2);
-    ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)c->gl_block_items * LPE));
+    ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)c->gl_block_items * LPE, 0));
     hipLaunchKernelGGL(gl_reduce_cm_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->gl_part.p, c->gl_slab0.p,
                        c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, b, c->gl_block_items, Zcm);
     HIPCHK(c, hipGetLastError());
@@ -1285,25 +1348,23 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
   return 0;
 }
 
-// Columns per pass of the k-wide / thin products through the pass-1 stream: 12 while the 12-column kernel fits its registers (up to 6
-// output items per lane: 72 accumulator registers of a wave's 128), 8 beyond (at 8 items per lane the 12-column form spills 76
-// registers).  Measured at a C3 shard (5 items per lane): projection 38.9 ms in 8-column passes, 33.0 ms in 12-column ones, k-means++
-// 62.2 -> 55.9 ms.  (Rounds 1-2 found the 12-column pass 2.2x as slow as the 8-column one — it spilled inside its loop; the rolled band
-// staging and the bounded number of LDS rows in flight of round 3 removed that.)  ISLE_GL_PANEL = 8 | 12 forces a width.
-// 10 at 7 items per lane (the Gram apply's own 10-column form, 70 accumulator registers, no spill): a pass costs what it costs at 8 columns
-// (the slots, not the columns, set its time: 2.20 ms per 8-column pass against 2.29 per 10-column one at config 3 on one GPU), so k = 1000 is
-// walked in 100 passes instead of 125.  Steps of 10 columns leave the panels 8-byte aligned inside the output rows: they are stored as float2.
+// Columns per pass of the k-wide / thin products through the pass-1 stream: 10, the widest panel a planar band holds (40-byte rows); 8 at
+// 8 output items per lane (the 10-column form spills 8 registers there).  A pass costs what its slots cost, hardly more for more columns
+// (2.20 ms per 8-column pass against 2.29 per 10-column one at config 3 on one GPU): k = 1000 is walked in 100 passes.  Steps of 10 columns
+// leave the panels 8-byte aligned inside the output rows: they are stored as float2.  (Up to round 3's 48-byte row-major bands 12-column
+// passes were used up to 6 items per lane: 33.0 ms per C3-shard projection against 38.9 in 8-column passes.)  ISLE_GL_PANEL = 8 | 10.
 static int gl_panel_width(const isle_ctx* c) {
   const char* e = c->knob(KN_GL_PANEL);
-  if (e && atoi(e) == 12) return 12;
   if (e && atoi(e) == 10) return 10;
   if (e && atoi(e) == 8) return 8;
-  return c->gl1.G <= 6 ? 12 : c->gl1.G == 7 ? 10 : 8;
+  return c->gl1.G <= 7 ? 10 : 8;
 }
 
 // Columns a panel pass stores: its own, and behind the last panel the padding columns of the row (ld = 4 ceil(k / 4); the consumers read
 // whole float4 of a row and rely on zeros there — the packed panel is zero beyond its columns, so the accumulators are).
 static inline int gl_panel_store_cols(int j0, int ncol, int k, int ld) { return j0 + ncol >= k ? ld - j0 : ncol; }
+// columns of the panel that starts at j0: the last panel must also cover the padding columns of the row with at most 10 stored columns
+static inline int gl_panel_cols(int PW, int j0, int k, int ld) { return k - j0 <= PW && ld - j0 > 10 ? 8 : std::min(PW, k - j0); }
 
 // one pass of the pass-1 stream over a packed panel (LPE = ceil(wcols / 4) float4 per row) -> columns [j0, j0 + wcols) of Out
 // (D x ld row-major, document order)
@@ -1316,28 +1377,30 @@ static int gl_panel_pass(isle_ctx* c, int wcols, int j0, int ld, float* Out) {
   const float4* in = (const float4*)c->gl_Xs.p;
   if (LPE == 1) return half ? launch_apply<1, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<1, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
   if (LPE == 2) return half ? launch_apply<2, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<2, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
-  return half ? launch_apply<3, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<3, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
+  if (LPE == 3 && half) return launch_apply<3, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
+  return isle_fail(c, ISLE_E_ARG, "LDS products: a panel of %d stored columns", wcols);
 }
 
 int k_gl_panel_width(const isle_ctx* c) { return gl_panel_width(c); }
 
 // Out (D x ld row-major, natural document order, ld = 4 ceil(nc / 4)) = B^T W for a THIN column-major operand W (V x nc, nc <= 32):
-// ceil(nc / 12) passes of the pass-1 stream.  The k-means++ round of a large shard: against the nc newest seeds the reference
-// itself forms B^T (U C_new^T) (SURVEY §8d "sparse form"): 8 nnz bytes per 12 columns instead of re-reading the D x k projection.
+// ceil(nc / 10) passes of the pass-1 stream.  The k-means++ round of a large shard: against the nc newest seeds the reference
+// itself forms B^T (U C_new^T) (SURVEY §8d "sparse form"): 8 nnz bytes per 10 columns instead of re-reading the D x k projection.
 int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out) {
   ISLECHK(k_band_build(c));
   if (c->gl_mode != 1) return isle_fail(c, ISLE_E_ARG, "k_gl_thin needs the LDS-banded form");
   if (ld % 4 || nc > ld) return isle_fail(c, ISLE_E_ARG, "k_gl_thin: bad leading dimension");
   const uint32_t V = (uint32_t)c->V;
-  HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
+  HIPCHK(c, c->gl_Xs.reserve(gl_packed_floats(V, 3, true)));
   const int PW = gl_panel_width(c);
-  for (int j0 = 0; j0 < nc; j0 += PW) {
-    const int ncol = std::min(PW, nc - j0);
+  for (int j0 = 0, ncol; j0 < nc; j0 += ncol) {
+    ncol = gl_panel_cols(PW, j0, nc, ld);
     const int wcols = gl_panel_store_cols(j0, ncol, nc, ld);
     const int LPE = (wcols + 3) / 4;
+    const bool half = wcols <= 4 * LPE - 2;
     const size_t n4 = (size_t)V * LPE;
-    hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Wcm + (size_t)j0 * V, (size_t)V, ncol, LPE, c->rowval.p,
-                       (float4*)c->gl_Xs.p);
+    hipLaunchKernelGGL(gl_pack_scale_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Wcm + (size_t)j0 * V, (size_t)V, ncol, LPE, (int)half,
+                       c->rowval.p, (char*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
     ISLECHK(gl_panel_pass(c, wcols, j0, ld, Out));
   }
@@ -1345,7 +1408,7 @@ int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out) {
 }
 
 // Out (D x ld row-major, natural document order) = B^T M for a wide row-major operand M (V x ld, k <= ld columns): the k-wide SpMM
-// of FPSparseMatrix::multiply_with (src/sparseMatrix.cpp:1749-1782) as ceil(k / 12) passes of the pass-1 stream, twelve
+// of FPSparseMatrix::multiply_with (src/sparseMatrix.cpp:1749-1782) as ceil(k / 10) passes of the pass-1 stream, ten
 // columns of diag(s) M staged per pass.  Per gathered nonzero the operand comes from LDS instead of the L2 / Infinity Cache
 // row gather of spmm_wide_k (~2x faster at C2).
 int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
@@ -1353,15 +1416,16 @@ int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
   if (c->gl_mode != 1) return isle_fail(c, ISLE_E_ARG, "k_gl_wide needs the LDS-banded form");
   if (ld % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: leading dimension %d not a multiple of 4", ld);
   const uint32_t V = (uint32_t)c->V;
-  HIPCHK(c, c->gl_Xs.reserve((size_t)V * 12));
+  HIPCHK(c, c->gl_Xs.reserve(gl_packed_floats(V, 3, true)));
   const int PW = gl_panel_width(c);
-  for (int j0 = 0; j0 < k; j0 += PW) {
-    const int ncol = std::min(PW, k - j0);
+  for (int j0 = 0, ncol; j0 < k; j0 += ncol) {
+    ncol = gl_panel_cols(PW, j0, k, ld);
     const int wcols = gl_panel_store_cols(j0, ncol, k, ld);
     const int LPE = (wcols + 3) / 4;
+    const bool half = wcols <= 4 * LPE - 2;
     const size_t n4 = (size_t)V * LPE;
-    hipLaunchKernelGGL(gl_pack_panel_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Mrm, ld, j0, ncol, LPE, c->rowval.p, n4,
-                       (float4*)c->gl_Xs.p);
+    hipLaunchKernelGGL(gl_pack_panel_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Mrm, ld, j0, ncol, LPE, (int)half, c->rowval.p, n4,
+                       (char*)c->gl_Xs.p);
     HIPCHK(c, hipGetLastError());
     ISLECHK(gl_panel_pass(c, wcols, j0, ld, Out));
   }

@@ -85,11 +85,11 @@ def _ragged(V, D, seed, row_constant):
     return vals, rows, offs
 
 
-@pytest.mark.parametrize("V,D", [(4500, 300), (3412, 64), (3413, 65), (6825, 3411), (7000, 9000), (100, 5), (90000, 300)])
+@pytest.mark.parametrize("V,D", [(4500, 300), (4078, 64), (4079, 65), (8157, 4077), (3412, 64), (7000, 9000), (100, 5), (90000, 300)])
 @pytest.mark.parametrize("b", [1, 5, 10, 12, 13, 25])
 def test_gram_apply_lds_form_ragged(hp, V, D, b):
     # B = diag(s) * pattern (what threshold_and_copy builds): the LDS-banded form must be chosen and agree with the oracle;
-    # sizes straddle the band size (3412 rows), slices of 64 and workgroup blocks of 4096, and the 81920-word vocabulary
+    # sizes straddle the band size (4078 rows), slices of 64 and workgroup blocks of 4096, and the 81920-word vocabulary
     # parts of the build's LDS histograms; empty / dense columns included
     from oracle.oracle import OracleCsc
     vals, rows, offs = _ragged(V, D, 11, True)
@@ -117,7 +117,7 @@ def test_items_per_lane_of_the_id_streams_do_not_change_the_operator(hp, small50
     from oracle.oracle import OracleCsc
     monkeypatch.setenv("ISLE_GL_G1", items[0])
     monkeypatch.setenv("ISLE_GL_G2", items[1])
-    for V, D in [(4500, 300), (3413, 65), (6825, 3411), (7000, 9000), (90000, 300)]:
+    for V, D in [(4500, 300), (4079, 65), (8157, 4077), (7000, 9000), (90000, 300)]:
         vals, rows, offs = _ragged(V, D, 11, True)
         o = OracleCsc(V, D, vals, rows, offs)
         hp.upload_csc(V, vals, rows, offs)
