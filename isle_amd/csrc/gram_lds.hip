@@ -538,7 +538,29 @@ __global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t nsl
       const uint32_t sl = 4 * r + t;
       v[t] = (used >> sl) & 1u ? (uint32_t)out[sl][lane] : occ[grp][sl];
     }
-    s[(size_t)r * 64] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    s[(size_t)r * 64] = make_uint2((v[0] | (v[1] << 16)) << 3, (v[2] | (v[3] << 16)) << 3);  // stored as byte offsets in the half plane (8 id)
+  }
+}
+
+// The stream gl_apply_k reads holds 8 * id (the row's byte offset in the float2 half plane; twice that in a float4 plane): gl_place_k
+// writes that form, this kernel converts the slices it leaves alone (more than GL_PLACE_MAXN super-rounds; all of them with ISLE_GL_PLACE=0).
+// ids are below 4096: the shift of a packed pair does not carry from the low id into the high one.
+__global__ __launch_bounds__(512) void gl_scale_ids_k(int G, size_t nslices, uint32_t min_n, const uint16_t* __restrict__ cnt,
+                                                       const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
+  const int lane = threadIdx.x & 63;
+  const size_t sid = (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  if (sid >= nslices) return;
+  const size_t wb = sid / (size_t)G;
+  const int g = (int)(sid - wb * (size_t)G);
+  const uint16_t* cc = cnt + wb * GL_GMAX;
+  const uint32_t n = cc[g];
+  if (n <= min_n) return;
+  int64_t sr0 = roff[wb];
+  for (int j = 0; j < g; ++j) sr0 += cc[j];
+  uint2* s = ids + (size_t)sr0 * 64 + lane;
+  for (uint32_t r = 0; r < n; ++r) {
+    const uint2 u = s[(size_t)r * 64];
+    s[(size_t)r * 64] = make_uint2(u.x << 3, u.y << 3);
   }
 }
 
@@ -581,6 +603,40 @@ __device__ inline void add4(float4& a, const float4 b) {
 // (Rounds 1-2 also carried "merged stream" forms — a lane's items sharing one stream per band, ids tagged with the item, a static
 // four-register id ring loaded by inline asm — built to cut the padded slots (2.17x -> 1.52x) and the id latency; measured no faster in
 // either pass, twice, and removed in round 3.)
+// the four rows of ring entry U into the accumulators of group g (inside gl_apply_k)
+#define GL_ROWS(U)                                                                                                      \
+  {                                                                                                                     \
+    const uint32_t a8[4] = {U.x & 0xffffu, U.x >> 16, U.y & 0xffffu, U.y >> 16};                                        \
+    _Pragma("unroll") for (int t2 = 0; t2 < 4; t2 += GL_INFLIGHT) {                                                    \
+      float4 v[GL_INFLIGHT][NFA];                                                                                       \
+      float2 h[GL_INFLIGHT];                                                                                            \
+      _Pragma("unroll") for (int t = 0; t < GL_INFLIGHT; ++t) {                                                         \
+        const uint32_t b16 = (a8[t2 + t] << 1) + p0s;                                                                   \
+        _Pragma("unroll") for (int l = 0; l < NF; ++l) v[t][l] = gl_lds_f4(b16 + l * GL_PSB);                           \
+        if (HALF) h[t] = gl_lds_f2(a8[t2 + t]);                                                                         \
+      }                                                                                                                 \
+      _Pragma("unroll") for (int t = 0; t < GL_INFLIGHT; ++t) {                                                         \
+        _Pragma("unroll") for (int l = 0; l < NF; ++l) add4(acc[g][l], v[t][l]);                                        \
+        if (HALF) {                                                                                                     \
+          acch[g].x += h[t].x;                                                                                          \
+          acch[g].y += h[t].y;                                                                                          \
+        }                                                                                                               \
+      }                                                                                                                 \
+      if (GL_INFLIGHT < 4) __builtin_amdgcn_sched_barrier(0);                                                           \
+    }                                                                                                                   \
+  }
+// loads from an LDS byte address (the dynamic LDS of gl_apply_k starts at address 0: the kernel has no static LDS)
+typedef float gl_v4f __attribute__((ext_vector_type(4)));
+typedef float gl_v2f __attribute__((ext_vector_type(2)));
+__device__ inline float4 gl_lds_f4(uint32_t addr) {
+  const gl_v4f v = *reinterpret_cast<const __attribute__((address_space(3))) gl_v4f*>(addr);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline float2 gl_lds_f2(uint32_t addr) {
+  const gl_v2f v = *reinterpret_cast<const __attribute__((address_space(3))) gl_v2f*>(addr);
+  return make_float2(v.x, v.y);
+}
+
 template <int LPE, bool HALF, int G>
 __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restrict__ In, uint32_t n_src, const uint2* __restrict__ ids,
                                                           const int64_t* __restrict__ roff, const uint16_t* __restrict__ cnt,
@@ -601,12 +657,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   constexpr int GL_INFLIGHT = G * (4 * NF + (HALF ? 2 : 0)) <= 56 ? 4 : 2;
   const GlDesc ds = desc[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool wvalid = (uint32_t)w < ds.nw;  // wave-uniform
+  const bool wvalid = (uint32_t)__builtin_amdgcn_readfirstlane(w) < ds.nw;  // wave-uniform, and known to the compiler as such
   const size_t wv = wvalid ? (size_t)ds.wave0 + (size_t)w * ds.wstride : (size_t)ds.wave0;
+  // LDS image: the half plane first (the stream holds a row's byte offset in it: 8 id), the float4 planes behind it (row at 16 id = one
+  // shift-add with the plane base from the stream's value; the second plane within the 16-bit offset field of the first's address)
+  constexpr uint32_t P0 = HALF ? GL_PS * 8u : 0u;  // byte offset of plane 0
+  // kept in a scalar register the compiler cannot see through: folded as a constant it becomes the offset field of the plane-0 read and
+  // pushes plane 1 (+ 65 504) out of the field's 16 bits — one more VALU add per gathered row
+  uint32_t p0s = P0;
+  asm volatile("" : "+s"(p0s));
   char* const lb = reinterpret_cast<char*>(xs);
   // the zero rows behind every plane: the staging below never lands on them
-  if (threadIdx.x < GL_NZ * NF) reinterpret_cast<float4*>(lb + (threadIdx.x / GL_NZ) * GL_PSB)[GL_RB + threadIdx.x % GL_NZ] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (HALF && threadIdx.x < GL_NZ) reinterpret_cast<float2*>(lb + NF * GL_PSB)[GL_RB + threadIdx.x] = make_float2(0.f, 0.f);
+  if (threadIdx.x < GL_NZ * NF) reinterpret_cast<float4*>(lb + P0 + (threadIdx.x / GL_NZ) * GL_PSB)[GL_RB + threadIdx.x % GL_NZ] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (HALF && threadIdx.x < GL_NZ) reinterpret_cast<float2*>(lb)[GL_RB + threadIdx.x] = make_float2(0.f, 0.f);
   float4 acc[G][NFA];
   float2 acch[G];
 #pragma unroll
@@ -615,9 +678,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     for (int l = 0; l < NF; ++l) acc[g][l] = make_float4(0.f, 0.f, 0.f, 0.f);
     acch[g] = make_float2(0.f, 0.f);
   }
-  // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array).  The ring is
-  // rotated in C++ (q0 = q1; ... q3 = *p): hipcc turns that into register moves behind a vmcnt(0), one or two loads in flight — a static
-  // ring with hand-placed waits was measured in round 2 and lost to its filler rounds (this form is bound by LDS issue).
+  // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
   uint2 q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
   p += 256;
@@ -637,7 +698,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
           // lanes past the band's rows stay masked: they must not land on the zero rows
           if (i < (hp ? (nrow + 1) / 2 : nrow)) {
             const char* gp = src + (size_t)plane * GL_RB * 16u + (size_t)i * 16u;
-            char* lp = lb + plane * GL_PSB + (i - lane) * 16u;  // wave-uniform LDS base, lane l lands 16 l behind it
+            char* lp = lb + (hp ? 0u : P0 + plane * GL_PSB) + (i - lane) * 16u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
           }
         }
@@ -651,36 +712,31 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     if (!wvalid) cw[0] = cw[1] = cw[2] = cw[3] = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const uint32_t n = (cw[g >> 1] >> (16 * (g & 1))) & 0xffffu;
-      for (uint32_t r = 0; r < n; ++r) {
-        const uint2 u = q0;
+      const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)((cw[g >> 1] >> (16 * (g & 1))) & 0xffffu));  // a scalar loop count
+      // two super-rounds per step: the ring moves by PAIRS (q0 = q2; q1 = q3; two loads), so the moves read entries loaded one whole step
+      // = two super-rounds earlier.  (Rotating by one — q0 = q1; ... q3 = *p — the move reads the load issued the step before and every
+      // step waits for it, s_waitcnt vmcnt(0) at the head of the loop: one load in flight where the ring was meant to keep four.  A C3
+      // shard, pass 1 / pass 2: 0.261 / 0.381 ms by one, 0.226 / 0.316 ms by two; a flat per-band loop over a ring addressed by name with
+      // the group as a switch — four in flight — 0.262 / 0.346 ms: its branches cost what the latency had.)
+      uint32_t r = 0;
+      for (; r + 2 <= n; r += 2) {
+        const uint2 ua = q0, ub = q1;
+        q0 = q2;
+        q1 = q3;
+        q2 = p[0];
+        q3 = p[64];
+        p += 128;
+        GL_ROWS(ua)
+        GL_ROWS(ub)
+      }
+      if (r < n) {
+        const uint2 ua = q0;
         q0 = q1;
         q1 = q2;
         q2 = q3;
         q3 = *p;
         p += 64;
-        const uint32_t a[4] = {(u.x & 0xffffu) << 4, (u.x >> 16) << 4, (u.y & 0xffffu) << 4, (u.y >> 16) << 4};  // byte offset in a plane
-#pragma unroll
-        for (int t2 = 0; t2 < 4; t2 += GL_INFLIGHT) {
-          float4 v[GL_INFLIGHT][NFA];
-          float2 h[GL_INFLIGHT];
-#pragma unroll
-          for (int t = 0; t < GL_INFLIGHT; ++t) {
-#pragma unroll
-            for (int l = 0; l < NF; ++l) v[t][l] = *reinterpret_cast<const float4*>(lb + a[t2 + t] + l * GL_PSB);
-            if (HALF) h[t] = *reinterpret_cast<const float2*>(lb + (a[t2 + t] >> 1) + NF * GL_PSB);
-          }
-#pragma unroll
-          for (int t = 0; t < GL_INFLIGHT; ++t) {
-#pragma unroll
-            for (int l = 0; l < NF; ++l) add4(acc[g][l], v[t][l]);
-            if (HALF) {
-              acch[g].x += h[t].x;
-              acch[g].y += h[t].y;
-            }
-          }
-          if (GL_INFLIGHT < 4) __builtin_amdgcn_sched_barrier(0);
-        }
+        GL_ROWS(ua)
       }
     }
   }
@@ -716,6 +772,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     }
   }
 }
+
+#undef GL_ROWS
 
 // packed panel (planar, banded: gl_planar_off) = s_w * M[w, j0 : j0 + ncol)  (zero padded), M row-major with leading dimension ld: one panel
 // of a wide operand.  One thread per (row, plane); with `half` the last plane holds two columns (float2).
@@ -933,13 +991,19 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
       HIPCHK(c, hipGetLastError());
     }
   }
-  if (nwb && !c->knob_zero(KN_GL_PLACE)) {
+  if (nwb) {
     const size_t nsl = nwb * (size_t)s.G;
-    hipLaunchKernelGGL((gl_place_k<4, 0>), dim3((unsigned)cdiv((long)nsl, 8)), dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p, s.ids.p);
-    hipLaunchKernelGGL((gl_place_k<GL_PLACE_MAXN, 4>), dim3((unsigned)cdiv((long)nsl, 8)), dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p,
-                       s.ids.p);
+    const dim3 grid((unsigned)cdiv((long)nsl, 8));
+    const bool place = !c->knob_zero(KN_GL_PLACE);
+    if (place) {
+      hipLaunchKernelGGL((gl_place_k<4, 0>), grid, dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p, s.ids.p);
+      hipLaunchKernelGGL((gl_place_k<GL_PLACE_MAXN, 4>), grid, dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p, s.ids.p);
+    }
+    hipLaunchKernelGGL(gl_scale_ids_k, grid, dim3(512), 0, c->stream, s.G, nsl, place ? (uint32_t)GL_PLACE_MAXN : 0u, s.cnt.p, s.roff.p, s.ids.p);
     HIPCHK(c, hipGetLastError());
   }
+  // the prefetch slack behind the stream: the padding id in the stream's final form
+  HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)(GL_RB * 8), n16_all - n16_body, c->stream));
   return 0;
 }
 

@@ -2,7 +2,7 @@
 # LDS / VALU counters of the Gram passes at a C3 shard
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r03_u
+OUT=${LDS_PMC_OUT:-gpurun_out/r03_lds_pmc}
 mkdir -p $OUT
 for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
@@ -10,8 +10,8 @@ for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_L
   echo "rc=$? $set"
 done
 python3 - <<'P'
-import csv, glob, collections
-for f in sorted(glob.glob("gpurun_out/r03_u/pmc_*/**/*counter_collection.csv", recursive=True)):
+import csv, glob, collections, os
+for f in sorted(glob.glob(os.environ.get("LDS_PMC_OUT","gpurun_out/r03_lds_pmc")+"/pmc_*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = (r["Kernel_Name"][:60], r["Counter_Name"])
