@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects round-3 measurements on the GPU box (run through gpurun from the repo root); summaries are copied into profiles/ afterwards.
-# usage: tools/r03_collect.sh <tag> <stage> [<stage> ...]     stages: bench benchfull prof pmc c2 c2prof shard shardprof tests
+# usage: tools/r03_collect.sh <tag> <stage> [<stage> ...]     stages: bench benchfull prof pmc pmcsmall c2 c2prof shard shardprof tests
 set -o pipefail
 TAG=$1; shift
 O=gpurun_out/r03_$TAG
@@ -14,6 +14,8 @@ prof) echo "== rocprof stats c3 (1 step)"; timeout -k 10 900 rocprofv3 --kernel-
 pmc) echo "== pmc FETCH_SIZE c3full"; timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 tools/pmc_probe.py c3full > $O/pmc_fetch.log 2>&1; echo rc=$?
      echo "== pmc WRITE_SIZE c3full"; timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 tools/pmc_probe.py c3full > $O/pmc_write.log 2>&1; echo rc=$?
      for f in $(find $O/pmc_fetch $O/pmc_write -name "*counter_collection.csv"); do echo $f; python3 tools/pmc_summarise.py $f | head -12; done > $O/pmc_summary.txt; cat $O/pmc_summary.txt;;
+pmcsmall) for wl in c2 c3shard; do for ctr in FETCH_SIZE WRITE_SIZE; do echo "== pmc $ctr $wl"; timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc_${wl}_$ctr -o x -- python3 tools/pmc_probe.py $wl > $O/pmc_${wl}_$ctr.log 2>&1; echo rc=$?; done; done
+     for f in $(find $O -name "*counter_collection.csv" -path "*pmc_c*"); do echo $f; python3 tools/pmc_summarise.py $f | head -12; done > $O/pmc_small_summary.txt; cat $O/pmc_small_summary.txt;;
 c2) echo "== bench c2"; timeout -k 10 400 python bench.py --workload c2 --steps 5 --warmup 2 > $O/c2_bench.json 2> $O/c2_bench.err; echo rc=$?;;
 c2prof) echo "== rocprof stats c2"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -o c2 -- python3 bench.py --workload c2 --steps 3 --warmup 1 --no-upstream --no-cpu-baseline > $O/c2_bench_under_rocprof.json 2> $O/c2_rocprof.err; echo rc=$?;;
 shard) echo "== bench c3shard"; timeout -k 10 400 python bench.py --workload c3shard --steps 2 --warmup 1 --no-upstream --no-cpu-baseline > $O/c3shard_bench.json 2> $O/c3shard_bench.err; echo rc=$?;;
