@@ -1397,12 +1397,17 @@ int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float
   if ((uint64_t)npairs > 48ull * D) return 0;
   if (npairs) {
     const size_t np = npairs;
-    HIPCHK(c, c->gl_key_a.reserve(np));
-    HIPCHK(c, c->gl_key_b.reserve(np));
-    HIPCHK(c, c->gl_val_a.reserve(np));
-    HIPCHK(c, c->gl_val_b.reserve(np));
-    HIPCHK(c, c->yy_pgrp.reserve(np));
-    HIPCHK(c, c->yy_res.reserve(np * 3));
+    // the pair count of the first iteration follows the seeds (± 20 % from step to step at config 3): grown with half as much again, or
+    // every step that sets a new maximum frees and allocates several GB in the middle of the loop (82 ms of idle GPU in a profiled step)
+    if (np > c->yy_pgrp.cap) {
+      const size_t cap = np + np / 2;
+      HIPCHK(c, c->gl_key_a.reserve(cap));
+      HIPCHK(c, c->gl_key_b.reserve(cap));
+      HIPCHK(c, c->gl_val_a.reserve(cap));
+      HIPCHK(c, c->gl_val_b.reserve(cap));
+      HIPCHK(c, c->yy_pgrp.reserve(cap));
+      HIPCHK(c, c->yy_res.reserve(cap * 3));
+    }
     hipLaunchKernelGGL(yy2_emit_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, nactive, active, (const unsigned long long*)c->yy_need.p, NW, c->yy_off.p,
                        c->gl_key_a.p, c->gl_val_a.p, c->yy_pgrp.p);
     HIPCHK(c, hipGetLastError());
