@@ -34,7 +34,7 @@ int isle_fail(isle_ctx* c, int code, const char* fmt, ...) {
 const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GRAM_LDS", "form", "0: Gram apply and k-wide products by the row-gather kernels (any CSC matrix) instead of the LDS-banded form (row-constant B)"},
     {"ISLE_GL_G1", "tuning", "4..8: output items per lane in pass 1 of the LDS-banded form (default: makespan model, gram_lds.hip)"},
-    {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4)"},
+    {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4, 6 beyond 1024 document bands)"},
     {"ISLE_GL_PLACE", "tuning", "0: a lane's entries stay packed at the front of its slots in ascending order instead of the bank-aware placement (gl_place_k)"},
     {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
     {"ISLE_GL_PANEL", "tuning", "8 | 10: columns per pass of the k-wide / thin products (default 10, 8 at 8 items per lane in pass 1)"},

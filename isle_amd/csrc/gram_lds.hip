@@ -1181,7 +1181,10 @@ int k_gl_build(isle_ctx* c) {
   // leave CUs idle
   {
     const char* e_g = c->knob(KN_GL_G2);  // items per lane in pass 2 (4 ... 8)
-    s2.G = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4;
+    // 4; 6 beyond 1024 document bands (more than 4 M documents): fewer word blocks, and every block stages every band of its columns.
+    // Measured with the final kernels, pass 2: config 3 on one GPU (2452 bands) 2.41 / 2.40 / 2.26 / 3.07 ms at 4 / 5 / 6 / 8; a C3 shard
+    // (307 bands) 0.309 / 0.334 / 0.314 at 4 / 5 / 6
+    s2.G = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : (s2.NB > 1024 ? 6 : 4);
   }
   const uint32_t G2 = (uint32_t)s2.G;
   uint32_t wpb = GL_WAVES;
