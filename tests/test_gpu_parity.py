@@ -109,6 +109,30 @@ def test_gram_apply_lds_form_ragged(hp, V, D, b):
     assert relerr(Z, Zo) <= 1e-5 + eo
 
 
+def test_bank_aware_placement_changes_the_order_of_the_sums_only(hp, monkeypatch):
+    """gl_place_k (gram_lds.hip) gives a lane's entries the slots in which the rows of a ds_read_b128 lane group lie on different LDS
+    banks; ISLE_GL_PLACE=0 leaves them packed at the front of their slots in ascending order.  Same operator: both forms against the
+    oracle and against each other (the sums differ in their order), on ragged matrices that straddle band and slice
+    boundaries; the placed form is bitwise reproducible across builds."""
+    from oracle.oracle import OracleCsc
+    for V, D in [(4500, 300), (4079, 65), (8157, 4077), (9000, 9000)]:
+        vals, rows, offs = _ragged(V, D, 5, True)
+        o = OracleCsc(V, D, vals, rows, offs)
+        X = np.random.default_rng(V).standard_normal((V, 10)).astype(np.float32)
+        Zo = o.gram_apply(X)
+        Z = {}
+        for place in ("1", "0", "1"):
+            monkeypatch.setenv("ISLE_GL_PLACE", place)
+            hp.upload_csc(V, vals, rows, offs)
+            Zp = hp.gram_apply(X)
+            assert hp.operator_form() == 1 and relerr(Zp, Zo) <= 1e-5
+            if place in Z:
+                assert np.array_equal(Zp.view(np.uint32), Z[place].view(np.uint32))
+            Z[place] = Zp
+        assert relerr(Z["1"], Z["0"]) <= 2e-6
+    monkeypatch.delenv("ISLE_GL_PLACE")
+
+
 @pytest.mark.parametrize("items", [("6", "4"), ("8", "8"), ("5", "7")])
 def test_items_per_lane_of_the_id_streams_do_not_change_the_operator(hp, small50, monkeypatch, items):
     """ISLE_GL_G1 / ISLE_GL_G2 (gram_lds.hip): 4 ... 8 output items per lane of a wave (the build picks 4 ... 7 for pass 1 by its
