@@ -6,20 +6,22 @@
 //     Y[d, :] = sum_{w in d} (s_w X[w, :])          pass 1, gather over the words of a document
 //     Z[w, :] = s_w * sum_{d contains w} Y[d, :]    pass 2, gather over the documents of a word
 // need no values in the sparse stream.  Why another form than the wave-per-segment gather of spmm.hip: that one is
-// bound by the vector-L1 tag path (~4 clk per gathered 48-B panel row).  Here the gathered operand is
-// staged through LDS in bands of GL_RB rows (160 KB), every lane owns whole output items (register accumulators, no
-// cross-lane reduction), and the pattern is a sliced-ELL stream of band-local u16 ids, 4 per lane per "super-round",
-// read fully coalesced with a 4-deep register prefetch ring.  tools/microbench/lds_band_gather.hip is the prototype
-// (0.24 ms for a 99 M-nonzero pass against 0.75 ms for the gather kernel).
+// bound by the vector-L1 tag path (~4 clk per gathered panel row).  Here the gathered operand is staged through LDS in
+// bands of GL_RB = 4078 rows (planar: a float4 plane per four columns, a float2 half plane for a 10-column panel — 40 bytes a row, 160 KB),
+// every lane owns whole output items (register accumulators, no cross-lane reduction), and the pattern is a sliced-ELL stream of
+// band-local u16 ids (stored as 8 * id), 4 per lane per "super-round", read fully coalesced through a register ring that moves by pairs.
+// tools/microbench/lds_band_gather.hip is the prototype (0.24 ms for a 99 M-nonzero pass against 0.75 ms for the gather kernel).
 //
 // Geometry.  Output items (documents in pass 1, words in pass 2) are ordered by decreasing nonzero count and cut into
 // slices of 64 consecutive positions; a wave owns G slices (one output item per lane and group; G = 4 ... 8 per side, chosen by the
 // build so that the workgroups fill whole rounds of the CUs: every workgroup stages every band it walks, so fewer, fatter workgroups
-// stage less), a workgroup is 16 waves.  Per (wave, source band, group) the stream holds cnt super-rounds = ceil(max lane count / 4); padding ids
-// point at a zero row kept behind the band in LDS.  Pass 1: a workgroup walks all word bands for its 4096 documents;
-// slices are dealt to waves in serpentine order over four quantile ranges so that all waves carry the same load.
-// Pass 2: a word block (64 consecutive slices) is split over document-band chunks in proportion to its work; chunk
-// partials go to slabs that gl_reduce_k sums in fixed order (and scales by s_w).
+// stage less), a workgroup is 16 waves.  Per (wave, source band, group) the stream holds cnt super-rounds = ceil(max lane count / 4); inside
+// such a slice gl_place_k gives a lane's entries the slots in which the rows a ds_read_b128 lane group reads lie on different LDS banks, and
+// the padding slots the zero row (16 of them behind every plane) of a bank class nobody uses.  Pass 1: a workgroup walks all word bands
+// for its 1024 G documents; slices are dealt to waves in serpentine order over quantile ranges so that all waves carry the same load;
+// Y leaves it as the packed (planar, banded) operand of pass 2.
+// Pass 2: a word block (16 G consecutive slices) is split over document-band chunks in proportion to its work; chunk
+// partials go to slabs that gl_reduce_cm_k sums in fixed order (and scales by s_w).
 //
 // The build never materialises a transposed copy of B: per document band one workgroup histograms the band's entries by
 // word in LDS (two u16 counters per dword) — first to count the (word, band) cells, then again as placement cursors

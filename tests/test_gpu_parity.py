@@ -433,11 +433,11 @@ def test_gather_form_forced_by_env(hp, small50, monkeypatch):
     assert relerr(res[1][2], res[0][2]) <= 1e-4
 
 
-@pytest.mark.parametrize("panel", ["12", "10", "8"])
+@pytest.mark.parametrize("panel", ["10", "8"])
 @pytest.mark.parametrize("k", [7, 13, 25, 30, 37])
 def test_wide_products_odd_topic_counts(hp, small50, monkeypatch, k, panel):
-    """k-wide products (projection, first full assignment) with topic counts that are not multiples of the panel (12, 10 or 8 columns
-    per pass of the pass-1 stream: ISLE_GL_PANEL; steps of 10 leave the panels 8-byte aligned inside the output rows) or of the padded
+    """k-wide products (projection, first full assignment) with topic counts that are not multiples of the panel (10 or 8 columns per
+    pass of the pass-1 stream: ISLE_GL_PANEL; steps of 10 leave the panels 8-byte aligned inside the output rows) or of the padded
     row (ldk = 4 ceil(k/4)): the LDS-banded form, the row-gather form and the oracle agree."""
     from oracle.oracle import lift
     B = small50
