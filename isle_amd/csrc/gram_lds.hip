@@ -1105,18 +1105,22 @@ int k_gl_build(isle_ctx* c) {
   // C3 shard G = 5: 312 / 313 us; config 3 on one GPU G = 4 / 6 / 8: 2610 / 2530 / 2310 against 2690 / 2490 / 2336 us.
   // ISLE_GL_G1 = 4..8 forces G.
   uint32_t wpw = GL_WAVES;
+  const uint32_t cus = c->knob(KN_GL_TEST_CUS) ? (uint32_t)std::max(1, atoi(c->knob(KN_GL_TEST_CUS))) : (uint32_t)c->num_cus;  // test hook: the geometry of a larger problem on a small one
   {
     const double t_slice = 0.05 * 2.5 * (double)c->nnz / 256.0 / std::max<uint32_t>(1u, s1.nslice);  // us: ~50 ns per super-round, ~2.5x padded
     const double t_stage = 2.0 * s1.NB;                                                               // us: ~2 us per band from L2
     const char* e_g = c->knob(KN_GL_G1);
-    const int g_lo = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4, g_hi = e_g ? g_lo : GL_GMAX;
+    const int g_lo = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : 4, g_hi = e_g ? g_lo : GL_GMAX - 1;  // 8: the 10-column kernel spills there
     double best = 1e300;
     for (int G = g_lo; G <= g_hi; ++G) {
       const uint32_t nwv = (s1.nslice + G - 1) / G;
       for (uint32_t cand = GL_WAVES; cand >= 1; --cand) {
         const uint32_t wgs = (nwv + cand - 1) / cand;
         const double fewer = 1.0 + 0.25 * (double)(GL_WAVES - cand) / GL_WAVES;  // fewer waves hide less of the id-stream latency
-        const double cost = (double)((wgs + c->num_cus - 1) / c->num_cus) * (cand * G * t_slice * fewer + t_stage);
+        const uint32_t rounds = (wgs + cus - 1) / cus;
+        // more than one round: the workgroups are spread over WHOLE rounds (below), a wave then owns nslice / (rounds x CUs x waves) slices
+        const double per_wave = rounds > 1 ? (double)s1.nslice / ((double)rounds * cus * cand) : (double)G;
+        const double cost = (double)rounds * (cand * per_wave * t_slice * fewer + t_stage);
         if (cost < best * 0.97) {  // prefer fewer items per lane and more waves per workgroup unless clearly worse
           best = cost;
           wpw = cand;
@@ -1126,6 +1130,20 @@ int k_gl_build(isle_ctx* c) {
     }
   }
   s1.nwv = (s1.nslice + s1.G - 1) / s1.G;
+  // More than one round of workgroups: their number is rounded up to whole rounds of the CUs — the waves of the last quantile range
+  // then own one slice less — and a workgroup takes ADJACENT waves (slices of neighbouring lengths: its waves reach the barrier of a band
+  // together; the workgroups differ by the length of their documents, the longest are launched first).  5.45 rounds of 7 slices per wave
+  // ran like 6 (all of config 3 on one GPU, pass 1); 6 rounds of 6.36 do the same work with the CUs busy to the end.  One round (a C3
+  // shard: 244 workgroups): the workgroups must finish together, so they take waves strided over the whole length order as before.
+  bool adjacent = false;
+  {
+    const uint32_t nwg0 = (s1.nwv + wpw - 1) / wpw;
+    if (nwg0 > cus && !c->knob_zero(KN_GL_ROUNDS)) {
+      const uint32_t nwg_r = (nwg0 + cus - 1) / cus * cus;
+      s1.nwv = nwg_r * wpw;
+      adjacent = true;
+    }
+  }
   {
     // serpentine over G quantile ranges of the length-ordered slices: every wave gets long, middle and short slices alike
     const int G = s1.G;
@@ -1148,7 +1166,7 @@ int k_gl_build(isle_ctx* c) {
     for (uint32_t j = 0; j < nwg; ++j) {
       uint32_t nw = 0;
       while (nw < wpw && (uint64_t)j + (uint64_t)nw * nwg < s1.nwv) ++nw;
-      ds[j] = GlDesc{j, nwg, nw, 0u, s1.NB, 0u, 0u, 0u};
+      ds[j] = adjacent ? GlDesc{j * wpw, 1u, (uint32_t)std::min<uint64_t>(wpw, s1.nwv - (uint64_t)j * wpw), 0u, s1.NB, 0u, 0u, 0u} : GlDesc{j, nwg, nw, 0u, s1.NB, 0u, 0u, 0u};
     }
     s1.ndesc = nwg;
     HIPCHK(c, s1.desc.reserve(nwg));

@@ -109,6 +109,46 @@ def test_gram_apply_lds_form_ragged(hp, V, D, b):
     assert relerr(Z, Zo) <= 1e-5 + eo
 
 
+@pytest.mark.parametrize("cus", ["3", "7"])
+def test_whole_rounds_of_workgroups_of_adjacent_waves(hp, small50, monkeypatch, cus):
+    """Pass 1 of a matrix that needs more than one round of workgroups (all of config 3 on one GPU: 1395 on 256 CUs) fills WHOLE rounds:
+    more waves, the last quantile range only partly dealt, workgroups of adjacent waves (k_gl_build).  ISLE_GL_TEST_CUS lays a small
+    matrix out as for a device of 3 or 7 CUs; ISLE_GL_ROUNDS=0 is the strided form.  Same operator (the slices are the same, so the
+    bits are), same k-wide products."""
+    from oracle.oracle import OracleCsc
+    monkeypatch.setenv("ISLE_GL_TEST_CUS", cus)
+    for V, D in [(9000, 70000), (4079, 33000)]:
+        rng = np.random.default_rng(D)
+        lens = rng.integers(1, 40, size=D)
+        offs = np.zeros(D + 1, np.int64)
+        offs[1:] = np.cumsum(lens)
+        rows = np.concatenate([np.sort(rng.choice(V, size=int(n), replace=False)) for n in lens]).astype(np.uint32)
+        vals = rng.uniform(0.5, 3.0, size=V).astype(np.float32)[rows]
+        o = OracleCsc(V, D, vals, rows, offs)
+        X = rng.standard_normal((V, 10)).astype(np.float32)
+        Zo = o.gram_apply(X)
+        Z = {}
+        for rounds in ("1", "0"):
+            monkeypatch.setenv("ISLE_GL_ROUNDS", rounds)
+            hp.upload_csc(V, vals, rows, offs)
+            Z[rounds] = hp.gram_apply(X)
+            assert hp.operator_form() == 1 and relerr(Z[rounds], Zo) <= 1e-5
+        assert np.array_equal(Z["1"].view(np.uint32), Z["0"].view(np.uint32))
+    B, k = small50, 50
+    U = B["oracle"].block_ks(k)["U"]
+    seeds = np.random.default_rng(3).choice(B["D"], size=k, replace=False).astype(np.uint64)
+    res = {}
+    for rounds in ("1", "0"):
+        monkeypatch.setenv("ISLE_GL_ROUNDS", rounds)
+        monkeypatch.setenv("ISLE_WIDE_LDS", "1")
+        upload(hp, B)
+        hp.set_U(U)
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=seeds)
+        lg = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        res[rounds] = (g["C_lowd"], lg["assign"])
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])
+
+
 def test_bank_aware_placement_changes_the_order_of_the_sums_only(hp, monkeypatch):
     """gl_place_k (gram_lds.hip) gives a lane's entries the slots in which the rows of a ds_read_b128 lane group lie on different LDS
     banks; ISLE_GL_PLACE=0 leaves them packed at the front of their slots in ascending order.  Same operator: both forms against the
