@@ -55,6 +55,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_PROJ_BOUNDS", "form", "hamerly: single lower bound in the projected Lloyd loop at k > 224 instead of tile bounds"},
     {"ISLE_PROJ_FULL", "form", "gemm | fused: full passes of the projected Lloyd loop as GEMM + epilogue or as the fused register kernel"},
     {"ISLE_FIRST_ASSIGN", "form", "sparse | projection: first assignment of Lloyd on B through the sparse product or through the projection"},
+    {"ISLE_GEMM_BF16X3", "form", "0: the D x k x k dot products of the assignment steps on the f32 matrix cores (gemm_f32.h) instead of the bf16 ones with operands split in three terms (gemm_bf16x3.h)"},
     {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
     {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
     {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},
@@ -1937,7 +1938,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // the doc-major layout and the same distance / bound epilogue (norms of centres and documents are the word-space ones)
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
-      ISLECHK(k_gemm_nn(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
+      ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
       if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
         float* cn_max_dev = c->Csum.p + 2 * k + 8;
         ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));

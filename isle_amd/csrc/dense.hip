@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "gemm_f32.h"
+#include "gemm_bf16x3.h"
 
 #include "common.h"
 #include "gridbar.h"
@@ -755,6 +756,21 @@ int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, in
   if (M == 0 || N == 0) return 0;
   if (M >= (1ull << 32) || (uint64_t)N * (uint64_t)ldb >= (1ull << 32)) return isle_fail(c, ISLE_E_ARG, "gemm: operand too large for 32-bit row / column offsets");
   HIPCHK(c, gemm_dispatch(c->stream, A, M, K, B, ldb, N, isle_gemm::StoreC{C, M}));
+  return 0;
+}
+
+// The D x k x k dot products of the assignment steps (projected full pass, first assignment of Lloyd on B): the bf16 matrix cores with
+// both operands split into three bf16 terms (gemm_bf16x3.h) — the six partial products down to 2^-16 of the leading one, each exact, summed
+// in f32: error against fp64 5.6e-8 of sum |a b| where gemm_f32.h has 8.6e-8 (tools/microbench/gemm3_probe.hip, random operands), 161
+// against 123 TFLOP/s at 1.25 M x 1000 x 1000, 102 against 67 at 1 M x 200 x 200.  Small products and ISLE_GEMM_BF16X3=0: gemm_f32.h.
+using Gemm3Huge = isle_gemm3::Cfg<2, 2, 4, 4, 4>;  // 256 x 256 x 16, 1024 threads
+int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family) {
+  if (c->knob_zero(KN_GEMM_BF16X3) || N < 64 || K < 32 || (M + 255) / 256 * (uint64_t)((N + 255) / 256) < 512)
+    return k_gemm_nn(c, A, M, K, B, ldb, N, C, family);
+  TimeScope ts(c, family);
+  if (M >= (1ull << 32)) return isle_fail(c, ISLE_E_ARG, "gemm: operand too large for 32-bit row offsets");
+  HIPCHK(c, c->gemm_b3.reserve((size_t)3 * isle_gemm3::kp8_of(K) * isle_gemm3::np_of<Gemm3Huge>(N)));
+  HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, isle_gemm3::StoreC{C, M}));
   return 0;
 }
 

@@ -1,0 +1,239 @@
+// isle_amd/csrc/gemm_bf16x3.h — C (M x N) = A (M x K) * B (K x N), all column-major f32, on the bf16 matrix cores of gfx950 with both
+// operands split into THREE bf16 terms:  x = x0 + x1 + x2  (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 significand
+// bits, the subtractions are exact), and
+//     a b  ~  a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)
+// — the six products down to 2^-16 of the leading one; the three dropped ones (a1 b2, a2 b1, a2 b2) are below 2^-23 |a b|, the
+// rounding of the f32 product itself.  Every partial product is exact in the MFMA (8 x 8 bits) and summed in f32, as
+// v_mfma_f32_32x32x2_f32 sums its own.  Six v_mfma_f32_32x32x16_bf16 (32 cycles each) do the work of eight v_mfma_f32_32x32x2_f32
+// (64 cycles each): 2.7 x the rate of gemm_f32.h at the same accuracy class (tools/microbench/gemm3_probe.hip: error against fp64
+// relative to sum |a_k b_k|, both kernels on the same random operands).
+//
+// Used for the D x k x k products of the assignment steps only (the projected full pass of Lloyd in span(U), the first assignment of
+// Lloyd on B: src/sparseMatrix.cpp:1819-1826 in its P * C^T form) — distances that feed an argmin, evaluated in another summation order
+// than the reference's anyway.  The eigen-solver's products (Ritz rotation, lift) stay on gemm_f32.h.
+//
+// Shape: as gemm_f32.h — a workgroup of WAVES_M x WAVES_N waves owns a TM x TN tile, a wave WMT x WNT tiles of 32 x 32; K is walked
+// in slabs of 16 (one MFMA k-step) through a two-stage LDS ring.  A is split on the fly between its global load and the LDS store
+// (three planes of 16-byte units = 8 consecutive k of one row: one ds_read_b128 is a lane's whole operand); B (K x N, a few MB) is
+// split once per call into the same units in global memory (gemm3_split_b_k), zero-padded to whole slabs and tiles, and copied.
+// The MFMA is issued "transposed" (first operand = B fragment), so a lane owns one ROW m of C: same epilogue as gemm_f32.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace isle_gemm3 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline void split3(float x, __bf16& x0, __bf16& x1, __bf16& x2) {
+  x0 = (__bf16)x;
+  const float r1 = x - (float)x0;
+  x1 = (__bf16)r1;
+  const float r2 = r1 - (float)x1;
+  x2 = (__bf16)r2;
+}
+
+// B3[(p * Kp8 + q) * Np + n] = the p-th bf16 term of B[8 q .. 8 q + 7][n]  (zero beyond K and N)
+__global__ __launch_bounds__(256) void gemm3_split_b_k(const float* __restrict__ B, int ldb, int K, int N, int Kp8, int Np, bf16x8* __restrict__ B3) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)Kp8 * Np) return;
+  const int q = (int)(i / Np), n = (int)(i - (size_t)q * Np);
+  bf16x8 v[3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * q + j;
+    const float x = (k < K && n < N) ? B[(size_t)n * ldb + k] : 0.f;
+    __bf16 t0, t1, t2;
+    split3(x, t0, t1, t2);
+    v[0][j] = t0;
+    v[1][j] = t1;
+    v[2][j] = t2;
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) B3[((size_t)p * Kp8 + q) * Np + n] = v[p];
+}
+
+template <int WMT_, int WNT_, int WAVES_M_, int WAVES_N_, int OCC_>
+struct Cfg {
+  static constexpr int WMT = WMT_, WNT = WNT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, OCC = OCC_, TK = 16;
+  static constexpr int TM = 32 * WMT * WAVES_M, TN = 32 * WNT * WAVES_N;
+  static constexpr int NT = 64 * WAVES_M * WAVES_N;
+  static constexpr int A_STAGE = 6 * TM, B_STAGE = 6 * TN;  // 16-byte units per stage: [plane 3][octet 2][row]
+  static constexpr size_t LDS_BYTES = (size_t)2 * (A_STAGE + B_STAGE) * 16;
+  static constexpr int A_UNITS = TM * 4 / NT;               // k-quads (4 floats of one row) per thread and slab
+  static constexpr int B_UNITS = (B_STAGE + NT - 1) / NT;   // 16-byte units of the split B per thread and slab
+  static_assert(TM * 4 % NT == 0, "tile / thread counts");
+};
+
+struct StoreC {
+  float* __restrict__ C;
+  uint64_t ldc;
+  __device__ inline void operator()(uint64_t m, int n, float v) const { C[(uint64_t)n * ldc + m] = v; }
+};
+
+template <class CF, class Epi>
+__global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __restrict__ A, uint64_t M, int K, const bf16x8* __restrict__ B3, int Kp8,
+                                                                  int Np, int N, uint32_t nMB, uint32_t nNT, Epi epi) {
+  constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, WMT = CF::WMT, WNT = CF::WNT;
+  extern __shared__ bf16x8 lds3[];
+  bf16x8* As = lds3;                    // [2][3][2][TM]
+  bf16x8* Bs = lds3 + 2 * CF::A_STAGE;  // [2][3][2][TN]
+  // tile of this workgroup: xcd = id % 8 owns row blocks xcd, xcd + 8, ...; its N-tiles are consecutive slots (gemm_f32.h)
+  const uint32_t wg = blockIdx.x, xcd = wg & 7u, slot = wg >> 3;
+  const uint32_t mb = (slot / nNT) * 8u + xcd, nt = slot % nNT;
+  if (mb >= nMB) return;
+  const uint64_t m0 = (uint64_t)mb * TM;
+  const int n0 = (int)nt * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave % CF::WAVES_M, wn = wave / CF::WAVES_M;
+
+  uint32_t arow[CF::A_UNITS];
+  int akq[CF::A_UNITS];
+#pragma unroll
+  for (int u = 0; u < CF::A_UNITS; ++u) {
+    const int unit = tid + u * NT;
+    akq[u] = unit / TM;
+    const uint64_t m = m0 + (uint32_t)(unit % TM);
+    arow[u] = (uint32_t)(m < M ? m : M - 1);  // clamped: rows past the end are computed on valid data, never stored
+  }
+  float ra[4 * CF::A_UNITS];
+  uint4 rb[CF::B_UNITS];
+  auto load_slab = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < CF::A_UNITS; ++u) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = min(k0 + 4 * akq[u] + t, K - 1);  // the k tail is zero on the B side, A stays finite data
+        ra[4 * u + t] = A[(uint64_t)k * M + arow[u]];
+      }
+    }
+    const int q0 = k0 >> 3;
+#pragma unroll
+    for (int u = 0; u < CF::B_UNITS; ++u) {
+      const int unit = min(tid + u * NT, CF::B_STAGE - 1);  // [plane][octet][n]
+      const int p = unit / (2 * TN), r = unit - p * 2 * TN, q = r / TN, n = r - q * TN;
+      rb[u] = *reinterpret_cast<const uint4*>(B3 + ((size_t)p * Kp8 + q0 + q) * Np + n0 + n);
+    }
+  };
+  auto store_slab = [&](int stage) {
+    char* a = reinterpret_cast<char*>(As + stage * CF::A_STAGE);
+#pragma unroll
+    for (int u = 0; u < CF::A_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      const int row = unit % TM;
+      bf16x4 v[3];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        __bf16 t0, t1, t2;
+        split3(ra[4 * u + t], t0, t1, t2);
+        v[0][t] = t0;
+        v[1][t] = t1;
+        v[2][t] = t2;
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(a + ((size_t)((p * 2 + (akq[u] >> 1)) * TM + row)) * 16 + (akq[u] & 1) * 8) = v[p];
+    }
+    uint4* b = reinterpret_cast<uint4*>(Bs + stage * CF::B_STAGE);
+#pragma unroll
+    for (int u = 0; u < CF::B_UNITS; ++u) {
+      const int unit = tid + u * NT;
+      if (unit < CF::B_STAGE) b[unit] = rb[u];
+    }
+  };
+
+  f32x16 acc[WNT][WMT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j)
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // (staging two slabs ahead through a second register set was measured: 161 -> 120 TFLOP/s where it did not spill, 43 where it did)
+  const int nslab = (K + 15) / 16;
+  load_slab(0);
+  store_slab(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nslab) load_slab((s + 1) * 16);
+    const bf16x8* a = As + cur * CF::A_STAGE + wm * (32 * WMT) + l31;
+    const bf16x8* b = Bs + cur * CF::B_STAGE + wn * (32 * WNT) + l31;
+    bf16x8 bv[WNT][3];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bv[j][p] = b[(p * 2 + h) * TN + 32 * j];
+    // the small terms first: a2 b0; a1 b1, a1 b0; a0 b2, a0 b1, a0 b0 — and the wave's WMT x WNT accumulators in turn inside a term, so
+    // that an MFMA never waits for the one before it
+#pragma unroll
+    for (int pa = 2; pa >= 0; --pa) {
+      bf16x8 av[WMT];
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) av[i] = a[(pa * 2 + h) * TM + 32 * i];
+#pragma unroll
+      for (int pb = 2 - pa; pb >= 0; --pb)
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+          for (int j = 0; j < WNT; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][pb], av[i], acc[j][i], 0, 0, 0);
+    }
+    if (s + 1 < nslab) store_slab(cur ^ 1);
+    __syncthreads();
+  }
+
+  // lane owns row m = l31 of each 32 x 32 tile; register r holds column (r & 3) + 8 (r >> 2) + 4 h
+  const bool full_n = n0 + TN <= N;
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+    const uint64_t m = m0 + wm * (32 * WMT) + i * 32 + l31;
+    if (m < M) {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int nb = n0 + wn * (32 * WNT) + j * 32 + 4 * h;
+        if (full_n) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) epi(m, nb + (r & 3) + 8 * (r >> 2), acc[j][i][r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nb + (r & 3) + 8 * (r >> 2);
+            if (n < N) epi(m, n, acc[j][i][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// padded extents of the split B for a tile width TN
+inline int kp8_of(int K) { return 2 * ((K + 15) / 16); }
+template <class CF>
+inline int np_of(int N) { return (N + CF::TN - 1) / CF::TN * CF::TN; }
+
+// B3 must hold 3 * kp8_of(K) * np_of<CF>(N) units of 16 bytes
+template <class CF, class Epi>
+inline hipError_t launch(hipStream_t stream, const float* A, uint64_t M, int K, const float* B, int ldb, int N, void* B3, Epi epi) {
+  const int Kp8 = kp8_of(K), Np = np_of<CF>(N);
+  const size_t nb = (size_t)Kp8 * Np;
+  hipLaunchKernelGGL(gemm3_split_b_k, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, B, ldb, K, N, Kp8, Np, reinterpret_cast<bf16x8*>(B3));
+  const uint32_t nMB = (uint32_t)((M + CF::TM - 1) / CF::TM), nNT = (uint32_t)(Np / CF::TN);
+  const uint64_t slots = (uint64_t)((nMB + 7) / 8) * nNT;  // per XCD
+  static bool lds_attr_set[64] = {};  // per device
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !lds_attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_k<CF, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) lds_attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16x3_k<CF, Epi>), dim3((uint32_t)(slots * 8)), dim3(CF::NT), CF::LDS_BYTES, stream, A, M, K, reinterpret_cast<const bf16x8*>(B3), Kp8,
+                     Np, N, nMB, nNT, epi);
+  return hipGetLastError();
+}
+
+}  // namespace isle_gemm3

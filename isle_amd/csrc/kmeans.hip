@@ -944,7 +944,7 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
     // dot products (5 GB at a C3 shard: 18 + 2 ms instead of 36).  ISLE_PROJ_FULL=gemm|fused forces a route.
     if (k_proj_full_by_gemm(c, D, k)) {
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
-      ISLECHK(k_gemm_nn(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));
+      ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));
       hipLaunchKernelGGL(proj_dots_tiles_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, (uint32_t)D, k, pn, cn, assign, ub, tlb, TL);
       HIPCHK(c, hipGetLastError());
       return 0;
