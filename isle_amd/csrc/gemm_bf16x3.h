@@ -55,16 +55,17 @@ __global__ __launch_bounds__(256) void gemm3_split_b_k(const float* __restrict__
   for (int p = 0; p < 3; ++p) B3[((size_t)p * Kp8 + q) * Np + n] = v[p];
 }
 
-template <int WMT_, int WNT_, int WAVES_M_, int WAVES_N_, int OCC_>
+template <int WMT_, int WNT_, int WAVES_M_, int WAVES_N_, int OCC_, int TK_ = 16>
 struct Cfg {
-  static constexpr int WMT = WMT_, WNT = WNT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, OCC = OCC_, TK = 16;
+  static constexpr int WMT = WMT_, WNT = WNT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, OCC = OCC_, TK = TK_;  // TK: 16 or 32 (one or two MFMA k-steps per slab)
+  static constexpr int KO = TK / 8;  // k-octets per slab
   static constexpr int TM = 32 * WMT * WAVES_M, TN = 32 * WNT * WAVES_N;
   static constexpr int NT = 64 * WAVES_M * WAVES_N;
-  static constexpr int A_STAGE = 6 * TM, B_STAGE = 6 * TN;  // 16-byte units per stage: [plane 3][octet 2][row]
+  static constexpr int A_STAGE = 3 * KO * TM, B_STAGE = 3 * KO * TN;  // 16-byte units per stage: [plane 3][octet KO][row]
   static constexpr size_t LDS_BYTES = (size_t)2 * (A_STAGE + B_STAGE) * 16;
-  static constexpr int A_UNITS = TM * 4 / NT;               // k-quads (4 floats of one row) per thread and slab
+  static constexpr int A_UNITS = TM * (TK / 4) / NT;        // k-quads (4 floats of one row) per thread and slab
   static constexpr int B_UNITS = (B_STAGE + NT - 1) / NT;   // 16-byte units of the split B per thread and slab
-  static_assert(TM * 4 % NT == 0, "tile / thread counts");
+  static_assert(TM * (TK / 4) % NT == 0 && (TK == 16 || TK == 32), "tile / thread counts");
 };
 
 struct StoreC {
@@ -76,7 +77,7 @@ struct StoreC {
 template <class CF, class Epi>
 __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __restrict__ A, uint64_t M, int K, const bf16x8* __restrict__ B3, int Kp8,
                                                                   int Np, int N, uint32_t nMB, uint32_t nNT, Epi epi) {
-  constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, WMT = CF::WMT, WNT = CF::WNT;
+  constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, WMT = CF::WMT, WNT = CF::WNT, TK = CF::TK, KO = CF::KO;
   extern __shared__ bf16x8 lds3[];
   bf16x8* As = lds3;                    // [2][3][2][TM]
   bf16x8* Bs = lds3 + 2 * CF::A_STAGE;  // [2][3][2][TN]
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
 #pragma unroll
     for (int u = 0; u < CF::B_UNITS; ++u) {
       const int unit = min(tid + u * NT, CF::B_STAGE - 1);  // [plane][octet][n]
-      const int p = unit / (2 * TN), r = unit - p * 2 * TN, q = r / TN, n = r - q * TN;
+      const int p = unit / (KO * TN), r = unit - p * KO * TN, q = r / TN, n = r - q * TN;
       rb[u] = *reinterpret_cast<const uint4*>(B3 + ((size_t)p * Kp8 + q0 + q) * Np + n0 + n);
     }
   };
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
         v[2][t] = t2;
       }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(a + ((size_t)((p * 2 + (akq[u] >> 1)) * TM + row)) * 16 + (akq[u] & 1) * 8) = v[p];
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(a + ((size_t)((p * KO + (akq[u] >> 1)) * TM + row)) * 16 + (akq[u] & 1) * 8) = v[p];
     }
     uint4* b = reinterpret_cast<uint4*>(Bs + stage * CF::B_STAGE);
 #pragma unroll
@@ -153,33 +154,37 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   // (staging two slabs ahead through a second register set was measured: 161 -> 120 TFLOP/s where it did not spill, 43 where it did)
-  const int nslab = (K + 15) / 16;
+  const int nslab = (K + TK - 1) / TK;
   load_slab(0);
   store_slab(0);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nslab) load_slab((s + 1) * 16);
+    if (s + 1 < nslab) load_slab((s + 1) * TK);
     const bf16x8* a = As + cur * CF::A_STAGE + wm * (32 * WMT) + l31;
     const bf16x8* b = Bs + cur * CF::B_STAGE + wn * (32 * WNT) + l31;
-    bf16x8 bv[WNT][3];
 #pragma unroll
-    for (int j = 0; j < WNT; ++j)
+    for (int ks = 0; ks < TK / 16; ++ks) {
+      const int oc = 2 * ks + h;  // the lane's octet of this k-step
+      bf16x8 bv[WNT][3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bv[j][p] = b[(p * 2 + h) * TN + 32 * j];
-    // the small terms first: a2 b0; a1 b1, a1 b0; a0 b2, a0 b1, a0 b0 — and the wave's WMT x WNT accumulators in turn inside a term, so
-    // that an MFMA never waits for the one before it
+      for (int j = 0; j < WNT; ++j)
 #pragma unroll
-    for (int pa = 2; pa >= 0; --pa) {
-      bf16x8 av[WMT];
+        for (int p = 0; p < 3; ++p) bv[j][p] = b[(p * KO + oc) * TN + 32 * j];
+      // the small terms first: a2 b0; a1 b1, a1 b0; a0 b2, a0 b1, a0 b0 — and the wave's WMT x WNT accumulators in turn inside a term, so
+      // that an MFMA never waits for the one before it
 #pragma unroll
-      for (int i = 0; i < WMT; ++i) av[i] = a[(pa * 2 + h) * TM + 32 * i];
+      for (int pa = 2; pa >= 0; --pa) {
+        bf16x8 av[WMT];
 #pragma unroll
-      for (int pb = 2 - pa; pb >= 0; --pb)
+        for (int i = 0; i < WMT; ++i) av[i] = a[(pa * KO + oc) * TM + 32 * i];
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
+        for (int pb = 2 - pa; pb >= 0; --pb)
 #pragma unroll
-          for (int j = 0; j < WNT; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][pb], av[i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][pb], av[i], acc[j][i], 0, 0, 0);
+      }
     }
     if (s + 1 < nslab) store_slab(cur ^ 1);
     __syncthreads();
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
 }
 
 // padded extents of the split B for a tile width TN
-inline int kp8_of(int K) { return 2 * ((K + 15) / 16); }
+inline int kp8_of(int K) { return 4 * ((K + 31) / 32); }  // whole slabs of 16 or 32
 template <class CF>
 inline int np_of(int N) { return (N + CF::TN - 1) / CF::TN * CF::TN; }
 

@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
       fill_k<<<(unsigned)(((size_t)s.ldb * s.N + 255) / 256), 256, 0, st>>>(B, (size_t)s.ldb * s.N, 2);
     }
     void* B3;
-    hipMalloc(&B3, (size_t)3 * (2 * ((s.K + 15) / 16)) * ((s.N + 255) / 256 * 256) * 16);
+    hipMalloc(&B3, (size_t)3 * (4 * ((s.K + 31) / 32)) * ((s.N + 255) / 256 * 256) * 16);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -137,6 +137,8 @@ int main(int argc, char** argv) {
   }
     RUN3("bf16 x 3 256x256 1024thr occ4", 2, 2, 4, 4, 4)
     RUN3("bf16 x 3 256x128 512thr occ2", 2, 2, 4, 2, 2)
+    RUN3("bf16 x 3 256x128 TK32 512thr occ2", 2, 2, 4, 2, 2, 32)
+    RUN3("bf16 x 3 256x128 TK32 1024thr", 2, 1, 4, 4, 4, 32)
     RUN3("bf16 x 3 128x256 512thr occ2", 2, 2, 2, 4, 2)
     RUN3("bf16 x 3 256x256 w128x64 512thr", 4, 2, 2, 4, 2)
 #ifdef WITH_ROCBLAS
