@@ -1255,7 +1255,9 @@ int k_gl_build(isle_ctx* c) {
       }
       // <= 12 bands (1.9 MB of Y) per column: measured at C2 / C3 shard, pass 2 in ms — per-block chunks 0.291 / 0.474, columns of
       // <= 8 bands 0.294 / 0.459, <= 12 bands 0.283 / 0.436, <= 16 bands 0.282 / 0.464
-      const uint32_t colbands = 12u;
+      // with the planar bands and the final kernels (round 3), all of config 3 on one GPU (2452 bands): 8 / 12 / 16 / 24 / 32 / 48 / 64 bands
+      // 2.42 / 2.28 / 2.20 / 2.15 / 2.16 / 2.26 / 2.43 ms; a C3 shard and C2 do not depend on it (their column count is set by the other term)
+      const uint32_t colbands = 24u;
       const double W = wgs_per_cu * c->num_cus;
       uint32_t NC = 8u * (uint32_t)std::ceil(std::max(W / (1.25 * nblk), (double)NB / colbands) / 8.0);
       NC = std::max(8u, std::min(NC, (NB / 8u) * 8u));
