@@ -175,6 +175,32 @@ def test_full_tile_pass_by_library_gemm_equals_the_fused_kernel(hp, monkeypatch)
     assert np.abs(lg["C_lowd"] - lf["C_lowd"]).max() <= 1e-3 * np.abs(lf["C_lowd"]).max()
 
 
+def test_assignment_products_on_the_bf16_matrix_cores_equal_the_f32_ones(hp, monkeypatch):
+    """The two D x k x k dot-product matrices of the assignment steps (full pass of Lloyd in span(U), first assignment of Lloyd on B) run
+    on the bf16 matrix cores with both operands split into three bf16 terms (gemm_bf16x3.h: the six partial products down to 2^-16 of
+    the leading one, each exact, summed in f32); ISLE_GEMM_BF16X3=0 puts them back on the f32 MFMA (gemm_f32.h).  Same partition
+    (near-ties apart), same iteration counts, centres equal to rounding — and both equal to the CPU oracle's."""
+    f, B, k = load_case("c3k1000")
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+    monkeypatch.setenv("ISLE_PROJ_FULL", "gemm")          # the small fixture would take the fused kernel
+    monkeypatch.setenv("ISLE_FIRST_ASSIGN", "projection")
+    out = {}
+    for mode in ("bf16x3", "f32"):
+        if mode == "f32":
+            monkeypatch.setenv("ISLE_GEMM_BF16X3", "0")
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = hp.run_lloyds(k)
+        out[mode] = (lp, ls)
+    (la, sa), (lb, sb) = out["bf16x3"], out["f32"]
+    assert la["iters"] == lb["iters"] and sa["iters"] == sb["iters"]
+    assert (la["assign"] == lb["assign"]).mean() >= 0.9999 and (sa["assign"] == sb["assign"]).mean() >= 0.9999
+    assert np.abs(la["C_lowd"] - lb["C_lowd"]).max() <= 1e-4 * np.abs(lb["C_lowd"]).max()
+    assert np.abs(sa["centers"] - sb["centers"]).max() <= 1e-4 * np.abs(sb["centers"]).max()
+
+
 def test_config5_edge_topics_at_k1000(hp):
     """BASELINE.json configs[4]: edge_topics = 1, max_edge_topics = 5000 at k = 1000 — catchwords, topic model and edge topics
     on the device from the fixture's partition, against the CPU restatement (src/trainer.cpp:577-654, :1116-1167)."""
