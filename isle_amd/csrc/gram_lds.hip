@@ -443,13 +443,13 @@ __device__ inline int gl_lane_group(int lane) {  // the four ds_read_b128 lane g
 // LDS of a wave is sized by it — 16 slots per lane for up to 4 super-rounds (most slices), 32 beyond — and eight slices share a workgroup
 // whatever the items per lane of the side are, so that the latency-bound claim loop runs at 16 ... 32 waves per CU.
 template <int MAXN, int MINN>
-__global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t nslices, const uint16_t* __restrict__ cnt,
+__global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid0, size_t nslices, const uint16_t* __restrict__ cnt,
                                                    const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
   constexpr int MS = 4 * MAXN;  // slots per lane
   __shared__ uint16_t ent_s[8][MS][64], out_s[8][MS][64];
   __shared__ uint32_t taken_s[8][4][16], taken32_s[8][2][32], owner_s[8][2][16], occ_s[8][4][MS];
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
-  const size_t sid = (size_t)blockIdx.x * 8 + wq;  // slice = (wave wv, band, group g) = wb * G + g
+  const size_t sid = sid0 + (size_t)blockIdx.x * 8 + wq;  // slice = (wave wv, band, group g) = wb * G + g
   if (sid >= nslices) return;
   const size_t wb = sid / (size_t)G;
   const int g = (int)(sid - wb * (size_t)G);
@@ -547,10 +547,10 @@ __global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t nsl
 // The stream gl_apply_k reads holds 8 * id (the row's byte offset in the float2 half plane; twice that in a float4 plane): gl_place_k
 // writes that form, this kernel converts the slices it leaves alone (more than GL_PLACE_MAXN super-rounds; all of them with ISLE_GL_PLACE=0).
 // ids are below 4096: the shift of a packed pair does not carry from the low id into the high one.
-__global__ __launch_bounds__(512) void gl_scale_ids_k(int G, size_t nslices, uint32_t min_n, const uint16_t* __restrict__ cnt,
+__global__ __launch_bounds__(512) void gl_scale_ids_k(int G, size_t sid0, size_t nslices, uint32_t min_n, const uint16_t* __restrict__ cnt,
                                                        const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
   const int lane = threadIdx.x & 63;
-  const size_t sid = (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  const size_t sid = sid0 + (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
   if (sid >= nslices) return;
   const size_t wb = sid / (size_t)G;
   const int g = (int)(sid - wb * (size_t)G);
@@ -948,6 +948,8 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   HIPCHK(c, s.slice_of.reserve(slice_of_host.size()));
   HIPCHK(c, hipMemcpyAsync(s.slice_of.p, slice_of_host.data(), slice_of_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   const size_t nwb = (size_t)s.nwv * s.NB;
+  if (nwb * 64 * GL_GMAX >= (1ull << 32))  // gl_fill1_k / gl_sort2_k take one workgroup per (wave, band): a launch of 2^32 threads does not run
+    return isle_fail(c, ISLE_E_ARG, "operator build: %zu (wave, band) cells exceed one launch", nwb);
   HIPCHK(c, s.cnt.reserve(nwb * GL_GMAX));
   HIPCHK(c, s.roff.reserve(nwb + 1));
   HIPCHK(c, c->gl_srsum.reserve(nwb));
@@ -995,14 +997,17 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   }
   if (nwb) {
     const size_t nsl = nwb * (size_t)s.G;
-    const dim3 grid((unsigned)cdiv((long)nsl, 8));
     const bool place = !c->knob_zero(KN_GL_PLACE);
-    if (place) {
-      hipLaunchKernelGGL((gl_place_k<4, 0>), grid, dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p, s.ids.p);
-      hipLaunchKernelGGL((gl_place_k<GL_PLACE_MAXN, 4>), grid, dim3(512), 0, c->stream, s.NB, s.G, nsl, s.cnt.p, s.roff.p, s.ids.p);
+    // at most 2^22 workgroups of 512 threads per launch (a launch of 2^32 threads or more does not run, and says nothing)
+    for (size_t sid0 = 0; sid0 < nsl; sid0 += (size_t)8 << 22) {
+      const dim3 grid((unsigned)cdiv((long)std::min<size_t>(nsl - sid0, (size_t)8 << 22), 8));
+      if (place) {
+        hipLaunchKernelGGL((gl_place_k<4, 0>), grid, dim3(512), 0, c->stream, s.NB, s.G, sid0, nsl, s.cnt.p, s.roff.p, s.ids.p);
+        hipLaunchKernelGGL((gl_place_k<GL_PLACE_MAXN, 4>), grid, dim3(512), 0, c->stream, s.NB, s.G, sid0, nsl, s.cnt.p, s.roff.p, s.ids.p);
+      }
+      hipLaunchKernelGGL(gl_scale_ids_k, grid, dim3(512), 0, c->stream, s.G, sid0, nsl, place ? (uint32_t)GL_PLACE_MAXN : 0u, s.cnt.p, s.roff.p, s.ids.p);
+      HIPCHK(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(gl_scale_ids_k, grid, dim3(512), 0, c->stream, s.G, nsl, place ? (uint32_t)GL_PLACE_MAXN : 0u, s.cnt.p, s.roff.p, s.ids.p);
-    HIPCHK(c, hipGetLastError());
   }
   // the prefetch slack behind the stream: the padding id in the stream's final form
   HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)(GL_RB * 8), n16_all - n16_body, c->stream));
