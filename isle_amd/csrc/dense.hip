@@ -792,9 +792,15 @@ __global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in,
 }
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out) {
   if (rows == 0 || cols == 0) return 0;
-  dim3 g(cdiv(rows, 32), cdiv(cols, 32)), blk(256);
-  hipLaunchKernelGGL(transpose_k, g, blk, 0, c->stream, in, rows, cols, ld_in, out, ld_out);
-  HIPCHK(c, hipGetLastError());
+  // row chunks of at most 2^31 threads per launch (10 M x 1000 is 2.5e9 threads in one: a launch of 2^32 or more does not run)
+  const uint64_t cb = cdiv(cols, 32);
+  const uint64_t rows_per = std::max<uint64_t>(32, ((1ull << 31) / 256 / cb) * 32);
+  for (uint64_t r0 = 0; r0 < rows; r0 += rows_per) {
+    const uint64_t nr = std::min(rows_per, rows - r0);
+    dim3 g((unsigned)cdiv(nr, 32), (unsigned)cb), blk(256);
+    hipLaunchKernelGGL(transpose_k, g, blk, 0, c->stream, in + r0, nr, cols, ld_in, out + r0 * ld_out, ld_out);
+    HIPCHK(c, hipGetLastError());
+  }
   return 0;
 }
 
