@@ -1922,8 +1922,16 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   const char* fa = c->knob(KN_FIRST_ASSIGN);
   const double t_dense = 2.0 * (double)D * k * k / 130e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
   const bool dense_pays = k <= 384 || (t_dense < t_sparse && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)));
-  const bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
-                              D > 0 && (dense_pays || (fa && !strcmp(fa, "projection"))) && !(fa && !strcmp(fa, "sparse"));
+  bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
+                        D > 0 && (dense_pays || (fa && !strcmp(fa, "projection"))) && !(fa && !strcmp(fa, "sparse"));
+  if (via_projection && c->dotsT.reserve((size_t)D * k) != hipSuccess) {
+    // the route is chosen from sizes alone (isle_scratch_ok), but on a device shared with other work the D x k scratch may still not be
+    // had: the sparse product gives the same assignment up to dot-product rounding, so take it instead of failing the call
+    (void)hipGetLastError();
+    fprintf(stderr, "[isle_hip] lloyds_sparse: no memory for the %.1f GB product of the first assignment; taking the sparse route\n",
+            (double)D * k * sizeof(float) / 1e9);
+    via_projection = false;
+  }
   c->lift_valid = false;  // the centres move below
   int it = 0;
   isle_host_mark("lloyds_sparse: loop starts");
@@ -1968,7 +1976,9 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // (the member lists), so that waves running together gather from one table in L2; ISLE_YY_MODE = doc | docg | group picks the form
       // (measured, Lloyd on B per step: C3 shard 176 ms by document -> 112 ms by group, all of config 3 on one GPU 825 -> 588 ms; at C2,
       // G = 25 and a 40 MB table, the three forms are within 10 % of each other and the plain one stays)
-      const int yy_mode = yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
+      // the forms that visit documents in member order (docg, group) hold a document's group bounds four per lane: at most 256 groups
+      // (k <= 2048); beyond, by document over the row-major centres, whatever ISLE_YY_MODE asks for
+      const int yy_mode = G > 256 ? 0 : yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
       const uint32_t* order = yy_mode && c->members_valid ? c->members.p : nullptr;
       if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
       ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));

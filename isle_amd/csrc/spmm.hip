@@ -1379,6 +1379,7 @@ int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float
   *done = false;
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
   if (D == 0 || G > 256) return 0;
+  if ((uint64_t)D * (uint64_t)(G - 1) >= (1ull << 32)) return 0;  // pair counts and offsets are 32-bit: the by-document form takes over
   const int NW = cdiv(G, 64);
   HIPCHK(c, c->yy_own.reserve((size_t)D * 3));
   HIPCHK(c, c->yy_need.reserve((size_t)D * NW));

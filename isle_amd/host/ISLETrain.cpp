@@ -1,57 +1,97 @@
-// isle_amd/host/ISLETrain.cpp — the reference's 12-argument CLI (drivers/ISLETrain.cpp:8-51) over the MI355X path.
+// isle_amd/host/ISLETrain.cpp — command line of the training path on MI355X.
+//
+// Contract taken from the reference's driver (drivers/ISLETrain.cpp:9-16 and :35-46): twelve positional arguments in this order,
 //
 //   ISLETrain <tdf_file> <vocab_file> <output_dir> <vocab_size> <num_docs> <max_entries> <num_topics>
 //             <apply tf-idf(0/1)> <sample(0/1)> <sample_rate> <edge topics(0/1)> <max_edge_topics>
 //
-// The same call sequence as the reference's main (:34-46) on ISLE::ISLETrainer (trainer_hip.h): the constructor loads the file (ingest
-// and thresholding on the device), train() runs the hot path src/trainer.cpp:490-571, catchwords and the topic model on the GPU, the
-// writers leave the reference's files in its log directory (src/utils.cpp:28-48): diagnosticLog.txt, timerLog.txt, M_hat_catch_sparse,
-// TopWordsPerTopic_catch.txt, EdgeModel_sparse; extra files HotPathClusters.tsv / HotPathSingularValues.txt.
+// the usage text and exit status 255 on any other count, and the order of the trainer calls.  Everything else here is this
+// repository's: the arguments are described by one table and parsed by it, numbers are range-checked instead of passed through
+// atol(), and a failed run exits with status 1 (the reference prints a message and exits 0, SURVEY App. C #3 — deliberate deviation).
+//
+// The trainer (trainer_hip.h) loads the file in its constructor (ingest and thresholding on the device), train() runs the hot path
+// src/trainer.cpp:490-571 plus catchwords and the topic model on the GPU; the writers leave diagnosticLog.txt, timerLog.txt,
+// M_hat_catch_sparse, TopWordsPerTopic_catch.txt, EdgeModel_sparse (and HotPathClusters.tsv / HotPathSingularValues.txt).
+#include <cerrno>
+#include <cstdlib>
+
 #include "trainer_hip.h"
 
-using namespace ISLE;
+namespace {
 
-int main(int argv, char** argc) {
-  if (argv != 13) {
-    std::cout << "Incorrect usage of ISLETrain. Use: \n"
-              << "trainFromFile <tdf_file> <vocab_file> <output_dir> "
-              << "<vocab_size> <num_docs> <max_entries> <num_topics> "
-              << "<apply tf-idf(0/1)> <sample(0/1)> <sample_rate> "
-              << "<edge topics(0/1) <max_edge_topics>" << std::endl;
-    exit(-1);
+enum class Kind { Text, Count, Flag, Rate };
+
+struct Positional {
+  const char* label;  // as it appears in the usage text
+  Kind kind;
+};
+
+// the order IS the interface
+const Positional kArgs[] = {
+    {"<tdf_file>", Kind::Text},    {"<vocab_file>", Kind::Text},   {"<output_dir>", Kind::Text},      {"<vocab_size>", Kind::Count},
+    {"<num_docs>", Kind::Count},   {"<max_entries>", Kind::Count}, {"<num_topics>", Kind::Count},     {"<apply tf-idf(0/1)>", Kind::Flag},
+    {"<sample(0/1)>", Kind::Flag}, {"<sample_rate>", Kind::Rate},  {"<edge topics(0/1)", Kind::Flag}, {"<max_edge_topics>", Kind::Count}};
+constexpr int kNumArgs = sizeof(kArgs) / sizeof(kArgs[0]);
+
+struct Parsed {
+  std::string text[kNumArgs];
+  unsigned long long count[kNumArgs] = {};
+  double rate[kNumArgs] = {};
+};
+
+[[noreturn]] void usage() {
+  // the reference's wording (its unbalanced "<edge topics(0/1)" included): scripts grep for it
+  std::cout << "Incorrect usage of ISLETrain. Use: \n"
+            << "trainFromFile";
+  for (const Positional& a : kArgs) std::cout << ' ' << a.label;
+  std::cout << std::endl;
+  std::exit(-1);
+}
+
+void parse(int n, char** v, Parsed& out) {
+  for (int i = 0; i < n; ++i) {
+    const char* s = v[i];
+    out.text[i] = s;
+    const Kind kind = kArgs[i].kind;
+    if (kind == Kind::Text) continue;
+    char* end = nullptr;
+    errno = 0;
+    if (kind == Kind::Rate) {
+      out.rate[i] = std::strtod(s, &end);
+    } else {
+      if (*s == '-') throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " must not be negative: " + s);
+      out.count[i] = std::strtoull(s, &end, 10);
+      if (kind == Kind::Flag && out.count[i] > 1) throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " is a 0/1 flag: " + s);
+    }
+    if (end == s || *end != '\0' || errno == ERANGE) throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " is not a number: " + s);
   }
-  const std::string tdf_file = argc[1];
-  const std::string vocab_file = argc[2];
-  const std::string output_dir = argc[3];
-  const word_id_t vocab_size = atol(argc[4]);
-  const doc_id_t num_docs = atol(argc[5]);
-  const offset_t max_entries = atol(argc[6]);
-  const doc_id_t num_topics = atol(argc[7]);
-  const bool tf_idf = atoi(argc[8]);
-  const bool sample = atoi(argc[9]);
-  const FPTYPE sample_rate = (FPTYPE)atof(argc[10]);
-  const bool compute_edge_topics = atoi(argc[11]);
-  const int max_edge_topics = atoi(argc[12]);
+}
 
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc != kNumArgs + 1) usage();
   try {
-    ISLETrainer trainer(vocab_size, num_docs, max_entries, num_topics, tf_idf, sample, sample_rate, ISLETrainer::data_ingest::FILE_DATA_LOAD, tdf_file,
-                        vocab_file, output_dir, compute_edge_topics, max_edge_topics);
+    Parsed a;
+    parse(kNumArgs, argv + 1, a);
+    const bool want_edge_topics = a.count[10] != 0;
+    ISLE::ISLETrainer trainer((ISLE::word_id_t)a.count[3], (ISLE::doc_id_t)a.count[4], (ISLE::offset_t)a.count[5], (ISLE::doc_id_t)a.count[6],
+                              a.count[7] != 0, a.count[8] != 0, (ISLE::FPTYPE)a.rate[9], ISLE::ISLETrainer::FILE_DATA_LOAD, a.text[0], a.text[1],
+                              a.text[2], want_edge_topics, (int)a.count[11]);
+    // drivers/ISLETrain.cpp:38-46: the sequence a caller of the class is expected to make
     trainer.train();
     trainer.output_cluster_summary();
     trainer.write_model_to_file();
-    if (compute_edge_topics) {
+    if (want_edge_topics) {
       trainer.train_edge_topics();
       trainer.write_edgemodel_to_file();
     }
     trainer.finish_log();
+    return 0;
   } catch (const std::exception& e) {
-    // the reference prints the message and still exits with 0 (drivers/ISLETrain.cpp:48-50): a failed training
-    // run then looks like a good one to a calling script.  Deliberate deviation: status 1.
     std::cerr << "ISLE Trainer failed: " << e.what() << std::endl;
-    return 1;
   } catch (...) {
     std::cerr << "ISLE Trainer failed" << std::endl;
-    return 1;
   }
-  return 0;
+  return 1;
 }

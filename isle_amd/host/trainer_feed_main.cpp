@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     {
       std::ifstream in(argv[1]);
       uint64_t d, w, cnt;
-      while (in >> d >> w >> cnt) docs.at(d - 1).push_back(std::make_pair((word_id_t)(w - 1), (count_t)cnt));  // tdf ids are 1-based
+      while (in >> d >> w >> cnt) docs.at(d - 1).push_back(std::make_pair((word_id_t)w, (count_t)cnt));  // tdf ids are 1-based; feed_data takes the word id as it is (src/trainer.cpp:224)
     }
     ISLETrainer trainer(vocab_size, num_docs, 0, num_topics, false, false, 0.0f, ISLETrainer::data_ingest::ITERATIVE_DATA_LOAD, argv[1], "", argv[2]);
     std::vector<doc_id_t> order(num_docs);

@@ -232,15 +232,17 @@ class ISLETrainer {
     after_matrices_built();
   }
 
-  // include/trainer.h:139-143, src/trainer.cpp:200-230: one document's words and counts (0-based ids)
+  // include/trainer.h:139-143, src/trainer.cpp:214-230: one document's words and counts.  The reference's convention, kept: `doc` is the
+  // 0-based column, `words[i]` are 1-BASED word ids as in a tdf file (it stores `words[w] - 1`, :224).  Where the reference would write
+  // outside its matrix, an id out of range is an error here.
   inline void feed_data(const doc_id_t doc, const word_id_t* const words, const count_t* const counts, const offset_t num_words) {
     if (how_data_loaded != ITERATIVE_DATA_LOAD) throw std::runtime_error("feed_data needs ITERATIVE_DATA_LOAD");
     if (is_data_loaded) throw std::runtime_error("feed_data after finalize_data");
     for (offset_t i = 0; i < num_words; ++i) {
-      if (doc >= num_docs || words[i] >= vocab_size) throw std::runtime_error("feed_data: id out of range");
+      if (doc >= num_docs || words[i] < 1 || words[i] > vocab_size) throw std::runtime_error("feed_data: id out of range (documents 0-based, words 1-based)");
       if (counts[i] == 0) continue;
       fed_doc.push_back(doc);
-      fed_word.push_back((uint32_t)words[i]);
+      fed_word.push_back((uint32_t)(words[i] - 1));
       fed_count.push_back((float)counts[i]);
     }
   }

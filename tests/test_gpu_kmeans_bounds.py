@@ -129,3 +129,41 @@ def test_tiny_and_degenerate_partitions(hp, D, k):
     sg, so = hp.run_lloyds(k), o.lloyds_sparse(lift(U, lo["C_lowd"]))
     assert sg["iters"] == so["iters"]
     same_partition(sg["assign"], so["assign"], sg["centers"].T, so["centers"].T)  # (V, k): a column per centre
+
+
+def test_more_than_256_yinyang_groups(hp):
+    """k > 2048 (more than 256 Yinyang groups of 8 centres): the member-ordered forms of the iteration hold four groups per lane and must
+    not be taken (groups beyond 256 were never lowered and the filter read LDS nobody wrote); whatever ISLE_YY_MODE asks
+    for, the partition must be the oracle's (src/sparseMatrix.cpp:1587-1746)."""
+    from conftest import corpus
+    V, D, k = 2400, 9000, 2056
+    B = corpus(V, D, 40, 11)
+    D = B["D"]
+    o = B["oracle"]
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(D, size=k, replace=False))
+    cen = np.zeros((B["V"], k), np.float32, order="F")
+    for j, d in enumerate(pick):  # centres = k documents of B
+        lo, hi = B["offs"][d], B["offs"][d + 1]
+        cen[B["rows"][lo:hi], j] = B["vals"][lo:hi]
+    so = o.lloyds_sparse(cen)
+    upload(hp, B)
+    old = os.environ.get("ISLE_YY_MODE")
+    try:
+        for mode in (None, "group", "docg"):
+            if mode is None:
+                os.environ.pop("ISLE_YY_MODE", None)
+            else:
+                os.environ["ISLE_YY_MODE"] = mode
+            sg = hp.run_lloyds(k, centers=cen)
+            if mode is None:
+                first = sg
+                assert (sg["assign"] == so["assign"]).mean() >= 0.999, float((sg["assign"] == so["assign"]).mean())
+                assert sg["iters"] == so["iters"]
+            assert sg["iters"] == first["iters"], mode
+            assert np.array_equal(sg["assign"], first["assign"]), (mode, float((sg["assign"] == first["assign"]).mean()))
+    finally:
+        if old is None:
+            os.environ.pop("ISLE_YY_MODE", None)
+        else:
+            os.environ["ISLE_YY_MODE"] = old
