@@ -69,6 +69,7 @@ struct GlDesc {  // one workgroup: 16 waves wave0 + i*wstride (i < nw), source b
 struct GlSide {
   uint32_t n_out = 0, n_src = 0, NB = 0, nslice = 0, nwv = 0, ndesc = 0;
   int G = 4;                  // groups of a wave = output items per lane (4 ... 8)
+  uint32_t wpg = 16;          // waves per workgroup of the apply kernel on this side
   DevBuf<uint32_t> slice_of;  // nwv x G: slice (64 consecutive output positions) of (wave, group), 0xffffffff = none
   DevBuf<int64_t> roff;       // nwv x NB + 1: first super-round of (wave, band)
   DevBuf<uint16_t> cnt;       // nwv x NB x 8: super-rounds (4 nonzeros per lane) of (wave, band, group), zero beyond G

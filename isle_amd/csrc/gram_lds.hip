@@ -613,9 +613,16 @@ __device__ inline void add4(float4& a, const float4 b) {
       float4 v[GL_INFLIGHT][NFA];                                                                                       \
       float2 h[GL_INFLIGHT];                                                                                            \
       _Pragma("unroll") for (int t = 0; t < GL_INFLIGHT; ++t) {                                                         \
-        const uint32_t b16 = (a8[t2 + t] << 1) + p0s;                                                                   \
-        _Pragma("unroll") for (int l = 0; l < NF; ++l) v[t][l] = gl_lds_f4(b16 + l * GL_PSB);                           \
-        if (HALF) h[t] = gl_lds_f2(a8[t2 + t]);                                                                         \
+        const uint32_t a8x = (GL_ABLATE & 4) ? (a8[t2 + t] & 8u) : a8[t2 + t];                                          \
+        const uint32_t b16 = (a8x << 1) + p0s;                                                                          \
+        if (GL_ABLATE & 16) {                                                                                           \
+          const float f = __builtin_bit_cast(float, a8x);                                                               \
+          _Pragma("unroll") for (int l = 0; l < NF; ++l) v[t][l] = make_float4(f, f, f, f);                             \
+          h[t] = make_float2(f, f);                                                                                     \
+        } else {                                                                                                        \
+          _Pragma("unroll") for (int l = 0; l < NF; ++l) v[t][l] = gl_lds_f4(b16 + l * GL_PSB);                         \
+          if (HALF) h[t] = gl_lds_f2(a8x);                                                                              \
+        }                                                                                                               \
       }                                                                                                                 \
       _Pragma("unroll") for (int t = 0; t < GL_INFLIGHT; ++t) {                                                         \
         _Pragma("unroll") for (int l = 0; l < NF; ++l) add4(acc[g][l], v[t][l]);                                        \
@@ -639,6 +646,39 @@ __device__ inline float2 gl_lds_f2(uint32_t addr) {
   return make_float2(v.x, v.y);
 }
 
+// one super-round of a lane's id stream (4 ids).  GL_IDS_NT: read with the non-temporal policy — the stream is read exactly once per
+// pass and should not push the staged operand (X: 4 MB, read by every workgroup; the band columns of Y) out of the XCD's L2
+#ifndef GL_IDS_NT
+#define GL_IDS_NT 1
+#endif
+#ifndef GL_ABLATE
+#define GL_ABLATE 0  // timing experiments only (tools/build_variant.sh): 1 no band staging, 2 no band barriers, 4 every gather reads row 0, 8 ids re-read from one place, 16 no LDS reads, 32 half the id loads, 64 loaded ids never consumed
+#endif
+// (a macro, not a function: with the plain load behind an inline function hipcc 7.2 allocated the kernel's registers differently and
+// the 10-column kernels at 6 and 7 items per lane spilled 10 / 74 registers — pass 1 of config 3 on one GPU 1.60 -> 2.77 ms)
+#if GL_IDS_NT
+__device__ inline uint2 gl_ld_ids_nt(const uint2* p) {
+  const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+#define gl_ld_ids(p) gl_ld_ids_nt(p)
+#else
+#define gl_ld_ids(p) (*(p))
+#endif
+
+// GL_STAMPS (diagnostic builds only, tools/build_variant.sh stamps "-DGL_STAMPS=1"): where a wave's cycles go, by s_memtime — waiting at
+// the barrier that ends a band, staging its own pieces of the next band, waiting at the barrier behind the staging, walking the band's
+// super-rounds.  Sums over all valid waves of a launch; k_gl_apply_cm prints them per pass.  No stamp executes in the regular build.
+#ifndef GL_STAMPS
+#define GL_STAMPS 0
+#endif
+#if GL_STAMPS
+__device__ unsigned long long gl_stamp_acc[8];
+#define GL_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define GL_STAMP(var)
+#endif
+
 template <int LPE, bool HALF, int G>
 __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restrict__ In, uint32_t n_src, const uint2* __restrict__ ids,
                                                           const int64_t* __restrict__ roff, const uint16_t* __restrict__ cnt,
@@ -658,8 +698,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   // four in flight against 0.322 with two; 8 items per lane 0.50 ms (spills inside the loop) against 0.38
   constexpr int GL_INFLIGHT = G * (4 * NF + (HALF ? 2 : 0)) <= 56 ? 4 : 2;
   const GlDesc ds = desc[blockIdx.x];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool wvalid = (uint32_t)__builtin_amdgcn_readfirstlane(w) < ds.nw;  // wave-uniform, and known to the compiler as such
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and known to the compiler as such: what hangs on it (the wave's
+                                                                          // place in the stream, its count records) is addressed from scalar registers
+  const int nwaves = (int)(blockDim.x >> 6);  // 16, or the side's waves per workgroup (GlSide::wpg)
+  const bool wvalid = (uint32_t)w < ds.nw;
   const size_t wv = wvalid ? (size_t)ds.wave0 + (size_t)w * ds.wstride : (size_t)ds.wave0;
   // LDS image: the half plane first (the stream holds a row's byte offset in it: 8 id), the float4 planes behind it (row at 16 id = one
   // shift-add with the plane base from the stream's value; the second plane within the 16-bit offset field of the first's address)
@@ -682,18 +725,24 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
   }
   // the wave's id stream is contiguous over bands and groups; reads run GL_PF super-rounds ahead (slack behind the array)
   const uint2* p = ids + (size_t)roff[wv * NB + ds.b0] * 64 + lane;
-  uint2 q0 = p[0], q1 = p[64], q2 = p[128], q3 = p[192];
+  uint2 q0 = gl_ld_ids(p), q1 = gl_ld_ids(p + 64), q2 = gl_ld_ids(p + 128), q3 = gl_ld_ids(p + 192);
   p += 256;
+#if GL_STAMPS
+  unsigned long long st_b1 = 0, st_stage = 0, st_b2 = 0, st_walk = 0, st_sr = 0;
+#endif
   for (uint32_t band = ds.b0; band < ds.b1; ++band) {
-    __syncthreads();  // every wave is done with the previous band
-    {
+    GL_STAMP(t0);
+    // the band's count record (GL_GMAX u16 super-round counts of this wave): asked for before the band is staged, used behind it (it used to be
+    // loaded behind the second barrier: one exposed memory round trip per band and wave)
+    const uint4 cc = *reinterpret_cast<const uint4*>(cnt + (wv * NB + band) * GL_GMAX);
+    if (!(GL_ABLATE & 2)) __syncthreads();  // every wave is done with the previous band
+    GL_STAMP(t1);
+    if (!(GL_ABLATE & 1)) {
       // stage the band: up to ten 1-KiB LDS-DMA pieces per wave (global_load_lds_dwordx4: no VGPR round trip, all in flight at once)
       const uint32_t nrow = min(GL_RB, n_src - band * GL_RB);
       const char* src = reinterpret_cast<const char*>(In) + (size_t)band * IMG;
 #pragma nounroll
-      for (int j = 0; j < (NPIECE + GL_WAVES - 1) / GL_WAVES; ++j) {  // rolled: unrolled, the address pairs stayed live beside the accumulators (spills)
-        const int q = j * GL_WAVES + w;  // wave-uniform piece
-        if (q < NPIECE) {
+      for (int q = w; q < NPIECE; q += nwaves) {  // wave-uniform piece; rolled: unrolled, the address pairs stayed live beside the accumulators (spills)
           const bool hp = q >= NF * 64;  // a piece of the half plane
           const int plane = hp ? NF : q >> 6;
           const uint32_t i = (uint32_t)(hp ? q - NF * 64 : q & 63) * 64u + lane;  // float4 of the plane
@@ -703,12 +752,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
             char* lp = lb + (hp ? 0u : P0 + plane * GL_PSB) + (i - lane) * 16u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
           }
-        }
       }
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
     }
-    __syncthreads();
-    const uint4 cc = *reinterpret_cast<const uint4*>(cnt + (wv * NB + band) * GL_GMAX);  // GL_GMAX u16 counts
+    GL_STAMP(t2);
+    if (!(GL_ABLATE & 2)) __syncthreads();
+    GL_STAMP(t3);
     uint32_t cw[4] = {(uint32_t)__builtin_amdgcn_readfirstlane(cc.x), (uint32_t)__builtin_amdgcn_readfirstlane(cc.y),
                       (uint32_t)__builtin_amdgcn_readfirstlane(cc.z), (uint32_t)__builtin_amdgcn_readfirstlane(cc.w)};
     if (!wvalid) cw[0] = cw[1] = cw[2] = cw[3] = 0;
@@ -723,26 +772,59 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
       uint32_t r = 0;
       for (; r + 2 <= n; r += 2) {
         const uint2 ua = q0, ub = q1;
-        q0 = q2;
-        q1 = q3;
-        q2 = p[0];
-        q3 = p[64];
-        p += 128;
+        if (!(GL_ABLATE & 64)) {  // 64: the loaded ids are never consumed (no wait for them at all; the first super-rounds are walked again and again)
+          q0 = q2;
+          q1 = q3;
+        }
+        q2 = gl_ld_ids(p);
+        if (GL_ABLATE & 32) {
+          q3 = q2;
+          p += 64;
+        } else {
+          q3 = gl_ld_ids(p + 64);
+          if (!(GL_ABLATE & 8)) p += 128;
+        }
         GL_ROWS(ua)
         GL_ROWS(ub)
       }
       if (r < n) {
         const uint2 ua = q0;
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
-        q3 = *p;
-        p += 64;
+        if (!(GL_ABLATE & 64)) {
+          q0 = q1;
+          q1 = q2;
+          q2 = q3;
+        }
+        q3 = gl_ld_ids(p);
+        if (!(GL_ABLATE & 8)) p += 64;
         GL_ROWS(ua)
       }
+#if GL_STAMPS
+      st_sr += n;
+#endif
     }
+#if GL_STAMPS
+    {
+      GL_STAMP(t4);
+      st_b1 += t1 - t0;
+      st_stage += t2 - t1;
+      st_b2 += t3 - t2;
+      st_walk += t4 - t3;
+    }
+#endif
   }
+#if GL_STAMPS
+  if (wvalid && lane == 0) {
+    atomicAdd(&gl_stamp_acc[0], st_b1);
+    atomicAdd(&gl_stamp_acc[1], st_stage);
+    atomicAdd(&gl_stamp_acc[2], st_b2);
+    atomicAdd(&gl_stamp_acc[3], st_walk);
+    atomicAdd(&gl_stamp_acc[4], st_sr);
+    atomicAdd(&gl_stamp_acc[5], 1ull);
+    atomicAdd(&gl_stamp_acc[6], (unsigned long long)(ds.b1 - ds.b0));
+  }
+#endif
   if (!wvalid) return;
+  if ((GL_ABLATE & 64) && (q2.x ^ q3.y) == 0x12345u) acc[0][0].x += 1.f;  // keeps the loads of the ablated ring alive
   float4* out = Out + (size_t)ds.slab * slab_stride;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -1017,8 +1099,10 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
 template <int LPE, bool HALF, int G>
 int launch_apply_g(isle_ctx* c, const GlSide& s, const float4* In, float4* Out, size_t slab_stride, const uint32_t* rowmap, uint32_t out_ld4,
                    uint32_t out_n2) {
-  ISLECHK(isle_max_lds(c, (const void*)gl_apply_k<LPE, HALF, G>, GL_LDS));
-  hipLaunchKernelGGL((gl_apply_k<LPE, HALF, G>), dim3(s.ndesc), dim3(GL_THREADS), GL_LDS, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
+  // LDS of this panel width: its planes (+ zero rows) only
+  constexpr uint32_t lds = (uint32_t)(HALF ? LPE - 1 : LPE) * GL_PSB + (HALF ? GL_PS * 8u : 0u);
+  ISLECHK(isle_max_lds(c, (const void*)gl_apply_k<LPE, HALF, G>, (int)lds));
+  hipLaunchKernelGGL((gl_apply_k<LPE, HALF, G>), dim3(s.ndesc), dim3(64 * s.wpg), lds, c->stream, In, s.n_src, s.ids.p, s.roff.p, s.cnt.p,
                      s.slice_of.p, s.desc.p, s.NB, Out, slab_stride, s.n_out, rowmap, out_ld4 ? out_ld4 : (uint32_t)LPE, out_n2);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -1109,7 +1193,8 @@ int k_gl_build(isle_ctx* c) {
   // take fewer waves per workgroup so that all CUs stay busy.  The model's figures against the measured ones, pass 1 with 10 columns:
   // C3 shard G = 5: 312 / 313 us; config 3 on one GPU G = 4 / 6 / 8: 2610 / 2530 / 2310 against 2690 / 2490 / 2336 us.
   // ISLE_GL_G1 = 4..8 forces G.
-  uint32_t wpw = GL_WAVES;
+  const uint32_t maxw = GL_WAVES;
+  uint32_t wpw = maxw;
   const uint32_t cus = c->knob(KN_GL_TEST_CUS) ? (uint32_t)std::max(1, atoi(c->knob(KN_GL_TEST_CUS))) : (uint32_t)c->num_cus;  // test hook: the geometry of a larger problem on a small one
   {
     const double t_slice = 0.05 * 2.5 * (double)c->nnz / 256.0 / std::max<uint32_t>(1u, s1.nslice);  // us: ~50 ns per super-round, ~2.5x padded
@@ -1119,7 +1204,7 @@ int k_gl_build(isle_ctx* c) {
     double best = 1e300;
     for (int G = g_lo; G <= g_hi; ++G) {
       const uint32_t nwv = (s1.nslice + G - 1) / G;
-      for (uint32_t cand = GL_WAVES; cand >= 1; --cand) {
+      for (uint32_t cand = maxw; cand >= 1; --cand) {
         const uint32_t wgs = (nwv + cand - 1) / cand;
         const double fewer = 1.0 + 0.25 * (double)(GL_WAVES - cand) / GL_WAVES;  // fewer waves hide less of the id-stream latency
         const uint32_t rounds = (wgs + cus - 1) / cus;
@@ -1135,6 +1220,7 @@ int k_gl_build(isle_ctx* c) {
     }
   }
   s1.nwv = (s1.nslice + s1.G - 1) / s1.G;
+  s1.wpg = wpw;
   // More than one round of workgroups: their number is rounded up to whole rounds of the CUs — the waves of the last quantile range
   // then own one slice less — and a workgroup takes ADJACENT waves (slices of neighbouring lengths: its waves reach the barrier of a band
   // together; the workgroups differ by the length of their documents, the longest are launched first).  5.45 rounds of 7 slices per wave
@@ -1212,11 +1298,12 @@ int k_gl_build(isle_ctx* c) {
     s2.G = e_g ? std::max(4, std::min(GL_GMAX, atoi(e_g))) : (s2.NB > 1024 ? 6 : 4);
   }
   const uint32_t G2 = (uint32_t)s2.G;
-  uint32_t wpb = GL_WAVES;
+  uint32_t wpb = maxw;
   while (wpb > 1 && (uint64_t)((s2.nslice + G2 * wpb - 1) / (G2 * wpb)) * s2.NB < 2ull * c->num_cus) wpb /= 2;
   const uint32_t bslices = G2 * wpb, bitems = 64 * bslices;
   const uint32_t nblk = (s2.nslice + bslices - 1) / bslices;
   s2.nwv = nblk * wpb;
+  s2.wpg = wpb;
   c->gl_block_items = bitems;
   {
     // serpentine inside the block keeps its waves level
@@ -1382,6 +1469,21 @@ static size_t gl_packed_floats(size_t n_rows, int LPE, bool half) {
 
 // Zcm (V x b column-major) = B (B^T Xcm): the operator application on the eigensolver's own layout, b <= 10 columns in a panel of
 // BP = 4, 8 or 12 (the packing of X is fused with its scaling, the slab reduction writes the column-major block)
+#if GL_STAMPS
+static void gl_stamps_report(isle_ctx* c, const char* what) {
+  unsigned long long h[8], z[8] = {};
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(gl_stamp_acc), sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(gl_stamp_acc), z, sizeof z);
+  const double w = h[5] ? (double)h[5] : 1.0, tot = (double)(h[0] + h[1] + h[2] + h[3]);
+  // s_memtime counts shader cycles (MI355X_MICROARCH.md, cycle constants): figures are kilocycles per wave
+  fprintf(stderr, "[gl stamps] %s: %llu waves, %.1f bands and %.0f super-rounds per wave; per wave %.1f kcycles = end-of-band barrier %.1f (%.0f %%) + own staging %.1f (%.0f %%) + "
+                  "barrier behind the staging %.1f (%.0f %%) + walking the super-rounds %.1f (%.0f %%: %.0f cycles per super-round)\n",
+          what, h[5], h[6] / w, h[4] / w, tot / w * 1e-3, h[0] / w * 1e-3, 100.0 * h[0] / tot, h[1] / w * 1e-3, 100.0 * h[1] / tot, h[2] / w * 1e-3, 100.0 * h[2] / tot,
+          h[3] / w * 1e-3, 100.0 * h[3] / tot, h[4] ? (double)h[3] / h[4] : 0.0);
+}
+#endif
+
 int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm) {
   const int LPE = BP / 4;
   if (LPE < 1 || LPE > 3 || b > BP || b <= BP - 4 || b > 10) return isle_fail(c, ISLE_E_ARG, "LDS Gram apply: b = %d in a panel of %d", b, BP);
@@ -1401,10 +1503,16 @@ int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm) {
     HIPCHK(c, hipGetLastError());
     // Y = B^T X, written as the packed operand of pass 2 (banded by document position)
     ISLECHK(launch_apply_any(c, LPE, half, c->gl1, (const float4*)c->gl_Xs.p, (float4*)c->Yrm.p, 0, GL_OUT_PLANAR));
+#if GL_STAMPS
+    gl_stamps_report(c, "pass 1");
+#endif
   }
   {
     TimeScope ts(c, one_pair ? -1 : ISLE_T_GRAM_PASS2);
     ISLECHK(launch_apply_any(c, LPE, half, c->gl2, (const float4*)c->Yrm.p, (float4*)c->gl_part.p, (size_t)c->gl_block_items * LPE, 0));
+#if GL_STAMPS
+    gl_stamps_report(c, "pass 2");
+#endif
     hipLaunchKernelGGL(gl_reduce_cm_k, dim3(cdiv((long)nx4, 256)), dim3(256), 0, c->stream, (const float4*)c->gl_part.p, c->gl_slab0.p,
                        c->gl_nch.p, c->wperm.p, c->rowval.p, V, LPE, b, c->gl_block_items, Zcm);
     HIPCHK(c, hipGetLastError());

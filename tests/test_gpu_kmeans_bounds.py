@@ -131,32 +131,40 @@ def test_tiny_and_degenerate_partitions(hp, D, k):
     same_partition(sg["assign"], so["assign"], sg["centers"].T, so["centers"].T)  # (V, k): a column per centre
 
 
-def test_more_than_256_yinyang_groups(hp):
-    """k > 2048 (more than 256 Yinyang groups of 8 centres): the member-ordered forms of the iteration hold four groups per lane and must
-    not be taken (groups beyond 256 were never lowered and the filter read LDS nobody wrote); whatever ISLE_YY_MODE asks
-    for, the partition must be the oracle's (src/sparseMatrix.cpp:1587-1746)."""
+def test_256_yinyang_groups_is_the_edge(hp):
+    """k = 2048 is the largest topic count the word-space assignment takes (256 Yinyang groups of 8 centres = four groups per lane in the
+    member-ordered forms; ADVICE round 3 asked what happens beyond: the kernels refuse k > 2048 with an error, and api.cpp takes the
+    by-document form for more than 256 groups should that limit ever move).  At the edge every form of the iteration must give the
+    oracle's partition (src/sparseMatrix.cpp:1587-1746)."""
     from conftest import corpus
-    V, D, k = 2400, 9000, 2056
+    from isle_amd._lib import IsleHipError
+    V, D, k = 2400, 9000, 2048
     B = corpus(V, D, 40, 11)
     D = B["D"]
     o = B["oracle"]
     rng = np.random.default_rng(3)
-    pick = np.sort(rng.choice(D, size=k, replace=False))
-    cen = np.zeros((B["V"], k), np.float32, order="F")
-    for j, d in enumerate(pick):  # centres = k documents of B
-        lo, hi = B["offs"][d], B["offs"][d + 1]
-        cen[B["rows"][lo:hi], j] = B["vals"][lo:hi]
+
+    def doc_centres(kk):  # centres = kk documents of B
+        pick = np.sort(rng.choice(D, size=kk, replace=False))
+        cen = np.zeros((B["V"], kk), np.float32, order="F")
+        for j, d in enumerate(pick):
+            lo, hi = B["offs"][d], B["offs"][d + 1]
+            cen[B["rows"][lo:hi], j] = B["vals"][lo:hi]
+        return cen
+
+    cen = doc_centres(k)
     so = o.lloyds_sparse(cen)
     upload(hp, B)
     old = os.environ.get("ISLE_YY_MODE")
     try:
-        for mode in (None, "group", "docg"):
+        first = None
+        for mode in (None, "group", "docg", "doc"):
             if mode is None:
                 os.environ.pop("ISLE_YY_MODE", None)
             else:
                 os.environ["ISLE_YY_MODE"] = mode
             sg = hp.run_lloyds(k, centers=cen)
-            if mode is None:
+            if first is None:
                 first = sg
                 assert (sg["assign"] == so["assign"]).mean() >= 0.999, float((sg["assign"] == so["assign"]).mean())
                 assert sg["iters"] == so["iters"]
@@ -167,3 +175,5 @@ def test_more_than_256_yinyang_groups(hp):
             os.environ.pop("ISLE_YY_MODE", None)
         else:
             os.environ["ISLE_YY_MODE"] = old
+    with pytest.raises(IsleHipError, match="too large"):
+        hp.run_lloyds(2056, centers=doc_centres(2056))

@@ -33,13 +33,14 @@ for setting in (sys.argv[1:] or [""]):
     op_build = t["op_build"][0] if "op_build" in t else -1.0
     if ref is None:
         ref = Z
-    hp.timing_reset()
-    reps = 20 if D < 5_000_000 else 6
-    for _ in range(reps):
-        hp.gram_apply(X)
-    t = hp.timing_get()
     err = float(np.linalg.norm(Z - ref) / np.linalg.norm(ref))
-    print("%-40s form=%d pass1 %.4f ms  pass2 %.4f ms  op_build %.1f ms (relerr vs first %.1e)" % (setting or "(default)", hp.operator_form(),
-          t["gram_pass1"][0] / reps, t["gram_pass2"][0] / reps, op_build, err), flush=True)
+    reps = int(os.environ.get("GRAM_PROBE_REPS", "20"))
+    for rnd in range(int(os.environ.get("GRAM_PROBE_ROUNDS", "1"))):  # several rounds show the run-to-run spread inside one process
+        hp.timing_reset()
+        for _ in range(reps):
+            hp.gram_apply(X)
+        t = hp.timing_get()
+        print("%-40s form=%d pass1 %.4f ms  pass2 %.4f ms  op_build %.1f ms (relerr vs first %.1e)" % (setting or "(default)", hp.operator_form(),
+              t["gram_pass1"][0] / reps, t["gram_pass2"][0] / reps, op_build, err), flush=True)
     for a, b in kv:
         del os.environ[a]
