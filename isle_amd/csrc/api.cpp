@@ -57,6 +57,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_FIRST_ASSIGN", "form", "sparse | projection: first assignment of Lloyd on B through the sparse product or through the projection"},
     {"ISLE_GEMM_BF16X3", "form", "0: the D x k x k dot products of the assignment steps on the f32 matrix cores (gemm_f32.h) instead of the bf16 ones with operands split in three terms (gemm_bf16x3.h)"},
     {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
+    {"ISLE_YY_FUSED", "form", "0: the by-group Yinyang iteration lowers the bounds (yy_filter_k) and tightens the active documents (yy2_tighten_k) in two launches instead of one (same bits)"},
     {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
     {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},
     {"ISLE_CHUNK_COLS", "tuning", "gather form: rows per chunk of the chunked-CSR copy"},
@@ -1981,7 +1982,13 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       const int yy_mode = G > 256 ? 0 : yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
       const uint32_t* order = yy_mode && c->members_valid ? c->members.p : nullptr;
       if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
-      ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
+      // by group: the bounds are lowered and the active documents tightened in one launch (the D x G bounds read once), ISLE_YY_FUSED=0: in two
+      const bool fused = yy_mode == 2 && !c->knob_zero(KN_YY_FUSED);
+      if (fused)
+        ISLECHK(k_yy_filter_tighten(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact, c->yy_cg.p, k, ld, c->cnorm.p, c->dnorm.p,
+                                    cn_max_dev));
+      else
+        ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
       const bool dbg = c->knob_on(KN_DEBUG_HAMERLY);
       unsigned long long* dbg_dev = nullptr;
       if (dbg) {  // diagnostic only: group scans and gathered nonzeros of this iteration
@@ -1992,7 +1999,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       bool done = false;
       unsigned long long npairs = 0;
       if (yy_mode == 2)
-        ISLECHK(k_yy2_assign(c, c->yy_cg.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, &done, &npairs));
+        ISLECHK(k_yy2_assign(c, c->yy_cg.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, &done, &npairs, fused));
       if (!done)
         ISLECHK(k_yy_scan(c, c->centers_rm.p, yy_mode ? c->yy_cg.p : nullptr, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p,
                           c->hub.p, c->yglb.p, dbg_dev));

@@ -51,7 +51,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_YY_MODE, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_YY_MODE, KN_YY_FUSED, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
@@ -366,13 +366,16 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
                        const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
                        float* ub = nullptr, float* lb = nullptr, int G = 0 /*> 0: lb holds G Yinyang group bounds per document*/);
+int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev,
+                        const float* gmax_dev, uint32_t* active, uint32_t* nactive, const float* Cg, int k, int ld, const float* cn, const float* dn,
+                        const float* cn_max);
 int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
                 uint32_t* active, uint32_t* nactive);
 int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G);  // c->yy_cg = the centres group-major (V x 8 floats per group)
 int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg /*nullable*/, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev,
               const uint32_t* active, const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr);
 int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
-                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out = nullptr);
+                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out = nullptr, bool pre_tightened = false);
 struct HamTop {  // largest and second largest centre movement of an iteration (Hamerly's bound update), device resident
   uint32_t amax;
   float d1, d2, pad;

@@ -63,7 +63,6 @@ __host__ __device__ inline size_t gl_planar_off(uint32_t row, int l, int LPE, bo
   return (size_t)band * gl_img_bytes(LPE, half) + (size_t)(l < NF ? l : NF) * GL_RB * 16u + (size_t)r * (l < NF ? 16u : 8u);
 }
 constexpr int GL_PLACE_MAXN = 8;  // slices of up to 8 super-rounds (32 slots per lane) are placed; longer ones keep their ascending order
-constexpr uint32_t GL_LDS = 163840;  // all of it (2 x 65 504 + 4094 x 8 = 163 760 bytes are used by the 10-column panel)
 constexpr int GL_PF = 4;  // super-rounds in flight per wave (4 x 512 B)
 constexpr uint32_t GL_NONE = 0xffffffffu;
 constexpr uint32_t GL_OUT_PLANAR = 0xffffffffu;  // gl_apply_k out_n2: the output is a packed (planar, banded) operand

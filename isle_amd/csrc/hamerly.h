@@ -36,3 +36,25 @@ __device__ inline uint32_t block_append_slot(bool act, uint32_t* __restrict__ co
   __syncthreads();
   return wbase[16] + wbase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+// the same, also telling the workgroup's first slot and how many slots it took (for a second phase over the workgroup's own elements)
+__device__ inline uint32_t block_append_slot_range(bool act, uint32_t* __restrict__ counter, uint32_t* base, uint32_t* total) {
+  __shared__ uint32_t wcnt2[16], wbase2[18];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  const unsigned long long m = __ballot(act);
+  __syncthreads();
+  if (lane == 0) wcnt2[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < nw; ++w) {
+      wbase2[w] = t;
+      t += wcnt2[w];
+    }
+    wbase2[16] = t ? atomicAdd(counter, t) : 0u;
+    wbase2[17] = t;
+  }
+  __syncthreads();
+  *base = wbase2[16];
+  *total = wbase2[17];
+  return wbase2[16] + wbase2[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}

@@ -1262,6 +1262,121 @@ __global__ __launch_bounds__(256) void yy2_tighten_k(const float* __restrict__ v
   }
 }
 
+// yy_filter_k and yy2_tighten_k in one launch (the by-group iteration): a workgroup lowers the group bounds of its block of documents
+// through the LDS tile as yy_filter_k does — same arithmetic, same outputs: glb, ub, the active list — and then its waves take the block's
+// ACTIVE documents in turn and run yy2_tighten_k's step on them with the bounds still in the tile: the D x G bound array (5 GB at 10 M
+// documents and k = 1000) is read once per iteration instead of twice.  own / need / cnt are indexed by the active slot as before.
+__global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const uint32_t* __restrict__ order /*nullable*/, const uint32_t* __restrict__ assign,
+                                                             float* __restrict__ ub, float* __restrict__ glb, int G, const float* __restrict__ delta,
+                                                             const float* __restrict__ gmax, uint32_t* __restrict__ active, uint32_t* __restrict__ nactive,
+                                                             int docs_per_block, const float* __restrict__ vals, const uint32_t* __restrict__ rows,
+                                                             const int64_t* __restrict__ offs, const float4* __restrict__ Cg, uint32_t V, int ld, int k, int NW,
+                                                             const float* __restrict__ cn, const float* __restrict__ dn, const float* __restrict__ cn_max_p,
+                                                             YyRes* __restrict__ own, unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt) {
+  extern __shared__ float tile[];  // docs_per_block x G bounds, then docs_per_block local indices of the active documents
+  uint32_t* lact = reinterpret_cast<uint32_t*>(tile + (size_t)docs_per_block * G);
+  const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
+  const uint32_t nd = min((uint32_t)docs_per_block, D - d0);
+  const uint32_t nel = nd * (uint32_t)G;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (order) {
+    for (uint32_t j0 = (uint32_t)w * 4; j0 < nd; j0 += 16) {
+      float* src[4];
+      float v[4][4];  // up to 256 groups: four per lane
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = min(j0 + u, nd - 1);
+        src[u] = glb + (size_t)order[d0 + j] * G;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int g = lane + 64 * t;
+          v[u][t] = g < G ? src[u][g] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + u < nd) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int g = lane + 64 * t;
+            if (g < G) {
+              float l = v[u][t] - gmax[g] * 1.000001f;
+              l = l > 0.f ? l * 0.999999f : l;
+              src[u][g] = l;
+              tile[(j0 + u) * (uint32_t)G + g] = l;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    uint32_t j = threadIdx.x / (uint32_t)G, g = threadIdx.x - j * (uint32_t)G;
+    const uint32_t sj = 256u / (uint32_t)G, sg = 256u - sj * (uint32_t)G;
+    for (uint32_t i = threadIdx.x; i < nel; i += 256) {
+      float* src = glb + (size_t)(d0 + j) * G + g;
+      float l = *src - gmax[g] * 1.000001f;
+      l = l > 0.f ? l * 0.999999f : l;
+      *src = l;
+      tile[i] = l;
+      j += sj;
+      g += sg;
+      if (g >= (uint32_t)G) {
+        g -= (uint32_t)G;
+        ++j;
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (uint32_t j0 = 0; j0 < (uint32_t)docs_per_block; j0 += 256) {  // one trip (docs_per_block <= 256): the append synchronises
+    const uint32_t j = j0 + threadIdx.x;
+    const bool in = j < nd;
+    uint32_t d = d0 + (in ? j : 0u);
+    if (order) d = order[d];
+    float u = 0.f, lmin = 3.4e38f;
+    if (in) {
+      u = (ub[d] + delta[assign[d]]) * 1.000001f;
+      for (int g = 0; g < G; ++g) lmin = fminf(lmin, tile[j * (uint32_t)G + g]);
+      ub[d] = u;
+    }
+    const bool act = in && u >= lmin;
+    const uint32_t slot = block_append_slot_range(act, nactive, &base, &total);
+    if (act) {
+      active[slot] = d;
+      lact[slot - base] = j;
+    }
+  }
+  __syncthreads();
+  // second phase: the tightening step of the block's active documents, a wave each in turn (yy2_tighten_k with the bounds read from the tile)
+  for (uint32_t i = (uint32_t)w; i < total; i += 4) {
+    const uint32_t j = lact[i], slot = base + i;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(order ? order[d0 + j] : d0 + j);
+    const float dnd = dn[d];
+    const int ga = (int)(assign[d] / YY_GROUP);
+    const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+    const int q = lane & 1;
+    const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
+    const int col = YY_GROUP * ga + 4 * q;
+    float dist[4];
+    yy_group_dists(dc, vals, rows, Cg + (size_t)ga * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
+    const YyTop2 t = yy_group_top2(dist, col, k);
+    const float u = sqrtf(t.m1);
+    const float uhi = u + fminf(sE, E / fmaxf(u, 1e-30f));
+    uint32_t tot = 0;
+    for (int jj = 0; jj < NW; ++jj) {
+      const int g = 64 * jj + lane;
+      const bool ndd = g < G && g != ga && tile[j * (uint32_t)G + min(g, G - 1)] <= uhi;
+      const unsigned long long m = __ballot(ndd);
+      tot += (uint32_t)__popcll(m);
+      if (lane == 0) need[(size_t)slot * NW + jj] = m;
+    }
+    if (lane == 0) {
+      own[slot] = YyRes{t.m1, t.m2, t.i1};
+      cnt[slot] = tot;
+    }
+  }
+}
+
 // pairs of slot e at off[e] ..: key = document << 8 | group (sorted on the low 8 bits only: stable, so a group's pairs keep the slot order),
 // val = pair index, pgrp = group (ascending inside a slot)
 __global__ __launch_bounds__(256) void yy2_emit_k(const uint32_t* __restrict__ nactive, const uint32_t* __restrict__ active,
@@ -1351,6 +1466,30 @@ int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// k_yy_filter and the tightening step of k_yy2_assign in one launch (yy2_filter_tighten_k); k_yy2_assign(..., pre_tightened = true) follows
+int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev,
+                        const float* gmax_dev, uint32_t* active, uint32_t* nactive, const float* Cg, int k, int ld, const float* cn, const float* dn,
+                        const float* cn_max) {
+  TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+  const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
+  HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
+  if (D == 0) return 0;
+  const int NW = cdiv(G, 64);
+  HIPCHK(c, c->yy_own.reserve((size_t)D * 3));
+  HIPCHK(c, c->yy_need.reserve((size_t)D * NW));
+  HIPCHK(c, c->yy_cnt.reserve((size_t)D + 1));
+  HIPCHK(c, hipMemsetAsync(c->yy_cnt.p, 0, ((size_t)D + 1) * sizeof(uint32_t), c->stream));
+  // blocks of 64 documents at k = 1000 (a 32 KB tile): five workgroups = twenty waves per CU for the gathers of the second phase
+  int dpb = 256;
+  while (dpb > 32 && (size_t)dpb * (G + 1) * sizeof(float) > 32 * 1024) dpb /= 2;
+  const size_t lds = (size_t)dpb * (G + 1) * sizeof(float);
+  ISLECHK(isle_max_lds(c, (const void*)yy2_filter_tighten_k, (int)lds));
+  hipLaunchKernelGGL(yy2_filter_tighten_k, dim3(cdiv(D, dpb)), dim3(256), lds, c->stream, D, order, assign, ub, glb, G, delta_dev, gmax_dev, active, nactive, dpb,
+                     c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, NW, cn, dn, cn_max, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p,
+                     c->yy_cnt.p);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t V = (uint32_t)c->V;
@@ -1374,7 +1513,7 @@ int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg, int k, int ld, int
 // The Yinyang iteration ordered by group (see the kernels): active -> assign / ub / glb.  *done = false if the pair list would be too
 // long (more than 48 pairs per document) — nothing has been changed then and the caller runs yy_scan_k instead.
 int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
-                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out) {
+                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out, bool pre_tightened) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   *done = false;
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
@@ -1386,10 +1525,12 @@ int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float
   HIPCHK(c, c->yy_cnt.reserve((size_t)D + 1));
   HIPCHK(c, c->yy_off.reserve((size_t)D + 2));
   HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(D) + 8));
-  HIPCHK(c, hipMemsetAsync(c->yy_cnt.p, 0, ((size_t)D + 1) * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(yy2_tighten_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, G, NW, cn, dn,
-                     cn_max, active, nactive, assign, glb, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p, c->yy_cnt.p);
-  HIPCHK(c, hipGetLastError());
+  if (!pre_tightened) {  // k_yy_filter_tighten has done this step with the bounds it had in LDS
+    HIPCHK(c, hipMemsetAsync(c->yy_cnt.p, 0, ((size_t)D + 1) * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(yy2_tighten_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, G, NW, cn, dn,
+                       cn_max, active, nactive, assign, glb, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p, c->yy_cnt.p);
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, uint32_t>(c->stream, c->yy_cnt.p, D, c->yy_off.p, reinterpret_cast<uint32_t*>(c->gl_scan.p))));
   uint32_t npairs = 0;
   HIPCHK(c, hipMemcpyAsync(&npairs, c->yy_off.p + D, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -151,6 +151,29 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         assert np.array_equal(res[mode][2], res["yinyang"][2])
 
 
+def test_fused_filter_and_tightening_give_the_bits_of_the_two_kernel_form(hp, monkeypatch):
+    """The by-group Yinyang iteration lowers the group bounds and tightens the active documents in ONE launch (yy2_filter_tighten_k: the bounds
+    stay in LDS between the two steps); ISLE_YY_FUSED=0 runs yy_filter_k and yy2_tighten_k as before.  Same arithmetic on the same values:
+    partition, iteration count and centres must be bit-equal (Lloyd on B, src/sparseMatrix.cpp:1587-1677), also against the by-document form."""
+    f, B, k = load_case("c3k1000")
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    out = {}
+    for name, env in (("fused", {}), ("two", {"ISLE_YY_FUSED": "0"}), ("doc", {"ISLE_YY_MODE": "doc"})):
+        for a, b in env.items():
+            monkeypatch.setenv(a, b)
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        out[name] = hp.run_lloyds(k)
+        for a in env:
+            monkeypatch.delenv(a)
+    for name in ("two", "doc"):
+        assert out[name]["iters"] == out["fused"]["iters"], name
+        assert np.array_equal(out[name]["assign"], out["fused"]["assign"]), name
+        assert np.array_equal(out[name]["centers"].view(np.uint32), out["fused"]["centers"].view(np.uint32)), name
+
+
 def test_full_tile_pass_by_library_gemm_equals_the_fused_kernel(hp, monkeypatch):
     """At large k the full passes of the projected Lloyd (iteration 0, and later iterations with more than half the documents
     active) are one library GEMM over the coordinate-major projection plus proj_dots_tiles_k; the fused matrix-core kernel

@@ -22,8 +22,12 @@ hp.compute_block_ks(k, seed=1, allow_noconv=True)
 g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
 lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
 ref = None
-for mode in ("doc", "docg", "group"):
-    os.environ["ISLE_YY_MODE"] = mode
+# settings: comma-separated ENV=VAL lists; default: the by-group form with the fused filter / tightening launch and without, then by document
+settings = sys.argv[2:] or ["ISLE_YY_MODE=group", "ISLE_YY_MODE=group,ISLE_YY_FUSED=0", "ISLE_YY_MODE=doc"]
+for setting in settings:
+    kv = [x.split("=") for x in setting.split(",") if x]
+    for a_, b_ in kv:
+        os.environ[a_] = b_
     for rep in range(3):
         if rep == 2:
             os.environ["ISLE_DEBUG_HAMERLY"] = "1"
@@ -37,6 +41,8 @@ for mode in ("doc", "docg", "group"):
         hp.timing_enable(False)
         if ref is None:
             ref = ls["assign"].copy()
-        print("ISLE_YY_MODE=%-6s run_lloyds: %.1f ms wall, %d iterations; device ms: sparse_assign %.1f, sparse_update %.1f; partition equal to the first run's: %s" %
-              (mode, dt * 1e3, ls["iters"], t["sparse_assign"][0], t["sparse_update"][0], bool(np.array_equal(ref, ls["assign"]))), flush=True)
+        print("%-40s run_lloyds: %.1f ms wall, %d iterations; device ms: sparse_assign %.1f, sparse_update %.1f; partition equal to the first run's: %s" %
+              (setting, dt * 1e3, ls["iters"], t["sparse_assign"][0], t["sparse_update"][0], bool(np.array_equal(ref, ls["assign"]))), flush=True)
     os.environ.pop("ISLE_DEBUG_HAMERLY", None)
+    for a_, b_ in kv:
+        os.environ.pop(a_, None)
