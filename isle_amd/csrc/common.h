@@ -8,6 +8,41 @@
 #include <string>
 #include <vector>
 
+// ------------------------------------------------------------------------------------------
+// Launch guard.  On this stack a kernel launch of 2^32 threads or more (grid x block) does not run and reports NO error — round 3's
+// yy2_scan_k at 10 M documents left collapsed partitions that way.  Every launch of the library goes through this redefinition of
+// hipLaunchKernelGGL: a launch that does not fit is not issued and is remembered (file:line), and the HIPCHK that follows every launch
+// turns it into ISLE_E_ARG with that location.  Index spaces that can exceed the limit (D x k = 10^10 at config 3) are walked by
+// grid-stride loops or chunked launches at their call sites; this guard is what makes a missed one loud.
+// ------------------------------------------------------------------------------------------
+struct IsleLaunchRefused {
+  const char* file = nullptr;
+  int line = 0;
+  unsigned long long threads = 0;
+};
+inline IsleLaunchRefused& isle_launch_refused() {
+  static thread_local IsleLaunchRefused r;
+  return r;
+}
+inline bool isle_launch_fits(dim3 g, dim3 b, const char* file, int line) {
+  const unsigned long long blocks = (unsigned long long)g.x * g.y * g.z, threads = blocks * ((unsigned long long)b.x * b.y * b.z);
+  if (threads < (1ull << 32)) return true;  // (and with it every dimension's work-item count, which is what the dispatch packet holds in 32 bits)
+  IsleLaunchRefused& r = isle_launch_refused();
+  if (!r.file) {
+    r.file = file;
+    r.line = line;
+    r.threads = threads;
+  }
+  fprintf(stderr, "[isle_hip] %s:%d: a launch of %llu threads (grid %u x %u x %u) was refused: 2^32 threads or more do not run on this stack\n", file, line, threads,
+          g.x, g.y, g.z);
+  return false;
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...)                                   \
+  do {                                                                                            \
+    if (isle_launch_fits(dim3(grid), dim3(block), __FILE__, __LINE__)) kern<<<dim3(grid), dim3(block), (lds), (stream)>>>(__VA_ARGS__); \
+  } while (0)
+
 #include "../../include/isle_hip.h"
 
 #define ISLE_WAVE 64
@@ -317,6 +352,11 @@ void isle_host_mark(const char* what);
     hipError_t e__ = (call);                                                                \
     if (e__ != hipSuccess)                                                                  \
       return isle_fail((ctx), ISLE_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+    if (isle_launch_refused().file) {                                                       \
+      const IsleLaunchRefused r__ = isle_launch_refused();                                  \
+      isle_launch_refused() = IsleLaunchRefused();                                          \
+      return isle_fail((ctx), ISLE_E_ARG, "%s:%d: kernel launch of %llu threads refused (2^32 or more do not run)", r__.file, r__.line, r__.threads); \
+    }                                                                                       \
   } while (0)
 
 #define ISLECHK(call)            \

@@ -87,3 +87,81 @@ def test_one_eighth_of_config3_at_k1000(hp):
     what bench.py --workload c3shard times."""
     r = _run(hp, 100_000, 1_250_000, 1000, 31337, n_pairs=32, n_sample=15_000)
     assert r["napplies"] == 200 + 100 * r["restarts"] and r["restarts"] <= 3
+
+
+def test_config3_at_its_own_size(hp, monkeypatch):
+    """BASELINE configs[2] itself: vocab 100k x 10M documents x 1.006 B nonzeros, k = 1000, all of it on one GPU — what bench.py times by
+    default.  Index spaces here reach 10^10 elements (the D x k projection and products: 40 GB each); round 3's silent 2^32-thread launch
+    (collapsed partitions for some seeds) existed only at this size.  Under asserts, one seed:
+      * sigma bound <= 1e-4 through the CPU oracle's operator on Ritz pairs spread over the spectrum;
+      * Lloyd in span(U) (src/sparseMatrix.cpp:1921-2072): tile bounds and no bounds (ISLE_NO_HAMERLY=1) give the same partition, bit for bit,
+        where both evaluate distances by the same kernel; the default route (GEMM full passes) agrees up to near-ties (<= 2 documents in a million);
+      * Lloyd on B (:1587-1746): Yinyang by group (default) and no bounds (ISLE_KMEANS_BOUNDS=none) give the same partition up to near-ties, same iterations;
+      * on 100 000 documents drawn at random the oracle's arg-min against the FETCHED centres of iteration 3 equals the library's next
+        assignment (:1553-1572), and every cluster is non-empty, none holds more than a fifth of the corpus."""
+    import psutil
+    if psutil.virtual_memory().available < 70e9:
+        pytest.skip("needs ~60 GB of host memory for the 10 M-document corpus and the oracle's copy")
+    from oracle.oracle import OracleCsc
+    from tools.synth import Corpus
+    V, D, k, seed = 100_000, 10_000_000, 1000, 31337
+    B = Corpus(V, D, k, seed).threshold(k, free_A=True)
+    Dn = B["D"]
+    hp.upload_csc(V, B["vals"], B["rows"], B["offs"])
+    r = hp.compute_block_ks(k, seed=1, allow_noconv=True)
+    assert r["rc"] == 0 and r["nconv"] == k and hp.operator_form() == 1
+    U = hp.get_U(k)
+    ev = r["evals"].astype(np.float64)
+    o = OracleCsc(V, Dn, B["vals"], B["rows"], B["offs"])
+    pick = np.unique(np.concatenate([np.arange(6), np.arange(k - 4, k), np.linspace(0, k - 1, 8).astype(np.int64)]))
+    AU = o.gram_apply(np.asfortranarray(U[:, pick])).astype(np.float64)
+    resid = np.linalg.norm(AU - U[:, pick].astype(np.float64) * ev[pick], axis=0) / ev[pick]
+    assert resid.max() / 2.0 <= SIGMA_TOL, "sigma bound %.2e" % (resid.max() / 2.0)
+    del o, AU
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
+    # Lloyd in span(U): bounds on / off.  Bit for bit where both runs evaluate a distance by the same kernel (every pass by the register
+    # kernel proj_assign_reg_k: ISLE_PROJ_FULL=fused, no hand-over from the k-means++ rounds); the default run takes its full passes through
+    # the GEMM and starts from what k-means++ kept — other summation orders, so a near-tie between two centres may fall the other way there
+    # (first measured here: 1 document of 10 M)
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    monkeypatch.setenv("ISLE_PROJ_FULL", "fused")
+    monkeypatch.setenv("ISLE_KMPP_TRACK", "0")
+    lp1 = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    monkeypatch.setenv("ISLE_NO_HAMERLY", "1")
+    lp0 = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    for name in ("ISLE_NO_HAMERLY", "ISLE_PROJ_FULL", "ISLE_KMPP_TRACK"):
+        monkeypatch.delenv(name)
+    assert lp1["iters"] == lp0["iters"]
+    assert np.array_equal(lp1["assign"], lp0["assign"]), float((lp1["assign"] == lp0["assign"]).mean())
+    assert np.array_equal(lp1["C_lowd"].view(np.uint32), lp0["C_lowd"].view(np.uint32))
+    assert lp["iters"] == lp0["iters"] and (lp["assign"] == lp0["assign"]).mean() >= 1.0 - 2e-6, float((lp["assign"] == lp0["assign"]).mean())
+    del lp0, lp1
+    # Lloyd on B: bounds on / off
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    ls = hp.run_lloyds(k, fetch_centers=False)
+    monkeypatch.setenv("ISLE_KMEANS_BOUNDS", "none")
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    ls0 = hp.run_lloyds(k, fetch_centers=False)
+    monkeypatch.delenv("ISLE_KMEANS_BOUNDS")
+    # (the unbounded loop forms its distances by the LDS-banded k-wide product, the bounded one by per-document gathers: equal up to near-ties)
+    assert ls["iters"] == ls0["iters"]
+    assert (ls["assign"] == ls0["assign"]).mean() >= 1.0 - 1e-5, float((ls["assign"] == ls0["assign"]).mean())  # measured: 26 documents of 10 M
+    sizes = np.bincount(ls["assign"], minlength=k)
+    assert (sizes > 0).all() and sizes.max() <= 0.2 * Dn, (int((sizes == 0).sum()), int(sizes.max()))
+    del ls0
+    # the library's assignment against fetched centres, checked by the oracle on a sample
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    l3 = hp.run_lloyds(k, max_reps=3)  # centres after three updates (V x k, fetched)
+    l4 = hp.run_lloyds(k, centers=l3["centers"], max_reps=1, fetch_centers=False)  # one assignment against them
+    cols = np.sort(np.random.default_rng(5).choice(Dn, 100_000, replace=False))
+    Bs = _columns(B, cols)
+    os_ = OracleCsc(V, len(cols), Bs["vals"], Bs["rows"], Bs["offs"])
+    so = os_.lloyds_sparse(l3["centers"], max_reps=1)
+    agree = float((so["assign"] == l4["assign"][cols]).mean())
+    assert agree >= 0.9999, agree  # near-ties between two centres are all that may differ (other summation order)
+    # and the bounded iteration 4 of the uninterrupted run is that full scan (the two sum a document's dot products in different orders:
+    # a near-tie between two centres may fall either way, nothing else)
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    l4b = hp.run_lloyds(k, max_reps=4, fetch_centers=False)
+    agree = float((l4b["assign"] == l4["assign"]).mean())
+    assert agree >= 0.99999, agree
