@@ -56,6 +56,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_PROJ_FULL", "form", "gemm | fused: full passes of the projected Lloyd loop as GEMM + epilogue or as the fused register kernel"},
     {"ISLE_FIRST_ASSIGN", "form", "sparse | projection: first assignment of Lloyd on B through the sparse product or through the projection"},
     {"ISLE_GEMM_BF16X3", "form", "0: the D x k x k dot products of the assignment steps on the f32 matrix cores (gemm_f32.h) instead of the bf16 ones with operands split in three terms (gemm_bf16x3.h)"},
+    {"ISLE_GEMM_EPILOGUE", "form", "0: the D x k x k products of the assignment steps are written to memory and read by dots_assign_cm_k / proj_dots_tiles_k instead of the epilogues inside the product (same bits)"},
     {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
     {"ISLE_YY_FUSED", "form", "0: the by-group Yinyang iteration lowers the bounds (yy_filter_k) and tightens the active documents (yy2_tighten_k) in two launches instead of one (same bits)"},
     {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
@@ -1922,10 +1923,11 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   // 44 ms) — and while its D x k scratch can be had (isle_scratch_ok) (ISLE_FIRST_ASSIGN=sparse|projection forces)
   const char* fa = c->knob(KN_FIRST_ASSIGN);
   const double t_dense = 2.0 * (double)D * k * k / 130e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
-  const bool dense_pays = k <= 384 || (t_dense < t_sparse && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)));
+  const bool fused_first = yinyang && k_gemm_assign_fused_ok(c, D, k, k);  // the product's epilogue forms the assignment: no D x k scratch
+  const bool dense_pays = k <= 384 || (t_dense < t_sparse && (fused_first || isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float))));
   bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
                         D > 0 && (dense_pays || (fa && !strcmp(fa, "projection"))) && !(fa && !strcmp(fa, "sparse"));
-  if (via_projection && c->dotsT.reserve((size_t)D * k) != hipSuccess) {
+  if (via_projection && !fused_first && c->dotsT.reserve((size_t)D * k) != hipSuccess) {
     // the route is chosen from sizes alone (isle_scratch_ok), but on a device shared with other work the D x k scratch may still not be
     // had: the sparse product gives the same assignment up to dot-product rounding, so take it instead of failing the call
     (void)hipGetLastError();
@@ -1946,13 +1948,20 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // D x k x k product on the projection that k-means++ / Lloyd in span(U) left on the device — one MFMA GEMM, a transposition into
       // the doc-major layout and the same distance / bound epilogue (norms of centres and documents are the word-space ones)
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
-      HIPCHK(c, c->dotsT.reserve((size_t)D * k));
-      ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
-      if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
+      if (yinyang && fused_first) {  // distances, group bounds and candidates formed inside the product: no D x k matrix in memory
+        float* cn_max_dev = c->Csum.p + 2 * k + 8;
+        ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
+        ISLECHK(k_gemm_assign_yy(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p, c->hub.p, c->yglb.p,
+                                 ISLE_T_SPARSE_ASSIGN));
+      } else if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
+        HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+        ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
         float* cn_max_dev = c->Csum.p + 2 * k + 8;
         ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
         ISLECHK(k_dots_assign_cm(c, c->dotsT.p, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p, c->hub.p, c->yglb.p));
       } else {
+        HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+        ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
         c->P_ready = false;  // P now holds the dot products (as with the LDS-banded wide product)
         c->Pt_ready = false;
         if (ld != k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, (size_t)D * ld * sizeof(float), c->stream));

@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "gridbar.h"
+#include "hamerly.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -771,6 +772,131 @@ int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float
   if (M >= (1ull << 32)) return isle_fail(c, ISLE_E_ARG, "gemm: operand too large for 32-bit row offsets");
   HIPCHK(c, c->gemm_b3.reserve((size_t)3 * isle_gemm3::kp8_of(K) * isle_gemm3::np_of<Gemm3Huge>(N)));
   HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, isle_gemm3::StoreC{C, M}));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The two assignment steps that rest on a D x k x k product — the first assignment of Lloyd on B through the projection (distsq_docs_to_centers /
+// closest_centers, src/sparseMatrix.cpp:1494-1572) and the full pass of Lloyd in span(U) (distsq_projected_docs_to_projected_centers /
+// projected_closest_centers, :1794-1871) — with their epilogues INSIDE the product (gemm_bf16x3.h, group epilogues): distances, group / tile
+// bounds and the per-slot candidates are formed from the accumulators; the D x k matrix (40 GB at config 3) is neither written nor read
+// again, and dots_assign_cm_k / proj_dots_tiles_k with their 12 + 10 ms per step are replaced by a pass over 16 candidates per document.
+// Same arithmetic on the same dot products as those kernels: assignments and bounds are bit-identical to the two-kernel route.
+// ------------------------------------------------------------------------------------------
+struct AssignRec {  // best of one 64-column slot of one document
+  float m1;
+  uint32_t i1;
+  float m2, ax;
+};
+struct YyGroupEpi {  // Lloyd on B: Yinyang groups of 8 centres (dots_assign_cm_k's rules)
+  static constexpr int kGroup = 8;
+  const float* __restrict__ cn;
+  const float* __restrict__ dn;
+  const float* __restrict__ cn_max;
+  float* __restrict__ lb;
+  int G, nslot;
+  AssignRec* __restrict__ part;
+  __device__ inline float rowdata(uint64_t m) const { return dn[m]; }
+  __device__ inline float dist(float dot, int col, float dnd) const { return fabsf((-2.0f * dot + cn[col]) + dnd); }
+  __device__ inline float aux(int) const { return 0.f; }
+  __device__ inline void group(uint64_t m, int g, float dnd, float m1, uint32_t, float, float) const {
+    const float E = 1e-4f * (dnd + *cn_max), sE = sqrtf(E);
+    lb[m * (uint64_t)G + g] = yy_slack_down_sq(m1, E, sE);
+  }
+  __device__ inline void slot(uint64_t m, int sl, float, float m1, uint32_t i1, float m2, float ax) const { part[m * (uint64_t)nslot + sl] = AssignRec{m1, i1, m2, ax}; }
+};
+__global__ __launch_bounds__(256) void yy_first_combine_k(const AssignRec* __restrict__ part, int nslot, uint32_t D, int G, const float* __restrict__ dn,
+                                                          const float* __restrict__ cn_max, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                          float* __restrict__ lb) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float best = 3.4e38f, m2 = 3.4e38f;
+  uint32_t bidx = 0xffffffffu;
+  for (int sl = 0; sl < nslot; ++sl) {  // ascending columns: a tie keeps the earlier centre
+    const AssignRec r = part[(size_t)d * nslot + sl];
+    if (r.m1 < best) {
+      best = r.m1;
+      bidx = r.i1;
+      m2 = r.m2;
+    }
+  }
+  const float E = 1e-4f * (dn[d] + *cn_max), sE = sqrtf(E);
+  lb[(size_t)d * G + bidx / 8] = yy_slack_down_sq(m2, E, sE);  // the assigned centre's group: its closest OTHER member
+  const float u = sqrtf(best);
+  ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+  assign[d] = bidx;
+}
+struct TileEpi {  // Lloyd in span(U): tiles of 32 centres (proj_dots_tiles_k's rules)
+  static constexpr int kGroup = 32;
+  const float* __restrict__ cn;
+  const float* __restrict__ pn;
+  float* __restrict__ lb;
+  int TL, nslot;
+  AssignRec* __restrict__ part;
+  __device__ inline float rowdata(uint64_t m) const { return pn[m]; }
+  __device__ inline float dist(float dot, int col, float nd) const { return fabsf((-2.0f * dot + cn[col]) + nd); }
+  __device__ inline float aux(int col) const { return cn[col]; }
+  __device__ inline void group(uint64_t m, int T, float nd, float m1, uint32_t, float, float tc) const {
+    float uu, ll;
+    hamerly_store_bounds(m1, m1, nd + tc, &uu, &ll);
+    lb[m * (uint64_t)TL + T] = ll;
+  }
+  __device__ inline void slot(uint64_t m, int sl, float, float m1, uint32_t i1, float m2, float ax) const { part[m * (uint64_t)nslot + sl] = AssignRec{m1, i1, m2, ax}; }
+};
+__global__ __launch_bounds__(256) void tiles_combine_k(const AssignRec* __restrict__ part, int nslot, uint32_t D, int TL, const float* __restrict__ pn,
+                                                       const float* __restrict__ cmax_p, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                       float* __restrict__ lb) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float best = 3.4e38f, second = 3.4e38f, btc = 0.f;
+  uint32_t bidx = 0xffffffffu;
+  for (int sl = 0; sl < nslot; ++sl) {
+    const AssignRec r = part[(size_t)d * nslot + sl];
+    if (r.m1 < best) {
+      best = r.m1;
+      bidx = r.i1;
+      second = r.m2;
+      btc = r.ax;
+    }
+  }
+  const float nd = pn[d];
+  assign[d] = bidx;
+  float uu, ll, l2;
+  hamerly_store_bounds(best, second, nd + btc, &uu, &l2);
+  hamerly_store_bounds(best, best, nd + *cmax_p, &uu, &ll);
+  ub[d] = uu;
+  lb[(size_t)d * TL + (bidx >> 5)] = l2;  // the assigned centre's tile: closest OTHER centre in it
+}
+// may the fused route be taken?  (the three-term bf16 product with 256 x 256 tiles; small products keep the two-kernel route)
+bool k_gemm_assign_fused_ok(isle_ctx* c, uint64_t M, int K, int N) {
+  return !c->knob_zero(KN_GEMM_BF16X3) && !c->knob_zero(KN_GEMM_EPILOGUE) && N >= 64 && K >= 32 && (M + 255) / 256 * (uint64_t)((N + 255) / 256) >= 512 &&
+         M < (1ull << 32);
+}
+// assign / ub / lb (D x G Yinyang group bounds) of the first assignment of Lloyd on B from A (D x k projection, coordinate-major) and the
+// k lifted centres' coordinates B (k x k, leading dimension ldb): dots_assign_cm_k's outputs without the D x k product in memory
+int k_gemm_assign_yy(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, int G, const float* cn, const float* dn,
+                     const float* cn_max, uint32_t* assign, float* ub, float* lb, int family) {
+  TimeScope ts(c, family);
+  const int nslot = (N + 63) / 64;
+  HIPCHK(c, c->gemm_b3.reserve((size_t)3 * isle_gemm3::kp8_of(K) * isle_gemm3::np_of<Gemm3Huge>(N)));
+  HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 4));
+  AssignRec* part = reinterpret_cast<AssignRec*>(c->assign_part.p);
+  HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, YyGroupEpi{cn, dn, cn_max, lb, G, nslot, part}));
+  hipLaunchKernelGGL(yy_first_combine_k, dim3(cdiv(M, 256)), dim3(256), 0, c->stream, part, nslot, (uint32_t)M, G, dn, cn_max, assign, ub, lb);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+// the same for the full pass of Lloyd in span(U): assign / ub / one lower bound per tile of 32 centres (row stride TL); cmax = max |c|^2 on the device
+int k_gemm_assign_tiles(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn, const float* pn,
+                        const float* cmax, uint32_t* assign, float* ub, float* tlb, int family) {
+  TimeScope ts(c, family);
+  const int nslot = (N + 63) / 64;
+  HIPCHK(c, c->gemm_b3.reserve((size_t)3 * isle_gemm3::kp8_of(K) * isle_gemm3::np_of<Gemm3Huge>(N)));
+  HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 4));
+  AssignRec* part = reinterpret_cast<AssignRec*>(c->assign_part.p);
+  HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, TileEpi{cn, pn, tlb, TL, nslot, part}));
+  hipLaunchKernelGGL(tiles_combine_k, dim3(cdiv(M, 256)), dim3(256), 0, c->stream, part, nslot, (uint32_t)M, TL, pn, cmax, assign, ub, tlb);
+  HIPCHK(c, hipGetLastError());
   return 0;
 }
 

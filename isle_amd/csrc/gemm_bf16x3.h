@@ -69,10 +69,49 @@ struct Cfg {
 };
 
 struct StoreC {
+  static constexpr int kGroup = 0;  // element epilogue: operator()(row, column, value)
   float* __restrict__ C;
   uint64_t ldc;
   __device__ inline void operator()(uint64_t m, int n, float v) const { C[(uint64_t)n * ldc + m] = v; }
 };
+
+// GROUP epilogues (kGroup = 8 or 32): the product is never stored.  Per row and per group of kGroup consecutive columns the kernel forms
+// from its accumulators  dist(value, column, rowdata(row))  for every column, the smallest distance with its first column, the runner-up
+// and the largest aux(column), and hands them to  group(row, group index, rowdata, m1, i1, m2, auxmax)  (one lane per row and group); per
+// row and per 64-column slot (the columns one wave owns) the best of the slot's groups goes to  slot(row, slot index, rowdata, m1, i1,
+// m2 of that group, auxmax of that group).  The assignment steps of k-means use this (dense.hip): group bounds and the per-slot
+// candidates leave the kernel, a small kernel picks the row's winner — instead of D x k x 4 bytes written and read again.
+// A lane holds, of a row of a 32 x 32 tile, columns (r & 3) + 8 (r >> 2) + 4 h in register r (h = lane / 32): a group of 8 is registers
+// 4 q .. 4 q + 3 of the lanes l and l + 32, a group of 32 all sixteen of both; the lane pair is merged by __shfl_xor(., 32).
+struct Top2 {
+  float m1, m2, ax;
+  uint32_t i1;
+};
+__device__ inline void top2_take(Top2& t, float d, uint32_t idx, float ax) {  // columns arrive in ascending order: a tie keeps the earlier one
+  if (d < t.m1) {
+    t.m2 = t.m1;
+    t.m1 = d;
+    t.i1 = idx;
+  } else {
+    t.m2 = fminf(t.m2, d);
+  }
+  t.ax = fmaxf(t.ax, ax);
+}
+__device__ inline void top2_merge(Top2& t, float om1, float om2, uint32_t oi1, float oax) {
+  if (om1 < t.m1 || (om1 == t.m1 && oi1 < t.i1)) {
+    t.m2 = fminf(t.m1, om2);
+    t.m1 = om1;
+    t.i1 = oi1;
+  } else {
+    t.m2 = fminf(t.m2, om1);
+  }
+  t.ax = fmaxf(t.ax, oax);
+}
+__device__ inline void top2_pair(Top2& t) {  // with the lane that holds the other half of the row's columns
+  const float om1 = __shfl_xor(t.m1, 32), om2 = __shfl_xor(t.m2, 32), oax = __shfl_xor(t.ax, 32);
+  const uint32_t oi1 = (uint32_t)__shfl_xor((int)t.i1, 32);
+  top2_merge(t, om1, om2, oi1, oax);
+}
 
 template <class CF, class Epi>
 __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __restrict__ A, uint64_t M, int K, const bf16x8* __restrict__ B3, int Kp8,
@@ -190,6 +229,56 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
     __syncthreads();
   }
 
+  if constexpr (Epi::kGroup != 0) {
+    static_assert(Epi::kGroup == 8 || Epi::kGroup == 32, "group epilogue: groups of 8 or 32 columns");
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+      const uint64_t m = m0 + wm * (32 * WMT) + i * 32 + l31;
+      const bool live = m < M;
+      const float rd = epi.rowdata(live ? m : M - 1);
+      Top2 best{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};  // of this wave's columns (one 64-column slot per 32 WNT columns ... WNT = 2)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int cb = n0 + wn * (32 * WNT) + j * 32;  // first column of the 32 x 32 tile
+        if (cb >= N) continue;                          // wave-uniform
+        float dist[16], ax[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = cb + 4 * h + (r & 3) + 8 * (r >> 2);
+          const bool in = col < N;
+          dist[r] = in ? epi.dist(acc[j][i][r], col, rd) : 3.4e38f;
+          ax[r] = in ? epi.aux(col) : 0.f;
+        }
+        if constexpr (Epi::kGroup == 8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Top2 t{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int col = cb + 4 * h + u + 8 * q;
+              if (col < N) top2_take(t, dist[4 * q + u], (uint32_t)col, ax[4 * q + u]);
+            }
+            top2_pair(t);
+            if (cb + 8 * q < N) {  // wave-uniform
+              if (live && h == (q & 1)) epi.group(m, (cb >> 3) + q, rd, t.m1, t.i1, t.m2, t.ax);
+              if (t.m1 < best.m1) best = t;  // groups in ascending order: a tie keeps the earlier group's (lower) column
+            }
+          }
+        } else {
+          Top2 t{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = cb + 4 * h + (r & 3) + 8 * (r >> 2);
+            if (col < N) top2_take(t, dist[r], (uint32_t)col, ax[r]);
+          }
+          top2_pair(t);
+          if (live && h == (j & 1)) epi.group(m, cb >> 5, rd, t.m1, t.i1, t.m2, t.ax);
+          if (t.m1 < best.m1) best = t;
+        }
+      }
+      if (live && h == 0 && n0 + wn * (32 * WNT) < N) epi.slot(m, (n0 + wn * (32 * WNT)) / (32 * WNT), rd, best.m1, best.i1, best.m2, best.ax);
+    }
+  } else {
   // lane owns row m = l31 of each 32 x 32 tile; register r holds column (r & 3) + 8 (r >> 2) + 4 h
   const bool full_n = n0 + TN <= N;
 #pragma unroll
@@ -211,6 +300,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
         }
       }
     }
+  }
   }
 }
 

@@ -16,6 +16,11 @@ __device__ inline void hamerly_store_bounds(float best_sq, float second_sq, floa
   *lb = fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
 }
 
+__device__ inline float yy_slack_down_sq(float m, float E, float sE) {  // lower bound from a squared distance
+  const float l = sqrtf(m);
+  return fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
+}
+
 // slot of this thread's element in a list all workgroups append to (valid only where act): ONE atomic per workgroup.  Every thread of
 // the workgroup must call it (it synchronises); order inside the list is arbitrary.
 __device__ inline uint32_t block_append_slot(bool act, uint32_t* __restrict__ counter) {

@@ -931,7 +931,7 @@ int k_kmpp_to_tiles(isle_ctx* c, uint64_t D, int k, const float* pn, const float
 
 bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k) {
   const char* pf = c->knob(KN_PROJ_FULL);
-  return c->Pt_ready && D > 0 && k >= 64 && isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float)) &&
+  return c->Pt_ready && D > 0 && k >= 64 && (k_gemm_assign_fused_ok(c, D, k, k) || isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float))) &&
          ((2.0 * (double)D * k * k >= 2e10 && !(pf && !strcmp(pf, "fused"))) || (pf && !strcmp(pf, "gemm")));
 }
 int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
@@ -943,6 +943,11 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
     // 69 of the fused kernel's full pass, k_gemm_nn) on the coordinate-major copy of P, followed by the epilogue above over the D x k
     // dot products (5 GB at a C3 shard: 18 + 2 ms instead of 36).  ISLE_PROJ_FULL=gemm|fused forces a route.
     if (k_proj_full_by_gemm(c, D, k)) {
+      if (k_gemm_assign_fused_ok(c, D, k, k)) {  // distances, tile bounds and candidates formed inside the product: no D x k matrix in memory
+        HIPCHK(c, c->cmax_buf.reserve(4));
+        ISLECHK(k_max_f32(c, cn, k, c->cmax_buf.p));
+        return k_gemm_assign_tiles(c, c->Pt.p, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ);
+      }
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
       ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));
       hipLaunchKernelGGL(proj_dots_tiles_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, (uint32_t)D, k, pn, cn, assign, ub, tlb, TL);

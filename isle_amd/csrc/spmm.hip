@@ -328,10 +328,6 @@ int k_frobenius(isle_ctx* c, double* out_host) {
 enum { WIDE_PROJECT = 0, WIDE_ASSIGN = 1 };
 #include "hamerly.h"
 constexpr int YY_GROUP = 8;  // centres per Yinyang group: two float4 of a centre row, never straddling a 64-byte line
-__device__ inline float yy_slack_down_sq(float m, float E, float sE) {  // lower bound from a squared distance
-  const float l = sqrtf(m);
-  return fmaxf(l - fminf(sE, E / fmaxf(l, 1e-30f)), 0.f);
-}
 
 // The assignment epilogue shared by the fused k-wide SpMM (spmm_wide_k) and the dots-from-memory variant (dots_assign_k):
 // lane `lane` holds the dot products of document d with centres 4 (lane + 64 it) .. + 3.

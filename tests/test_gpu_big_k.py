@@ -174,6 +174,34 @@ def test_fused_filter_and_tightening_give_the_bits_of_the_two_kernel_form(hp, mo
         assert np.array_equal(out[name]["centers"].view(np.uint32), out["fused"]["centers"].view(np.uint32)), name
 
 
+def test_assignment_epilogues_inside_the_product_give_the_bits_of_the_two_kernel_route(hp, monkeypatch):
+    """The two D x k x k assignment steps (full pass of Lloyd in span(U), first assignment of Lloyd on B through the projection:
+    src/sparseMatrix.cpp:1794-1871, 1494-1572) form distances, tile / group bounds and the assignment INSIDE the matrix product's epilogue
+    (gemm_bf16x3.h group epilogues + a pass over 16 candidates per document); ISLE_GEMM_EPILOGUE=0 writes the D x k product and runs
+    proj_dots_tiles_k / dots_assign_cm_k over it.  Same dot products, same arithmetic: partitions, iteration counts, centres bit-equal."""
+    from tools.synth import make_B
+    V, D, k = 6000, 140_000, 1000  # 547 row blocks x 4 column tiles: the three-term bf16 product with 256 x 256 tiles is taken
+    B = make_B(V, D, k, 77)
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=3)
+    out = {}
+    for name, env in (("fused", {"ISLE_KMPP_TRACK": "0"}), ("two", {"ISLE_KMPP_TRACK": "0", "ISLE_GEMM_EPILOGUE": "0"})):
+        for a, b in env.items():
+            monkeypatch.setenv(a, b)
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = hp.run_lloyds(k)
+        out[name] = (lp, ls)
+        for a in env:
+            monkeypatch.delenv(a)
+    for i in (0, 1):
+        assert out["fused"][i]["iters"] == out["two"][i]["iters"]
+        assert np.array_equal(out["fused"][i]["assign"], out["two"][i]["assign"]), float((out["fused"][i]["assign"] == out["two"][i]["assign"]).mean())
+    assert np.array_equal(out["fused"][0]["C_lowd"].view(np.uint32), out["two"][0]["C_lowd"].view(np.uint32))
+    assert np.array_equal(out["fused"][1]["centers"].view(np.uint32), out["two"][1]["centers"].view(np.uint32))
+
+
 def test_full_tile_pass_by_library_gemm_equals_the_fused_kernel(hp, monkeypatch):
     """At large k the full passes of the projected Lloyd (iteration 0, and later iterations with more than half the documents
     active) are one library GEMM over the coordinate-major projection plus proj_dots_tiles_k; the fused matrix-core kernel
