@@ -429,6 +429,7 @@ int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const
 int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev);  // no host round trip
 int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev);
 int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev);
+int k_csc_validate(isle_ctx* c, unsigned long long* err_host2);  // the uploaded CSC arrays on the device: [0] first bad column + 1 (0 = fine), [1] what (spmm.hip)
 int k_doc_norms(isle_ctx* c, float* dn);
 int k_centers_from_rows(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool first_of_run = true);
 
