@@ -514,6 +514,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   }
   c->lift_valid = false;  // the centres move below
   int it = 0;
+  std::vector<float> delta_host;  // the k centre movements of the last update (Yinyang: choice of the movers)
   isle_host_mark("lloyds_sparse: loop starts");
   for (; it < max_reps; ++it) {
     {
@@ -570,9 +571,38 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
       // by group: the bounds are lowered and the active documents tightened in one launch (the D x G bounds read once), ISLE_YY_FUSED=0: in two
       const bool fused = yy_mode == 2 && !c->knob_zero(KN_YY_FUSED);
+      // Movers.  A group's bound falls by the LARGEST movement among its eight centres, for every document: one centre that jumped (a
+      // cluster of a handful of documents that gained or lost one) takes a whole group's bound away and makes nearly every document
+      // active (config 3: 98 % in iterations 3 - 5, because of 1 - 3 centres).  Up to ten centres whose movement stands out (more than
+      // twice the eleventh largest) are therefore left out of their groups' maxima and bounded by their exact new distances — one thin
+      // pass of the pass-1 stream for b_d . c over all documents (k_yy_filter_tighten).  Exact: min(bound lowered by the other members'
+      // movement, distance to the mover) is a lower bound of the group as before.  Same movements on every rank (the centres are all-reduced).
+      YyMovers mv;
+      const float* gmax_use = gmax_dev;
+      if (fused && !c->knob_zero(KN_YY_MOVERS) && (int)delta_host.size() == k && k > 16) {
+        std::vector<int> ord(k);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::partial_sort(ord.begin(), ord.begin() + 11, ord.end(), [&](int a, int b) { return delta_host[a] > delta_host[b] || (delta_host[a] == delta_host[b] && a < b); });
+        const float ref = delta_host[ord[10]];
+        for (int j = 0; j < 10; ++j)
+          if (delta_host[ord[j]] > 2.0f * ref && delta_host[ord[j]] > 1e-4f) mv.id[mv.n++] = (uint32_t)ord[j];
+        if (mv.n) {
+          mv.ld = 4 * ((mv.n + 3) / 4);
+          std::vector<float> gm(G, 0.f);
+          for (int i = 0; i < k; ++i) {
+            bool is_mover = false;
+            for (int j = 0; j < mv.n; ++j) is_mover = is_mover || mv.id[j] == (uint32_t)i;
+            if (!is_mover) gm[i / 8] = std::max(gm[i / 8], delta_host[i]);
+          }
+          HIPCHK(c, c->yy_gmax2.reserve(G));
+          HIPCHK(c, hipMemcpyAsync(c->yy_gmax2.p, gm.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));  // gm is stack-owned
+          gmax_use = c->yy_gmax2.p;
+        }
+      }
       if (fused)
-        ISLECHK(k_yy_filter_tighten(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact, c->yy_cg.p, k, ld, c->cnorm.p, c->dnorm.p,
-                                    cn_max_dev));
+        ISLECHK(k_yy_filter_tighten(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_use, c->active.p, nact, c->yy_cg.p, k, ld, c->cnorm.p, c->dnorm.p,
+                                    cn_max_dev, mv, c->centers_rm.p));
       else
         ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
       const bool dbg = c->knob_on(KN_DEBUG_HAMERLY);
@@ -608,6 +638,23 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
           ISLECHK(fetch_sizes(c, k, szs));
           long long smin = szs[0], smax = szs[0], empty = 0;
           for (auto v : szs) { smin = std::min(smin, v); smax = std::max(smax, v); empty += v == 0; }
+          {
+            int n1 = 0, n2 = 0, n3 = 0;
+            for (float v : sd) {
+              n1 += v > 0.3f;
+              n2 += v > 0.1f;
+              n3 += v > 0.03f;
+            }
+            std::vector<float> gs(gm);
+            std::sort(gs.begin(), gs.end());
+            int g1 = 0, g2 = 0;
+            for (float v : gs) {
+              g1 += v > 0.1f;
+              g2 += v > 0.03f;
+            }
+            fprintf(stderr, "[yinyang] iter %d: centres that moved more than 0.3 / 0.1 / 0.03: %d / %d / %d of %d; groups whose largest movement exceeds 0.1 / 0.03: %d / %d of %d\n", it, n1,
+                    n2, n3, k, g1, g2, G);
+          }
           fprintf(stderr, "[yinyang] iter %d: movement median %.3g max %.3g; |c|^2 median %.3g max %.3g (cn_max %.3g); cluster sizes %lld..%lld, %lld empty\n", it,
                   sd[k / 2], sd[k - 1], sc[k / 2], sc[k - 1], cm, smin, smax, empty);
         }
@@ -643,8 +690,14 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
     if (hamerly && it + 1 < max_reps) {  // centre movements for the next filter
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, delta_dev, c->centers_old.p));
-      if (yinyang) ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
-      else ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));
+      if (yinyang) {
+        ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
+        // ... and a copy of the k movements for the choice of the movers (read behind the stop rule's synchronisation)
+        delta_host.resize(k);
+        HIPCHK(c, hipMemcpyAsync(delta_host.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      } else {
+        ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));
+      }
     }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));

@@ -86,7 +86,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_YY_MODE, KN_YY_FUSED, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
@@ -267,6 +267,8 @@ struct isle_ctx {
   DevBuf<float> Pt;        // ldk x D coordinate-major copy (projected assignment), only for ldk <= 256
   DevBuf<float> dotsT;     // D x k centre-major dot products (first assignment of Lloyd on B through the projection)
   DevBuf<uint4> gemm_b3;   // the small operand of k_gemm_nn_assign split into three bf16 terms (gemm_bf16x3.h)
+  DevBuf<float> yy_gmax2;     // G floats: the groups' largest movements without the movers
+  DevBuf<float> yy_mdots;     // D x 12: dot products of every document with the movers' centres (YyMovers)
   DevBuf<float> cmax_buf;     // one float: the largest centre norm of a full projected pass
   DevBuf<float> assign_part;  // per document and 64-column slot the best centre of the slot (16 bytes: k_gemm_assign_yy / _tiles, dense.hip)
   DevBuf<float> lift_C;    // the k x k coefficients the device-resident centres were lifted from (centres = U lift_C^T)
@@ -408,9 +410,15 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
                        const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
                        float* ub = nullptr, float* lb = nullptr, int G = 0 /*> 0: lb holds G Yinyang group bounds per document*/);
+// The centres of a Yinyang iteration that moved far (at most ten: one thin pass): they are left out of their groups' movements and bounded by
+// their exact new distances instead (yy2_filter_tighten_k)
+struct YyMovers {
+  int n = 0, ld = 0;   // ld = 4 ceil(n / 4): row stride of the D x n dot products
+  uint32_t id[10] = {};
+};
 int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev,
                         const float* gmax_dev, uint32_t* active, uint32_t* nactive, const float* Cg, int k, int ld, const float* cn, const float* dn,
-                        const float* cn_max);
+                        const float* cn_max, const YyMovers& mv, const float* Crm);
 int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
                 uint32_t* active, uint32_t* nactive);
 int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G);  // c->yy_cg = the centres group-major (V x 8 floats per group)

@@ -1301,6 +1301,15 @@ __global__ __launch_bounds__(256) void yy2_tighten_k(const float* __restrict__ v
   }
 }
 
+// V x n column-major block of n columns of a row-major V x ld matrix (the movers' centres as the thin operand of k_gl_thin)
+__global__ __launch_bounds__(256) void yy_gather_cols_k(const float* __restrict__ Crm, uint32_t V, int ld, YyMovers mv, float* __restrict__ Wcm) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)V * mv.n) return;
+  const int j = (int)(i / V);
+  const uint32_t w = (uint32_t)(i - (size_t)j * V);
+  Wcm[i] = Crm[(size_t)w * ld + mv.id[j]];
+}
+
 // yy_filter_k and yy2_tighten_k in one launch (the by-group iteration): a workgroup lowers the group bounds of its block of documents
 // through the LDS tile as yy_filter_k does — same arithmetic, same outputs: glb, ub, the active list — and then its waves take the block's
 // ACTIVE documents in turn and run yy2_tighten_k's step on them with the bounds still in the tile: the D x G bound array (5 GB at 10 M
@@ -1311,7 +1320,8 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
                                                              int docs_per_block, const float* __restrict__ vals, const uint32_t* __restrict__ rows,
                                                              const int64_t* __restrict__ offs, const float4* __restrict__ Cg, uint32_t V, int ld, int k, int NW,
                                                              const float* __restrict__ cn, const float* __restrict__ dn, const float* __restrict__ cn_max_p,
-                                                             YyRes* __restrict__ own, unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt) {
+                                                             YyRes* __restrict__ own, unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt,
+                                                             YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: b_d . c_mover*/) {
   extern __shared__ float tile[];  // docs_per_block x G bounds, then docs_per_block local indices of the active documents
   uint32_t* lact = reinterpret_cast<uint32_t*>(tile + (size_t)docs_per_block * G);
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
@@ -1374,7 +1384,25 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
     if (order) d = order[d];
     float u = 0.f, lmin = 3.4e38f;
     if (in) {
-      u = (ub[d] + delta[assign[d]]) * 1.000001f;
+      const uint32_t a = assign[d];
+      u = (ub[d] + delta[a]) * 1.000001f;
+      if (mv.n) {
+        // the few centres that moved far were left out of their groups' movements (gmax): their groups' bounds take the exact new
+        // distances to them instead — min(bound lowered by the others' movement, distance to the mover) bounds the group as before
+        const float dnd = dn[d];
+        const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+        for (int jm = 0; jm < mv.n; ++jm) {
+          const uint32_t cj = mv.id[jm];
+          if (cj == a) continue;  // the assigned centre does not bound its own group
+          const float dist = fabsf((-2.0f * mdots[(size_t)d * mv.ld + jm] + cn[cj]) + dnd);
+          const float l = yy_slack_down_sq(dist, E, sE);
+          const uint32_t at = j * (uint32_t)G + (cj >> 3);
+          if (l < tile[at]) {
+            tile[at] = l;
+            glb[(size_t)d * G + (cj >> 3)] = l;
+          }
+        }
+      }
       for (int g = 0; g < G; ++g) lmin = fminf(lmin, tile[j * (uint32_t)G + g]);
       ub[d] = u;
     }
@@ -1508,9 +1536,16 @@ int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
 // k_yy_filter and the tightening step of k_yy2_assign in one launch (yy2_filter_tighten_k); k_yy2_assign(..., pre_tightened = true) follows
 int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev,
                         const float* gmax_dev, uint32_t* active, uint32_t* nactive, const float* Cg, int k, int ld, const float* cn, const float* dn,
-                        const float* cn_max) {
+                        const float* cn_max, const YyMovers& mv, const float* Crm) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
+  if (mv.n && D) {  // b_d . c_mover for every document: one thin pass of the pass-1 stream (k_gl_thin), ten columns at most
+    HIPCHK(c, c->Tmp.reserve((size_t)V * mv.n));
+    HIPCHK(c, c->yy_mdots.reserve((size_t)D * mv.ld));
+    hipLaunchKernelGGL(yy_gather_cols_k, dim3(cdiv((long)((size_t)V * mv.n), 256)), dim3(256), 0, c->stream, Crm, V, ld, mv, c->Tmp.p);
+    HIPCHK(c, hipGetLastError());
+    ISLECHK(k_gl_thin(c, c->Tmp.p, mv.n, mv.ld, c->yy_mdots.p));
+  }
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
   const int NW = cdiv(G, 64);
@@ -1525,7 +1560,7 @@ int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assi
   ISLECHK(isle_max_lds(c, (const void*)yy2_filter_tighten_k, (int)lds));
   hipLaunchKernelGGL(yy2_filter_tighten_k, dim3(cdiv(D, dpb)), dim3(256), lds, c->stream, D, order, assign, ub, glb, G, delta_dev, gmax_dev, active, nactive, dpb,
                      c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, NW, cn, dn, cn_max, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p,
-                     c->yy_cnt.p);
+                     c->yy_cnt.p, mv, c->yy_mdots.p);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
