@@ -15,6 +15,27 @@
 // ------------------------------------------------------------------------------------------
 // k-means in the projected space
 // ------------------------------------------------------------------------------------------
+// The movers of an iteration (YyMovers): up to ten centres whose movement stands out — more than twice the eleventh largest — and the
+// groups' (Yinyang: 8 centres) or tiles' (projected loop: 32) largest movements WITHOUT them.  The same on every rank (replicated inputs).
+static void choose_movers(const std::vector<float>& delta, int k, int group, int G, YyMovers* mv, std::vector<float>* gmax_excl) {
+  mv->n = 0;
+  if ((int)delta.size() != k || k <= 16) return;
+  std::vector<int> ord(k);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::partial_sort(ord.begin(), ord.begin() + 11, ord.end(), [&](int a, int b) { return delta[a] > delta[b] || (delta[a] == delta[b] && a < b); });
+  const float ref = delta[ord[10]];
+  for (int j = 0; j < 10; ++j)
+    if (delta[ord[j]] > 2.0f * ref && delta[ord[j]] > 1e-4f) mv->id[mv->n++] = (uint32_t)ord[j];
+  if (!mv->n) return;
+  mv->ld = 4 * ((mv->n + 3) / 4);
+  gmax_excl->assign(G, 0.f);
+  for (int i = 0; i < k; ++i) {
+    bool is_mover = false;
+    for (int j = 0; j < mv->n; ++j) is_mover = is_mover || mv->id[j] == (uint32_t)i;
+    if (!is_mover) (*gmax_excl)[i / group] = std::max((*gmax_excl)[i / group], delta[i]);
+  }
+}
+
 static int ensure_P(isle_ctx* c, int k) {
   if (c->U_k != k) return isle_fail(c, ISLE_E_ARG, "U has %d columns, k = %d (run isle_hip_block_ks / set_U first)", c->U_k, k);
   if (c->P_ready) return 0;
@@ -320,6 +341,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[projected Lloyd] first assignment %s\n", from_kmpp ? "taken from the k-means++ rounds" : "computed");
   StopRule stop(c, k);
   int it = 0;
+  std::vector<float> pdelta_host;  // the k centre movements of the last update (tile bounds: choice of the movers)
   isle_host_mark("lloyds_projected: loop starts");
   for (; it < max_reps; ++it) {
     ISLECHK(k_rownorms(c, c->Cdev.p, k, k, ldk, c->cnorm.p));                                          // :1938
@@ -337,8 +359,33 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
         // then holds neighbours, whose needed tiles coincide
         {  // candidates by the grown upper bounds, then the exact distance to the own centre for those (pt_tighten_k)
           uint32_t* ncand = c->pcand.p + D;
-          ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_dev,
-                              c->pneed.p, c->pcand.p, ncand));
+          // movers (see Lloyd on B below): a tile of 32 centres loses its bound to ONE centre that jumped; up to ten such centres are left out
+          // of their tiles' movements and bounded by their exact new distances  P_d . c = b_d^T (U c): a thin product of B with U C_m^T
+          // (the k-means++ rounds' route), one pass of the pass-1 stream
+          YyMovers mv;
+          const float* tmove_use = tmove_dev;
+          if (!c->knob_zero(KN_YY_MOVERS) && c->gl_mode == 1 && c->band_ready && c->U_k == k && D) {
+            std::vector<float> tm;
+            choose_movers(pdelta_host, k, 32, T, &mv, &tm);
+            if (mv.n) {
+              HIPCHK(c, c->yy_gmax2.reserve(std::max(T, 64)));
+              HIPCHK(c, hipMemcpyAsync(c->yy_gmax2.p, tm.data(), (size_t)T * sizeof(float), hipMemcpyHostToDevice, c->stream));
+              HIPCHK(c, c->Tmp.reserve((size_t)c->V * 32 + (size_t)16 * ldk));
+              float* Cm = c->Tmp.p + (size_t)c->V * 32;  // the movers' centres, one row each
+              for (int j = 0; j < mv.n; ++j)
+                HIPCHK(c, hipMemcpyAsync(Cm + (size_t)j * ldk, c->Cdev.p + (size_t)mv.id[j] * ldk, (size_t)ldk * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+              HIPCHK(c, hipStreamSynchronize(c->stream));  // tm is stack-owned
+              HIPCHK(c, c->yy_mdots.reserve((size_t)D * mv.ld));
+              ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, k, Cm, ldk, mv.n, c->Tmp.p, ISLE_T_LLOYD_PROJ));  // W = U C_m^T  (V x n col-major)
+              {
+                TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+                ISLECHK(k_gl_thin(c, c->Tmp.p, mv.n, mv.ld, c->yy_mdots.p));
+              }
+              tmove_use = c->yy_gmax2.p;
+            }
+          }
+          ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_use,
+                              c->pneed.p, c->pcand.p, ncand, mv, c->yy_mdots.p, c->cnorm.p, c->pnorm.p));
           ISLECHK(k_pt_tighten(c, c->P.p, c->pnorm.p, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->pcand.p, ncand, c->hub.p, c->ptlb.p, T, TL,
                                c->pneed.p, c->active.p, nact));
         }
@@ -392,8 +439,13 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
     ISLECHK(k_proj_finalize(c, c->Csum.p, c->counts.p, k, ldk, c->Cdev.p));                             // :1988-1992
     if (hamerly && it + 1 < max_reps) {
       ISLECHK(k_rownorms_diff(c, c->Cdev.p, c->Cold.p, k, k, ldk, delta_dev));
-      if (tiles) ISLECHK(k_yy_delta(c, delta_dev, k, T, 32, tmove_dev));  // rounded-up movements and their maxima per tile
-      else ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));  // rounded-up movements and their top two, on the device
+      if (tiles) {
+        ISLECHK(k_yy_delta(c, delta_dev, k, T, 32, tmove_dev));  // rounded-up movements and their maxima per tile
+        pdelta_host.resize(k);  // ... and a copy for the choice of the movers (read behind the stop rule's synchronisation)
+        HIPCHK(c, hipMemcpyAsync(pdelta_host.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      } else {
+        ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));  // rounded-up movements and their top two, on the device
+      }
     }
     bool conv = false;
     ISLECHK(stop.converged(sizes, c->assign.p, &conv));
@@ -579,21 +631,10 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // movement, distance to the mover) is a lower bound of the group as before.  Same movements on every rank (the centres are all-reduced).
       YyMovers mv;
       const float* gmax_use = gmax_dev;
-      if (fused && !c->knob_zero(KN_YY_MOVERS) && (int)delta_host.size() == k && k > 16) {
-        std::vector<int> ord(k);
-        std::iota(ord.begin(), ord.end(), 0);
-        std::partial_sort(ord.begin(), ord.begin() + 11, ord.end(), [&](int a, int b) { return delta_host[a] > delta_host[b] || (delta_host[a] == delta_host[b] && a < b); });
-        const float ref = delta_host[ord[10]];
-        for (int j = 0; j < 10; ++j)
-          if (delta_host[ord[j]] > 2.0f * ref && delta_host[ord[j]] > 1e-4f) mv.id[mv.n++] = (uint32_t)ord[j];
+      if (fused && !c->knob_zero(KN_YY_MOVERS)) {
+        std::vector<float> gm;
+        choose_movers(delta_host, k, 8, G, &mv, &gm);
         if (mv.n) {
-          mv.ld = 4 * ((mv.n + 3) / 4);
-          std::vector<float> gm(G, 0.f);
-          for (int i = 0; i < k; ++i) {
-            bool is_mover = false;
-            for (int j = 0; j < mv.n; ++j) is_mover = is_mover || mv.id[j] == (uint32_t)i;
-            if (!is_mover) gm[i / 8] = std::max(gm[i / 8], delta_host[i]);
-          }
           HIPCHK(c, c->yy_gmax2.reserve(G));
           HIPCHK(c, hipMemcpyAsync(c->yy_gmax2.p, gm.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));  // gm is stack-owned

@@ -512,7 +512,7 @@ bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k);  // the full tile-boun
 int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
                         float* ub, float* tlb, int TL, const uint32_t* active, uint32_t n, const uint32_t* need, float* Pa, float* pna);
 int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* tlb, int T, int TL, const float* delta_dev,
-                const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive);
+                const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive, const YyMovers& mv, const float* mdots, const float* cn, const float* pn);
 int k_pt_tighten(isle_ctx* c, const float* P, const float* pn, int ldk, const float* C, const float* cn, const uint32_t* assign, const uint32_t* cand,
                  const uint32_t* ncand, float* ub, const float* tlb, int T, int TL, uint32_t* need, uint32_t* active, uint32_t* nactive);
 int k_rownorms_diff(isle_ctx* c, const float* A, const float* B, int rows, int k, int ldk, float* out);

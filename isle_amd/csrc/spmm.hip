@@ -855,7 +855,8 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
 __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ order, uint32_t D, const uint32_t* __restrict__ assign,
                                                     float* __restrict__ ub, float* __restrict__ tlb, int T, int TL, const float* __restrict__ delta,
                                                     const float* __restrict__ tmove, uint32_t* __restrict__ need, uint32_t* __restrict__ active,
-                                                    uint32_t* __restrict__ nactive) {
+                                                    uint32_t* __restrict__ nactive, YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: P_d . c_mover*/,
+                                                    const float* __restrict__ cn, const float* __restrict__ pn) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const bool in = i < D;
   uint32_t d = 0;
@@ -867,6 +868,23 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
     ub[d] = u;
     float4* row = reinterpret_cast<float4*>(tlb + (size_t)d * TL);
     uint32_t mask = 0u;
+    // movers (see YyMovers): centres left out of their tiles' movements; their exact new distances bound their tiles instead.  The
+    // bounds of their tiles are collected first (at most ten), applied while the row is walked.
+    float ml[10];
+    if (mv.n) {
+      const float nd = pn[d];
+#pragma unroll
+      for (int jm = 0; jm < 10; ++jm) {
+        ml[jm] = 3.4e38f;
+        if (jm < mv.n && mv.id[jm] != a) {  // the assigned centre does not bound its own tile
+          const uint32_t cj = mv.id[jm];
+          const float dist = fabsf((-2.0f * mdots[(size_t)d * mv.ld + jm] + cn[cj]) + nd);
+          float uu, ll;
+          hamerly_store_bounds(dist, dist, nd + cn[cj], &uu, &ll);
+          ml[jm] = ll;
+        }
+      }
+    }
     for (int q = 0; q < TL / 4; ++q) {
       float4 v = row[q];
       float l[4] = {v.x, v.y, v.z, v.w};
@@ -876,6 +894,11 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
         if (t < T) {
           float x = l[e] - tmove[t] * 1.000001f;
           x = x > 0.f ? x * 0.999999f : x;
+          if (mv.n) {
+#pragma unroll
+            for (int jm = 0; jm < 10; ++jm)
+              if (jm < mv.n && (int)(mv.id[jm] >> 5) == t) x = fminf(x, ml[jm]);
+          }
           l[e] = x;
           if (u >= x) mask |= 1u << t;
         }
@@ -948,13 +971,14 @@ int k_pt_tighten(isle_ctx* c, const float* P, const float* pn, int ldk, const fl
 }
 
 int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* tlb, int T, int TL, const float* delta_dev,
-                const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive) {
+                const float* tmove_dev, uint32_t* need, uint32_t* active, uint32_t* nactive, const YyMovers& mv, const float* mdots, const float* cn,
+                const float* pn) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   const uint32_t D = (uint32_t)c->D;
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
   hipLaunchKernelGGL(pt_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, tlb, T, TL, delta_dev, tmove_dev, need, active,
-                     nactive);
+                     nactive, mv, mdots, cn, pn);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
