@@ -60,6 +60,9 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
     {"ISLE_YY_FUSED", "form", "0: the by-group Yinyang iteration lowers the bounds (yy_filter_k) and tightens the active documents (yy2_tighten_k) in two launches instead of one (same bits)"},
     {"ISLE_YY_MOVERS", "form", "0: every centre's movement lowers its Yinyang group's bound (default: up to ten centres that moved far beyond the rest are bounded by their exact new distances instead)"},
+    {"ISLE_YY_ORDER", "form", "doc: the by-group Yinyang iteration visits the documents in their own order instead of the member lists' (same bits)"},
+    {"ISLE_PT_SORT", "form", "0: the active documents of a projected Lloyd iteration keep the order of the member lists (default: ordered by the set of tiles they have to re-examine, so that a workgroup's documents ask for the same tiles; same partitions)"},
+    {"ISLE_PROJ_SUMS", "form", "fresh: the centroid sums of Lloyd in span(U) are formed from all member rows every iteration (default: kept up to date by the documents that changed centre; both bitwise reproducible, the two differ in rounding)"},
     {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
     {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},
     {"ISLE_CHUNK_COLS", "tuning", "gather form: rows per chunk of the chunked-CSR copy"},

@@ -341,6 +341,11 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[projected Lloyd] first assignment %s\n", from_kmpp ? "taken from the k-means++ rounds" : "computed");
   StopRule stop(c, k);
   int it = 0;
+  const bool pt_sorted = !c->knob_zero(KN_PT_SORT);  // the active documents are ordered by the tiles they need: the filter walks the documents in their own order
+  const char* psm = c->knob(KN_PROJ_SUMS);
+  const bool delta_sums = !(psm && !strcmp(psm, "fresh")) && D < (1ull << 31);
+  if (delta_sums) HIPCHK(c, c->proj_counted.reserve(D ? D : 1));
+  if (c->multi()) HIPCHK(c, c->Csum_local.reserve((size_t)k * ldk));
   std::vector<float> pdelta_host;  // the k centre movements of the last update (tile bounds: choice of the movers)
   isle_host_mark("lloyds_projected: loop starts");
   for (; it < max_reps; ++it) {
@@ -384,7 +389,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
               tmove_use = c->yy_gmax2.p;
             }
           }
-          ISLECHK(k_pt_filter(c, c->members_valid ? c->members.p : nullptr, c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_use,
+          ISLECHK(k_pt_filter(c, pt_sorted ? nullptr : (c->members_valid ? c->members.p : nullptr), c->assign.p, c->hub.p, c->ptlb.p, T, TL, delta_dev, tmove_use,
                               c->pneed.p, c->pcand.p, ncand, mv, c->yy_mdots.p, c->cnorm.p, c->pnorm.p));
           ISLECHK(k_pt_tighten(c, c->P.p, c->pnorm.p, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->pcand.p, ncand, c->hub.p, c->ptlb.p, T, TL,
                                c->pneed.p, c->active.p, nact));
@@ -397,6 +402,8 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
           std::vector<uint32_t> act(na), need(D);
           if (na) HIPCHK(c, hipMemcpy(act.data(), c->active.p, na * sizeof(uint32_t), hipMemcpyDeviceToHost));
           if (D) HIPCHK(c, hipMemcpy(need.data(), c->pneed.p, D * sizeof(uint32_t), hipMemcpyDeviceToHost));
+          if (na > 256 && !c->knob_zero(KN_PT_SORT))  // the order k_proj_assign_tiles gives the list
+            std::stable_sort(act.begin(), act.end(), [&](uint32_t a, uint32_t b) { return need[a] < need[b]; });
           double tiles_sum = 0, union_sum = 0;
           for (uint32_t i = 0; i < na; i += 128) {
             uint32_t u = 0;
@@ -431,7 +438,19 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
                                    c->hub.p, c->hlb.p));
     }
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
-    ISLECHK(k_proj_accumulate(c, c->P.p, D, k, ldk, c->assign.p, c->Csum.p, c->counts.p));              // :1957-1984
+    {
+      // sums of the members' rows (:1957-1984): afresh in the first iteration, afterwards from the documents that changed centre
+      float* sums = c->multi() ? c->Csum_local.p : c->Csum.p;  // this rank's sums
+      bool updated = false;
+      if (delta_sums && it > 0) ISLECHK(k_proj_accumulate_delta(c, c->P.p, D, k, ldk, c->assign.p, c->proj_counted.p, sums, c->counts.p, &updated));
+      if (!updated) {
+        ISLECHK(k_proj_accumulate(c, c->P.p, D, k, ldk, c->assign.p, sums, c->counts.p));
+        if (delta_sums && D) HIPCHK(c, hipMemcpyAsync(c->proj_counted.p, c->assign.p, D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+      } else {
+        c->members_valid = false;  // the lists are those of an earlier assignment
+      }
+      if (c->multi()) HIPCHK(c, hipMemcpyAsync(c->Csum.p, sums, (size_t)k * ldk * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
     ISLECHK(allreduce_sum<float>(c, c->Csum.p, (size_t)k * ldk));
     std::vector<long long> sizes;
     ISLECHK(fetch_sizes(c, k, sizes));
@@ -619,7 +638,8 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // the forms that visit documents in member order (docg, group) hold a document's group bounds four per lane: at most 256 groups
       // (k <= 2048); beyond, by document over the row-major centres, whatever ISLE_YY_MODE asks for
       const int yy_mode = G > 256 ? 0 : yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
-      const uint32_t* order = yy_mode && c->members_valid ? c->members.p : nullptr;
+      const char* yord = c->knob(KN_YY_ORDER);
+      const uint32_t* order = yy_mode && c->members_valid && !(yord && !strcmp(yord, "doc")) ? c->members.p : nullptr;
       if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
       // by group: the bounds are lowered and the active documents tightened in one launch (the D x G bounds read once), ISLE_YY_FUSED=0: in two
       const bool fused = yy_mode == 2 && !c->knob_zero(KN_YY_FUSED);

@@ -86,7 +86,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
@@ -299,6 +299,10 @@ struct isle_ctx {
   DevBuf<uint32_t> pcand;  // D + 1: candidates of the first filter stage (last = count)
   DevBuf<int> seg_desc;    // projected centroid sums: chunk descriptors (beg, end) and the centres' first chunks
   DevBuf<float> seg_part;  // one partial row per chunk
+  DevBuf<uint32_t> proj_counted;  // D: the centre under which a document is counted in the projected sums (k_proj_accumulate_delta)
+  DevBuf<uint32_t> proj_nch;      // number of documents that changed centre
+  DevBuf<float> proj_dpart;       // k x 8 x ldk partial sums of the changes
+  DevBuf<float> Csum_local;       // several ranks: this rank's sums (Csum holds the all-reduced ones)
   DevBuf<uint32_t> active; // D + 1 (last = count)
   DevBuf<unsigned long long> dbg_cnt;  // diagnostics (ISLE_DEBUG_HAMERLY)
   // what the k-means++ rounds keep for Lloyd's first assignment in span(U) (kmeans.hip kmpp_min_dots_track_k)
@@ -518,6 +522,8 @@ int k_pt_tighten(isle_ctx* c, const float* P, const float* pn, int ldk, const fl
 int k_rownorms_diff(isle_ctx* c, const float* A, const float* B, int rows, int k, int ldk, float* out);
 int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out);
 int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, float* Csum, int* counts);
+int k_proj_accumulate_delta(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, uint32_t* counted, float* Csum,
+                            const int* counts, bool* done);
 int k_proj_finalize(isle_ctx* c, const float* Csum, const int* counts, int k, int ldk, float* C);
 int k_count_sizes(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, int* counts);
 int k_compare_u32(isle_ctx* c, const uint32_t* a, const uint32_t* b, uint64_t n, int* flag_dev);

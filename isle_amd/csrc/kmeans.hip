@@ -847,13 +847,77 @@ __global__ __launch_bounds__(256) void compact_rows_k(const float* __restrict__ 
   if (threadIdx.x < 32 && i0 + threadIdx.x < n) pna[i0 + threadIdx.x] = pn[active[i0 + threadIdx.x]];
 }
 
+// The same for long lists: 64 documents per workgroup and 256 coordinates at a time — a row is read in 1 kB pieces (one float4 per lane,
+// sixteen rows in flight per wave) and a coordinate's 64 documents leave as one 256-byte store, where the 32 x 32 tiles above move 128 bytes
+// either way (config 3, 2 M active documents of 4 kB: 7.8 -> ms).
+__global__ __launch_bounds__(256) void compact_rows64_k(const float* __restrict__ P, const float* __restrict__ pn, int ldk,
+                                                         const uint32_t* __restrict__ active, uint32_t n, float* __restrict__ Pa,
+                                                         float* __restrict__ pna) {
+  extern __shared__ float t64[];  // 64 x 257
+  const uint32_t i0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t myd = active[min(i0 + (uint32_t)lane, n - 1)];
+  for (int j0 = 0; j0 < ldk; j0 += 256) {
+    __syncthreads();
+    const int j = j0 + 4 * lane;  // ldk is a multiple of 4: a float4 is inside the row or outside it
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const uint32_t d = (uint32_t)__shfl((int)myd, w * 16 + u);
+      v[u] = *reinterpret_cast<const float4*>(P + (size_t)d * ldk + min(j, ldk - 4));
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      float* r = t64 + (size_t)(w * 16 + u) * 257 + 4 * lane;
+      r[0] = v[u].x;
+      r[1] = v[u].y;
+      r[2] = v[u].z;
+      r[3] = v[u].w;
+    }
+    __syncthreads();
+    if (i0 + lane < n) {
+#pragma unroll 8
+      for (int cc = 0; cc < 64; ++cc) {
+        const int cj = j0 + w * 64 + cc;
+        if (cj < ldk) Pa[(size_t)cj * n + i0 + lane] = t64[(size_t)lane * 257 + w * 64 + cc];
+      }
+    }
+  }
+  if (threadIdx.x < 64 && i0 + threadIdx.x < n) pna[i0 + threadIdx.x] = pn[myd];
+}
+
+static int k_compact_rows(isle_ctx* c, const float* P, const float* pn, int ldk, const uint32_t* active, uint32_t n, float* Pa, float* pna) {
+  if (n >= 4096 && ldk >= 256 && ldk % 4 == 0) {
+    const size_t lds = (size_t)64 * 257 * sizeof(float);
+    ISLECHK(isle_max_lds(c, (const void*)compact_rows64_k, (int)lds));
+    hipLaunchKernelGGL(compact_rows64_k, dim3(cdiv(n, 64)), dim3(256), lds, c->stream, P, pn, ldk, active, n, Pa, pna);
+  } else {
+    hipLaunchKernelGGL(compact_rows_k, dim3(cdiv(n, 32)), dim3(256), 0, c->stream, P, pn, ldk, active, n, Pa, pna);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// Keys of the active documents of a tile-bound iteration: the set of tiles a document has to re-examine (pt_filter_k / pt_tighten_k).
+// A workgroup of proj_assign_reg_k<.., PR_TILES> examines the UNION of its 128 documents' sets; in member order that union was 9 of the
+// 32 tiles at config 3 where a document asks for 2 - 3, so the active list is sorted by the set first (as a number: largest tile, then the
+// next ...).  The order of the list changes no document's result: every distance a workgroup forms is exact and only tightens bounds.
+__global__ __launch_bounds__(256) void pt_need_keys_k(const uint32_t* __restrict__ active, uint32_t n, const uint32_t* __restrict__ need,
+                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const uint32_t d = active[i];
+    key[i] = need[d];
+    val[i] = d;
+  }
+}
+
 // assignment of the n active documents (Hamerly); results are written through `active` into assign / ub / lb
 int k_proj_assign_active(isle_ctx* c, const float* P, const float* pn, int k, int ldk, const float* C, const float* cn,
                          const uint32_t* active, uint32_t n, float* Pa, float* pna, uint32_t* assign, float* ub, float* lb) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(compact_rows_k, dim3(cdiv(n, 32)), dim3(256), 0, c->stream, P, pn, ldk, active, n, Pa, pna);
-  HIPCHK(c, hipGetLastError());
+  ISLECHK(k_compact_rows(c, P, pn, ldk, active, n, Pa, pna));
   bool done = false;
   ISLECHK(launch_proj_reg<PR_ARGMIN>(c, n, k, ldk, C, cn, pna, assign, nullptr, &done, Pa, active, ub, lb));
   if (!done) return isle_fail(c, ISLE_E_ARG, "projected assignment: register kernel unavailable");
@@ -957,8 +1021,18 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
     ISLECHK(launch_proj_reg<PR_TILES>(c, D, k, ldk, C, cn, pn, assign, nullptr, &done, nullptr, nullptr, ub, tlb, nullptr, TL));
   } else {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(compact_rows_k, dim3(cdiv(n, 32)), dim3(256), 0, c->stream, P, pn, ldk, active, n, Pa, pna);
-    HIPCHK(c, hipGetLastError());
+    if (need && n > 256 && !c->knob_zero(KN_PT_SORT)) {  // documents that ask for the same tiles next to each other (pt_need_keys_k)
+      HIPCHK(c, c->gl_key_a.reserve(n));
+      HIPCHK(c, c->gl_key_b.reserve(n));
+      HIPCHK(c, c->gl_val_a.reserve(n));
+      HIPCHK(c, c->gl_val_b.reserve(n));
+      hipLaunchKernelGGL(pt_need_keys_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, active, n, need, c->gl_key_a.p, c->gl_val_a.p);
+      HIPCHK(c, hipGetLastError());
+      bool in_a = true;
+      ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, n, ((k + 31) / 32 + 7) & ~7, &in_a));
+      active = in_a ? c->gl_val_a.p : c->gl_val_b.p;
+    }
+    ISLECHK(k_compact_rows(c, P, pn, ldk, active, n, Pa, pna));
     ISLECHK(launch_proj_reg<PR_TILES>(c, n, k, ldk, C, cn, pna, assign, nullptr, &done, Pa, active, ub, tlb, need, TL));
   }
   if (!done) return isle_fail(c, ISLE_E_ARG, "projected assignment with tile bounds: shape not covered (k = %d)", k);
@@ -1250,6 +1324,159 @@ int k_proj_accumulate(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, c
   hipLaunchKernelGGL(proj_segsum_reduce_k, dim3(cdiv(ldk, 256), k), dim3(256), 0, c->stream, c->seg_part.p, c0_dev, ldk, Csum);
   HIPCHK(c, hipGetLastError());
   if (!pinned) HIPCHK(c, hipStreamSynchronize(c->stream));  // ch / c0 are pageable host memory
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same sums kept up to date by the documents that changed centre (iterations after the first: 1 - 5 % of the documents at config 3,
+// where the fresh sums read all 40 GB of P: 6.7 ms an iteration).  `counted[d]` is the centre under which document d sits in Csum.
+// A changed document contributes two entries, +row under its new centre and -row under its old one; the entries are sorted by
+// (centre, document, sign) — so their order does not depend on the order in which workgroups appended them — every centre's run is cut
+// in PD_PARTS equal parts, one workgroup per part sums its rows in that order (proj_delta_sum_k, the wave pattern of proj_segsum_k), and
+// proj_delta_apply_k adds the parts to the centre's row in a fixed order.  No atomics on the sums: the centres stay bitwise reproducible.
+// They are no longer the bits of the fresh sums (the additions associate differently); a centre that loses all members is reset to zero.
+// ------------------------------------------------------------------------------------------
+constexpr int PD_PARTS = 8;
+__global__ __launch_bounds__(256) void proj_changed_k(const uint32_t* __restrict__ assign, uint32_t* __restrict__ counted, uint32_t D, int dbits,
+                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t cap /*entries*/,
+                                                       uint32_t* __restrict__ counter) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t a = d < D ? assign[d] : 0u, o = d < D ? counted[d] : 0u;
+  const bool ch = d < D && a != o;
+  const uint32_t slot = block_append_slot(ch, counter);
+  if (ch) {
+    counted[d] = a;
+    if (2 * (uint64_t)slot + 1 < cap) {  // beyond the capacity the caller recomputes the sums from scratch (the counter tells)
+      key[2 * (size_t)slot] = ((uint64_t)a << (dbits + 1)) | ((uint64_t)d << 1);
+      key[2 * (size_t)slot + 1] = ((uint64_t)o << (dbits + 1)) | ((uint64_t)d << 1) | 1ull;
+      val[2 * (size_t)slot] = d;
+      val[2 * (size_t)slot + 1] = d;
+    }
+  }
+}
+template <int NIT>
+__global__ __launch_bounds__(256) void proj_delta_sum_k(const float* __restrict__ P, int ldk, const uint64_t* __restrict__ key, uint32_t n, int dbits,
+                                                         float* __restrict__ part /*[centre][PD_PARTS][ldk]*/) {
+  extern __shared__ float red[];  // 4 x ldk
+  __shared__ uint32_t range[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = ldk / 4;
+  const uint32_t cc = blockIdx.x, pt = blockIdx.y;
+  if (threadIdx.x < 2) {  // first entry of centre cc (thread 0) and of centre cc + 1 (thread 1)
+    const uint64_t target = (uint64_t)(cc + threadIdx.x) << (dbits + 1);
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (key[mid] < target) lo = mid + 1;
+      else hi = mid;
+    }
+    range[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  const uint32_t r0 = range[0], len = range[1] - range[0];
+  const uint32_t beg = r0 + (uint32_t)(((uint64_t)len * pt) / PD_PARTS), end = r0 + (uint32_t)(((uint64_t)len * (pt + 1)) / PD_PARTS);
+  float4 acc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint64_t dmask = (1ull << dbits) - 1ull;
+  for (uint32_t b0 = beg; b0 < end; b0 += 256) {  // 256 entries at a time: this wave takes b0 + wave, + 4, ...
+    const uint32_t e0 = min(end, b0 + 256);
+    const uint32_t myi = b0 + wave + 4 * lane;
+    const uint64_t myk = myi < e0 ? key[myi] : 0ull;
+    const int cnt = e0 > b0 + wave ? (int)min(64u, (e0 - b0 - wave + 3) / 4) : 0;
+    for (int j = 0; j < cnt; j += 4) {
+      float4 v[4][NIT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int src = min(j + u, cnt - 1);
+        const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)myk, src), khi = (uint32_t)__shfl((int)(uint32_t)(myk >> 32), src);
+        const uint64_t kk = ((uint64_t)khi << 32) | klo;
+        const float4* row = reinterpret_cast<const float4*>(P + (size_t)((kk >> 1) & dmask) * ldk);
+        const float sgn = j + u < cnt ? ((kk & 1ull) ? -1.f : 1.f) : 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int q = lane + 64 * it;
+          const float4 x = q < nq ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[u][it] = make_float4(x.x * sgn, x.y * sgn, x.z * sgn, x.w * sgn);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          acc[it].x += v[u][it].x;
+          acc[it].y += v[u][it].y;
+          acc[it].z += v[u][it].z;
+          acc[it].w += v[u][it].w;
+        }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = lane + 64 * it;
+    if (q < nq) reinterpret_cast<float4*>(red + (size_t)wave * ldk)[q] = acc[it];
+  }
+  __syncthreads();
+  float* out = part + ((size_t)cc * PD_PARTS + pt) * ldk;
+  for (int j = threadIdx.x; j < ldk; j += 256) out[j] = (red[j] + red[ldk + j]) + (red[2 * ldk + j] + red[3 * ldk + j]);
+}
+__global__ __launch_bounds__(256) void proj_delta_apply_k(const float* __restrict__ part, const int* __restrict__ counts, int ldk, float* __restrict__ Csum) {
+  const int cc = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ldk) return;
+  const float* p = part + (size_t)cc * PD_PARTS * ldk + j;
+  float v[PD_PARTS];
+#pragma unroll
+  for (int u = 0; u < PD_PARTS; ++u) v[u] = p[(size_t)u * ldk];
+  const float dsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  static_assert(PD_PARTS == 8, "the sum above is written out for eight parts");
+  Csum[(size_t)cc * ldk + j] = counts[cc] > 0 ? Csum[(size_t)cc * ldk + j] + dsum : 0.f;
+}
+
+// Csum (this rank's sums, `counted` = the assignment they hold) brought up to `assign`.  *done = false: too many documents changed (or the
+// lists do not fit): the caller computes the sums afresh.
+int k_proj_accumulate_delta(isle_ctx* c, const float* P, uint64_t D, int k, int ldk, const uint32_t* assign, uint32_t* counted, float* Csum,
+                            const int* counts, bool* done) {
+  TimeScope ts(c, ISLE_T_LLOYD_PROJ);
+  *done = false;
+  if (D == 0 || D >= (1ull << 31)) return 0;
+  int dbits = 1, cbits = 1;
+  while ((1ull << dbits) < D) ++dbits;
+  while ((1 << cbits) < k) ++cbits;
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(2 * (D / 8 + 1), 0x7fffffffull);  // entries: at most an eighth of the documents changing
+  HIPCHK(c, c->gl_key_a.reserve(cap));
+  HIPCHK(c, c->gl_key_b.reserve(cap));
+  HIPCHK(c, c->gl_val_a.reserve(cap));
+  HIPCHK(c, c->gl_val_b.reserve(cap));
+  HIPCHK(c, c->proj_dpart.reserve((size_t)k * PD_PARTS * ldk));
+  HIPCHK(c, c->proj_nch.reserve(4));
+  HIPCHK(c, hipMemsetAsync(c->proj_nch.p, 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(proj_changed_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, assign, counted, (uint32_t)D, dbits, c->gl_key_a.p, c->gl_val_a.p, cap,
+                     c->proj_nch.p);
+  HIPCHK(c, hipGetLastError());
+  uint32_t* n_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 128);  // page-locked
+  HIPCHK(c, hipMemcpyAsync(n_pin, c->proj_nch.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint64_t n = 2 * (uint64_t)*n_pin;
+  if (n > cap) return 0;  // `counted` already holds the new assignment: the fresh sums the caller computes agree with it
+  *done = true;
+  if (n == 0) return 0;
+  bool in_a = true;
+  ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, n, dbits + 1 + cbits, &in_a));
+  const uint64_t* keys = in_a ? c->gl_key_a.p : c->gl_key_b.p;
+  const size_t lds = 4 * (size_t)ldk * sizeof(float);
+  const int nit = cdiv(ldk / 4, 64);
+  dim3 g((unsigned)k, PD_PARTS), b(256);
+#define LD(N) hipLaunchKernelGGL(proj_delta_sum_k<N>, g, b, lds, c->stream, P, ldk, keys, (uint32_t)n, dbits, c->proj_dpart.p)
+  if (nit <= 1) LD(1);
+  else if (nit <= 2) LD(2);
+  else if (nit <= 4) LD(4);
+  else if (nit <= 8) LD(8);
+  else return isle_fail(c, ISLE_E_ARG, "k too large");
+#undef LD
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(proj_delta_apply_k, dim3(cdiv(ldk, 256), k), dim3(256), 0, c->stream, c->proj_dpart.p, counts, ldk, Csum);
+  HIPCHK(c, hipGetLastError());
   return 0;
 }
 

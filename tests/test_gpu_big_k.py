@@ -202,6 +202,51 @@ def test_assignment_epilogues_inside_the_product_give_the_bits_of_the_two_kernel
     assert np.array_equal(out["fused"][1]["centers"].view(np.uint32), out["two"][1]["centers"].view(np.uint32))
 
 
+def test_active_documents_ordered_by_their_tiles_give_the_same_bits(hp, monkeypatch):
+    """Lloyd in span(U) with tile bounds orders the active documents of an iteration by the set of tiles they re-examine (pt_need_keys_k +
+    radix sort), so that a workgroup's 128 documents ask for the same 2 - 3 tiles instead of 9 - 13 between them; ISLE_PT_SORT=0 keeps the
+    member lists' order.  Every distance formed is exact and the order only changes which bounds happen to be tightened on the way:
+    partition, iteration count and centres bit-equal (src/sparseMatrix.cpp:1794-1871)."""
+    f, B, k = load_case("c3k1000")
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+    out = {}
+    for name, env in (("sorted", {}), ("members", {"ISLE_PT_SORT": "0"}), ("members, fresh sums", {"ISLE_PT_SORT": "0", "ISLE_PROJ_SUMS": "fresh"}),
+                      ("sorted, fresh sums", {"ISLE_PROJ_SUMS": "fresh"})):
+        for a, b in env.items():
+            monkeypatch.setenv(a, b)
+        out[name] = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        for a in env:
+            monkeypatch.delenv(a)
+    for a, b in (("sorted", "members"), ("sorted, fresh sums", "members, fresh sums")):
+        assert out[a]["iters"] == out[b]["iters"]
+        assert np.array_equal(out[a]["assign"], out[b]["assign"])
+        assert np.array_equal(out[a]["C_lowd"].view(np.uint32), out[b]["C_lowd"].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["c2k200", "c3k1000"])
+def test_centroid_sums_kept_up_to_date_agree_with_fresh_sums(hp, monkeypatch, case):
+    """After its first iteration Lloyd in span(U) brings the centroid sums up to date with the rows of the documents that changed centre
+    (proj_changed_k, proj_delta_sum_k: sorted by centre, document and sign, summed in that order — no atomics) instead of summing all
+    member rows again (src/sparseMatrix.cpp:1957-1992 sums them all; ISLE_PROJ_SUMS=fresh does).  The two associate the additions
+    differently: centres equal to rounding, the same iteration count, partitions equal up to ties at rounding level — and the default is
+    bitwise reproducible run after run, like the fresh sums."""
+    f, B, k = load_case(case)
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+    a1 = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    a2 = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    monkeypatch.setenv("ISLE_PROJ_SUMS", "fresh")
+    fr = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    monkeypatch.delenv("ISLE_PROJ_SUMS")
+    assert np.array_equal(a1["C_lowd"].view(np.uint32), a2["C_lowd"].view(np.uint32)) and np.array_equal(a1["assign"], a2["assign"])
+    assert a1["iters"] == fr["iters"]
+    assert (a1["assign"] == fr["assign"]).mean() >= 1 - 1e-4
+    assert np.abs(a1["C_lowd"] - fr["C_lowd"]).max() <= 1e-5 * np.abs(fr["C_lowd"]).max()
+
+
 def test_full_tile_pass_by_library_gemm_equals_the_fused_kernel(hp, monkeypatch):
     """At large k the full passes of the projected Lloyd (iteration 0, and later iterations with more than half the documents
     active) are one library GEMM over the coordinate-major projection plus proj_dots_tiles_k; the fused matrix-core kernel
