@@ -57,6 +57,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_FIRST_ASSIGN", "form", "sparse | projection: first assignment of Lloyd on B through the sparse product or through the projection"},
     {"ISLE_GEMM_BF16X3", "form", "0: the D x k x k dot products of the assignment steps on the f32 matrix cores (gemm_f32.h) instead of the bf16 ones with operands split in three terms (gemm_bf16x3.h)"},
     {"ISLE_GEMM_EPILOGUE", "form", "0: the D x k x k products of the assignment steps are written to memory and read by dots_assign_cm_k / proj_dots_tiles_k instead of the epilogues inside the product (same bits)"},
+    {"ISLE_GEMM_TERMS", "form", "3: the assignment products run once with three bf16 terms per operand (default: two terms first, the rows whose arg-min that leaves open again with three; same assignment)"},
     {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
     {"ISLE_YY_FUSED", "form", "0: the by-group Yinyang iteration lowers the bounds (yy_filter_k) and tightens the active documents (yy2_tighten_k) in two launches instead of one (same bits)"},
     {"ISLE_YY_MOVERS", "form", "0: every centre's movement lowers its Yinyang group's bound (default: up to ten centres that moved far beyond the rest are bounded by their exact new distances instead)"},

@@ -600,8 +600,8 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       if (yinyang && fused_first) {  // distances, group bounds and candidates formed inside the product: no D x k matrix in memory
         float* cn_max_dev = c->Csum.p + 2 * k + 8;
         ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
-        ISLECHK(k_gemm_assign_yy(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p, c->hub.p, c->yglb.p,
-                                 ISLE_T_SPARSE_ASSIGN));
+        ISLECHK(k_gemm_assign_yy(c, c->Pt.p, c->P.p, c->ldk, c->pnorm.p, D, k, c->lift_C.p, c->lift_ld, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p,
+                                 c->hub.p, c->yglb.p, ISLE_T_SPARSE_ASSIGN));
       } else if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
         HIPCHK(c, c->dotsT.reserve((size_t)D * k));
         ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));

@@ -86,7 +86,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_SUMS, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
@@ -270,6 +270,10 @@ struct isle_ctx {
   DevBuf<float> yy_gmax2;     // G floats: the groups' largest movements without the movers
   DevBuf<float> yy_mdots;     // D x 12: dot products of every document with the movers' centres (YyMovers)
   DevBuf<float> cmax_buf;     // one float: the largest centre norm of a full projected pass
+  DevBuf<uint32_t> ga_redo;   // rows the two-term pass of an assignment product left open (last = count), dense.hip gemm_assign_two_pass
+  DevBuf<float> ga_bn;             // squared norms of the product's columns and their maximum
+  DevBuf<float> ga_rows, ga_rown;  // those rows gathered coordinate-major, their squared norms
+  uint32_t ga_last_redo = 0;  // their number in the last product (diagnostic: isle_hip_measure)
   DevBuf<float> assign_part;  // per document and 64-column slot the best centre of the slot (16 bytes: k_gemm_assign_yy / _tiles, dense.hip)
   DevBuf<float> lift_C;    // the k x k coefficients the device-resident centres were lifted from (centres = U lift_C^T)
   int lift_ld = 0, lift_k = 0;
@@ -484,10 +488,11 @@ int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, in
 // the same product for the D x k x k dot products of the assignment steps: bf16 matrix cores, operands split in three bf16 terms (gemm_bf16x3.h)
 int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family);
 bool k_gemm_assign_fused_ok(isle_ctx* c, uint64_t M, int K, int N);
-int k_gemm_assign_yy(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, int G, const float* cn, const float* dn,
-                     const float* cn_max, uint32_t* assign, float* ub, float* lb, int family);
-int k_gemm_assign_tiles(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn, const float* pn,
-                        const float* cmax, uint32_t* assign, float* ub, float* tlb, int family);
+int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* an, uint64_t M, int K, const float* B, int ldb, int N, int G,
+                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family);
+int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
+                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family);
+int k_compact_rows(isle_ctx* c, const float* P, const float* pn, int ldk, const uint32_t* active, uint32_t n, float* Pa, float* pna);
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl
 int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x n col-major*/);
 int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev, int nvec);  // evd_tridiag.hip; 1 = use another solver; evals_host[nvec..n) = 0

@@ -783,10 +783,17 @@ int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float
 // again, and dots_assign_cm_k / proj_dots_tiles_k with their 12 + 10 ms per step are replaced by a pass over 16 candidates per document.
 // Same arithmetic on the same dot products as those kernels: assignments and bounds are bit-identical to the two-kernel route.
 // ------------------------------------------------------------------------------------------
+// Two passes since round 4 (ISLE_GEMM_TERMS=3: one): the product first runs with TWO bf16 terms per operand (three partial products, half
+// the matrix-core work: 58 against 108 ms for 10 M x 1000 x 1000) and every distance it forms is within  eps = GA_ETA (|row|^2 + max |c|^2)
+// of the three-term value — 3 * 2^-18 |a_k b_k| per term for the dropped a1 b1 and the two remainders, times two for the distance, plus
+// the f32 accumulation of both routes.  Lower bounds are taken from d - eps, the upper bound from d + eps; a row whose two smallest
+// distances are closer than 2 eps (its arg-min is not decided, exact ties included) goes on a list, and the listed rows are gathered and
+// run through the three-term product with the same epilogue: the assignment is, row by row, the three-term route's.
+constexpr float GA_ETA = 2.5e-5f;
 struct AssignRec {  // best of one 64-column slot of one document
   float m1;
   uint32_t i1;
-  float m2, ax;
+  float m2, ax, r2;  // runner-up of the best's group, largest aux of that group, smallest distance among the slot's other columns
 };
 struct YyGroupEpi {  // Lloyd on B: Yinyang groups of 8 centres (dots_assign_cm_k's rules)
   static constexpr int kGroup = 8;
@@ -796,108 +803,202 @@ struct YyGroupEpi {  // Lloyd on B: Yinyang groups of 8 centres (dots_assign_cm_
   float* __restrict__ lb;
   int G, nslot;
   AssignRec* __restrict__ part;
-  __device__ inline float rowdata(uint64_t m) const { return dn[m]; }
+  const uint32_t* __restrict__ map;  // row of the product -> document (null: identity)
+  float eta;                         // 0: three-term product
+  const float* __restrict__ an;      // squared norms of the product's rows (the projections) and the largest squared norm of its columns (the
+  const float* __restrict__ bmax;    // centres' coordinates): the operands the two-term error is relative to (dn, cn are word-space norms)
+  __device__ inline uint64_t doc(uint64_t m) const { return map ? map[m] : m; }
+  __device__ inline float rowdata(uint64_t m) const { return dn[doc(m)]; }
   __device__ inline float dist(float dot, int col, float dnd) const { return fabsf((-2.0f * dot + cn[col]) + dnd); }
   __device__ inline float aux(int) const { return 0.f; }
   __device__ inline void group(uint64_t m, int g, float dnd, float m1, uint32_t, float, float) const {
     const float E = 1e-4f * (dnd + *cn_max), sE = sqrtf(E);
-    lb[m * (uint64_t)G + g] = yy_slack_down_sq(m1, E, sE);
+    const float eps = eta > 0.f ? eta * (an[doc(m)] + *bmax) : 0.f;
+    lb[doc(m) * (uint64_t)G + g] = yy_slack_down_sq(fmaxf(m1 - eps, 0.f), E, sE);
   }
-  __device__ inline void slot(uint64_t m, int sl, float, float m1, uint32_t i1, float m2, float ax) const { part[m * (uint64_t)nslot + sl] = AssignRec{m1, i1, m2, ax}; }
+  __device__ inline void slot(uint64_t m, int sl, float, float m1, uint32_t i1, float m2, float ax, float r2) const {
+    part[m * (uint64_t)nslot + sl] = AssignRec{m1, i1, m2, ax, r2};
+  }
 };
-__global__ __launch_bounds__(256) void yy_first_combine_k(const AssignRec* __restrict__ part, int nslot, uint32_t D, int G, const float* __restrict__ dn,
-                                                          const float* __restrict__ cn_max, uint32_t* __restrict__ assign, float* __restrict__ ub,
-                                                          float* __restrict__ lb) {
-  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float best = 3.4e38f, m2 = 3.4e38f;
-  uint32_t bidx = 0xffffffffu;
+// the row's winner over its slots, and whether the runner-up leaves it open (two-term pass only)
+struct AssignPick {
+  float best, m2, ax, run2;
+  uint32_t bidx;
+};
+__device__ inline AssignPick assign_pick(const AssignRec* __restrict__ part, size_t row, int nslot) {
+  AssignPick p{3.4e38f, 3.4e38f, 0.f, 3.4e38f, 0xffffffffu};
   for (int sl = 0; sl < nslot; ++sl) {  // ascending columns: a tie keeps the earlier centre
-    const AssignRec r = part[(size_t)d * nslot + sl];
-    if (r.m1 < best) {
-      best = r.m1;
-      bidx = r.i1;
-      m2 = r.m2;
+    const AssignRec r = part[row * nslot + sl];
+    if (r.m1 < p.best) {
+      p.run2 = fminf(fminf(p.run2, p.best), r.r2);
+      p.best = r.m1;
+      p.bidx = r.i1;
+      p.m2 = r.m2;
+      p.ax = r.ax;
+    } else {
+      p.run2 = fminf(p.run2, r.m1);
     }
   }
-  const float E = 1e-4f * (dn[d] + *cn_max), sE = sqrtf(E);
-  lb[(size_t)d * G + bidx / 8] = yy_slack_down_sq(m2, E, sE);  // the assigned centre's group: its closest OTHER member
-  const float u = sqrtf(best);
-  ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
-  assign[d] = bidx;
+  return p;
+}
+__global__ __launch_bounds__(256) void yy_first_combine_k(const AssignRec* __restrict__ part, int nslot, uint32_t n, int G, const float* __restrict__ dn,
+                                                          const float* __restrict__ cn_max, uint32_t* __restrict__ assign, float* __restrict__ ub,
+                                                          float* __restrict__ lb, const uint32_t* __restrict__ map, float eta,
+                                                          const float* __restrict__ an, const float* __restrict__ bmax,
+                                                          uint32_t* __restrict__ redo, uint32_t* __restrict__ nredo) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < n;
+  bool open = false;
+  if (in) {
+    const uint32_t d = map ? map[i] : i;
+    const AssignPick p = assign_pick(part, i, nslot);
+    const float eps = eta > 0.f ? eta * (an[d] + *bmax) : 0.f;
+    const float E = 1e-4f * (dn[d] + *cn_max), sE = sqrtf(E);
+    lb[(size_t)d * G + p.bidx / 8] = yy_slack_down_sq(fmaxf(p.m2 - eps, 0.f), E, sE);  // the assigned centre's group: its closest OTHER member
+    const float u = sqrtf(p.best + eps);
+    ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
+    assign[d] = p.bidx;
+    open = eta > 0.f && p.run2 - p.best <= 2.f * eps;
+  }
+  if (eta > 0.f) {  // uniform over the launch
+    const uint32_t at = block_append_slot(open, nredo);
+    if (open) redo[at] = map ? map[i] : i;
+  }
 }
 struct TileEpi {  // Lloyd in span(U): tiles of 32 centres (proj_dots_tiles_k's rules)
   static constexpr int kGroup = 32;
   const float* __restrict__ cn;
   const float* __restrict__ pn;
+  const float* __restrict__ cmax;
   float* __restrict__ lb;
   int TL, nslot;
   AssignRec* __restrict__ part;
-  __device__ inline float rowdata(uint64_t m) const { return pn[m]; }
+  const uint32_t* __restrict__ map;
+  float eta;
+  __device__ inline uint64_t doc(uint64_t m) const { return map ? map[m] : m; }
+  __device__ inline float rowdata(uint64_t m) const { return pn[doc(m)]; }
   __device__ inline float dist(float dot, int col, float nd) const { return fabsf((-2.0f * dot + cn[col]) + nd); }
   __device__ inline float aux(int col) const { return cn[col]; }
   __device__ inline void group(uint64_t m, int T, float nd, float m1, uint32_t, float, float tc) const {
     float uu, ll;
-    hamerly_store_bounds(m1, m1, nd + tc, &uu, &ll);
-    lb[m * (uint64_t)TL + T] = ll;
+    const float lo = fmaxf(m1 - eta * (nd + *cmax), 0.f);
+    hamerly_store_bounds(lo, lo, nd + tc, &uu, &ll);
+    lb[doc(m) * (uint64_t)TL + T] = ll;
   }
-  __device__ inline void slot(uint64_t m, int sl, float, float m1, uint32_t i1, float m2, float ax) const { part[m * (uint64_t)nslot + sl] = AssignRec{m1, i1, m2, ax}; }
+  __device__ inline void slot(uint64_t m, int sl, float, float m1, uint32_t i1, float m2, float ax, float r2) const {
+    part[m * (uint64_t)nslot + sl] = AssignRec{m1, i1, m2, ax, r2};
+  }
 };
-__global__ __launch_bounds__(256) void tiles_combine_k(const AssignRec* __restrict__ part, int nslot, uint32_t D, int TL, const float* __restrict__ pn,
+__global__ __launch_bounds__(256) void tiles_combine_k(const AssignRec* __restrict__ part, int nslot, uint32_t n, int TL, const float* __restrict__ pn,
                                                        const float* __restrict__ cmax_p, uint32_t* __restrict__ assign, float* __restrict__ ub,
-                                                       float* __restrict__ lb) {
-  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float best = 3.4e38f, second = 3.4e38f, btc = 0.f;
-  uint32_t bidx = 0xffffffffu;
-  for (int sl = 0; sl < nslot; ++sl) {
-    const AssignRec r = part[(size_t)d * nslot + sl];
-    if (r.m1 < best) {
-      best = r.m1;
-      bidx = r.i1;
-      second = r.m2;
-      btc = r.ax;
-    }
+                                                       float* __restrict__ lb, const uint32_t* __restrict__ map, float eta,
+                                                       uint32_t* __restrict__ redo, uint32_t* __restrict__ nredo) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < n;
+  bool open = false;
+  if (in) {
+    const uint32_t d = map ? map[i] : i;
+    const AssignPick p = assign_pick(part, i, nslot);
+    const float nd = pn[d];
+    const float eps = eta * (nd + *cmax_p);
+    assign[d] = p.bidx;
+    float uu, ll, l2;
+    hamerly_store_bounds(p.best + eps, fmaxf(p.m2 - eps, 0.f), nd + p.ax, &uu, &l2);
+    hamerly_store_bounds(p.best + eps, p.best + eps, nd + *cmax_p, &uu, &ll);
+    ub[d] = uu;
+    lb[(size_t)d * TL + (p.bidx >> 5)] = l2;  // the assigned centre's tile: closest OTHER centre in it
+    open = eta > 0.f && p.run2 - p.best <= 2.f * eps;
   }
-  const float nd = pn[d];
-  assign[d] = bidx;
-  float uu, ll, l2;
-  hamerly_store_bounds(best, second, nd + btc, &uu, &l2);
-  hamerly_store_bounds(best, best, nd + *cmax_p, &uu, &ll);
-  ub[d] = uu;
-  lb[(size_t)d * TL + (bidx >> 5)] = l2;  // the assigned centre's tile: closest OTHER centre in it
+  if (eta > 0.f) {
+    const uint32_t at = block_append_slot(open, nredo);
+    if (open) redo[at] = map ? map[i] : i;
+  }
 }
-// may the fused route be taken?  (the three-term bf16 product with 256 x 256 tiles; small products keep the two-kernel route)
+// may the fused route be taken?  (the bf16 product with 256 x 256 tiles; small products keep the two-kernel route)
 bool k_gemm_assign_fused_ok(isle_ctx* c, uint64_t M, int K, int N) {
   return !c->knob_zero(KN_GEMM_BF16X3) && !c->knob_zero(KN_GEMM_EPILOGUE) && N >= 64 && K >= 32 && (M + 255) / 256 * (uint64_t)((N + 255) / 256) >= 512 &&
          M < (1ull << 32);
 }
-// assign / ub / lb (D x G Yinyang group bounds) of the first assignment of Lloyd on B from A (D x k projection, coordinate-major) and the
-// k lifted centres' coordinates B (k x k, leading dimension ldb): dots_assign_cm_k's outputs without the D x k product in memory
-int k_gemm_assign_yy(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, int G, const float* cn, const float* dn,
-                     const float* cn_max, uint32_t* assign, float* ub, float* lb, int family) {
-  TimeScope ts(c, family);
+using Gemm2Huge = isle_gemm3::Cfg<2, 2, 4, 4, 4, 16, 2>;  // the same tile with two bf16 terms per operand
+// Both assignment steps: first pass (two terms unless ISLE_GEMM_TERMS=3) over all rows, then the rows it left open through the three-term
+// product.  make(map, eta) builds the epilogue, combine(part, n, map, eta, redo, nredo) launches the step's combine kernel.
+template <class MakeEpi, class Combine>
+static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* rown, uint64_t M, int K, const float* B, int ldb, int N,
+                                MakeEpi make, Combine combine) {
   const int nslot = (N + 63) / 64;
+  static_assert(sizeof(AssignRec) == 20, "");
+  const char* gt = c->knob(KN_GEMM_TERMS);
+  const bool two = !(gt && atoi(gt) == 3) && Arm != nullptr;
   HIPCHK(c, c->gemm_b3.reserve((size_t)3 * isle_gemm3::kp8_of(K) * isle_gemm3::np_of<Gemm3Huge>(N)));
-  HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 4));
+  HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 5));
   AssignRec* part = reinterpret_cast<AssignRec*>(c->assign_part.p);
-  HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, YyGroupEpi{cn, dn, cn_max, lb, G, nslot, part}));
-  hipLaunchKernelGGL(yy_first_combine_k, dim3(cdiv(M, 256)), dim3(256), 0, c->stream, part, nslot, (uint32_t)M, G, dn, cn_max, assign, ub, lb);
+  if (!two) {
+    HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, nullptr, 0.f)));
+    combine(part, (uint32_t)M, nullptr, 0.f, nullptr, nullptr);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  HIPCHK(c, c->ga_redo.reserve(M + 1));
+  uint32_t* nredo = c->ga_redo.p + M;
+  HIPCHK(c, hipMemsetAsync(nredo, 0, sizeof(uint32_t), c->stream));
+  HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, nullptr, GA_ETA)));
+  combine(part, (uint32_t)M, nullptr, GA_ETA, c->ga_redo.p, nredo);
+  HIPCHK(c, hipGetLastError());
+  uint32_t* n_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 192);  // page-locked
+  HIPCHK(c, hipMemcpyAsync(n_pin, nredo, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint32_t n = *n_pin;
+  c->ga_last_redo = n;
+  if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[assignment product] the two-term pass left %u of %llu rows open\n", n, (unsigned long long)M);
+  if (n == 0) return 0;
+  if ((uint64_t)n * 4 > M) {  // hardly a saving left: the whole product again with three terms
+    HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, nullptr, 0.f)));
+    combine(part, (uint32_t)M, nullptr, 0.f, nullptr, nullptr);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  // the open rows, gathered coordinate-major (the product's A layout); the list is in arrival order — every row's result is its own
+  HIPCHK(c, c->ga_rows.reserve((size_t)n * lda_rm));
+  HIPCHK(c, c->ga_rown.reserve(n));
+  ISLECHK(k_compact_rows(c, Arm, rown, lda_rm, c->ga_redo.p, n, c->ga_rows.p, c->ga_rown.p));
+  HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, c->ga_rows.p, (uint64_t)n, K, B, ldb, N, c->gemm_b3.p, make(part, c->ga_redo.p, 0.f)));
+  combine(part, n, c->ga_redo.p, 0.f, nullptr, nullptr);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-// the same for the full pass of Lloyd in span(U): assign / ub / one lower bound per tile of 32 centres (row stride TL); cmax = max |c|^2 on the device
-int k_gemm_assign_tiles(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn, const float* pn,
-                        const float* cmax, uint32_t* assign, float* ub, float* tlb, int family) {
+// assign / ub / lb (D x G Yinyang group bounds) of the first assignment of Lloyd on B from A (D x k projection, coordinate-major; Arm the
+// same rows row-major with leading dimension lda_rm, for the second pass) and the k lifted centres' coordinates B (k x k, leading dimension
+// ldb): dots_assign_cm_k's outputs without the D x k product in memory
+int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* an, uint64_t M, int K, const float* B, int ldb, int N, int G,
+                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family) {
   TimeScope ts(c, family);
   const int nslot = (N + 63) / 64;
-  HIPCHK(c, c->gemm_b3.reserve((size_t)3 * isle_gemm3::kp8_of(K) * isle_gemm3::np_of<Gemm3Huge>(N)));
-  HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 4));
-  AssignRec* part = reinterpret_cast<AssignRec*>(c->assign_part.p);
-  HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, TileEpi{cn, pn, tlb, TL, nslot, part}));
-  hipLaunchKernelGGL(tiles_combine_k, dim3(cdiv(M, 256)), dim3(256), 0, c->stream, part, nslot, (uint32_t)M, TL, pn, cmax, assign, ub, tlb);
-  HIPCHK(c, hipGetLastError());
-  return 0;
+  // largest squared norm of the product's columns (rows of B as stored: centre n's K coordinates)
+  HIPCHK(c, c->ga_bn.reserve((size_t)N + 4));
+  float* bmax = c->ga_bn.p + N;
+  if (an) {
+    ISLECHK(k_rownorms(c, B, N, K, ldb, c->ga_bn.p));
+    ISLECHK(k_max_f32(c, c->ga_bn.p, N, bmax));
+  }
+  return gemm_assign_two_pass(
+      c, A, an ? Arm : nullptr, lda_rm, an, M, K, B, ldb, N,
+      [&](AssignRec* part, const uint32_t* map, float eta) { return YyGroupEpi{cn, dn, cn_max, lb, G, nslot, part, map, eta, an, bmax}; },
+      [&](const AssignRec* part, uint32_t n, const uint32_t* map, float eta, uint32_t* redo, uint32_t* nredo) {
+        hipLaunchKernelGGL(yy_first_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, G, dn, cn_max, assign, ub, lb, map, eta, an, bmax, redo,
+                           nredo);
+      });
+}
+// the same for the full pass of Lloyd in span(U): assign / ub / one lower bound per tile of 32 centres (row stride TL); cmax = max |c|^2 on the device
+int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
+                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family) {
+  TimeScope ts(c, family);
+  const int nslot = (N + 63) / 64;
+  return gemm_assign_two_pass(
+      c, A, Arm, lda_rm, pn, M, K, B, ldb, N,
+      [&](AssignRec* part, const uint32_t* map, float eta) { return TileEpi{cn, pn, cmax, tlb, TL, nslot, part, map, eta}; },
+      [&](const AssignRec* part, uint32_t n, const uint32_t* map, float eta, uint32_t* redo, uint32_t* nredo) {
+        hipLaunchKernelGGL(tiles_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, TL, pn, cmax, assign, ub, tlb, map, eta, redo, nredo);
+      });
 }
 
 // in: element (r, cidx) at in[cidx*ld_in + r], r < rows, cidx < cols.  out[r*ld_out + cidx] = in(r, cidx).

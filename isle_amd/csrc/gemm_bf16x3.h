@@ -55,17 +55,21 @@ __global__ __launch_bounds__(256) void gemm3_split_b_k(const float* __restrict__
   for (int p = 0; p < 3; ++p) B3[((size_t)p * Kp8 + q) * Np + n] = v[p];
 }
 
-template <int WMT_, int WNT_, int WAVES_M_, int WAVES_N_, int OCC_, int TK_ = 16>
+// NP_ = 3: the six products above.  NP_ = 2: x ~ x0 + x1 (the remainder is below 2^-17 |x|) and a b ~ a0 b0 + (a0 b1 + a1 b0): three
+// products, |error| <= 2^-16 |a b| per term (a1 b1 <= 2^-18, the two remainders 2^-17 each) — for callers that carry that bound along
+// (dense.hip: the assignment steps widen their bounds by it and recompute the rows whose arg-min it leaves open with NP_ = 3).
+template <int WMT_, int WNT_, int WAVES_M_, int WAVES_N_, int OCC_, int TK_ = 16, int NP_ = 3>
 struct Cfg {
   static constexpr int WMT = WMT_, WNT = WNT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, OCC = OCC_, TK = TK_;  // TK: 16 or 32 (one or two MFMA k-steps per slab)
+  static constexpr int NP = NP_;     // bf16 terms per operand
   static constexpr int KO = TK / 8;  // k-octets per slab
   static constexpr int TM = 32 * WMT * WAVES_M, TN = 32 * WNT * WAVES_N;
   static constexpr int NT = 64 * WAVES_M * WAVES_N;
-  static constexpr int A_STAGE = 3 * KO * TM, B_STAGE = 3 * KO * TN;  // 16-byte units per stage: [plane 3][octet KO][row]
+  static constexpr int A_STAGE = NP * KO * TM, B_STAGE = NP * KO * TN;  // 16-byte units per stage: [plane NP][octet KO][row]
   static constexpr size_t LDS_BYTES = (size_t)2 * (A_STAGE + B_STAGE) * 16;
   static constexpr int A_UNITS = TM * (TK / 4) / NT;        // k-quads (4 floats of one row) per thread and slab
   static constexpr int B_UNITS = (B_STAGE + NT - 1) / NT;   // 16-byte units of the split B per thread and slab
-  static_assert(TM * (TK / 4) % NT == 0 && (TK == 16 || TK == 32), "tile / thread counts");
+  static_assert(TM * (TK / 4) % NT == 0 && (TK == 16 || TK == 32) && (NP == 2 || NP == 3), "tile / thread counts");
 };
 
 struct StoreC {
@@ -79,7 +83,7 @@ struct StoreC {
 // from its accumulators  dist(value, column, rowdata(row))  for every column, the smallest distance with its first column, the runner-up
 // and the largest aux(column), and hands them to  group(row, group index, rowdata, m1, i1, m2, auxmax)  (one lane per row and group); per
 // row and per 64-column slot (the columns one wave owns) the best of the slot's groups goes to  slot(row, slot index, rowdata, m1, i1,
-// m2 of that group, auxmax of that group).  The assignment steps of k-means use this (dense.hip): group bounds and the per-slot
+// m2 of that group, auxmax of that group, smallest distance among the slot's other columns).  The assignment steps of k-means use this (dense.hip): group bounds and the per-slot
 // candidates leave the kernel, a small kernel picks the row's winner — instead of D x k x 4 bytes written and read again.
 // A lane holds, of a row of a 32 x 32 tile, columns (r & 3) + 8 (r >> 2) + 4 h in register r (h = lane / 32): a group of 8 is registers
 // 4 q .. 4 q + 3 of the lanes l and l + 32, a group of 32 all sixteen of both; the lane pair is merged by __shfl_xor(., 32).
@@ -116,10 +120,10 @@ __device__ inline void top2_pair(Top2& t) {  // with the lane that holds the oth
 template <class CF, class Epi>
 __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __restrict__ A, uint64_t M, int K, const bf16x8* __restrict__ B3, int Kp8,
                                                                   int Np, int N, uint32_t nMB, uint32_t nNT, Epi epi) {
-  constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, WMT = CF::WMT, WNT = CF::WNT, TK = CF::TK, KO = CF::KO;
+  constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, WMT = CF::WMT, WNT = CF::WNT, TK = CF::TK, KO = CF::KO, NP = CF::NP;
   extern __shared__ bf16x8 lds3[];
-  bf16x8* As = lds3;                    // [2][3][2][TM]
-  bf16x8* Bs = lds3 + 2 * CF::A_STAGE;  // [2][3][2][TN]
+  bf16x8* As = lds3;                    // [2][NP][KO][TM]
+  bf16x8* Bs = lds3 + 2 * CF::A_STAGE;  // [2][NP][KO][TN]
   // tile of this workgroup: xcd = id % 8 owns row blocks xcd, xcd + 8, ...; its N-tiles are consecutive slots (gemm_f32.h)
   const uint32_t wg = blockIdx.x, xcd = wg & 7u, slot = wg >> 3;
   const uint32_t mb = (slot / nNT) * 8u + xcd, nt = slot % nNT;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
         v[2][t] = t2;
       }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(a + ((size_t)((p * KO + (akq[u] >> 1)) * TM + row)) * 16 + (akq[u] & 1) * 8) = v[p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(a + ((size_t)((p * KO + (akq[u] >> 1)) * TM + row)) * 16 + (akq[u] & 1) * 8) = v[p];
     }
     uint4* b = reinterpret_cast<uint4*>(Bs + stage * CF::B_STAGE);
 #pragma unroll
@@ -205,20 +209,20 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
 #pragma unroll
     for (int ks = 0; ks < TK / 16; ++ks) {
       const int oc = 2 * ks + h;  // the lane's octet of this k-step
-      bf16x8 bv[WNT][3];
+      bf16x8 bv[WNT][NP];
 #pragma unroll
       for (int j = 0; j < WNT; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bv[j][p] = b[(p * KO + oc) * TN + 32 * j];
+        for (int p = 0; p < NP; ++p) bv[j][p] = b[(p * KO + oc) * TN + 32 * j];
       // the small terms first: a2 b0; a1 b1, a1 b0; a0 b2, a0 b1, a0 b0 — and the wave's WMT x WNT accumulators in turn inside a term, so
       // that an MFMA never waits for the one before it
 #pragma unroll
-      for (int pa = 2; pa >= 0; --pa) {
+      for (int pa = NP - 1; pa >= 0; --pa) {
         bf16x8 av[WMT];
 #pragma unroll
         for (int i = 0; i < WMT; ++i) av[i] = a[(pa * KO + oc) * TM + 32 * i];
 #pragma unroll
-        for (int pb = 2 - pa; pb >= 0; --pb)
+        for (int pb = NP - 1 - pa; pb >= 0; --pb)
 #pragma unroll
           for (int i = 0; i < WMT; ++i)
 #pragma unroll
@@ -237,6 +241,15 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
       const bool live = m < M;
       const float rd = epi.rowdata(live ? m : M - 1);
       Top2 best{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};  // of this wave's columns (one 64-column slot per 32 WNT columns ... WNT = 2)
+      float run2 = 3.4e38f;                           // smallest distance of the slot's columns other than best.i1
+      auto fold = [&](const Top2& t) {                // groups in ascending order: a tie keeps the earlier group's (lower) column
+        if (t.m1 < best.m1) {
+          run2 = fminf(fminf(run2, best.m1), t.m2);
+          best = t;
+        } else {
+          run2 = fminf(run2, t.m1);
+        }
+      };
 #pragma unroll
       for (int j = 0; j < WNT; ++j) {
         const int cb = n0 + wn * (32 * WNT) + j * 32;  // first column of the 32 x 32 tile
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
             top2_pair(t);
             if (cb + 8 * q < N) {  // wave-uniform
               if (live && h == (q & 1)) epi.group(m, (cb >> 3) + q, rd, t.m1, t.i1, t.m2, t.ax);
-              if (t.m1 < best.m1) best = t;  // groups in ascending order: a tie keeps the earlier group's (lower) column
+              fold(t);
             }
           }
         } else {
@@ -273,10 +286,10 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
           }
           top2_pair(t);
           if (live && h == (j & 1)) epi.group(m, cb >> 5, rd, t.m1, t.i1, t.m2, t.ax);
-          if (t.m1 < best.m1) best = t;
+          fold(t);
         }
       }
-      if (live && h == 0 && n0 + wn * (32 * WNT) < N) epi.slot(m, (n0 + wn * (32 * WNT)) / (32 * WNT), rd, best.m1, best.i1, best.m2, best.ax);
+      if (live && h == 0 && n0 + wn * (32 * WNT) < N) epi.slot(m, (n0 + wn * (32 * WNT)) / (32 * WNT), rd, best.m1, best.i1, best.m2, best.ax, run2);
     }
   } else {
   // lane owns row m = l31 of each 32 x 32 tile; register r holds column (r & 3) + 8 (r >> 2) + 4 h

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) void compact_rows64_k(const float* __restrict_
   if (threadIdx.x < 64 && i0 + threadIdx.x < n) pna[i0 + threadIdx.x] = pn[myd];
 }
 
-static int k_compact_rows(isle_ctx* c, const float* P, const float* pn, int ldk, const uint32_t* active, uint32_t n, float* Pa, float* pna) {
+int k_compact_rows(isle_ctx* c, const float* P, const float* pn, int ldk, const uint32_t* active, uint32_t n, float* Pa, float* pna) {
   if (n >= 4096 && ldk >= 256 && ldk % 4 == 0) {
     const size_t lds = (size_t)64 * 257 * sizeof(float);
     ISLECHK(isle_max_lds(c, (const void*)compact_rows64_k, (int)lds));
@@ -1010,7 +1010,7 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
       if (k_gemm_assign_fused_ok(c, D, k, k)) {  // distances, tile bounds and candidates formed inside the product: no D x k matrix in memory
         HIPCHK(c, c->cmax_buf.reserve(4));
         ISLECHK(k_max_f32(c, cn, k, c->cmax_buf.p));
-        return k_gemm_assign_tiles(c, c->Pt.p, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ);
+        return k_gemm_assign_tiles(c, c->Pt.p, P, ldk, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ);
       }
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
       ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));

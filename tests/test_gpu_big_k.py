@@ -247,6 +247,38 @@ def test_centroid_sums_kept_up_to_date_agree_with_fresh_sums(hp, monkeypatch, ca
     assert np.abs(a1["C_lowd"] - fr["C_lowd"]).max() <= 1e-5 * np.abs(fr["C_lowd"]).max()
 
 
+def test_two_term_assignment_products_give_the_three_term_assignment(hp, monkeypatch):
+    """The two D x k x k assignment products run with TWO bf16 terms per operand first (three partial products instead of six); every
+    distance is then within 2.5e-5 (|row|^2 + max |centre|^2) of the three-term value, bounds are widened by that much, and the rows whose
+    two smallest distances are closer than twice that are run again through the three-term product (dense.hip gemm_assign_two_pass).
+    ISLE_GEMM_TERMS=3 runs the three-term product alone.  Partitions, iteration counts and centres bit-equal in both loops
+    (src/sparseMatrix.cpp:1794-1871, 1494-1572) — also when centres coincide, so that every document near them is left open."""
+    from tools.synth import make_B
+    V, D, k = 6000, 140_000, 1000
+    B = make_B(V, D, k, 78)
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=5)
+    twins = g["C_lowd"].copy()
+    twins[1::2] = twins[0::2]  # every centre twice: the arg-min of every document is an exact tie: every row is left open
+    for start in (g["C_lowd"], twins):
+        out = {}
+        for name, env in (("two", {"ISLE_KMPP_TRACK": "0"}), ("three", {"ISLE_KMPP_TRACK": "0", "ISLE_GEMM_TERMS": "3"})):
+            for a, b in env.items():
+                monkeypatch.setenv(a, b)
+            lp = hp.run_lloyds_on_projected_space(k, start, max_reps=3)
+            hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+            ls = hp.run_lloyds(k, max_reps=3)
+            out[name] = (lp, ls)
+            for a in env:
+                monkeypatch.delenv(a)
+        for i in (0, 1):
+            assert out["two"][i]["iters"] == out["three"][i]["iters"]
+            assert np.array_equal(out["two"][i]["assign"], out["three"][i]["assign"]), float((out["two"][i]["assign"] == out["three"][i]["assign"]).mean())
+        assert np.array_equal(out["two"][0]["C_lowd"].view(np.uint32), out["three"][0]["C_lowd"].view(np.uint32))
+        assert np.array_equal(out["two"][1]["centers"].view(np.uint32), out["three"][1]["centers"].view(np.uint32))
+
+
 def test_full_tile_pass_by_library_gemm_equals_the_fused_kernel(hp, monkeypatch):
     """At large k the full passes of the projected Lloyd (iteration 0, and later iterations with more than half the documents
     active) are one library GEMM over the coordinate-major projection plus proj_dots_tiles_k; the fused matrix-core kernel
