@@ -8,7 +8,7 @@ SRCS=${@:-gram_lds.hip}
 HERE=$(cd "$(dirname "$0")" && pwd); CS=$HERE/../isle_amd/csrc; OUT=$HERE/variants; mkdir -p $OUT/obj_$NAME
 make -s -C $CS ../libisle_hip.so
 OBJS=""
-for o in api spmm gram_lds evd_tridiag dense kmeans threshold post ingest infer; do
+for o in api api_ks api_kmeans api_stages spmm gram_lds evd_tridiag dense kmeans threshold post ingest infer; do
   src=""; for s in $SRCS; do [ "${s%.*}" = "$o" ] && src=$s; done
   if [ -n "$src" ]; then
     x=""; [ "${src##*.}" = "cpp" ] && x="-x hip"
