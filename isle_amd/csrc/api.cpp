@@ -63,6 +63,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_YY_MOVERS", "form", "0: every centre's movement lowers its Yinyang group's bound (default: up to ten centres that moved far beyond the rest are bounded by their exact new distances instead)"},
     {"ISLE_YY_ORDER", "form", "doc: the by-group Yinyang iteration visits the documents in their own order instead of the member lists' (same bits)"},
     {"ISLE_PT_SORT", "form", "0: the active documents of a projected Lloyd iteration keep the order of the member lists (default: ordered by the set of tiles they have to re-examine, so that a workgroup's documents ask for the same tiles; same partitions)"},
+    {"ISLE_PROJ_ACTIVE", "form", "tiles: the active documents of a projected Lloyd iteration re-examine only the tiles their bounds name (register kernel, f32 matrix cores); default gemm: all centres through the assignment product on their gathered rows wherever that product is taken (every tile bound refreshed, the arithmetic of the full passes)"},
     {"ISLE_PROJ_SUMS", "form", "fresh: the centroid sums of Lloyd in span(U) are formed from all member rows every iteration (default: kept up to date by the documents that changed centre; both bitwise reproducible, the two differ in rounding)"},
     {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
     {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},

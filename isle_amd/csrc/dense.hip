@@ -924,7 +924,7 @@ using Gemm2Huge = isle_gemm3::Cfg<2, 2, 4, 4, 4, 16, 2>;  // the same tile with 
 // product.  make(map, eta) builds the epilogue, combine(part, n, map, eta, redo, nredo) launches the step's combine kernel.
 template <class MakeEpi, class Combine>
 static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* rown, uint64_t M, int K, const float* B, int ldb, int N,
-                                MakeEpi make, Combine combine) {
+                                MakeEpi make, Combine combine, const uint32_t* map0 = nullptr /*row of A -> document (null: identity)*/) {
   const int nslot = (N + 63) / 64;
   static_assert(sizeof(AssignRec) == 20, "");
   const char* gt = c->knob(KN_GEMM_TERMS);
@@ -933,16 +933,16 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
   HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 5));
   AssignRec* part = reinterpret_cast<AssignRec*>(c->assign_part.p);
   if (!two) {
-    HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, nullptr, 0.f)));
-    combine(part, (uint32_t)M, nullptr, 0.f, nullptr, nullptr);
+    HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, 0.f)));
+    combine(part, (uint32_t)M, map0, 0.f, nullptr, nullptr);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
   HIPCHK(c, c->ga_redo.reserve(M + 1));
   uint32_t* nredo = c->ga_redo.p + M;
   HIPCHK(c, hipMemsetAsync(nredo, 0, sizeof(uint32_t), c->stream));
-  HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, nullptr, GA_ETA)));
-  combine(part, (uint32_t)M, nullptr, GA_ETA, c->ga_redo.p, nredo);
+  HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, GA_ETA)));
+  combine(part, (uint32_t)M, map0, GA_ETA, c->ga_redo.p, nredo);
   HIPCHK(c, hipGetLastError());
   uint32_t* n_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 192);  // page-locked
   HIPCHK(c, hipMemcpyAsync(n_pin, nredo, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -952,8 +952,8 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
   if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[assignment product] the two-term pass left %u of %llu rows open\n", n, (unsigned long long)M);
   if (n == 0) return 0;
   if ((uint64_t)n * 4 > M) {  // hardly a saving left: the whole product again with three terms
-    HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, nullptr, 0.f)));
-    combine(part, (uint32_t)M, nullptr, 0.f, nullptr, nullptr);
+    HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, 0.f)));
+    combine(part, (uint32_t)M, map0, 0.f, nullptr, nullptr);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
@@ -990,7 +990,7 @@ int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, 
 }
 // the same for the full pass of Lloyd in span(U): assign / ub / one lower bound per tile of 32 centres (row stride TL); cmax = max |c|^2 on the device
 int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
-                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family) {
+                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0) {
   TimeScope ts(c, family);
   const int nslot = (N + 63) / 64;
   return gemm_assign_two_pass(
@@ -998,7 +998,8 @@ int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_r
       [&](AssignRec* part, const uint32_t* map, float eta) { return TileEpi{cn, pn, cmax, tlb, TL, nslot, part, map, eta}; },
       [&](const AssignRec* part, uint32_t n, const uint32_t* map, float eta, uint32_t* redo, uint32_t* nredo) {
         hipLaunchKernelGGL(tiles_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, TL, pn, cmax, assign, ub, tlb, map, eta, redo, nredo);
-      });
+      },
+      map0);
 }
 
 // in: element (r, cidx) at in[cidx*ld_in + r], r < rows, cidx < cols.  out[r*ld_out + cidx] = in(r, cidx).

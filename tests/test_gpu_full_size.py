@@ -120,21 +120,22 @@ def test_config3_at_its_own_size(hp, monkeypatch):
     del o, AU
     g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
     # Lloyd in span(U): bounds on / off.  Bit for bit where both runs evaluate a distance by the same kernel (every pass by the register
-    # kernel proj_assign_reg_k: ISLE_PROJ_FULL=fused, no hand-over from the k-means++ rounds); the default run takes its full passes through
+    # kernel proj_assign_reg_k: ISLE_PROJ_FULL=fused, ISLE_PROJ_ACTIVE=tiles, no hand-over from the k-means++ rounds); the default run takes its full passes through
     # the GEMM and starts from what k-means++ kept — other summation orders, so a near-tie between two centres may fall the other way there
-    # (first measured here: 1 document of 10 M)
+    # (first measured here: 1 document of 10 M; 13 since the active documents go through the product as well)
     lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
     monkeypatch.setenv("ISLE_PROJ_FULL", "fused")
+    monkeypatch.setenv("ISLE_PROJ_ACTIVE", "tiles")
     monkeypatch.setenv("ISLE_KMPP_TRACK", "0")
     lp1 = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
     monkeypatch.setenv("ISLE_NO_HAMERLY", "1")
     lp0 = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
-    for name in ("ISLE_NO_HAMERLY", "ISLE_PROJ_FULL", "ISLE_KMPP_TRACK"):
+    for name in ("ISLE_NO_HAMERLY", "ISLE_PROJ_FULL", "ISLE_PROJ_ACTIVE", "ISLE_KMPP_TRACK"):
         monkeypatch.delenv(name)
     assert lp1["iters"] == lp0["iters"]
     assert np.array_equal(lp1["assign"], lp0["assign"]), float((lp1["assign"] == lp0["assign"]).mean())
     assert np.array_equal(lp1["C_lowd"].view(np.uint32), lp0["C_lowd"].view(np.uint32))
-    assert lp["iters"] == lp0["iters"] and (lp["assign"] == lp0["assign"]).mean() >= 1.0 - 2e-6, float((lp["assign"] == lp0["assign"]).mean())
+    assert lp["iters"] == lp0["iters"] and (lp["assign"] == lp0["assign"]).mean() >= 1.0 - 5e-6, float((lp["assign"] == lp0["assign"]).mean())
     del lp0, lp1
     # Lloyd on B: bounds on / off
     hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
