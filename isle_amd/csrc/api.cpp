@@ -129,6 +129,7 @@ void isle_host_mark(const char* what) {
 
 TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
   if (fam < 0 || !c->timing || !((c->timing_mask >> fam) & 1u)) return;
+  if (c->ts_open) return;  // inside another scope (a launcher called by a launcher): the outer one times both, nothing is counted twice
   if (!c->ev_free.empty()) {
     ep = c->ev_free.back();
     c->ev_free.pop_back();
@@ -137,9 +138,11 @@ TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
   }
   ep.fam = fam;
   on = (hipEventRecord(ep.a, c->stream) == hipSuccess);
+  if (on) c->ts_open = true;
 }
 TimeScope::~TimeScope() {
   if (!on) return;
+  c->ts_open = false;
   (void)hipEventRecord(ep.b, c->stream);
   c->ev_used.push_back(ep);
 }

@@ -273,6 +273,7 @@ struct isle_ctx {
   DevBuf<uint32_t> ga_redo;   // rows the two-term pass of an assignment product left open (last = count), dense.hip gemm_assign_two_pass
   DevBuf<float> ga_bn;             // squared norms of the product's columns and their maximum
   DevBuf<float> ga_rows, ga_rown;  // those rows gathered coordinate-major, their squared norms
+  bool ts_open = false;       // a TimeScope is open (nested scopes are not timed again)
   uint32_t ga_last_redo = 0;  // their number in the last product (diagnostic: isle_hip_measure)
   DevBuf<float> assign_part;  // per document and 64-column slot the best centre of the slot (16 bytes: k_gemm_assign_yy / _tiles, dense.hip)
   DevBuf<float> lift_C;    // the k x k coefficients the device-resident centres were lifted from (centres = U lift_C^T)

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_cnt_k(const uint32_t* __restr
     if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[base + band];
     const uint32_t sr = (wave_max_u32(n) + 3) >> 2;
     if (lane == 0) {
-      if (sr > 0xffffu) *overflow = 1;
+      if (sr > 0x7fffu) *overflow = 1;  // bit 15 marks a half last super-round (gl_place_k)
       cnt[(wv * NB + band) * GL_GMAX + g] = (uint16_t)sr;
       sh[g] = sr;
     }
@@ -442,7 +442,7 @@ __device__ inline int gl_lane_group(int lane) {  // the four ds_read_b128 lane g
 // LDS of a wave is sized by it — 16 slots per lane for up to 4 super-rounds (most slices), 32 beyond — and eight slices share a workgroup
 // whatever the items per lane of the side are, so that the latency-bound claim loop runs at 16 ... 32 waves per CU.
 template <int MAXN, int MINN>
-__global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid0, size_t nslices, const uint16_t* __restrict__ cnt,
+__global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid0, size_t nslices, uint16_t* __restrict__ cnt,
                                                    const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
   constexpr int MS = 4 * MAXN;  // slots per lane
   __shared__ uint16_t ent_s[8][MS][64], out_s[8][MS][64];
@@ -452,13 +452,14 @@ __global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid
   if (sid >= nslices) return;
   const size_t wb = sid / (size_t)G;
   const int g = (int)(sid - wb * (size_t)G);
-  const uint16_t* cc = cnt + wb * GL_GMAX;
-  const uint32_t n = cc[g];
+  // (bit 15 of a count is set by this kernel and gl_scale_ids_k, other waves of the same launch among them: counts are read masked)
+  const volatile uint16_t* cc = cnt + wb * GL_GMAX;
+  const uint32_t n = cc[g] & 0x7fffu;
   if (n <= (uint32_t)MINN || n > (uint32_t)MAXN) return;  // wave-uniform
   int64_t sr0 = roff[wb];
-  for (int j = 0; j < g; ++j) sr0 += cc[j];
+  for (int j = 0; j < g; ++j) sr0 += cc[j] & 0x7fffu;
   uint2* s = ids + (size_t)sr0 * 64 + lane;
-  const uint32_t S = 4 * n;
+  const uint32_t S4 = 4 * n;
   volatile uint16_t(*ent)[64] = ent_s[wq];
   volatile uint16_t(*out)[64] = out_s[wq];
   volatile uint32_t(*taken)[16] = taken_s[wq];
@@ -476,10 +477,17 @@ __global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid
       len += id[t] < GL_RB ? 1u : 0u;
     }
   }
+  // No lane has more than 4 n - 2 entries: the last two slots of the last super-round stay empty in EVERY lane, bit 15 of the count says so
+  // and gl_apply_k does not read them (half of the slices: 8 % of the LDS reads of a pass).  The entries are then placed in S = 4 n - 2 slots.
+  uint32_t mxlen = len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mxlen = max(mxlen, (uint32_t)__shfl_xor((int)mxlen, off));
+  const bool half_last = mxlen + 2 <= S4;
+  const uint32_t S = half_last ? S4 - 2 : S4;
   taken[lane >> 4][lane & 15] = 0u;
   taken32[lane >> 5][lane & 31] = 0u;
   if (lane < 32) owner[lane >> 4][lane & 15] = 0xffffffffu;
-  for (uint32_t i = lane; i < 4 * S; i += 64) occ[i / S][i % S] = 0u;
+  for (uint32_t i = lane; i < 4 * S4; i += 64) occ[i / S4][i % S4] = 0u;
   const uint32_t maskS = S == 32 ? 0xffffffffu : (1u << S) - 1u;
   uint32_t used = 0, j = 0, st = ((uint32_t)lane * 7u) % S;
   while (true) {
@@ -514,12 +522,12 @@ __global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid
   }
   // padding rows: slot = lane; per half one class that is free in both lane groups (else one per group)
   uint32_t o[4] = {0, 0, 0, 0};
-  if ((uint32_t)lane < S) {
+  if ((uint32_t)lane < S4) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = occ[q][lane] & 0xffffu;
   }
   __builtin_amdgcn_wave_barrier();
-  if ((uint32_t)lane < S) {
+  if ((uint32_t)lane < S4) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t both = ~(o[2 * h] | o[2 * h + 1]) & 0xffffu;
@@ -541,28 +549,34 @@ __global__ __launch_bounds__(512) void gl_place_k(uint32_t NB, int G, size_t sid
     }
     s[(size_t)r * 64] = make_uint2((v[0] | (v[1] << 16)) << 3, (v[2] | (v[3] << 16)) << 3);  // stored as byte offsets in the half plane (8 id)
   }
+  if (half_last && lane == 0) cnt[wb * GL_GMAX + g] = (uint16_t)(n | 0x8000u);
 }
 
 // The stream gl_apply_k reads holds 8 * id (the row's byte offset in the float2 half plane; twice that in a float4 plane): gl_place_k
 // writes that form, this kernel converts the slices it leaves alone (more than GL_PLACE_MAXN super-rounds; all of them with ISLE_GL_PLACE=0).
 // ids are below 4096: the shift of a packed pair does not carry from the low id into the high one.
-__global__ __launch_bounds__(512) void gl_scale_ids_k(int G, size_t sid0, size_t nslices, uint32_t min_n, const uint16_t* __restrict__ cnt,
+__global__ __launch_bounds__(512) void gl_scale_ids_k(int G, size_t sid0, size_t nslices, uint32_t min_n, uint16_t* __restrict__ cnt,
                                                        const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
   const int lane = threadIdx.x & 63;
   const size_t sid = sid0 + (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
   if (sid >= nslices) return;
   const size_t wb = sid / (size_t)G;
   const int g = (int)(sid - wb * (size_t)G);
-  const uint16_t* cc = cnt + wb * GL_GMAX;
-  const uint32_t n = cc[g];
+  const volatile uint16_t* cc = cnt + wb * GL_GMAX;
+  const uint32_t n = cc[g] & 0x7fffu;
   if (n <= min_n) return;
   int64_t sr0 = roff[wb];
-  for (int j = 0; j < g; ++j) sr0 += cc[j];
+  for (int j = 0; j < g; ++j) sr0 += cc[j] & 0x7fffu;
   uint2* s = ids + (size_t)sr0 * 64 + lane;
+  uint32_t len = 0;  // these slices keep their entries packed at the front: the same rule for the last two slots as in gl_place_k
   for (uint32_t r = 0; r < n; ++r) {
     const uint2 u = s[(size_t)r * 64];
+    len += ((u.x & 0xffffu) < GL_RB) + ((u.x >> 16) < GL_RB) + ((u.y & 0xffffu) < GL_RB) + ((u.y >> 16) < GL_RB);
     s[(size_t)r * 64] = make_uint2(u.x << 3, u.y << 3);
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, off));
+  if (len + 2 <= 4 * n && lane == 0) cnt[wb * GL_GMAX + g] = (uint16_t)(n | 0x8000u);
 }
 
 // total super-rounds of every (word block, band zone): the weights used to size the band chunks.  grid = (blocks, zones)
@@ -605,13 +619,15 @@ __device__ inline void add4(float4& a, const float4 b) {
 // four-register id ring loaded by inline asm — built to cut the padded slots (2.17x -> 1.52x) and the id latency; measured no faster in
 // either pass, twice, and removed in round 3.)
 // the four rows of ring entry U into the accumulators of group g (inside gl_apply_k)
-#define GL_ROWS(U)                                                                                                      \
+#define GL_ROWS(U) GL_ROWS_N(U, 4)
+#define GL_ROWS_N(U, NR)                                                                                                \
   {                                                                                                                     \
     const uint32_t a8[4] = {U.x & 0xffffu, U.x >> 16, U.y & 0xffffu, U.y >> 16};                                        \
-    _Pragma("unroll") for (int t2 = 0; t2 < 4; t2 += GL_INFLIGHT) {                                                    \
-      float4 v[GL_INFLIGHT][NFA];                                                                                       \
-      float2 h[GL_INFLIGHT];                                                                                            \
-      _Pragma("unroll") for (int t = 0; t < GL_INFLIGHT; ++t) {                                                         \
+    constexpr int GL_STEP = GL_INFLIGHT < (NR) ? GL_INFLIGHT : (NR);                                                    \
+    _Pragma("unroll") for (int t2 = 0; t2 < (NR); t2 += GL_STEP) {                                                     \
+      float4 v[GL_STEP][NFA];                                                                                           \
+      float2 h[GL_STEP];                                                                                                \
+      _Pragma("unroll") for (int t = 0; t < GL_STEP; ++t) {                                                             \
         const uint32_t a8x = (GL_ABLATE & 4) ? (a8[t2 + t] & 8u) : a8[t2 + t];                                          \
         const uint32_t b16 = (a8x << 1) + p0s;                                                                          \
         if (GL_ABLATE & 16) {                                                                                           \
@@ -623,14 +639,14 @@ __device__ inline void add4(float4& a, const float4 b) {
           if (HALF) h[t] = gl_lds_f2(a8x);                                                                              \
         }                                                                                                               \
       }                                                                                                                 \
-      _Pragma("unroll") for (int t = 0; t < GL_INFLIGHT; ++t) {                                                         \
+      _Pragma("unroll") for (int t = 0; t < GL_STEP; ++t) {                                                             \
         _Pragma("unroll") for (int l = 0; l < NF; ++l) add4(acc[g][l], v[t][l]);                                        \
         if (HALF) {                                                                                                     \
           acch[g].x += h[t].x;                                                                                          \
           acch[g].y += h[t].y;                                                                                          \
         }                                                                                                               \
       }                                                                                                                 \
-      if (GL_INFLIGHT < 4) __builtin_amdgcn_sched_barrier(0);                                                           \
+      if (GL_STEP < (NR)) __builtin_amdgcn_sched_barrier(0);                                                            \
     }                                                                                                                   \
   }
 // loads from an LDS byte address (the dynamic LDS of gl_apply_k starts at address 0: the kernel has no static LDS)
@@ -762,7 +778,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
     if (!wvalid) cw[0] = cw[1] = cw[2] = cw[3] = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)((cw[g >> 1] >> (16 * (g & 1))) & 0xffffu));  // a scalar loop count
+      const uint32_t nf = (uint32_t)__builtin_amdgcn_readfirstlane((int)((cw[g >> 1] >> (16 * (g & 1))) & 0xffffu));
+      // bit 15 (gl_place_k / gl_scale_ids_k): every lane's last two slots of the group's last super-round are padding — only its first two are read
+      const bool half_last = (GL_ABLATE & 128) ? (nf & 0x7fffu) != 0u : (nf >> 15) != 0u;
+      const uint32_t n = nf & 0x7fffu;  // a scalar loop count
       // two super-rounds per step: the ring moves by PAIRS (q0 = q2; q1 = q3; two loads), so the moves read entries loaded one whole step
       // = two super-rounds earlier.  (Rotating by one — q0 = q1; ... q3 = *p — the move reads the load issued the step before and every
       // step waits for it, s_waitcnt vmcnt(0) at the head of the loop: one load in flight where the ring was meant to keep four.  A C3
@@ -784,7 +803,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
           if (!(GL_ABLATE & 8)) p += 128;
         }
         GL_ROWS(ua)
-        GL_ROWS(ub)
+        if (half_last && r + 2 == n) {
+          GL_ROWS_N(ub, 2)
+        } else {
+          GL_ROWS(ub)
+        }
       }
       if (r < n) {
         const uint2 ua = q0;
@@ -795,7 +818,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
         }
         q3 = gl_ld_ids(p);
         if (!(GL_ABLATE & 8)) p += 64;
-        GL_ROWS(ua)
+        if (half_last) {
+          GL_ROWS_N(ua, 2)
+        } else {
+          GL_ROWS(ua)
+        }
       }
 #if GL_STAMPS
       st_sr += n;
@@ -857,6 +884,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
 }
 
 #undef GL_ROWS
+#undef GL_ROWS_N
 
 // packed panel (planar, banded: gl_planar_off) = s_w * M[w, j0 : j0 + ncol)  (zero padded), M row-major with leading dimension ld: one panel
 // of a wide operand.  One thread per (row, plane); with `half` the last plane holds two columns (float2).
@@ -1450,6 +1478,25 @@ int k_gl_build(isle_ctx* c) {
         fprintf(stderr, " %llu/%u", t, nch[ob]);
       }
       fprintf(stderr, "\n");
+    }
+    if (c->knob_on(KN_GL_VERBOSE)) {  // how many (wave, band, group) slices end in a half super-round, and the slices' lengths
+      for (const GlSide* sd : {&s1, &s2}) {
+        const size_t ncnt = (size_t)sd->nwv * sd->NB * GL_GMAX;
+        std::vector<uint16_t> h(ncnt);
+        HIPCHK(c, hipMemcpy(h.data(), sd->cnt.p, ncnt * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        unsigned long long nsl = 0, nhalf = 0, sr = 0, hist[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < ncnt; ++i) {
+          const uint32_t n = h[i] & 0x7fffu;
+          if (!n) continue;
+          ++nsl;
+          nhalf += h[i] >> 15;
+          sr += n;
+          ++hist[n < 5 ? n : 5];
+        }
+        fprintf(stderr, "[gram_lds] pass %d: %llu slices, %llu super-rounds, %.1f %% end in a half one; slices of 1/2/3/4/5+ super-rounds: %.1f %.1f %.1f %.1f %.1f %%\n",
+                sd == &s1 ? 1 : 2, nsl, sr, 100.0 * nhalf / std::max(1ull, nsl), 100.0 * hist[1] / std::max(1ull, nsl), 100.0 * hist[2] / std::max(1ull, nsl),
+                100.0 * hist[3] / std::max(1ull, nsl), 100.0 * hist[4] / std::max(1ull, nsl), 100.0 * hist[5] / std::max(1ull, nsl));
+      }
     }
     if (c->knob_on(KN_GL_VERBOSE))
       fprintf(stderr,
