@@ -142,6 +142,12 @@ int isle_hip_gram_apply(isle_ctx* ctx, const float* X_colmajor, int b, float* Z_
  * Environment ISLE_GRAM_LDS=0 forces the gather form. */
 int isle_hip_operator_form(isle_ctx* ctx, int* form);
 
+/* The environment switches the library honours (no reference counterpart: the reference's choices are compile-time macros,
+ * include/hyperparams.h).  Every switch is in ONE table (isle_amd/csrc/common.h IsleKnob); entry `index` of it: its name, its kind
+ * ("form": selects between exact forms of one computation, "tuning", "diagnostic", "test hook") and a sentence on its effect.
+ * Returns the number of switches (also for index out of range, with the outputs untouched).  Needs no context and no GPU. */
+int isle_hip_switch_info(int index, const char** name, const char** kind, const char** what);
+
 /* FPSparseMatrix::compute_block_ks  src/sparseMatrix.cpp:1195-1220  driving
  * BlockKs<ProdOp>(op, nev, ncv, maxit, blk, tol) init()+compute()
  * block-ks/restarted_block_ks.h:190-321.  The reference passes

@@ -11,6 +11,7 @@ SYMBOLS = {
     "isle_hip_create": (_P, [_I]),
     "isle_hip_destroy": (None, [_P]),
     "isle_hip_last_error": (C.c_char_p, [_P]),
+    "isle_hip_switch_info": (_I, [_I, _P, _P, _P]),
     "isle_hip_comm_unique_id": (_I, [_P]),
     "isle_hip_comm_init": (_I, [_P, _I, _I, _P]),
     "isle_hip_comm_init_host": (_I, [_P, _I, _I, _P, _P]),

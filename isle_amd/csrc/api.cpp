@@ -127,6 +127,15 @@ void isle_host_mark(const char* what) {
   if (ms >= 0.2) fprintf(stderr, "[host] %8.3f ms before %s\n", ms, what);
 }
 
+extern "C" int isle_hip_switch_info(int index, const char** name, const char** kind, const char** what) {
+  if (index >= 0 && index < KN_COUNT) {
+    if (name) *name = isle_knob_table[index].name;
+    if (kind) *kind = isle_knob_table[index].kind;
+    if (what) *what = isle_knob_table[index].what;
+  }
+  return KN_COUNT;
+}
+
 TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
   if (fam < 0 || !c->timing || !((c->timing_mask >> fam) & 1u)) return;
   if (c->ts_open) return;  // inside another scope (a launcher called by a launcher): the outer one times both, nothing is counted twice

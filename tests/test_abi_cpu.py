@@ -29,6 +29,36 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert isinstance(lib, ctypes.CDLL)
 
 
+def test_every_environment_switch_is_in_the_table_and_in_the_design_document():
+    """One table holds every switch (common.h IsleKnob, exported by isle_hip_switch_info); the sources read the environment nowhere else, and
+    DESIGN.md section 8 lists exactly the table's switches."""
+    import ctypes as C
+    import isle_amd
+    lib = isle_amd.load_library()
+    n = lib.isle_hip_switch_info(-1, None, None, None)
+    assert n >= 30
+    names, kinds = [], []
+    for i in range(n):
+        a, b, w = C.c_char_p(), C.c_char_p(), C.c_char_p()
+        assert lib.isle_hip_switch_info(i, C.byref(a), C.byref(b), C.byref(w)) == n
+        names.append(a.value.decode())
+        kinds.append(b.value.decode())
+        assert w.value and len(w.value) > 10
+    assert len(set(names)) == n and all(x.startswith("ISLE_") for x in names)
+    assert set(kinds) <= {"form", "tuning", "diagnostic", "test hook"}
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    sec = design[design.index("## 8. Environment switches"):design.index("## 9. Out of scope")]
+    listed = set(re.findall(r"^\| `(ISLE_[A-Z0-9_]+)` \|", sec, flags=re.M))
+    assert listed == set(names), (sorted(listed - set(names)), sorted(set(names) - listed))
+    # no getenv("ISLE_...") outside the table's reader (ISLE_HOST_TRACE is read once per process, before any context exists)
+    src = os.path.join(ROOT, "isle_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            txt = open(os.path.join(src, f)).read()
+            for m in re.finditer(r'getenv\("(ISLE_[A-Z0-9_]+)"\)', txt):
+                assert m.group(1) == "ISLE_HOST_TRACE", (f, m.group(1))
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
