@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void gemm3_split_b_k(const float* __restrict__
   for (int p = 0; p < 3; ++p) B3[((size_t)p * Kp8 + q) * Np + n] = v[p];
 }
 
-// NP_ = 3: the six products above.  NP_ = 2: x ~ x0 + x1 (the remainder is below 2^-17 |x|) and a b ~ a0 b0 + (a0 b1 + a1 b0): three
-// products, |error| <= 2^-16 |a b| per term (a1 b1 <= 2^-18, the two remainders 2^-17 each) — for callers that carry that bound along
+// NP_ = 3: the six products above.  NP_ = 2: x ~ x0 + x1 (the remainder is at most 2^-16 |x|: bf16 rounds to 8 significand bits) and
+// a b ~ a0 b0 + (a0 b1 + a1 b0): three products, |error| <= 3 * 2^-16 |a b| per term (a1 b1 and the two remainders, 2^-16 each; 1e-6 on
+// data) — for callers that carry that bound along
 // (dense.hip: the assignment steps widen their bounds by it and recompute the rows whose arg-min it leaves open with NP_ = 3).
 template <int WMT_, int WNT_, int WAVES_M_, int WAVES_N_, int OCC_, int TK_ = 16, int NP_ = 3>
 struct Cfg {
