@@ -316,9 +316,9 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
                                 else "bf16x3 (both operands split in three bf16 terms, six of the nine partial products kept on v_mfma_f32_32x32x16_bf16, f32 "
                                      "accumulation; error against fp64 5.6e-8 of sum|a b| vs 8.6e-8 for the f32 matrix cores; gemm_bf16x3.h)"
                                 if os.environ.get("ISLE_GEMM_TERMS") == "3" else
-                                "bf16x2 then bf16x3 (two bf16 terms per operand first: three partial products, every distance within 5.5e-5 (|row|^2 + max |c|^2) "
+                                "bf16x2 then bf16x3 (two bf16 terms per operand first: three partial products, every distance within 8.2e-5 (|row|^2 + max |c|^2) "
                                 "of the three-term value, bounds widened by that; the rows whose two smallest distances are closer than twice that — "
-                                "0.04 % at config 3 — are run again with three terms (six products, error against fp64 5.6e-8 of sum|a b|): the assignment "
+                                "0.06 % at config 3 — are run again with three terms (six products, error against fp64 5.6e-8 of sum|a b|): the assignment "
                                 "is the three-term product's, bit for bit; gemm_bf16x3.h, dense.hip gemm_assign_two_pass)"),
     }
     out = {

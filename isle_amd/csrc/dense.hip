@@ -784,14 +784,17 @@ int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float
 // Same arithmetic on the same dot products as those kernels: assignments and bounds are bit-identical to the two-kernel route.
 // ------------------------------------------------------------------------------------------
 // Two passes since round 4 (ISLE_GEMM_TERMS=3: one): the product first runs with TWO bf16 terms per operand (three partial products, half
-// the matrix-core work: 58 against 108 ms for 10 M x 1000 x 1000) and every distance it forms is within  eps = GA_ETA (|row|^2 + max |c|^2)
+// the matrix-core work: 58 against 108 ms for 10 M x 1000 x 1000) and every distance it forms is within  eps = ga_eta(K) (|row|^2 + max |c|^2)
 // of the three-term value: bf16 keeps 8 significand bits (rounding error <= 2^-8 |x|), so |x1| <= 2^-8 |x| and the remainder x - x0 - x1 is
 // <= 2^-16 |x|; the dropped a1 b1 and the two remainders are <= 3 * 2^-16 |a_k b_k| per term, the dot product is within 4.6e-5 |a| |b| <=
-// 2.3e-5 (|a|^2 + |b|^2), the distance within twice that = 4.6e-5 (|a|^2 + |b|^2); the rest of GA_ETA covers the f32 accumulation of both
-// routes (tests/test_two_term_bound_cpu.py checks the chain in NumPy; measured on data: 1e-6).  Lower bounds are taken from d - eps, the upper bound from d + eps; a row whose two smallest
+// 2.3e-5 (|a|^2 + |b|^2), the distance within twice that = 4.6e-5 (|a|^2 + |b|^2) = GA_ETA_TRUNC (tests/test_two_term_bound_cpu.py checks the
+// chain in NumPy).  The f32 accumulation of the two routes is bounded the worst-case way as well: an accumulator takes 3 (6) MFMA results per
+// 16 k, each addition within 2^-24 of the running sum <= sum |a_k b_k|, i.e. 9 ceil(K / 16) 2^-24 for both routes together: ga_eta(1000) =
+// 8.2e-5.  (On data the two routes differ by 1e-6; the margin costs a few thousand more rows in the second pass.)  Lower bounds are taken from d - eps, the upper bound from d + eps; a row whose two smallest
 // distances are closer than 2 eps (its arg-min is not decided, exact ties included) goes on a list, and the listed rows are gathered and
 // run through the three-term product with the same epilogue: the assignment is, row by row, the three-term route's.
-constexpr float GA_ETA = 5.5e-5f;
+constexpr float GA_ETA_TRUNC = 4.65e-5f;
+static float ga_eta(int K) { return GA_ETA_TRUNC + 1.05f * 9.f * (float)((K + 15) / 16) * 5.9604645e-8f; }
 struct AssignRec {  // best of one 64-column slot of one document
   float m1;
   uint32_t i1;
@@ -940,11 +943,12 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
     HIPCHK(c, hipGetLastError());
     return 0;
   }
+  const float eta2 = ga_eta(K);
   HIPCHK(c, c->ga_redo.reserve(M + 1));
   uint32_t* nredo = c->ga_redo.p + M;
   HIPCHK(c, hipMemsetAsync(nredo, 0, sizeof(uint32_t), c->stream));
-  HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, GA_ETA)));
-  combine(part, (uint32_t)M, map0, GA_ETA, c->ga_redo.p, nredo);
+  HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, eta2)));
+  combine(part, (uint32_t)M, map0, eta2, c->ga_redo.p, nredo);
   HIPCHK(c, hipGetLastError());
   uint32_t* n_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 192);  // page-locked
   HIPCHK(c, hipMemcpyAsync(n_pin, nredo, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
