@@ -70,49 +70,54 @@ std::string log_dir_name(uint64_t num_topics, const std::string& base, bool samp
 // concat_float (include/utils.h:405-478): "<topic>\t<word>\t<weight>\n", 1-based, entries <= 1e-8 skipped, the weight
 // written as integer part, '.', then SIX digits produced by repeated multiplication in FPTYPE — truncated, not rounded
 // (the before_dec / after_dec arguments of concat_float never reach ftoa_mv).
+// The weight's text, exactly as the reference's writer emits it: the integer part in decimal (at most its six low digits), a point, then six
+// fraction digits peeled off one at a time by multiplying the float remainder by ten (single precision, truncating).  Returns the length.
+inline size_t weight_text(float w, char* out) {
+  size_t len = 0;
+  unsigned int whole = (unsigned int)w;
+  char digits[8];
+  int nd = 0;
+  do {
+    digits[nd++] = (char)('0' + whole % 10);
+    whole /= 10;
+  } while (whole > 0 && nd < 6);
+  while (nd > 0) out[len++] = digits[--nd];
+  out[len++] = '.';
+  float rest = w - (float)((int)w);
+  for (int place = 0; place < 6; ++place) {
+    rest *= 10;
+    const int digit = (int)rest;
+    out[len++] = (char)('0' + digit);
+    rest -= digit;
+  }
+  return len;
+}
 void write_dense_as_sparse(const std::string& filename, const float* M, uint64_t vocab_size, uint64_t ncols) {
-  std::string buf;
-  buf.reserve(1 << 24);
-  FILE* f = std::fopen(filename.c_str(), "wb");
-  if (!f) throw std::runtime_error("cannot open " + filename);
-  char tmp[64];
-  for (uint64_t topic = 0; topic < ncols; ++topic)
-    for (uint64_t word = 0; word < vocab_size; ++word) {
-      float num = M[topic * vocab_size + word];
-      if (!(num > 0.00000001f)) continue;
-      buf += std::to_string(topic + 1);
-      buf += '\t';
-      buf += std::to_string(word + 1);
-      buf += '\t';
-      int i = 0;
-      unsigned int num_int = (unsigned int)num;
-      if (num_int == 0) {
-        tmp[i++] = '0';
-      } else {
-        char rev[16];
-        int n = 0;
-        for (int d = 0; d < 6 && num_int > 0; ++d) {
-          rev[n++] = (char)('0' + num_int % 10);
-          num_int /= 10;
-        }
-        while (n) tmp[i++] = rev[--n];
-      }
-      tmp[i++] = '.';
-      float frac = num - (float)((int)num);
-      for (int d = 0; d < 6; ++d) {
-        frac *= 10;
-        tmp[i++] = (char)('0' + (int)frac);
-        frac -= (int)frac;
-      }
-      tmp[i++] = '\n';
-      buf.append(tmp, (size_t)i);
-      if (buf.size() > (1u << 24) - 256) {
-        std::fwrite(buf.data(), 1, buf.size(), f);
-        buf.clear();
+  constexpr size_t kFlushAt = (size_t(1) << 24) - 256;
+  FILE* fp = std::fopen(filename.c_str(), "wb");
+  if (!fp) throw std::runtime_error("cannot open " + filename);
+  std::string pending;
+  pending.reserve(size_t(1) << 24);
+  char text[32];
+  for (uint64_t col = 0; col < ncols; ++col) {
+    const float* column = M + col * vocab_size;
+    for (uint64_t row = 0; row < vocab_size; ++row) {
+      const float w = column[row];
+      if (!(w > 0.00000001f)) continue;  // the reference skips entries at or below 1e-8
+      pending += std::to_string(col + 1);
+      pending += '\t';
+      pending += std::to_string(row + 1);
+      pending += '\t';
+      pending.append(text, weight_text(w, text));
+      pending += '\n';
+      if (pending.size() > kFlushAt) {
+        std::fwrite(pending.data(), 1, pending.size(), fp);
+        pending.clear();
       }
     }
-  std::fwrite(buf.data(), 1, buf.size(), f);
-  std::fclose(f);
+  }
+  std::fwrite(pending.data(), 1, pending.size(), fp);
+  std::fclose(fp);
 }
 }  // namespace trainer_detail
 
