@@ -92,49 +92,77 @@ void read_sparse_model(const std::string& path, uint64_t num_topics, uint64_t vo
   *entries = n;
 }
 
-// MMappedOutput::concat_float -> ftoa_mv (include/utils.h:421-478): integer part, '.', six digits by repeated multiplication in
-// FPTYPE (truncated, not rounded)
-void append_float(std::string& s, float num) {
-  if (num == 0.0f) {
-    s += "0.0";
+// The weight as the reference's writer prints it (MMappedOutput::concat_float, include/utils.h:421-478): "0.0" for zero, a sign, the integer
+// part, a point, and six fraction digits taken one at a time by multiplying the single-precision remainder by ten (truncating).
+void append_weight(std::string& out, float w) {
+  if (w == 0.0f) {
+    out += "0.0";
     return;
   }
-  if (num < 0.f) {
-    s += '-';
-    num = -num;
+  if (w < 0.f) {
+    out += '-';
+    w = -w;
   }
-  s += std::to_string((unsigned int)num);
-  s += '.';
-  float frac = num - (float)((int)num);
-  for (int d = 0; d < 6; ++d) {
-    frac *= 10;
-    s += (char)('0' + (int)frac);
-    frac -= (int)frac;
+  out += std::to_string((unsigned int)w);
+  out += '.';
+  float rest = w - (float)((int)w);
+  for (int place = 0; place < 6; ++place) {
+    rest *= 10;
+    const int digit = (int)rest;
+    out += (char)('0' + digit);
+    rest -= digit;
   }
+}
+
+// the eleven positional arguments (drivers/ISLEInfer.cpp:11-33: this order is the interface)
+struct InferArgs {
+  std::string model_path, docs_path, out_dir;
+  uint64_t topics = 0, vocab = 0, first_doc = 0, last_doc = 0, doc_entries = 0;
+  int iterations = 0;
+  float lipschitz = 0.f;
+};
+
+[[noreturn]] void usage() {
+  // the reference's wording, as scripts may grep for it
+  std::cout << "Incorrect usage of ISLEInfer. Use: \n"
+            << "inferFromFile <sparse_model_file> <infer_file> <output_dir> "
+            << "<num_topics> <vocab_size> <min_doc_id_in_infer_file> <max_doc_id_in_infer_file>"
+            << "<nnzs_in_infer_file> <nnzs_in_sparse_model_file> "
+            << "<iters>[0 for default]  "
+            << "Lifschitz_constant_guess>[0 for default]" << std::endl;
+  std::exit(-1);
+}
+
+InferArgs read_args(int argc, char** argv) {
+  if (argc != 12) usage();
+  InferArgs a;
+  a.model_path = argv[1];
+  a.docs_path = argv[2];
+  a.out_dir = argv[3];
+  a.topics = std::strtoull(argv[4], nullptr, 10);
+  a.vocab = std::strtoull(argv[5], nullptr, 10);
+  a.first_doc = std::strtoull(argv[6], nullptr, 10);
+  a.last_doc = std::strtoull(argv[7], nullptr, 10);
+  a.doc_entries = std::strtoull(argv[8], nullptr, 10);
+  // argv[9], the model's entry count, is not needed: the model file is read to its end
+  a.iterations = (int)std::strtol(argv[10], nullptr, 10);
+  if (a.iterations == 0) a.iterations = 15;  // INFER_ITERS_DEFAULT, include/hyperparams.h:81
+  a.lipschitz = std::strtof(argv[11], nullptr);
+  if (a.lipschitz == 0.0f) a.lipschitz = 10.0f;  // INFER_LF_DEAFULT :82
+  if (a.topics < 1 || a.vocab < 1 || a.last_doc < a.first_doc) throw std::runtime_error("bad <num_topics> / <vocab_size> / document range");
+  return a;
 }
 
 }  // namespace
 
-int main(int argv, char** argc) {
-  if (argv != 12) {
-    std::cout << "Incorrect usage of ISLEInfer. Use: \n"
-              << "inferFromFile <sparse_model_file> <infer_file> <output_dir> "
-              << "<num_topics> <vocab_size> <min_doc_id_in_infer_file> <max_doc_id_in_infer_file>"
-              << "<nnzs_in_infer_file> <nnzs_in_sparse_model_file> "
-              << "<iters>[0 for default]  "
-              << "Lifschitz_constant_guess>[0 for default]" << std::endl;
-    exit(-1);
-  }
+int main(int argc, char** argv) {
   try {
-    const std::string sparse_model_file = argc[1], infer_file = argc[2], output_dir = argc[3];
-    const uint64_t num_topics = (uint64_t)atol(argc[4]), vocab_size = (uint64_t)atol(argc[5]);
-    const uint64_t doc_begin = (uint64_t)atol(argc[6]), doc_end = (uint64_t)atol(argc[7]);
-    const uint64_t max_entries = (uint64_t)atol(argc[8]);
-    int iters = (int)atol(argc[10]);
-    if (iters == 0) iters = 15;  // INFER_ITERS_DEFAULT, include/hyperparams.h:81
-    float Lfguess = (float)atof(argc[11]);
-    if (Lfguess == 0.0f) Lfguess = 10.0f;  // INFER_LF_DEAFULT :82
-    if (num_topics < 1 || vocab_size < 1 || doc_end < doc_begin) throw std::runtime_error("bad <num_topics> / <vocab_size> / document range");
+    const InferArgs args = read_args(argc, argv);
+    const std::string &sparse_model_file = args.model_path, &infer_file = args.docs_path, &output_dir = args.out_dir;
+    const uint64_t num_topics = args.topics, vocab_size = args.vocab, doc_begin = args.first_doc, doc_end = args.last_doc;
+    const uint64_t max_entries = args.doc_entries;
+    const int iters = args.iterations;
+    const float Lfguess = args.lipschitz;
 
     std::cout << "Loading sparse model file: " << sparse_model_file << std::endl;
     std::vector<float> model_by_word;
@@ -183,7 +211,7 @@ int main(int argv, char** argc) {
           buf += '\t';
           buf += std::to_string(1 + top_topic[d * 5 + i]);
           buf += '\t';
-          append_float(buf, top_weight[d * 5 + i]);
+          append_weight(buf, top_weight[d * 5 + i]);
           buf += '\n';
           if (buf.size() > (1u << 24)) {
             std::fwrite(buf.data(), 1, buf.size(), f);
