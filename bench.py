@@ -2,7 +2,10 @@
 """bench.py — ISLE training hot path (truncated SVD + k-means) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1, either form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...` (the launcher's RANK / WORLD_SIZE are used), or plain `python bench.py --gpus N ...`: with no launcher environment the
+    script itself starts N fresh rank processes, one per GPU, before any torch / HIP call (launch_ranks), forwards rank 0's line and
+    returns the worst exit status.  Fewer than N visible GPUs is an error unless ISLE_BENCH_REHEARSE=1.
 
 A *step* is one pass of the hot path of ISLETrainer::train() (reference src/trainer.cpp:490-571) over the
 device-resident thresholded matrix B: compute_block_ks -> kmeans_init_on_projected_space ->
@@ -62,6 +65,43 @@ def csc_columns(B, cols):
     return dict(vals=B["vals"][idx], rows=B["rows"][idx], offs=so)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: start N fresh rank processes of this script (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1) and wait for them.  The parent makes no torch or HIP
+    call, before or after: the children are new processes, nothing is exec'ed from a process that holds the GPU.  Rank 0 inherits this
+    process's stdout (its one JSON line is the result), the other ranks' stdout goes to stderr.  Returns the worst exit status; when one
+    rank fails the others are given 30 s to notice (their collectives would wait for ever) and are then ended by PID."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr.fileno()))
+    log("bench.py launcher: started %d ranks (pids %s), rendezvous 127.0.0.1:%d" % (n, [p.pid for p in procs], port))
+    worst, first_failure = 0, None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc not in (None, 0) and first_failure is None:
+                first_failure = time.time()
+                log("bench.py launcher: rank %d exited with status %d" % (r, rc))
+        if first_failure is not None and time.time() - first_failure > 30:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    for p in procs:
+        rc = p.returncode
+        worst = max(worst, rc if rc >= 0 else 128 - rc)
+    return worst
+
+
 def main():
     # stdout carries exactly ONE line, the JSON result: libraries that write to file descriptor 1 on their own (Gloo reports its
     # connections there when a process group is created) are sent to stderr, the result goes to the saved descriptor
@@ -81,11 +121,16 @@ def main():
     ap.add_argument("--blk", type=int, default=0, help="experiment: block size of the eigensolver (0 = the reference's 10)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has made no torch / HIP call and makes none)
+        os.dup2(result_fd, 1)
+        os.close(result_fd)
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
     if world > 1 and "OMP_NUM_THREADS" not in os.environ:  # the ranks share the node's cores (corpus generation, thresholding)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // max(local_world, 1)))
@@ -93,6 +138,12 @@ def main():
     if defaulted:
         args.workload = "c3"
     import torch
+    if world > 1 and os.environ.get("ISLE_BENCH_REHEARSE") != "1":
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        ndev = torch.cuda.device_count()  # counts, does not initialise the device
+        if ndev < local_world:
+            raise SystemExit("bench.py: --gpus %d needs %d GPUs on this node, %d visible (ISLE_BENCH_REHEARSE=1 rehearses the N-rank flow on "
+                             "GPU 0 through the host-staged test transport; its line is marked as not a measurement)" % (args.gpus, local_world, ndev))
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -110,6 +161,12 @@ def main():
                                    "avg_gram_apply_ms": sec["roofline"]["avg_launch_ms"]}
         except Exception as e:  # the headline line must not depend on the secondary run
             out["secondary_c2"] = {"error": repr(e)[:300]}
+    if out is not None and defaulted and world == 1 and not args.no_secondary:
+        # SURVEY 8(d)'s second figure: full ISLETrain wall time, tdf text in -> M_hat_catch_sparse out, at BASELINE configs[1]
+        try:
+            out["full_cli_c2"] = full_cli_leg("c2")
+        except Exception as e:
+            out["full_cli_c2"] = {"error": repr(e)[:300]}
     if out is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -117,6 +174,63 @@ def main():
         if gate is not None and not gate["passed"]:
             log("bench.py: ACCURACY GATE FAILED: " + "; ".join(gate["failed"]))
             sys.exit(3)
+
+
+def full_cli_leg(workload):
+    """The reference's own command line on the device (drivers/ISLETrain.cpp:35-46 -> isle_amd/host/ISLETrain): the workload's corpus is
+    written as tdf text + a vocabulary file under /dev/shm (or /tmp), the twelve-argument CLI runs once as a child process, its wall time
+    and the stage times of its reference-format timerLog.txt (include/timer.h:62-85) are reported, the files are deleted."""
+    import shutil
+    import subprocess
+    import tempfile
+    from tools.synth import Corpus
+    V, D, k, seed = WORKLOADS[workload]
+    t0 = time.time()
+    corp = Corpus(V, D, k, seed)
+    text = corp.tdf_bytes()
+    entries = int(corp.nnz_A)
+    del corp
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * text.size + (1 << 30) else "/tmp"
+    tmp = tempfile.mkdtemp(prefix="isle_cli_", dir=base)
+    try:
+        tdf = os.path.join(tmp, "corpus.tdf")
+        text.tofile(tdf)
+        tdf_bytes = int(text.size)
+        del text
+        vocab = os.path.join(tmp, "vocab.txt")
+        with open(vocab, "w") as f:
+            f.write("\n".join("w%d" % i for i in range(V)))
+        outdir = os.path.join(tmp, "out")
+        os.mkdir(outdir)
+        t_prep = time.time() - t0
+        cmd = [os.path.join(ROOT, "isle_amd", "host", "ISLETrain"), tdf, vocab, outdir, str(V), str(D), str(entries), str(k), "0", "0", "0", "0", "5000"]
+        t1 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t1
+        res = {"workload": "%s = BASELINE.json configs[%d]: vocab=%d, docs=%d, tdf entries=%d, num_topics=%d, sample=0, edge topics off"
+                           % (workload, CONFIG_INDEX[workload], V, D, entries, k),
+               "command": "isle_amd/host/ISLETrain <tdf> <vocab> <out> %d %d %d %d 0 0 0 0 5000 (tdf text %d bytes under %s, page cache warm)"
+                          % (V, D, entries, k, tdf_bytes, base),
+               "returncode": r.returncode, "wall_s": round(wall, 3), "docs_per_s": round(D / wall, 1) if r.returncode == 0 else None,
+               "corpus_and_tdf_preparation_s": round(t_prep, 1)}
+        if r.returncode != 0:
+            res["stderr_tail"] = r.stderr[-400:]
+            return res
+        logdir = os.path.join(outdir, sorted(os.listdir(outdir))[0])
+        stages = {}
+        with open(os.path.join(logdir, "timerLog.txt")) as f:
+            for ln in f:
+                ln = ln.strip()
+                if not ln.startswith(("Time for ", "Total time for ")) or "(user)" not in ln:
+                    continue
+                name = ln.split("..")[0].replace("Time for ", "").strip()
+                sysw = ln.split("(user)")[1].strip().split("s(")[0]  # the "(sys)" column is wall-clock (BASELINE.md section 2)
+                stages[name] = round(stages.get(name, 0.0) + float(sysw), 4)
+        res["stages_s"] = stages
+        res["output_files_bytes"] = {fn: os.path.getsize(os.path.join(logdir, fn)) for fn in sorted(os.listdir(logdir))}
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, full):
@@ -315,7 +429,7 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
                                 or ((D_loc + 255) // 256) * ((k + 255) // 256) < 512
                                 else "bf16x3 (both operands split in three bf16 terms, six of the nine partial products kept on v_mfma_f32_32x32x16_bf16, f32 "
                                      "accumulation; error against fp64 5.6e-8 of sum|a b| vs 8.6e-8 for the f32 matrix cores; gemm_bf16x3.h)"
-                                if os.environ.get("ISLE_GEMM_TERMS") == "3" else
+                                if os.environ.get("ISLE_GEMM_TERMS") == "3" or os.environ.get("ISLE_GEMM_EPILOGUE") == "0" else
                                 "bf16x2 then bf16x3 (two bf16 terms per operand first: three partial products, every distance within 8.2e-5 (|row|^2 + max |c|^2) "
                                 "of the three-term value, bounds widened by that; the rows whose two smallest distances are closer than twice that — "
                                 "0.06 % at config 3 — are run again with three terms (six products, error against fp64 5.6e-8 of sum|a b|): the assignment "

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "api_internal.h"
 
@@ -41,7 +42,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_PANEL", "tuning", "8 | 10: columns per pass of the k-wide / thin products (default 10, 8 at 8 items per lane in pass 1)"},
     {"ISLE_WIDE_GATHER", "form", "k-wide products (projection, first word-space assignment) by the row-gather kernel"},
     {"ISLE_WIDE_LDS", "form", "k-wide products through the LDS-banded pass-1 stream whatever the vocabulary size"},
-    {"ISLE_KS_ROWSHARD", "form", "1: several ranks orthogonalise row slices of the Krylov block (all-reduced coefficients, all-gathered block); default 0 = replicated"},
+    {"ISLE_KS_ROWSHARD", "form", "0: every rank orthogonalises the whole Krylov block (default with several ranks: row slices, all-reduced coefficients, all-gathered block)"},
     {"ISLE_KS_SYNC", "form", "expand loop without the speculative pipeline (one host synchronisation per step)"},
     {"ISLE_KS_ORTHO_PASSES", "form", "3: the reference's three Gram-Schmidt passes per Krylov step instead of two"},
     {"ISLE_QR_FUSED", "form", "1: panel QR as one persistent launch (bitwise equal to the kernel chain, no faster)"},
@@ -68,7 +69,9 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_CENTERS_FRESH", "form", "centroid counts recounted from the member lists every iteration instead of updated by the documents that moved"},
     {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},
     {"ISLE_CHUNK_COLS", "tuning", "gather form: rows per chunk of the chunked-CSR copy"},
+    {"ISLE_COMM_TIMEOUT_S", "tuning", "seconds without a completed collective, while collectives are pending, after which the watchdog aborts the RCCL communicator and the call returns ISLE_E_COMM (default 300; 0: no watchdog)"},
     {"ISLE_FORCE_COMM", "test hook", "create a 1-rank RCCL communicator so that every collective call site runs on one GPU"},
+    {"ISLE_TEST_STALL_MS", "test hook", "a kernel that spins for this many milliseconds is queued ahead of every RCCL collective (the watchdog's test)"},
     {"ISLE_HOST_TRACE", "diagnostic", "print host wall time between marks of the control loops"},
     {"ISLE_DEBUG_HAMERLY", "diagnostic", "print active documents / group scans per Lloyd iteration"},
     {"ISLE_DEBUG_EVD", "diagnostic", "print sweeps / orthogonality defect of the small EVD"},
@@ -193,11 +196,74 @@ static int host_exchange(isle_ctx* c, int kind, void* dev, size_t count_per_rank
   return 0;
 }
 
+// ---- watchdog of the RCCL collectives (see isle_ctx::wd_*) ----
+__global__ void wd_mark_k(volatile uint32_t* done, uint32_t seq) {
+  *done = seq;
+  __threadfence_system();
+}
+__global__ void wd_stall_k(unsigned long long ticks) {  // test hook: spin for `ticks` of the 100 MHz wall clock, then end
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+static void wd_loop(isle_ctx* c) {
+  (void)hipSetDevice(c->device);
+  uint32_t last_done = *c->wd_done;
+  auto last_change = std::chrono::steady_clock::now();
+  while (!c->wd_stop.load()) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    const uint32_t done = *c->wd_done, issued = c->wd_issued.load();
+    const auto now = std::chrono::steady_clock::now();
+    if (done != last_done || done == issued) {  // progress, or nothing pending
+      last_done = done;
+      last_change = now;
+      continue;
+    }
+    if (std::chrono::duration<double>(now - last_change).count() > c->wd_timeout_s) {
+      fprintf(stderr, "[isle_hip] rank %d: collective %u of %u issued has not completed for %.0f s: aborting the communicator\n", c->rank, done + 1, issued,
+              c->wd_timeout_s);
+      c->comm_dead.store(1);
+      (void)ncclCommAbort(c->comm);
+      return;
+    }
+  }
+}
+static int wd_start(isle_ctx* c) {
+  if (const char* e = c->knob(KN_COMM_TIMEOUT)) c->wd_timeout_s = atof(e);
+  if (!(c->wd_timeout_s > 0.0) || c->wd_thread.joinable()) return 0;
+  c->wd_done = reinterpret_cast<volatile uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 256);  // page-locked
+  *c->wd_done = 0;
+  c->wd_issued.store(0);
+  c->wd_stop.store(false);
+  c->wd_thread = std::thread(wd_loop, c);
+  return 0;
+}
+static void wd_end(isle_ctx* c) {
+  c->wd_stop.store(true);
+  if (c->wd_thread.joinable()) c->wd_thread.join();
+}
+static int wd_before(isle_ctx* c) {  // ahead of an RCCL call
+  if (c->comm_dead.load()) return isle_fail(c, ISLE_E_COMM, "the communicator was aborted after a collective timed out");
+  if (const char* e = c->knob(KN_TEST_STALL_MS)) {
+    hipLaunchKernelGGL(wd_stall_k, dim3(1), dim3(1), 0, c->stream, (unsigned long long)(atof(e) * 1e5));
+    HIPCHK(c, hipGetLastError());
+  }
+  return 0;
+}
+static int wd_after(isle_ctx* c) {  // behind it: the device reports the collective's completion
+  if (!c->wd_thread.joinable()) return 0;
+  const uint32_t seq = c->wd_issued.load() + 1;
+  hipLaunchKernelGGL(wd_mark_k, dim3(1), dim3(1), 0, c->stream, c->wd_done, seq);
+  c->wd_issued.store(seq);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int isle_allreduce(isle_ctx* c, void* buf, size_t count, int dtype, bool max_op) {
   if (!c->multi() || !count) return 0;
   if (c->host_xchg) return host_exchange(c, max_op ? ISLE_XCHG_ALLREDUCE_MAX : ISLE_XCHG_ALLREDUCE_SUM, buf, count, dtype);
+  ISLECHK(wd_before(c));
   NCCLCHK(c, ncclAllReduce(buf, buf, count, kNcclType[dtype], max_op ? ncclMax : ncclSum, c->comm, c->stream));
-  return 0;
+  return wd_after(c);
 }
 
 int isle_allgather(isle_ctx* c, const void* send, void* recv, size_t count_per_rank, int dtype) {
@@ -208,8 +274,9 @@ int isle_allgather(isle_ctx* c, const void* send, void* recv, size_t count_per_r
     if ((const void*)mine != send) HIPCHK(c, hipMemcpyAsync(mine, send, bytes, hipMemcpyDeviceToDevice, c->stream));
     return host_exchange(c, ISLE_XCHG_ALLGATHER, recv, count_per_rank, dtype);
   }
+  ISLECHK(wd_before(c));
   NCCLCHK(c, ncclAllGather(send, recv, count_per_rank, kNcclType[dtype], c->comm, c->stream));
-  return 0;
+  return wd_after(c);
 }
 
 // Control decisions of the replicated parts (rank of a Krylov block, restart index, form of the small EVD) are taken per rank from
@@ -294,7 +361,8 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->comm) ncclCommDestroy(c->comm);
+  wd_end(c);
+  if (c->comm && !c->comm_dead.load()) ncclCommDestroy(c->comm);  // (an aborted communicator is already gone)
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_stage) (void)hipHostFree(c->pin_stage);
   for (auto& e : c->ev_used) {
@@ -334,7 +402,7 @@ extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* 
   ncclUniqueId id;
   memcpy(&id, uid, sizeof id);
   NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
-  return 0;
+  return wd_start(c);
 }
 
 extern "C" int isle_hip_comm_init_host(isle_ctx* c, int world, int rank, isle_host_exchange_fn fn, void* user) {
@@ -376,6 +444,20 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   // themselves — 1 B of them at config 3 — are checked by a kernel behind the copy)
   for (uint64_t d = 0; d < D; ++d)
     if (offs[d + 1] < offs[d] || (uint64_t)offs[d + 1] > nnz) return isle_fail(c, ISLE_E_ARG, "offsets not monotone at column %llu", (unsigned long long)d);
+  // everything derived from the previous matrix is void from here on, whether or not the new one is accepted
+  c->band_ready = false;
+  c->gl_mode = -1;
+  c->P_ready = false;
+  c->Pt_ready = false;
+  c->lift_valid = false;
+  c->members_valid = false;
+  c->U_k = 0;
+  c->centers_ready = false;
+  c->assign_valid = false;
+  c->p_catch_ready = false;
+  c->p_model_ready = false;
+  c->b_from_threshold = false;
+  c->kmpp_track_k = 0;
   c->V = V;
   c->D = D;
   c->nnz = nnz;
@@ -394,25 +476,15 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
     unsigned long long bad[2] = {0, 0};
     ISLECHK(k_csc_validate(c, bad));
     if (bad[0]) {
-      c->D = 0;  // nothing usable was uploaded
+      c->V = 0;  // nothing usable was uploaded: later calls refuse with "no matrix uploaded"
+      c->D = 0;
       c->nnz = 0;
       const unsigned long long col = bad[0] - 1;
-      return bad[1] == 2 ? isle_fail(c, ISLE_E_ARG, "row index out of range in column %llu", col)
-                         : isle_fail(c, ISLE_E_ARG, "rows not strictly ascending in column %llu", col);
+      return bad[1] == 2   ? isle_fail(c, ISLE_E_ARG, "row index out of range in column %llu", col)
+             : bad[1] == 1 ? isle_fail(c, ISLE_E_ARG, "offsets not monotone at column %llu", col)
+                           : isle_fail(c, ISLE_E_ARG, "rows not strictly ascending in column %llu", col);
     }
   }
-  c->band_ready = false;
-  c->gl_mode = -1;
-  c->P_ready = false;
-  c->Pt_ready = false;
-  c->lift_valid = false;
-  c->members_valid = false;
-  c->U_k = 0;
-  c->centers_ready = false;
-  c->assign_valid = false;
-  c->p_catch_ready = false;
-  c->p_model_ready = false;
-  c->b_from_threshold = false;
   return 0;
 }
 

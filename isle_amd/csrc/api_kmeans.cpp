@@ -289,6 +289,22 @@ static int fetch_sizes(isle_ctx* c, int k, std::vector<long long>& sizes) {
   return 0;
 }
 
+// The k centre movements of the last update, on the host for choose_movers: through the page-locked area and behind a stream
+// synchronisation of its own (the stop rule synchronises only when the cluster sizes stayed the same)
+static int fetch_delta(isle_ctx* c, const float* delta_dev, int k, std::vector<float>& out) {
+  out.resize(k);
+  float* h = reinterpret_cast<float*>(c->pin + isle_ctx::PIN_SMALL + (224u << 10));  // page-locked, 32 KB
+  if ((size_t)k * sizeof(float) > (32u << 10)) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  HIPCHK(c, hipMemcpyAsync(h, delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(out.data(), h, (size_t)k * sizeof(float));
+  return 0;
+}
+
 extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int max_reps, int* iters_run, uint32_t* assign_out) {
   if (!c || !C_lowd || k < 1) return ISLE_E_ARG;
   ISLECHK(isle_enter(c));
@@ -462,8 +478,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
       ISLECHK(k_rownorms_diff(c, c->Cdev.p, c->Cold.p, k, k, ldk, delta_dev));
       if (tiles) {
         ISLECHK(k_yy_delta(c, delta_dev, k, T, 32, tmove_dev));  // rounded-up movements and their maxima per tile
-        pdelta_host.resize(k);  // ... and a copy for the choice of the movers (read behind the stop rule's synchronisation)
-        HIPCHK(c, hipMemcpyAsync(pdelta_host.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        ISLECHK(fetch_delta(c, delta_dev, k, pdelta_host));  // ... and a copy for the choice of the movers
       } else {
         ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));  // rounded-up movements and their top two, on the device
       }
@@ -653,7 +668,10 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // movement, distance to the mover) is a lower bound of the group as before.  Same movements on every rank (the centres are all-reduced).
       YyMovers mv;
       const float* gmax_use = gmax_dev;
-      if (fused && !c->knob_zero(KN_YY_MOVERS)) {
+      // (the movers' distances are a thin product through the pass-1 stream: LDS-banded form only — the gather form, ISLE_GRAM_LDS=0 or a
+      // matrix whose rows are not single-valued, keeps every centre inside its group's movement)
+      if (fused && !c->knob_zero(KN_YY_MOVERS)) ISLECHK(k_band_build(c));
+      if (fused && !c->knob_zero(KN_YY_MOVERS) && c->gl_mode == 1) {
         std::vector<float> gm;
         choose_movers(delta_host, k, 8, G, &mv, &gm);
         if (mv.n) {
@@ -755,9 +773,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, delta_dev, c->centers_old.p));
       if (yinyang) {
         ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
-        // ... and a copy of the k movements for the choice of the movers (read behind the stop rule's synchronisation)
-        delta_host.resize(k);
-        HIPCHK(c, hipMemcpyAsync(delta_host.data(), delta_dev, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        ISLECHK(fetch_delta(c, delta_dev, k, delta_host));  // ... and a copy of the k movements for the choice of the movers
       } else {
         ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));
       }

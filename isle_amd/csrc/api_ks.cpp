@@ -90,8 +90,9 @@ struct Ks {
     // its share of V^T F, an all-reduce of the m x w coefficients (80 kB at m = 2000), the update of its rows — for every pass —
     // and at the end the slices of F are all-gathered (4 MB at V = 100k), so every rank again holds the whole, bitwise equal F for
     // the replicated panel QR.  The step is HBM-bound on reading the basis (0.15 s of a 1.15 s C3-shard step): it now divides by
-    // the number of ranks at the price of passes + 1 small collectives per step.  ISLE_KS_ROWSHARD=0 keeps it replicated.
-    const bool shard = c->multi() && !dense_A && c->knob_on(KN_KS_ROWSHARD) && !c->knob_zero(KN_KS_ROWSHARD);
+    // the number of ranks at the price of passes + 1 small collectives per step.  Default with several ranks since round 5 (a collective
+    // that never completes is turned into ISLE_E_COMM by the watchdog, api.cpp); ISLE_KS_ROWSHARD=0 keeps it replicated.
+    const bool shard = c->multi() && !dense_A && !c->knob_zero(KN_KS_ROWSHARD);
     if (!shard) {
       for (int p = 0; p < passes; ++p) {
         float* cf = base + (size_t)p * m * w;

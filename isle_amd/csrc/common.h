@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------
@@ -87,7 +89,7 @@ enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
-  KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_FORCE_COMM,
+  KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
 };
@@ -154,6 +156,16 @@ struct isle_ctx {
   isle_host_exchange_fn host_xchg = nullptr;
   void* host_xchg_user = nullptr;
   bool multi() const { return comm != nullptr || host_xchg != nullptr; }
+  // watchdog of the RCCL collectives (api.cpp, wd_*): behind every collective the device writes its sequence number into a page-locked
+  // word; a thread started with the communicator compares it with the number issued and, when collectives are pending and none has
+  // completed for ISLE_COMM_TIMEOUT_S seconds, aborts the communicator — the stream drains, every HIPCHK from then on returns ISLE_E_COMM
+  // and the caller gets an error instead of a hang (a rank that died, or a rank whose replicated state diverged and left the sequence)
+  std::atomic<uint32_t> wd_issued{0};
+  volatile uint32_t* wd_done = nullptr;  // page-locked, device-visible
+  std::atomic<int> comm_dead{0};
+  std::atomic<bool> wd_stop{false};
+  std::thread wd_thread;
+  double wd_timeout_s = 300.0;
 
   // --- B (this rank's column shard), CSC
   uint64_t V = 0, D = 0, nnz = 0, doc_offset = 0, D_global = 0;
@@ -363,6 +375,8 @@ void isle_host_mark(const char* what);
 #define HIPCHK(ctx, call)                                                                   \
   do {                                                                                      \
     hipError_t e__ = (call);                                                                \
+    if ((ctx) && (ctx)->comm_dead.load(std::memory_order_relaxed))                          \
+      return isle_fail((ctx), ISLE_E_COMM, "%s:%d: a collective did not complete within %.0f s (ISLE_COMM_TIMEOUT_S): the communicator was aborted", __FILE__, __LINE__, (ctx)->wd_timeout_s); \
     if (e__ != hipSuccess)                                                                  \
       return isle_fail((ctx), ISLE_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
     if (isle_launch_refused().file) {                                                       \

@@ -325,7 +325,8 @@ int k_frobenius(isle_ctx* c, double* out_host) {
 // ------------------------------------------------------------------------------------------
 // Validity of an uploaded CSC matrix, checked on the device (the reference asserts the same in MKL_SpSpTrProd's constructor,
 // include/matUtils.h:138-148): offsets monotone, row indices below V and strictly ascending inside a column.  err[0] = smallest failing
-// column + 1 (0: none), err[1] = what failed there (1 offsets, 2 range, 3 order).  A thread per column; 1 B nonzeros in a few ms where the
+// column + 1 and what failed there (1 offsets, 2 range, 3 order) as ONE word, (column + 1) << 2 | kind, under atomicMin: column and kind
+// always belong together (err[1] unused).  A thread per column; 1 B nonzeros in a few ms where the
 // host loop it replaces took seconds.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void csc_validate_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint64_t D, uint32_t V,
@@ -345,10 +346,7 @@ __global__ __launch_bounds__(256) void csc_validate_k(const uint32_t* __restrict
       prev = r;
     }
   }
-  if (bad) {
-    const unsigned long long old = atomicMin(&err[0], d + 1);
-    if (old > d + 1) err[1] = (unsigned long long)bad;  // (racy between two failing columns: the kind reported may belong to another failing column)
-  }
+  if (bad) atomicMin(&err[0], ((unsigned long long)(d + 1) << 2) | (unsigned long long)bad);
 }
 int k_csc_validate(isle_ctx* c, unsigned long long* err_host2) {
   const uint64_t D = c->D;
@@ -361,7 +359,12 @@ int k_csc_validate(isle_ctx* c, unsigned long long* err_host2) {
   }
   HIPCHK(c, hipMemcpyAsync(err_host2, c->dbg_cnt.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (err_host2[0] == ~0ull) err_host2[0] = 0;
+  if (err_host2[0] == ~0ull) {
+    err_host2[0] = err_host2[1] = 0;
+  } else {  // decode: [0] = column + 1, [1] = kind
+    err_host2[1] = err_host2[0] & 3ull;
+    err_host2[0] >>= 2;
+  }
   return 0;
 }
 

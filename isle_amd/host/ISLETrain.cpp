@@ -6,14 +6,17 @@
 //             <apply tf-idf(0/1)> <sample(0/1)> <sample_rate> <edge topics(0/1)> <max_edge_topics>
 //
 // the usage text and exit status 255 on any other count, and the order of the trainer calls.  Everything else here is this
-// repository's: the arguments are described by one table and parsed by it, numbers are range-checked instead of passed through
-// atol(), and a failed run exits with status 1 (the reference prints a message and exits 0, SURVEY App. C #3 — deliberate deviation).
+// repository's: the arguments are described by one table and parsed by it, every number is checked against the range of the type the
+// trainer takes it as (the reference passes atol() / atoi() results through casts), a flag is true for any non-zero value as with the
+// reference's (bool)atoi(), and a failed run exits with status 1 (the reference prints a message and exits 0, SURVEY App. C #3 —
+// deliberate deviation).
 //
 // The trainer (trainer_hip.h) loads the file in its constructor (ingest and thresholding on the device), train() runs the hot path
 // src/trainer.cpp:490-571 plus catchwords and the topic model on the GPU; the writers leave diagnosticLog.txt, timerLog.txt,
 // M_hat_catch_sparse, TopWordsPerTopic_catch.txt, EdgeModel_sparse (and HotPathClusters.tsv / HotPathSingularValues.txt).
 #include <cerrno>
 #include <cstdlib>
+#include <limits>
 
 #include "trainer_hip.h"
 
@@ -24,13 +27,18 @@ enum class Kind { Text, Count, Flag, Rate };
 struct Positional {
   const char* label;  // as it appears in the usage text
   Kind kind;
+  unsigned long long max;  // largest value the receiving type holds (counts and flags)
 };
+constexpr unsigned long long kMaxId = 0xfffffff0ull;  // what the C ABI accepts for a vocabulary / document count (include/isle_hip.h)
+constexpr unsigned long long kMaxOffset = (unsigned long long)std::numeric_limits<ISLE::offset_t>::max();
+constexpr unsigned long long kMaxInt = (unsigned long long)std::numeric_limits<int>::max();
 
 // the order IS the interface
 const Positional kArgs[] = {
-    {"<tdf_file>", Kind::Text},    {"<vocab_file>", Kind::Text},   {"<output_dir>", Kind::Text},      {"<vocab_size>", Kind::Count},
-    {"<num_docs>", Kind::Count},   {"<max_entries>", Kind::Count}, {"<num_topics>", Kind::Count},     {"<apply tf-idf(0/1)>", Kind::Flag},
-    {"<sample(0/1)>", Kind::Flag}, {"<sample_rate>", Kind::Rate},  {"<edge topics(0/1)", Kind::Flag}, {"<max_edge_topics>", Kind::Count}};
+    {"<tdf_file>", Kind::Text, 0},          {"<vocab_file>", Kind::Text, 0},        {"<output_dir>", Kind::Text, 0},
+    {"<vocab_size>", Kind::Count, kMaxId},  {"<num_docs>", Kind::Count, kMaxId},    {"<max_entries>", Kind::Count, kMaxOffset},
+    {"<num_topics>", Kind::Count, kMaxInt}, {"<apply tf-idf(0/1)>", Kind::Flag, kMaxInt}, {"<sample(0/1)>", Kind::Flag, kMaxInt},
+    {"<sample_rate>", Kind::Rate, 0},       {"<edge topics(0/1)", Kind::Flag, kMaxInt},   {"<max_edge_topics>", Kind::Count, kMaxInt}};
 constexpr int kNumArgs = sizeof(kArgs) / sizeof(kArgs[0]);
 
 struct Parsed {
@@ -61,9 +69,11 @@ void parse(int n, char** v, Parsed& out) {
     } else {
       if (*s == '-') throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " must not be negative: " + s);
       out.count[i] = std::strtoull(s, &end, 10);
-      if (kind == Kind::Flag && out.count[i] > 1) throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " is a 0/1 flag: " + s);
     }
     if (end == s || *end != '\0' || errno == ERANGE) throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " is not a number: " + s);
+    if (kind != Kind::Rate && out.count[i] > kArgs[i].max)
+      throw std::runtime_error(std::string("argument ") + std::to_string(i + 1) + " " + kArgs[i].label + " is out of range (largest accepted " +
+                               std::to_string(kArgs[i].max) + "): " + s);
   }
 }
 

@@ -74,3 +74,15 @@ def test_tdf_entry_count_must_match(tmp_path):
     open(tdf, "w").write("1 1 2\n1 2 1\n2 1 3\n")
     r = subprocess.run([os.path.join(HOST, "prestage_dump"), tdf, "5", "2", "4", "1", "0", str(tmp_path / "o.bin")], capture_output=True, text=True)
     assert r.returncode == 1 and "max_entries" in r.stderr  # include/utils.h:227
+
+
+def test_isletrain_refuses_numbers_its_types_cannot_hold():
+    # every count is checked against the type the trainer takes it as, before anything touches a file or the device
+    exe = os.path.join(HOST, "ISLETrain")
+    base = ["none.tdf", "none.vocab", "/tmp", "100", "10", "50", "3", "0", "0", "0.1", "0", "5"]
+    for pos, bad, what in ((3, "5000000000", "<vocab_size>"), (11, "3000000000", "<max_edge_topics>"), (5, "18446744073709551615", "<max_entries>"),
+                           (6, "-3", "negative"), (4, "12x", "not a number")):
+        a = list(base)
+        a[pos] = bad
+        r = subprocess.run([exe] + a, capture_output=True, text=True)
+        assert r.returncode == 1 and what in r.stderr, (bad, r.stderr)

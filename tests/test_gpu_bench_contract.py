@@ -50,3 +50,27 @@ def test_two_rank_line_through_the_launcher():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _check(r.stdout, 2, 1)
     assert "REHEARSAL" in d["config"]["parallelism"]
+
+
+def test_plain_gpus_2_rehearsal():
+    """The driver's own form, `python bench.py --gpus 2 ...` with no launcher: the script starts its two ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["ISLE_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 2, 1)
+    assert "REHEARSAL" in d["config"]["parallelism"]
+    assert "launcher: started 2 ranks" in r.stderr
+
+
+def test_plain_gpus_2_without_two_gpus_fails_loudly():
+    """One GPU on the box and no rehearsal flag: no line, a non-zero status and the reason on stderr — never a silent one-rank run."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "ISLE_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs 2 GPUs" in r.stderr

@@ -151,6 +151,29 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         assert np.array_equal(res[mode][2], res["yinyang"][2])
 
 
+def test_gather_form_runs_the_by_group_iteration_without_movers(hp, monkeypatch):
+    """ISLE_GRAM_LDS=0 (or any matrix whose rows are not single-valued) has no LDS-banded stream for the movers' thin product: Lloyd on B
+    at k >= 256 (by-group Yinyang iteration, fused filter) must run — round 4 failed there with "k_gl_thin needs the LDS-banded form" as
+    soon as one centre's movement stood out — and give the partition of the LDS-banded form up to near-ties."""
+    f, B, k = load_case("c3k1000")
+    res = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("ISLE_GRAM_LDS", form)
+        upload(hp, B)
+        hp.compute_block_ks(k, allow_noconv=True)
+        assert hp.operator_form() == int(form)
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = hp.run_lloyds(k, fetch_centers=False)
+        assert ls["iters"] >= 3  # several Yinyang iterations ran
+        res[form] = (lp, ls)
+    monkeypatch.delenv("ISLE_GRAM_LDS")
+    upload(hp, B)  # leave the session's context in the default form
+    assert (res["0"][0]["assign"] == res["1"][0]["assign"]).mean() >= 0.999
+    assert (res["0"][1]["assign"] == res["1"][1]["assign"]).mean() >= 0.998
+
+
 def test_fused_filter_and_tightening_give_the_bits_of_the_two_kernel_form(hp, monkeypatch):
     """The by-group Yinyang iteration lowers the group bounds and tightens the active documents in ONE launch (yy2_filter_tighten_k: the bounds
     stay in LDS between the two steps); ISLE_YY_FUSED=0 runs yy_filter_k and yy2_tighten_k as before.  Same arithmetic on the same values:

@@ -73,3 +73,36 @@ def test_one_rank_communicator_is_the_identity():
     assert (np.array(a["lp_assign"]) == np.array(b["lp_assign"])).mean() >= 0.999
     assert (np.array(a["ls_assign"]) == np.array(b["ls_assign"])).mean() >= 0.999
     assert abs(a["cen"] - b["cen"]) <= 1e-4 * a["cen"]
+
+
+STALL = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import corpus
+from isle_amd import HotPath
+from isle_amd._lib import IsleHipError
+B = corpus(2000, 5000, 20, 0)
+hp = HotPath(0)
+hp.comm_init(1, 0, HotPath.comm_unique_id())
+hp.upload_csc(B["V"], B["vals"], B["rows"], B["offs"], doc_offset=0, docs_global=B["D"])
+X = np.random.default_rng(0).standard_normal((B["V"], 10)).astype(np.float32)
+try:
+    hp.gram_apply(X)
+    print("NO ERROR")
+except IsleHipError as e:
+    print("ERROR %%s" %% e)
+''' % (ROOT, ROOT)
+
+
+def test_a_collective_that_does_not_complete_becomes_an_error():
+    """The watchdog of the RCCL collectives (api.cpp wd_*): ISLE_TEST_STALL_MS queues a kernel that spins for 4 s ahead of the all-reduce of
+    the Gram apply, ISLE_COMM_TIMEOUT_S=1 lets the watchdog give up after 1 s without a completed collective: the communicator is aborted
+    and the call returns ISLE_E_COMM (-5) instead of blocking; with the default timeout the same stall is simply waited for."""
+    env = dict(os.environ, ISLE_FORCE_COMM="1", ISLE_TEST_STALL_MS="4000", ISLE_COMM_TIMEOUT_S="1")
+    r = subprocess.run([sys.executable, "-c", STALL], capture_output=True, text=True, env=env, timeout=300)
+    assert "ERROR isle_hip error -5" in r.stdout and "did not complete within 1 s" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "aborting the communicator" in r.stderr
+    env["ISLE_COMM_TIMEOUT_S"] = "300"
+    env["ISLE_TEST_STALL_MS"] = "1500"
+    r = subprocess.run([sys.executable, "-c", STALL], capture_output=True, text=True, env=env, timeout=300)
+    assert "NO ERROR" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

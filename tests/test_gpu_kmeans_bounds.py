@@ -177,3 +177,20 @@ def test_256_yinyang_groups_is_the_edge(hp):
             os.environ["ISLE_YY_MODE"] = old
     with pytest.raises(IsleHipError, match="too large"):
         hp.run_lloyds(2056, centers=doc_centres(2056))
+
+
+def test_duplicate_documents_almost_always_share_a_centre(hp, small50, monkeypatch):
+    """Identical columns of B need not project to identical bits here (the bank-aware placement orders a lane's sums by the lane, DESIGN.md
+    section 2), so two copies may split where two centres are tied to rounding — a deviation from the reference, whose `isamin` sends
+    duplicates to one centre (src/sparseMatrix.cpp:1868-1870).  Held here: of 2000 duplicated pairs at most 2 split (measured at 1 M and
+    1.25 M documents: profiles/r05_duplicates.json); with ISLE_GL_PLACE=0 (entries in ascending order in every lane) none does."""
+    from tools.dup_probe import run, with_duplicates
+    k = 50
+    Bd, src, dst = with_duplicates(small50, 0.1)
+    res = run(hp, Bd, src, dst, k)
+    assert res["pairs"] == 2000
+    assert res["split_after_lloyd_in_span_U"] <= 2 and res["split_after_lloyd_on_B"] <= 2, res
+    monkeypatch.setenv("ISLE_GL_PLACE", "0")
+    res0 = run(hp, Bd, src, dst, k)
+    monkeypatch.delenv("ISLE_GL_PLACE")
+    assert res0["split_after_lloyd_in_span_U"] == 0 and res0["split_after_lloyd_on_B"] == 0, res0

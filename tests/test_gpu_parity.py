@@ -393,7 +393,7 @@ def test_lloyds_projected_matches_oracle(hp, small50):
     lo = B["oracle"].lloyds_projected(U, ko["C_lowd"])
     lg = hp.run_lloyds_on_projected_space(k, ko["C_lowd"])
     assert lg["iters"] == lo["iters"]
-    assert (lg["assign"] == lo["assign"]).mean() >= 0.99
+    assert (lg["assign"] == lo["assign"]).mean() >= 0.999
     assert relerr(lg["C_lowd"], lo["C_lowd"]) <= 1e-3
 
 
@@ -409,12 +409,12 @@ def test_lift_and_sparse_lloyds_match_oracle(hp, small50):
     so = B["oracle"].lloyds_sparse(cen_o)
     sg = hp.run_lloyds(k)  # device-resident lifted centres
     assert sg["iters"] == so["iters"]
-    assert (sg["assign"] == so["assign"]).mean() >= 0.99
+    assert (sg["assign"] == so["assign"]).mean() >= 0.999
     assert relerr(sg["centers"], so["centers"]) <= 1e-3
     assert np.bincount(sg["assign"], minlength=k).sum() == B["D"]  # partition complete (trainer.cpp:567-570)
     # host-provided centres take the same path
     sg2 = hp.run_lloyds(k, centers=cen_o)
-    assert (sg2["assign"] == so["assign"]).mean() >= 0.99
+    assert (sg2["assign"] == so["assign"]).mean() >= 0.999
 
 
 @pytest.mark.parametrize("k", [50, 37])
@@ -444,7 +444,7 @@ def test_first_sparse_assignment_through_the_projection(hp, small50, monkeypatch
     assert a[2] == b[2]
     assert (a[0] == b[0]).mean() >= 0.999 and relerr(a[1], b[1]) <= 1e-4
     so = B["oracle"].lloyds_sparse(lift(U, a[3]))
-    assert (a[0] == so["assign"]).mean() >= 0.99 and a[2] == so["iters"]
+    assert (a[0] == so["assign"]).mean() >= 0.999 and a[2] == so["iters"]
     assert relerr(a[1], so["centers"]) <= 1e-3
 
 
@@ -500,9 +500,9 @@ def test_wide_products_odd_topic_counts(hp, small50, monkeypatch, k, panel):
     assert relerr(a[0], b[0]) <= 1e-5 and np.abs(a[1] - b[1]).max() <= 1e-4 * b[1].max()
     assert (a[2] == b[2]).mean() >= 0.995 and (a[3] == b[3]).mean() >= 0.995
     lo = B["oracle"].lloyds_projected(U, a[0])
-    assert (a[2] == lo["assign"]).mean() >= 0.99
+    assert (a[2] == lo["assign"]).mean() >= 0.999
     so = B["oracle"].lloyds_sparse(lift(U, lo["C_lowd"]))
-    assert (a[3] == so["assign"]).mean() >= 0.99
+    assert (a[3] == so["assign"]).mean() >= 0.999
 
 
 def test_sparse_lloyd_wide_vocabulary(hp, monkeypatch):
@@ -553,7 +553,16 @@ def test_full_hot_path_end_to_end(hp, small50):
     # reaches 0.81-0.87 on this kind of corpus
     planted = B["planted"]
     agree = sum(np.bincount(planted[sg["assign"] == c]).max() for c in range(k) if sizes[c] > 0) / B["D"]
-    assert agree >= 0.6
+    assert agree >= 0.75, agree
+    # ... and no worse than the oracle's own partition from the same eigenvectors and the same seeds
+    from oracle.oracle import lift
+    o, U = B["oracle"], hp.get_U(k)
+    lo = o.lloyds_projected(U, g["C_lowd"])
+    so = o.lloyds_sparse(lift(U, lo["C_lowd"]))
+    so_sizes = np.bincount(so["assign"], minlength=k)
+    agree_o = sum(np.bincount(planted[so["assign"] == c]).max() for c in range(k) if so_sizes[c] > 0) / B["D"]
+    assert agree >= agree_o - 0.005, (agree, agree_o)
+    assert (sg["assign"] == so["assign"]).mean() >= 0.999
 
 
 def test_config1_size_sigma_and_kmeans(hp):
@@ -569,11 +578,11 @@ def test_config1_size_sigma_and_kmeans(hp):
     g = hp.kmeans_init_on_projected_space(k, inject_seeds=ko["seeds"])
     lo = B["oracle"].lloyds_projected(o["U"], ko["C_lowd"])
     lg = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
-    assert lg["iters"] == lo["iters"] and (lg["assign"] == lo["assign"]).mean() >= 0.99
+    assert lg["iters"] == lo["iters"] and (lg["assign"] == lo["assign"]).mean() >= 0.999
     from oracle.oracle import lift
     hp.left_multiply_by_U(lo["C_lowd"], fetch=False)
     so, sg = B["oracle"].lloyds_sparse(lift(o["U"], lo["C_lowd"])), hp.run_lloyds(k)
-    assert sg["iters"] == so["iters"] and (sg["assign"] == so["assign"]).mean() >= 0.99
+    assert sg["iters"] == so["iters"] and (sg["assign"] == so["assign"]).mean() >= 0.999
 
 
 def test_config4_importance_sampled_matrix(hp):
@@ -592,7 +601,7 @@ def test_config4_importance_sampled_matrix(hp):
     ko = B["oracle"].kmeanspp(o["U"], k, seed=4)
     g = hp.kmeans_init_on_projected_space(k, inject_seeds=ko["seeds"])
     lo, lg = B["oracle"].lloyds_projected(o["U"], ko["C_lowd"]), hp.run_lloyds_on_projected_space(k, g["C_lowd"])
-    assert (lg["assign"] == lo["assign"]).mean() >= 0.99
+    assert (lg["assign"] == lo["assign"]).mean() >= 0.999
 
 
 def test_operator_is_bitwise_reproducible_across_builds(hp, small50):
