@@ -17,7 +17,8 @@
 // ------------------------------------------------------------------------------------------
 // The movers of an iteration (YyMovers): up to ten centres whose movement stands out — more than twice the eleventh largest — and the
 // groups' (Yinyang: 8 centres) or tiles' (projected loop: 32) largest movements WITHOUT them.  The same on every rank (replicated inputs).
-static void choose_movers(const std::vector<float>& delta, int k, int group, int G, YyMovers* mv, std::vector<float>* gmax_excl) {
+static void choose_movers(const std::vector<float>& delta, int k, int group, int G, YyMovers* mv, std::vector<float>* gmax_excl,
+                          const std::vector<uint32_t>* slot_of_id = nullptr /*regrouped Yinyang groups: centre i sits in group slot_of_id[i] / group*/) {
   mv->n = 0;
   if ((int)delta.size() != k || k <= 16) return;
   std::vector<int> ord(k);
@@ -32,7 +33,8 @@ static void choose_movers(const std::vector<float>& delta, int k, int group, int
   for (int i = 0; i < k; ++i) {
     bool is_mover = false;
     for (int j = 0; j < mv->n; ++j) is_mover = is_mover || mv->id[j] == (uint32_t)i;
-    if (!is_mover) (*gmax_excl)[i / group] = std::max((*gmax_excl)[i / group], delta[i]);
+    const int gi = (int)(slot_of_id ? (*slot_of_id)[i] : (uint32_t)i) / group;
+    if (!is_mover) (*gmax_excl)[gi] = std::max((*gmax_excl)[gi], delta[i]);
   }
 }
 
@@ -602,6 +604,20 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   }
   c->lift_valid = false;  // the centres move below
   int it = 0;
+  // the forms that visit documents in member order (docg, group) hold a document's group bounds four per lane: at most 256 groups
+  // (k <= 2048); beyond, by document over the row-major centres, whatever ISLE_YY_MODE asks for
+  const int yy_mode = !yinyang ? 0 : G > 256 ? 0 : yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
+  // Regrouping (round 5).  A Yinyang group's bound is the distance to its CLOSEST member, so one centre every document is near spoils the
+  // bound of its whole group — and the centres of small squared norm (the large, diffuse clusters) are near every document that lies
+  // far from everything else: with groups of eight consecutive labels those few centres sit in as many groups and an undecided document
+  // scans them all (config 3: 10 - 15 groups per active document in the first iterations).  The groups are therefore formed from the
+  // centres in the order of their squared norms at the loop's entry (stable: equal norms keep their labels' order), through slot
+  // tables (YyMap); labels, ties and everything outside the by-group kernels stay in the centres' own numbering.  Config 3 on one GPU:
+  // 137 M -> 39 M (document, group) pairs per step, Lloyd on B 296 -> 199 ms, same partition (tools/yy_probe.py, profiles/r05_d_*).
+  // Taken with the by-group form behind the product's first assignment; ISLE_YY_REGROUP=0 keeps groups of consecutive labels.
+  const bool regroup = yinyang && yy_mode == 2 && via_projection && fused_first && !c->knob_zero(KN_YY_REGROUP);
+  YyMap ymap;
+  std::vector<uint32_t> slot_of_id_host;
   std::vector<float> delta_host;  // the k centre movements of the last update (Yinyang: choice of the movers)
   isle_host_mark("lloyds_sparse: loop starts");
   for (; it < max_reps; ++it) {
@@ -609,6 +625,25 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, c->cnorm.p));  // :1604
     }
+    if (it == 0 && regroup) {  // the slot tables, from the norms just computed (the same on every rank: the centres are replicated)
+      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+      std::vector<float> cnh(k);
+      HIPCHK(c, hipMemcpyAsync(c->pin + isle_ctx::PIN_SMALL + (224u << 10), c->cnorm.p, std::min<size_t>((size_t)k * sizeof(float), 32u << 10), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      memcpy(cnh.data(), c->pin + isle_ctx::PIN_SMALL + (224u << 10), (size_t)k * sizeof(float));  // (k <= 2048: by-group form)
+      std::vector<uint32_t> id_of_slot((size_t)8 * G, 0xffffffffu);
+      std::iota(id_of_slot.begin(), id_of_slot.begin() + k, 0u);
+      std::stable_sort(id_of_slot.begin(), id_of_slot.begin() + k, [&](uint32_t a, uint32_t b) { return cnh[a] < cnh[b]; });
+      slot_of_id_host.assign(k, 0u);
+      for (int s2 = 0; s2 < k; ++s2) slot_of_id_host[id_of_slot[s2]] = (uint32_t)s2;
+      ISLECHK(k_yy_map_upload(c, id_of_slot.data(), slot_of_id_host.data(), k, G, &ymap));
+      HIPCHK(c, c->yy_cns.reserve((size_t)8 * G));
+    }
+    if (regroup) {
+      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+      ISLECHK(k_yy_gather_by_slot(c, ymap, k, G, c->cnorm.p, c->yy_cns.p));
+    }
+    const float* cn_grp = regroup ? c->yy_cns.p : c->cnorm.p;  // the norms as the by-group kernels index them
     if (it == 0 && via_projection) {
       // B^T (U C^T) = (U^T B)^T C^T: the k-wide sparse product of the first assignment (distsq_docs_to_centers, :1494-1550) is a dense
       // D x k x k product on the projection that k-means++ / Lloyd in span(U) left on the device — one MFMA GEMM, a transposition into
@@ -617,8 +652,15 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       if (yinyang && fused_first) {  // distances, group bounds and candidates formed inside the product: no D x k matrix in memory
         float* cn_max_dev = c->Csum.p + 2 * k + 8;
         ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
-        ISLECHK(k_gemm_assign_yy(c, c->Pt.p, c->P.p, c->ldk, c->pnorm.p, D, k, c->lift_C.p, c->lift_ld, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p,
+        const float* liftC = c->lift_C.p;
+        if (regroup) {  // the product's columns in slot order: its groups of eight columns are the regrouped groups
+          HIPCHK(c, c->yy_liftC.reserve((size_t)k * c->lift_ld));
+          ISLECHK(k_yy_rows_by_slot(c, ymap, k, c->lift_C.p, c->lift_ld, c->yy_liftC.p));
+          liftC = c->yy_liftC.p;
+        }
+        ISLECHK(k_gemm_assign_yy(c, c->Pt.p, c->P.p, c->ldk, c->pnorm.p, D, k, liftC, c->lift_ld, k, G, cn_grp, c->dnorm.p, cn_max_dev, c->assign.p,
                                  c->hub.p, c->yglb.p, ISLE_T_SPARSE_ASSIGN));
+        if (regroup) ISLECHK(k_yy_labels_to_ids(c, ymap, c->assign.p, D));  // columns (slots) -> centres
       } else if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
         HIPCHK(c, c->dotsT.reserve((size_t)D * k));
         ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
@@ -652,12 +694,9 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // (the member lists), so that waves running together gather from one table in L2; ISLE_YY_MODE = doc | docg | group picks the form
       // (measured, Lloyd on B per step: C3 shard 176 ms by document -> 112 ms by group, all of config 3 on one GPU 825 -> 588 ms; at C2,
       // G = 25 and a 40 MB table, the three forms are within 10 % of each other and the plain one stays)
-      // the forms that visit documents in member order (docg, group) hold a document's group bounds four per lane: at most 256 groups
-      // (k <= 2048); beyond, by document over the row-major centres, whatever ISLE_YY_MODE asks for
-      const int yy_mode = G > 256 ? 0 : yy_mode_env >= 0 ? yy_mode_env : (G >= 32 ? 2 : 0);
       const char* yord = c->knob(KN_YY_ORDER);
       const uint32_t* order = yy_mode && c->members_valid && !(yord && !strcmp(yord, "doc")) ? c->members.p : nullptr;
-      if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G));
+      if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G, ymap));
       // by group: the bounds are lowered and the active documents tightened in one launch (the D x G bounds read once), ISLE_YY_FUSED=0: in two
       const bool fused = yy_mode == 2 && !c->knob_zero(KN_YY_FUSED);
       // Movers.  A group's bound falls by the LARGEST movement among its eight centres, for every document: one centre that jumped (a
@@ -673,7 +712,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       if (fused && !c->knob_zero(KN_YY_MOVERS)) ISLECHK(k_band_build(c));
       if (fused && !c->knob_zero(KN_YY_MOVERS) && c->gl_mode == 1) {
         std::vector<float> gm;
-        choose_movers(delta_host, k, 8, G, &mv, &gm);
+        choose_movers(delta_host, k, 8, G, &mv, &gm, regroup ? &slot_of_id_host : nullptr);
         if (mv.n) {
           HIPCHK(c, c->yy_gmax2.reserve(G));
           HIPCHK(c, hipMemcpyAsync(c->yy_gmax2.p, gm.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -682,8 +721,8 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
         }
       }
       if (fused)
-        ISLECHK(k_yy_filter_tighten(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_use, c->active.p, nact, c->yy_cg.p, k, ld, c->cnorm.p, c->dnorm.p,
-                                    cn_max_dev, mv, c->centers_rm.p));
+        ISLECHK(k_yy_filter_tighten(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_use, c->active.p, nact, c->yy_cg.p, k, ld, cn_grp, c->dnorm.p,
+                                    cn_max_dev, mv, c->centers_rm.p, ymap, c->cnorm.p));
       else
         ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
       const bool dbg = c->knob_on(KN_DEBUG_HAMERLY);
@@ -696,10 +735,10 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       bool done = false;
       unsigned long long npairs = 0;
       if (yy_mode == 2)
-        ISLECHK(k_yy2_assign(c, c->yy_cg.p, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, &done, &npairs, fused));
+        ISLECHK(k_yy2_assign(c, c->yy_cg.p, k, ld, G, cn_grp, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, &done, &npairs, fused, ymap));
       if (!done)
-        ISLECHK(k_yy_scan(c, c->centers_rm.p, yy_mode ? c->yy_cg.p : nullptr, k, ld, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p,
-                          c->hub.p, c->yglb.p, dbg_dev));
+        ISLECHK(k_yy_scan(c, c->centers_rm.p, yy_mode ? c->yy_cg.p : nullptr, k, ld, G, cn_grp, c->dnorm.p, cn_max_dev, c->active.p, nact, c->assign.p,
+                          c->hub.p, c->yglb.p, dbg_dev, ymap));
       if (dbg) {
         uint32_t na = 0;
         unsigned long long cnt[2] = {0, 0};
@@ -772,7 +811,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
       ISLECHK(k_colnorms_rm(c, c->centers_rm.p, V, k, ld, delta_dev, c->centers_old.p));
       if (yinyang) {
-        ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev));  // movements and group maxima stay on the device
+        ISLECHK(k_yy_delta(c, delta_dev, k, G, 8, gmax_dev, ymap.id_of_slot));  // movements and group maxima stay on the device
         ISLECHK(fetch_delta(c, delta_dev, k, delta_host));  // ... and a copy of the k movements for the choice of the movers
       } else {
         ISLECHK(k_ham_delta(c, delta_dev, k, top_dev));

@@ -88,7 +88,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
@@ -334,6 +334,9 @@ struct isle_ctx {
   std::vector<float> kmpp_C_host;  // the seeds' coordinates as handed to the caller (k x k)
   // Yinyang iteration ordered by group (spmm.hip, k_yy2_assign)
   DevBuf<float> yy_cg;                 // centres group-major: G tables of V x 8 floats
+  DevBuf<uint32_t> yy_map;             // regrouped Yinyang groups: id_of_slot (8 G) then slot_of_id (k)
+  DevBuf<float> yy_cns;                // squared centre norms by slot (8 G)
+  DevBuf<float> yy_liftC;              // the lift coefficients' rows by slot (first assignment through the projection)
   DevBuf<uint32_t> yy_own, yy_res;     // YyRes (3 words) per active slot / per pair
   DevBuf<unsigned long long> yy_need;  // per active slot: bit mask of the groups to scan
   DevBuf<uint32_t> yy_cnt, yy_off;     // pairs per active slot, their exclusive scan
@@ -439,16 +442,36 @@ struct YyMovers {
   int n = 0, ld = 0;   // ld = 4 ceil(n / 4): row stride of the D x n dot products
   uint32_t id[10] = {};
 };
+// Which centres share a Yinyang group.  Null pointers: group g = centres 8 g .. 8 g + 7 (the identity).  Otherwise the groups are made
+// of SLOTS: slot s = 8 g + t holds centre id_of_slot[s] (s < k; the slots behind are padding), slot_of_id is the inverse.  The kernels
+// of the by-group iteration index tables and bounds by slot and report centres by id; ties between equal distances go to the smaller ID
+// whatever the slots' order, as the reference's isamin does (src/sparseMatrix.cpp:1553-1572).
+struct YyMap {
+  const uint32_t* id_of_slot = nullptr;
+  const uint32_t* slot_of_id = nullptr;
+#if defined(__HIPCC__)
+  __device__ inline uint32_t id(uint32_t s) const { return id_of_slot ? id_of_slot[s] : s; }
+  __device__ inline uint32_t slot(uint32_t i) const { return slot_of_id ? slot_of_id[i] : i; }
+#endif
+};
 int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev,
                         const float* gmax_dev, uint32_t* active, uint32_t* nactive, const float* Cg, int k, int ld, const float* cn, const float* dn,
-                        const float* cn_max, const YyMovers& mv, const float* Crm);
+                        const float* cn_max, const YyMovers& mv, const float* Crm, const YyMap& map = YyMap(), const float* cn_by_id = nullptr);
+// the maps of a regrouping (host arrays of 8 G and k entries) on the device; cn_slot[s] = cn[id_of_slot[s]]; rows of a small matrix by slot;
+// labels written by slot turned into ids
+int k_yy_map_upload(isle_ctx* c, const uint32_t* id_of_slot_host, const uint32_t* slot_of_id_host, int k, int G, YyMap* map);
+int k_yy_gather_by_slot(isle_ctx* c, const YyMap& map, int k, int G, const float* cn, float* cn_slot);
+int k_yy_rows_by_slot(isle_ctx* c, const YyMap& map, int k, const float* in, int ld, float* out);
+int k_yy_labels_to_ids(isle_ctx* c, const YyMap& map, uint32_t* assign, uint64_t D);
 int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
                 uint32_t* active, uint32_t* nactive);
-int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G);  // c->yy_cg = the centres group-major (V x 8 floats per group)
+int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G, const YyMap& map = YyMap());  // c->yy_cg = the centres group-major (V x 8 floats per group)
 int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg /*nullable*/, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev,
-              const uint32_t* active, const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr);
+              const uint32_t* active, const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr,
+              const YyMap& map = YyMap());
 int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev, const uint32_t* active,
-                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out = nullptr, bool pre_tightened = false);
+                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out = nullptr, bool pre_tightened = false,
+                 const YyMap& map = YyMap());
 struct HamTop {  // largest and second largest centre movement of an iteration (Hamerly's bound update), device resident
   uint32_t amax;
   float d1, d2, pad;
@@ -458,7 +481,7 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
                      uint32_t* active, uint32_t* nactive, int fam = ISLE_T_SPARSE_ASSIGN);
 int k_member_lists(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev, int* max_out, std::vector<int>* counts_host = nullptr);
 int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, const int* counts_dev);  // no host round trip
-int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev);
+int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev, const uint32_t* id_of_slot = nullptr);
 int k_max_f32(isle_ctx* c, const float* v, int n, float* out_dev);
 int k_csc_validate(isle_ctx* c, unsigned long long* err_host2);  // the uploaded CSC arrays on the device: [0] first bad column + 1 (0 = fine), [1] what (spmm.hip)
 int k_doc_norms(isle_ctx* c, float* dn);

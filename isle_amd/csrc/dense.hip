@@ -817,7 +817,7 @@ struct YyGroupEpi {  // Lloyd on B: Yinyang groups of 8 centres (dots_assign_cm_
   __device__ inline float dist(float dot, int col, float dnd) const { return fabsf((-2.0f * dot + cn[col]) + dnd); }
   __device__ inline float aux(int) const { return 0.f; }
   __device__ inline void group(uint64_t m, int g, float dnd, float m1, uint32_t, float, float) const {
-    const float E = 1e-4f * (dnd + *cn_max), sE = sqrtf(E);
+    const float E = ISLE_SLACK_REL * (dnd + *cn_max), sE = sqrtf(E);
     const float eps = eta > 0.f ? eta * (an[doc(m)] + *bmax) : 0.f;
     lb[doc(m) * (uint64_t)G + g] = yy_slack_down_sq(fmaxf(m1 - eps, 0.f), E, sE);
   }
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void yy_first_combine_k(const AssignRec* __res
     const uint32_t d = map ? map[i] : i;
     const AssignPick p = assign_pick(part, i, nslot);
     const float eps = eta > 0.f ? eta * (an[d] + *bmax) : 0.f;
-    const float E = 1e-4f * (dn[d] + *cn_max), sE = sqrtf(E);
+    const float E = ISLE_SLACK_REL * (dn[d] + *cn_max), sE = sqrtf(E);
     lb[(size_t)d * G + p.bidx / 8] = yy_slack_down_sq(fmaxf(p.m2 - eps, 0.f), E, sE);  // the assigned centre's group: its closest OTHER member
     const float u = sqrtf(p.best + eps);
     ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));

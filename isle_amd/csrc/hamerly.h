@@ -8,8 +8,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef ISLE_SLACK_REL
+#define ISLE_SLACK_REL 1e-4f  // E = ISLE_SLACK_REL * (|b|^2 + |c|^2): the absolute error allowed for in a computed squared distance
+#endif
+
 __device__ inline void hamerly_store_bounds(float best_sq, float second_sq, float norm_sum /* |b|^2 + max |c|^2 */, float* ub, float* lb) {
-  const float E = 1e-4f * norm_sum;
+  const float E = ISLE_SLACK_REL * norm_sum;
   const float sE = sqrtf(E);
   const float u = sqrtf(best_sq), l = sqrtf(second_sq);
   *ub = u + fminf(sE, E / fmaxf(u, 1e-30f));

@@ -1217,19 +1217,21 @@ int k_member_lists_dev(isle_ctx* c, const uint32_t* assign, uint64_t D, int k, c
 }
 
 // Yinyang bookkeeping on the device: delta[i] <- rounded-up movement of centre i, gmax[g] <- largest movement in group g
-__global__ void yy_delta_k(float* __restrict__ delta, int k, int G, int group, float* __restrict__ gmax) {
+// (id_of_slot: the group's members are the centres its slots hold, see YyMap)
+__global__ void yy_delta_k(float* __restrict__ delta, int k, int G, int group, float* __restrict__ gmax, const uint32_t* __restrict__ id_of_slot) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   float m = 0.f;
-  for (int i = group * g; i < min(k, group * g + group); ++i) {
+  for (int s = group * g; s < min(k, group * g + group); ++s) {
+    const int i = id_of_slot ? (int)id_of_slot[s] : s;
     const float dv = sqrtf(fmaxf(delta[i], 0.f)) * (1.0f + 1e-5f) + 1e-7f;  // rounded up
     delta[i] = dv;
     m = fmaxf(m, dv);
   }
   gmax[g] = m;
 }
-int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev) {
-  hipLaunchKernelGGL(yy_delta_k, dim3(cdiv(G, 64)), dim3(64), 0, c->stream, delta_dev, k, G, group, gmax_dev);
+int k_yy_delta(isle_ctx* c, float* delta_dev, int k, int G, int group, float* gmax_dev, const uint32_t* id_of_slot) {
+  hipLaunchKernelGGL(yy_delta_k, dim3(cdiv(G, 64)), dim3(64), 0, c->stream, delta_dev, k, G, group, gmax_dev, id_of_slot);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -428,7 +428,7 @@ __device__ inline void wide_assign_epilogue(const float4 (&acc)[NIT], int lane, 
   if (ub && G > 0) {
     // Yinyang group bounds: for every group of YY_GROUP consecutive centres the distance to its closest member other than
     // the assigned centre.  A lane holds 4 consecutive centres, lane ^ 1 the other half of the group.
-    const float E = 1e-4f * (dnd + cmax), sE = sqrtf(E);
+    const float E = ISLE_SLACK_REL * (dnd + cmax), sE = sqrtf(E);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int cidx = lane + 64 * it;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void dots_assign_cm_k(const float* __restrict_
   const bool live = j < nd;
   const uint32_t d = d0 + (live ? j : 0u);
   const float dnd = dn[d];
-  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+  const float E = ISLE_SLACK_REL * (dnd + *cn_max_p), sE = sqrtf(E);
   float best = 3.4e38f, bg_m2 = 3.4e38f;
   uint32_t bidx = 0xffffffffu;
   int bg = 0;
@@ -1080,16 +1080,19 @@ struct YyTop2 {
   float m1, m2;
   uint32_t i1;
 };
-__device__ inline YyTop2 yy_group_top2(const float dist[4], int c0, int k) {
+// (c0 + j is a SLOT; the centre it holds is map.id(slot) — the slot itself without a regrouping.  Equal distances: the smaller id, whatever
+// the slots' order.)
+__device__ inline YyTop2 yy_group_top2(const float dist[4], int c0, int k, const YyMap& map = YyMap()) {
   YyTop2 t{3.4e38f, 3.4e38f, 0xffffffffu};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int cc = c0 + j;
     if (cc < k) {
-      if (dist[j] < t.m1) {
+      const uint32_t id = map.id((uint32_t)cc);
+      if (dist[j] < t.m1 || (dist[j] == t.m1 && id < t.i1)) {
         t.m2 = t.m1;
         t.m1 = dist[j];
-        t.i1 = (uint32_t)cc;
+        t.i1 = id;
       } else {
         t.m2 = fminf(t.m2, dist[j]);
       }
@@ -1199,7 +1202,8 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
                                                   uint32_t V, int ld, int k, int G, const float* __restrict__ cn,
                                                   const float* __restrict__ dn, const float* __restrict__ cn_max_p, const uint32_t* __restrict__ active,
                                                   const uint32_t* __restrict__ nactive, uint32_t* __restrict__ assign, float* __restrict__ ub,
-                                                  float* __restrict__ glb, unsigned long long* __restrict__ dbg /*nullable: [0] group scans, [1] their nonzeros*/) {
+                                                  float* __restrict__ glb, unsigned long long* __restrict__ dbg /*nullable: [0] group scans, [1] their nonzeros*/,
+                                                  YyMap map) {
   const int lane = threadIdx.x & 63;
   uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   slot = __builtin_amdgcn_readfirstlane(slot);
@@ -1207,8 +1211,8 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
   const uint32_t d = __builtin_amdgcn_readfirstlane(active[slot]);
   const float dnd = dn[d];
   const uint32_t a = assign[d];
-  const int ga = (int)(a / YY_GROUP);
-  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+  const int ga = (int)(map.slot(a) / YY_GROUP);
+  const float E = ISLE_SLACK_REL * (dnd + *cn_max_p), sE = sqrtf(E);
   const int q = lane & 1;
   float* gl = glb + (size_t)d * G;
   const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
   float dist[4];
   int nscan = 1;
   scan_group(ga, dist);                                   // tighten: exact distance to the assigned centre (and its group)
-  absorb(ga, yy_group_top2(dist, YY_GROUP * ga + 4 * q, k));
+  absorb(ga, yy_group_top2(dist, YY_GROUP * ga + 4 * q, k, map));
   for (int g = 0; g < G; ++g) {
     if (g == ga) continue;
     const float u = sqrtf(best);
@@ -1242,7 +1246,7 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
     if (lg <= uhi) {                                      // wave-uniform
       ++nscan;
       scan_group(g, dist);
-      absorb(g, yy_group_top2(dist, YY_GROUP * g + 4 * q, k));
+      absorb(g, yy_group_top2(dist, YY_GROUP * g + 4 * q, k, map));
     }
   }
   if (dbg && lane == 0) {
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
     const float u = sqrtf(best);
     ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
     assign[d] = bidx;
-    gl[bidx / YY_GROUP] = yy_slack_down(best_group_second, E, sE);  // the assigned centre does not bound its own group
+    gl[map.slot(bidx) / YY_GROUP] = yy_slack_down(best_group_second, E, sE);  // the assigned centre does not bound its own group
   }
 }
 
@@ -1271,8 +1275,10 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
 //       the upper bound and the bounds of the scanned groups exactly as yy_scan_k leaves them.
 // Per (document, group) the distances are the same sums in the same order as yy_scan_k's (yy_group_dists).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void yy2_pack_k(const float* __restrict__ Crm, uint32_t V, int ld, int G, float4* __restrict__ Cg) {
-  // Cg[(g * V + w) * 2 + q] = Crm[w * ld + 8 g + 4 q .. + 3] (zero beyond ld); consecutive threads read consecutive float4 of a row
+__global__ __launch_bounds__(256) void yy2_pack_k(const float* __restrict__ Crm, uint32_t V, int ld, int G, float4* __restrict__ Cg, int k,
+                                                   const uint32_t* __restrict__ id_of_slot /*nullable*/) {
+  // Cg[(g * V + w) * 2 + q] = Crm[w * ld + 8 g + 4 q .. + 3] (zero beyond ld); consecutive threads read consecutive float4 of a row.
+  // Regrouped: the four slots' centres are gathered from the row (a 4 KB row is read by its 2 G threads: the lines come from cache)
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int nq = 2 * G;
   if (i >= (size_t)V * nq) return;
@@ -1280,7 +1286,15 @@ __global__ __launch_bounds__(256) void yy2_pack_k(const float* __restrict__ Crm,
   const int gq = (int)(i - (size_t)w * nq);
   const int col = 4 * gq;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < ld) v = *reinterpret_cast<const float4*>(Crm + (size_t)w * ld + col);
+  if (id_of_slot) {
+    const float* row = Crm + (size_t)w * ld;
+    if (col < k) v.x = row[id_of_slot[col]];
+    if (col + 1 < k) v.y = row[id_of_slot[col + 1]];
+    if (col + 2 < k) v.z = row[id_of_slot[col + 2]];
+    if (col + 3 < k) v.w = row[id_of_slot[col + 3]];
+  } else if (col < ld) {
+    v = *reinterpret_cast<const float4*>(Crm + (size_t)w * ld + col);
+  }
   Cg[((size_t)(gq >> 1) * V + w) * 2 + (gq & 1)] = v;
 }
 
@@ -1296,21 +1310,21 @@ __global__ __launch_bounds__(256) void yy2_tighten_k(const float* __restrict__ v
                                                       const float* __restrict__ dn, const float* __restrict__ cn_max_p,
                                                       const uint32_t* __restrict__ active, const uint32_t* __restrict__ nactive,
                                                       const uint32_t* __restrict__ assign, const float* __restrict__ glb, YyRes* __restrict__ own,
-                                                      unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt) {
+                                                      unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt, YyMap map) {
   const int lane = threadIdx.x & 63;
   uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   slot = __builtin_amdgcn_readfirstlane(slot);
   if (slot >= *nactive) return;
   const uint32_t d = __builtin_amdgcn_readfirstlane(active[slot]);
   const float dnd = dn[d];
-  const int ga = (int)(assign[d] / YY_GROUP);
-  const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+  const int ga = (int)(map.slot(assign[d]) / YY_GROUP);
+  const float E = ISLE_SLACK_REL * (dnd + *cn_max_p), sE = sqrtf(E);
   const int q = lane & 1;
   const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
   const int col = YY_GROUP * ga + 4 * q;
   float dist[4];
   yy_group_dists(dc, vals, rows, Cg + (size_t)ga * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
-  const YyTop2 t = yy_group_top2(dist, col, k);
+  const YyTop2 t = yy_group_top2(dist, col, k, map);
   const float u = sqrtf(t.m1);
   const float uhi = u + fminf(sE, E / fmaxf(u, 1e-30f));
   const float* gl = glb + (size_t)d * G;
@@ -1348,7 +1362,8 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
                                                              const int64_t* __restrict__ offs, const float4* __restrict__ Cg, uint32_t V, int ld, int k, int NW,
                                                              const float* __restrict__ cn, const float* __restrict__ dn, const float* __restrict__ cn_max_p,
                                                              YyRes* __restrict__ own, unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt,
-                                                             YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: b_d . c_mover*/) {
+                                                             YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: b_d . c_mover*/, YyMap map,
+                                                             const float* __restrict__ cn_by_id /*the movers' norms (cn is indexed by slot)*/) {
   extern __shared__ float tile[];  // docs_per_block x G bounds, then docs_per_block local indices of the active documents
   uint32_t* lact = reinterpret_cast<uint32_t*>(tile + (size_t)docs_per_block * G);
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
@@ -1417,16 +1432,17 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
         // the few centres that moved far were left out of their groups' movements (gmax): their groups' bounds take the exact new
         // distances to them instead — min(bound lowered by the others' movement, distance to the mover) bounds the group as before
         const float dnd = dn[d];
-        const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+        const float E = ISLE_SLACK_REL * (dnd + *cn_max_p), sE = sqrtf(E);
         for (int jm = 0; jm < mv.n; ++jm) {
           const uint32_t cj = mv.id[jm];
           if (cj == a) continue;  // the assigned centre does not bound its own group
-          const float dist = fabsf((-2.0f * mdots[(size_t)d * mv.ld + jm] + cn[cj]) + dnd);
+          const float dist = fabsf((-2.0f * mdots[(size_t)d * mv.ld + jm] + cn_by_id[cj]) + dnd);
           const float l = yy_slack_down_sq(dist, E, sE);
-          const uint32_t at = j * (uint32_t)G + (cj >> 3);
+          const uint32_t gj = map.slot(cj) >> 3;
+          const uint32_t at = j * (uint32_t)G + gj;
           if (l < tile[at]) {
             tile[at] = l;
-            glb[(size_t)d * G + (cj >> 3)] = l;
+            glb[(size_t)d * G + gj] = l;
           }
         }
       }
@@ -1446,14 +1462,14 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
     const uint32_t j = lact[i], slot = base + i;
     const uint32_t d = __builtin_amdgcn_readfirstlane(order ? order[d0 + j] : d0 + j);
     const float dnd = dn[d];
-    const int ga = (int)(assign[d] / YY_GROUP);
-    const float E = 1e-4f * (dnd + *cn_max_p), sE = sqrtf(E);
+    const int ga = (int)(map.slot(assign[d]) / YY_GROUP);
+    const float E = ISLE_SLACK_REL * (dnd + *cn_max_p), sE = sqrtf(E);
     const int q = lane & 1;
     const YyDoc dc = yy_load_doc(vals, rows, offs, d, lane);
     const int col = YY_GROUP * ga + 4 * q;
     float dist[4];
     yy_group_dists(dc, vals, rows, Cg + (size_t)ga * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
-    const YyTop2 t = yy_group_top2(dist, col, k);
+    const YyTop2 t = yy_group_top2(dist, col, k, map);
     const float u = sqrtf(t.m1);
     const float uhi = u + fminf(sE, E / fmaxf(u, 1e-30f));
     uint32_t tot = 0;
@@ -1498,7 +1514,7 @@ __global__ __launch_bounds__(256) void yy2_emit_k(const uint32_t* __restrict__ n
 __global__ __launch_bounds__(256) void yy2_scan_k(const float* __restrict__ vals, const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                    const float4* __restrict__ Cg, uint32_t V, int ld, int k, const float* __restrict__ cn,
                                                    const float* __restrict__ dn, uint32_t npairs, const uint64_t* __restrict__ key,
-                                                   const uint32_t* __restrict__ val, YyRes* __restrict__ res) {
+                                                   const uint32_t* __restrict__ val, YyRes* __restrict__ res, YyMap map) {
   const int lane = threadIdx.x & 63;
   // the grid is capped (a launch of more than 2^32 threads does not run: 2^26 pairs at four per workgroup): waves stride over the pairs
   for (uint64_t i64 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i64 < npairs; i64 += (uint64_t)gridDim.x * 4) {
@@ -1513,7 +1529,7 @@ __global__ __launch_bounds__(256) void yy2_scan_k(const float* __restrict__ vals
     const int col = YY_GROUP * g + 4 * q;
     float dist[4];
     yy_group_dists(dc, vals, rows, Cg + (size_t)g * V * 2 + q, 2, (col < ld) ? 1.f : 0.f, lane, col, k, cn, dnd, dist);
-    const YyTop2 t = yy_group_top2(dist, col, k);
+    const YyTop2 t = yy_group_top2(dist, col, k, map);
     if (lane == 0) res[p] = YyRes{t.m1, t.m2, t.i1};
   }
 }
@@ -1522,13 +1538,13 @@ __global__ __launch_bounds__(256) void yy2_scan_k(const float* __restrict__ vals
 __global__ __launch_bounds__(256) void yy2_combine_k(const uint32_t* __restrict__ nactive, const uint32_t* __restrict__ active, const YyRes* __restrict__ own,
                                                       const uint32_t* __restrict__ off, const uint8_t* __restrict__ pgrp,
                                                       const YyRes* __restrict__ res, const float* __restrict__ dn, const float* __restrict__ cn_max_p, int G,
-                                                      uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb) {
+                                                      uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb, YyMap map) {
   const uint32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= *nactive) return;
   const uint32_t d = active[e];
-  const float E = 1e-4f * (dn[d] + *cn_max_p), sE = sqrtf(E);
+  const float E = ISLE_SLACK_REL * (dn[d] + *cn_max_p), sE = sqrtf(E);
   float* gl = glb + (size_t)d * G;
-  const int ga = (int)(assign[d] / YY_GROUP);
+  const int ga = (int)(map.slot(assign[d]) / YY_GROUP);
   float best = 3.4e38f, best_group_second = 3.4e38f;
   uint32_t bidx = 0xffffffffu;
   auto absorb = [&](int g, const YyRes& t) {
@@ -1544,7 +1560,47 @@ __global__ __launch_bounds__(256) void yy2_combine_k(const uint32_t* __restrict_
   const float u = sqrtf(best);
   ub[d] = u + fminf(sE, E / fmaxf(u, 1e-30f));
   assign[d] = bidx;
-  gl[bidx / YY_GROUP] = yy_slack_down(best_group_second, E, sE);  // the assigned centre does not bound its own group
+  gl[map.slot(bidx) / YY_GROUP] = yy_slack_down(best_group_second, E, sE);  // the assigned centre does not bound its own group
+}
+
+// ---- regrouped Yinyang groups (YyMap, common.h): maps on the device, values and rows by slot, labels back to ids
+__global__ __launch_bounds__(256) void yy_gather_by_slot_k(const float* __restrict__ v, const uint32_t* __restrict__ id_of_slot, int k, int n, float* __restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < n) out[s] = s < k ? v[id_of_slot[s]] : 0.f;
+}
+__global__ __launch_bounds__(256) void yy_rows_by_slot_k(const float* __restrict__ in, int ld, int k, const uint32_t* __restrict__ id_of_slot, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)k * ld) return;
+  const int s = (int)(i / ld), j = (int)(i - (size_t)s * ld);
+  out[i] = in[(size_t)id_of_slot[s] * ld + j];
+}
+__global__ __launch_bounds__(256) void yy_labels_to_ids_k(uint32_t* __restrict__ assign, uint64_t D, const uint32_t* __restrict__ id_of_slot) {
+  for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < D; d += (uint64_t)gridDim.x * 256) assign[d] = id_of_slot[assign[d]];
+}
+int k_yy_map_upload(isle_ctx* c, const uint32_t* id_of_slot_host, const uint32_t* slot_of_id_host, int k, int G, YyMap* map) {
+  HIPCHK(c, c->yy_map.reserve((size_t)8 * G + k));
+  HIPCHK(c, hipMemcpyAsync(c->yy_map.p, id_of_slot_host, (size_t)8 * G * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->yy_map.p + 8 * G, slot_of_id_host, (size_t)k * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host arrays are the caller's
+  map->id_of_slot = c->yy_map.p;
+  map->slot_of_id = c->yy_map.p + 8 * G;
+  return 0;
+}
+int k_yy_gather_by_slot(isle_ctx* c, const YyMap& map, int k, int G, const float* cn, float* cn_slot) {
+  hipLaunchKernelGGL(yy_gather_by_slot_k, dim3(cdiv(8 * G, 256)), dim3(256), 0, c->stream, cn, map.id_of_slot, k, 8 * G, cn_slot);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_yy_rows_by_slot(isle_ctx* c, const YyMap& map, int k, const float* in, int ld, float* out) {
+  hipLaunchKernelGGL(yy_rows_by_slot_k, dim3(cdiv((long)((size_t)k * ld), 256)), dim3(256), 0, c->stream, in, ld, k, map.id_of_slot, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_yy_labels_to_ids(isle_ctx* c, const YyMap& map, uint32_t* assign, uint64_t D) {
+  if (!D) return 0;
+  hipLaunchKernelGGL(yy_labels_to_ids_k, dim3((unsigned)std::min<uint64_t>((D + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, assign, D, map.id_of_slot);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 
 int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
@@ -1563,7 +1619,7 @@ int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
 // k_yy_filter and the tightening step of k_yy2_assign in one launch (yy2_filter_tighten_k); k_yy2_assign(..., pre_tightened = true) follows
 int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev,
                         const float* gmax_dev, uint32_t* active, uint32_t* nactive, const float* Cg, int k, int ld, const float* cn, const float* dn,
-                        const float* cn_max, const YyMovers& mv, const float* Crm) {
+                        const float* cn_max, const YyMovers& mv, const float* Crm, const YyMap& map, const float* cn_by_id) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
   if (mv.n && D) {  // b_d . c_mover for every document: one thin pass of the pass-1 stream (k_gl_thin), ten columns at most
@@ -1587,26 +1643,26 @@ int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assi
   ISLECHK(isle_max_lds(c, (const void*)yy2_filter_tighten_k, (int)lds));
   hipLaunchKernelGGL(yy2_filter_tighten_k, dim3(cdiv(D, dpb)), dim3(256), lds, c->stream, D, order, assign, ub, glb, G, delta_dev, gmax_dev, active, nactive, dpb,
                      c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, NW, cn, dn, cn_max, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p,
-                     c->yy_cnt.p, mv, c->yy_mdots.p);
+                     c->yy_cnt.p, mv, c->yy_mdots.p, map, cn_by_id ? cn_by_id : cn);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G) {
+int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G, const YyMap& map) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t V = (uint32_t)c->V;
   HIPCHK(c, c->yy_cg.reserve((size_t)V * 8 * G));
   const size_t n = (size_t)V * 2 * G;
-  hipLaunchKernelGGL(yy2_pack_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, Crm, V, ld, G, (float4*)c->yy_cg.p);
+  hipLaunchKernelGGL(yy2_pack_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, Crm, V, ld, G, (float4*)c->yy_cg.p, c->centers_k, map.id_of_slot);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
-              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg) {
+              const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg, const YyMap& map) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t D = (uint32_t)c->D;
   if (D == 0) return 0;
   hipLaunchKernelGGL(yy_scan_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, Crm, (const float4*)Cg, (uint32_t)c->V, ld, k, G,
-                     cn, dn, cn_max, active, nactive, assign, ub, glb, dbg);
+                     cn, dn, cn_max, active, nactive, assign, ub, glb, dbg, map);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1614,7 +1670,8 @@ int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg, int k, int ld, int
 // The Yinyang iteration ordered by group (see the kernels): active -> assign / ub / glb.  *done = false if the pair list would be too
 // long (more than 48 pairs per document) — nothing has been changed then and the caller runs yy_scan_k instead.
 int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max, const uint32_t* active,
-                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out, bool pre_tightened) {
+                 const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, bool* done, unsigned long long* pairs_out, bool pre_tightened,
+                 const YyMap& map) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   *done = false;
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
@@ -1629,7 +1686,7 @@ int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float
   if (!pre_tightened) {  // k_yy_filter_tighten has done this step with the bounds it had in LDS
     HIPCHK(c, hipMemsetAsync(c->yy_cnt.p, 0, ((size_t)D + 1) * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(yy2_tighten_k, dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, G, NW, cn, dn,
-                       cn_max, active, nactive, assign, glb, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p, c->yy_cnt.p);
+                       cn_max, active, nactive, assign, glb, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p, c->yy_cnt.p, map);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, uint32_t>(c->stream, c->yy_cnt.p, D, c->yy_off.p, reinterpret_cast<uint32_t*>(c->gl_scan.p))));
@@ -1657,11 +1714,11 @@ int k_yy2_assign(isle_ctx* c, const float* Cg, int k, int ld, int G, const float
     bool in_a = true;
     ISLECHK(k_sort_pairs_u64(c, c->gl_key_a.p, c->gl_val_a.p, c->gl_key_b.p, c->gl_val_b.p, np, 8, &in_a));
     hipLaunchKernelGGL(yy2_scan_k, dim3((unsigned)std::min<size_t>(cdiv((long)np, 4), (size_t)1 << 22)), dim3(256), 0, c->stream, c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, cn, dn,
-                       npairs, in_a ? c->gl_key_a.p : c->gl_key_b.p, in_a ? c->gl_val_a.p : c->gl_val_b.p, (YyRes*)c->yy_res.p);
+                       npairs, in_a ? c->gl_key_a.p : c->gl_key_b.p, in_a ? c->gl_val_a.p : c->gl_val_b.p, (YyRes*)c->yy_res.p, map);
     HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(yy2_combine_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, nactive, active, (const YyRes*)c->yy_own.p, c->yy_off.p, c->yy_pgrp.p,
-                     (const YyRes*)c->yy_res.p, dn, cn_max, G, assign, ub, glb);
+                     (const YyRes*)c->yy_res.p, dn, cn_max, G, assign, ub, glb, map);
   HIPCHK(c, hipGetLastError());
   *done = true;
   return 0;

@@ -151,6 +151,33 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         assert np.array_equal(res[mode][2], res["yinyang"][2])
 
 
+def test_regrouped_yinyang_groups_give_the_same_partition(hp, monkeypatch):
+    """Round 5: the Yinyang groups of the by-group iteration are formed from the centres in the order of their squared norms (slot tables,
+    YyMap) instead of eight consecutive labels.  Bounds are bounds whichever centres share a group, labels and ties stay in the centres' own
+    numbering: partition, iteration count and centres must equal the consecutive-label form's (ISLE_YY_REGROUP=0) bit for bit, and the
+    no-bounds loop's partition (src/sparseMatrix.cpp:1587-1677)."""
+    f, B, k = load_case("c3k1000")
+    upload(hp, B)
+    hp.compute_block_ks(k, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    res = {}
+    for name, env in (("regrouped", {}), ("consecutive", {"ISLE_YY_REGROUP": "0"}), ("two_launches", {"ISLE_YY_FUSED": "0"}),
+                      ("none", {"ISLE_KMEANS_BOUNDS": "none"})):
+        for a, b in env.items():
+            monkeypatch.setenv(a, b)
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        res[name] = hp.run_lloyds(k)
+        for a in env:
+            monkeypatch.delenv(a)
+    for name in ("consecutive", "two_launches"):
+        assert res[name]["iters"] == res["regrouped"]["iters"]
+        assert np.array_equal(res[name]["assign"], res["regrouped"]["assign"]), name
+        assert np.array_equal(res[name]["centers"].view(np.uint32), res["regrouped"]["centers"].view(np.uint32)), name
+    assert res["none"]["iters"] == res["regrouped"]["iters"]
+    assert np.array_equal(res["none"]["assign"], res["regrouped"]["assign"])
+
+
 def test_gather_form_runs_the_by_group_iteration_without_movers(hp, monkeypatch):
     """ISLE_GRAM_LDS=0 (or any matrix whose rows are not single-valued) has no LDS-banded stream for the movers' thin product: Lloyd on B
     at k >= 256 (by-group Yinyang iteration, fused filter) must run — round 4 failed there with "k_gl_thin needs the LDS-banded form" as

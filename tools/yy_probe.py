@@ -5,6 +5,7 @@ per iteration the active documents and the group scans.  usage: yy_probe.py [c3s
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -20,8 +21,29 @@ hp = HotPath(0)
 hp.upload_csc(V, B["vals"], B["rows"], B["offs"])
 hp.compute_block_ks(k, seed=1, allow_noconv=True)
 g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
-lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+for rep in range(2):
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
+    hp.timing_enable(True)
+    hp.timing_reset()
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    t = hp.timing_get()
+    hp.timing_enable(False)
+    print("run_lloyds_on_projected_space: %d iterations, device ms %.1f" % (lp["iters"], t["lloyd_proj"][0]), flush=True)
 ref = None
+# PROBE_PERM=norm | normdesc | random: the centres are handed to the lift in another ORDER (a relabelling: the Yinyang groups are eight
+# consecutive labels) — the partition is the same up to that relabelling; what changes is which centres share a group
+C_l = lp["C_lowd"]
+perm = np.arange(k)
+pm = os.environ.get("PROBE_PERM")
+if pm in ("norm", "normdesc"):
+    perm = np.argsort((C_l.astype(np.float64) ** 2).sum(1), kind="stable")
+    if pm == "normdesc":
+        perm = perm[::-1].copy()
+elif pm == "random":
+    perm = np.random.default_rng(5).permutation(k)
+elif pm == "size":
+    perm = np.argsort(-np.bincount(lp["assign"], minlength=k), kind="stable")
+C_l = np.ascontiguousarray(C_l[perm])
 # settings: comma-separated ENV=VAL lists; default: the by-group form with the fused filter / tightening launch and without, then by document
 settings = sys.argv[2:] or ["ISLE_YY_MODE=group", "ISLE_YY_MODE=group,ISLE_YY_FUSED=0", "ISLE_YY_MODE=doc"]
 for setting in settings:
@@ -31,7 +53,7 @@ for setting in settings:
     for rep in range(3):
         if rep == 2:
             os.environ["ISLE_DEBUG_HAMERLY"] = "1"
-        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        hp.left_multiply_by_U(C_l, fetch=False)
         hp.timing_enable(True)
         hp.timing_reset()
         t0 = time.perf_counter()
@@ -39,10 +61,12 @@ for setting in settings:
         dt = time.perf_counter() - t0
         t = hp.timing_get()
         hp.timing_enable(False)
+        ls["assign"] = perm[ls["assign"]].astype(np.uint32)  # back to the labels of Lloyd in span(U)
         if ref is None:
             ref = ls["assign"].copy()
-        print("%-40s run_lloyds: %.1f ms wall, %d iterations; device ms: sparse_assign %.1f, sparse_update %.1f; partition equal to the first run's: %s" %
-              (setting, dt * 1e3, ls["iters"], t["sparse_assign"][0], t["sparse_update"][0], bool(np.array_equal(ref, ls["assign"]))), flush=True)
+        print("%-40s run_lloyds: %.1f ms wall, %d iterations; device ms: sparse_assign %.1f, sparse_update %.1f; partition equal to the first run's: %s (%d documents differ; crc %08x; Lloyd in span(U): %d iterations, crc %08x)" %
+              (setting, dt * 1e3, ls["iters"], t["sparse_assign"][0], t["sparse_update"][0], bool(np.array_equal(ref, ls["assign"])), int((ref != ls["assign"]).sum()),
+               zlib.crc32(ls["assign"].tobytes()), lp["iters"], zlib.crc32(lp["assign"].tobytes())), flush=True)
     os.environ.pop("ISLE_DEBUG_HAMERLY", None)
     for a_, b_ in kv:
         os.environ.pop(a_, None)
