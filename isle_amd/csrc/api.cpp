@@ -59,6 +59,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GEMM_BF16X3", "form", "0: the D x k x k dot products of the assignment steps on the f32 matrix cores (gemm_f32.h) instead of the bf16 ones with operands split in three terms (gemm_bf16x3.h)"},
     {"ISLE_GEMM_EPILOGUE", "form", "0: the D x k x k products of the assignment steps are written to memory and read by dots_assign_cm_k / proj_dots_tiles_k instead of the epilogues inside the product (same bits)"},
     {"ISLE_GEMM_TERMS", "form", "3: the assignment products run once with three bf16 terms per operand (default: two terms first, the rows whose arg-min that leaves open again with three; same assignment)"},
+    {"ISLE_GEMM_DMA", "form", "0: the two-term pass of the assignment products splits A on the fly and stages it through registers (gemm_bf16x3_k) instead of reading the projection's pre-split copy by LDS-DMA through a ring of stages (gemm_bf16x2_dma_k; same products in the same order: same bits)"},
     {"ISLE_YY_MODE", "form", "doc | docg | group: Yinyang iteration by document (row-major / group-major centres) or ordered by group (default: group at k >= 256)"},
     {"ISLE_YY_FUSED", "form", "0: the by-group Yinyang iteration lowers the bounds (yy_filter_k) and tightens the active documents (yy2_tighten_k) in two launches instead of one (same bits)"},
     {"ISLE_YY_MOVERS", "form", "0: every centre's movement lowers its Yinyang group's bound (default: up to ten centres that moved far beyond the rest are bounded by their exact new distances instead)"},
@@ -450,6 +451,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   c->gl_mode = -1;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->Pt2_ready = false;
   c->lift_valid = false;
   c->members_valid = false;
   c->U_k = 0;

@@ -48,10 +48,20 @@ static int ensure_P(isle_ctx* c, int k) {
   c->P_ready = true;
   c->P_gen++;
   c->Pt_ready = false;
+  c->Pt2_ready = false;
   if (c->D) {  // coordinate-major copy for the register-resident MFMA distance kernels
     HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
     ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
     c->Pt_ready = true;
+    // ... and, where the assignment products run with their epilogues inside (a large shard), its two bf16 terms in the layout the LDS-DMA
+    // product stages (gemm_bf16x2_dma_k): the split is made once per projection instead of in every product's staging path
+    c->Pt2_ready = false;
+    if (k_gemm_assign_fused_ok(c, c->D, k, k) && !c->knob_zero(KN_GEMM_DMA) && !(c->knob(KN_GEMM_TERMS) && atoi(c->knob(KN_GEMM_TERMS)) == 3)) {
+      TimeScope ts(c, ISLE_T_PROJECT);
+      HIPCHK(c, c->Pt2.reserve(k_gemm_split_a_bytes(c->D, k) / sizeof(uint4)));
+      ISLECHK(k_gemm_split_a(c, c->Pt.p, c->D, k, c->Pt2.p));
+      c->Pt2_ready = true;
+    }
   }
   return 0;
 }
@@ -659,7 +669,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
           liftC = c->yy_liftC.p;
         }
         ISLECHK(k_gemm_assign_yy(c, c->Pt.p, c->P.p, c->ldk, c->pnorm.p, D, k, liftC, c->lift_ld, k, G, cn_grp, c->dnorm.p, cn_max_dev, c->assign.p,
-                                 c->hub.p, c->yglb.p, ISLE_T_SPARSE_ASSIGN));
+                                 c->hub.p, c->yglb.p, ISLE_T_SPARSE_ASSIGN, c->Pt2_ready ? c->Pt2.p : nullptr));
         if (regroup) ISLECHK(k_yy_labels_to_ids(c, ymap, c->assign.p, D));  // columns (slots) -> centres
       } else if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
         HIPCHK(c, c->dotsT.reserve((size_t)D * k));
@@ -672,6 +682,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
         ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
         c->P_ready = false;  // P now holds the dot products (as with the LDS-banded wide product)
         c->Pt_ready = false;
+        c->Pt2_ready = false;
         if (ld != k) HIPCHK(c, hipMemsetAsync(c->P.p, 0, (size_t)D * ld * sizeof(float), c->stream));
         ISLECHK(k_transpose(c, c->dotsT.p, D, (uint64_t)k, D, c->P.p, (uint64_t)ld));
         ISLECHK(k_dots_assign(c, k, ld, c->cnorm.p, c->dnorm.p, c->assign.p, c->hub.p, c->hlb.p, 0));

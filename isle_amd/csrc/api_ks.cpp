@@ -401,6 +401,7 @@ int install_U(isle_ctx* c, const float* Ucm_dev, int k) {
   c->U_k = k;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->Pt2_ready = false;
   c->lift_valid = false;
   c->centers_ready = false;
   return 0;

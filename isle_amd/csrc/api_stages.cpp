@@ -226,6 +226,7 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   c->gl_mode = -1;
   c->P_ready = false;
   c->Pt_ready = false;
+  c->Pt2_ready = false;
   c->lift_valid = false;
   c->members_valid = false;
   c->U_k = 0;

@@ -88,7 +88,7 @@ struct DevBuf {
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN,
-  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
+  KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
   KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
@@ -292,6 +292,8 @@ struct isle_ctx {
   int lift_ld = 0, lift_k = 0;
   bool lift_valid = false;
   bool Pt_ready = false;
+  DevBuf<uint4> Pt2;       // the coordinate-major copy split in two bf16 terms, as the LDS image of every (row block, slab): the A operand of the
+  bool Pt2_ready = false;  // LDS-DMA assignment products (gemm_bf16x3.h, gemm_bf16x2_dma_k); valid with Pt
   DevBuf<float> min_dist;  // D
   DevBuf<double> cum;      // D + 1
   DevBuf<double> scan_blk;
@@ -527,9 +529,13 @@ int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, in
 int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family);
 bool k_gemm_assign_fused_ok(isle_ctx* c, uint64_t M, int K, int N);
 int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* an, uint64_t M, int K, const float* B, int ldb, int N, int G,
-                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family);
+                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family, const void* A2 = nullptr);
 int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
-                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0 = nullptr);
+                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0 = nullptr,
+                        const void* A2 = nullptr);
+// A2 = the two bf16 terms of a coordinate-major M x K operand in the layout gemm_bf16x2_dma_k stages by LDS-DMA (gemm_bf16x3.h); bytes it needs
+int k_gemm_split_a(isle_ctx* c, const float* A, uint64_t M, int K, void* A2);
+size_t k_gemm_split_a_bytes(uint64_t M, int K);
 int k_compact_rows(isle_ctx* c, const float* P, const float* pn, int ldk, const uint32_t* active, uint32_t n, float* Pa, float* pna);
 int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint64_t ld_in, float* out, uint64_t ld_out);  // out[c*ld_out + r]... see impl
 int k_jacobi_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, float* vecs_dev /*n x n col-major*/);

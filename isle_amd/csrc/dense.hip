@@ -927,9 +927,16 @@ bool k_gemm_assign_fused_ok(isle_ctx* c, uint64_t M, int K, int N) {
 using Gemm2Huge = isle_gemm3::Cfg<2, 2, 4, 4, 4, 16, 2>;  // the same tile with two bf16 terms per operand
 // Both assignment steps: first pass (two terms unless ISLE_GEMM_TERMS=3) over all rows, then the rows it left open through the three-term
 // product.  make(map, eta) builds the epilogue, combine(part, n, map, eta, redo, nredo) launches the step's combine kernel.
+using Gemm2Dma = isle_gemm3::CfgDma<2, 16>;  // the two-term product with A pre-split and staged by LDS-DMA (gemm_bf16x2_dma_k)
+int k_gemm_split_a(isle_ctx* c, const float* A, uint64_t M, int K, void* A2) {
+  HIPCHK(c, isle_gemm3::split_a(c->stream, A, M, K, A2, Gemm2Dma::TK));
+  return 0;
+}
+size_t k_gemm_split_a_bytes(uint64_t M, int K) { return isle_gemm3::a2_units(M, K, Gemm2Dma::TK) * 16; }
 template <class MakeEpi, class Combine>
 static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* rown, uint64_t M, int K, const float* B, int ldb, int N,
-                                MakeEpi make, Combine combine, const uint32_t* map0 = nullptr /*row of A -> document (null: identity)*/) {
+                                MakeEpi make, Combine combine, const uint32_t* map0 = nullptr /*row of A -> document (null: identity)*/,
+                                const void* A2 = nullptr /*A split beforehand (k_gemm_split_a): the first pass reads it by LDS-DMA*/) {
   const int nslot = (N + 63) / 64;
   static_assert(sizeof(AssignRec) == 20, "");
   const char* gt = c->knob(KN_GEMM_TERMS);
@@ -947,7 +954,10 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
   HIPCHK(c, c->ga_redo.reserve(M + 1));
   uint32_t* nredo = c->ga_redo.p + M;
   HIPCHK(c, hipMemsetAsync(nredo, 0, sizeof(uint32_t), c->stream));
-  HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, eta2)));
+  if (A2 && !c->knob_zero(KN_GEMM_DMA))
+    HIPCHK(c, isle_gemm3::launch_dma<Gemm2Dma>(c->stream, A2, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, eta2)));
+  else
+    HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, eta2)));
   combine(part, (uint32_t)M, map0, eta2, c->ga_redo.p, nredo);
   HIPCHK(c, hipGetLastError());
   uint32_t* n_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 192);  // page-locked
@@ -976,7 +986,7 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
 // same rows row-major with leading dimension lda_rm, for the second pass) and the k lifted centres' coordinates B (k x k, leading dimension
 // ldb): dots_assign_cm_k's outputs without the D x k product in memory
 int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* an, uint64_t M, int K, const float* B, int ldb, int N, int G,
-                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family) {
+                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family, const void* A2) {
   TimeScope ts(c, family);
   const int nslot = (N + 63) / 64;
   // largest squared norm of the product's columns (rows of B as stored: centre n's K coordinates)
@@ -992,11 +1002,12 @@ int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, 
       [&](const AssignRec* part, uint32_t n, const uint32_t* map, float eta, uint32_t* redo, uint32_t* nredo) {
         hipLaunchKernelGGL(yy_first_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, G, dn, cn_max, assign, ub, lb, map, eta, an, bmax, redo,
                            nredo);
-      });
+      },
+      nullptr, A2);
 }
 // the same for the full pass of Lloyd in span(U): assign / ub / one lower bound per tile of 32 centres (row stride TL); cmax = max |c|^2 on the device
 int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
-                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0) {
+                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0, const void* A2) {
   TimeScope ts(c, family);
   const int nslot = (N + 63) / 64;
   return gemm_assign_two_pass(
@@ -1005,7 +1016,7 @@ int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_r
       [&](const AssignRec* part, uint32_t n, const uint32_t* map, float eta, uint32_t* redo, uint32_t* nredo) {
         hipLaunchKernelGGL(tiles_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, TL, pn, cmax, assign, ub, tlb, map, eta, redo, nredo);
       },
-      map0);
+      map0, A2);
 }
 
 // in: element (r, cidx) at in[cidx*ld_in + r], r < rows, cidx < cols.  out[r*ld_out + cidx] = in(r, cidx).

@@ -118,6 +118,94 @@ __device__ inline void top2_pair(Top2& t) {  // with the lane that holds the oth
   top2_merge(t, om1, om2, oi1, oax);
 }
 
+// The epilogue of a workgroup's TM x TN tile from the waves' accumulators (shared by gemm_bf16x3_k and gemm_bf16x2_dma_k)
+template <class CF, class Epi>
+__device__ inline void tile_epilogue(f32x16 (&acc)[CF::WNT][CF::WMT], uint64_t m0, int n0, int wm, int wn, int l31, int h, uint64_t M, int N, const Epi& epi) {
+  constexpr int TN = CF::TN, WMT = CF::WMT, WNT = CF::WNT;
+  if constexpr (Epi::kGroup != 0) {
+    static_assert(Epi::kGroup == 8 || Epi::kGroup == 32, "group epilogue: groups of 8 or 32 columns");
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+      const uint64_t m = m0 + wm * (32 * WMT) + i * 32 + l31;
+      const bool live = m < M;
+      const float rd = epi.rowdata(live ? m : M - 1);
+      Top2 best{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};  // of this wave's columns (one 64-column slot per 32 WNT columns ... WNT = 2)
+      float run2 = 3.4e38f;                           // smallest distance of the slot's columns other than best.i1
+      auto fold = [&](const Top2& t) {                // groups in ascending order: a tie keeps the earlier group's (lower) column
+        if (t.m1 < best.m1) {
+          run2 = fminf(fminf(run2, best.m1), t.m2);
+          best = t;
+        } else {
+          run2 = fminf(run2, t.m1);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int cb = n0 + wn * (32 * WNT) + j * 32;  // first column of the 32 x 32 tile
+        if (cb >= N) continue;                          // wave-uniform
+        float dist[16], ax[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = cb + 4 * h + (r & 3) + 8 * (r >> 2);
+          const bool in = col < N;
+          dist[r] = in ? epi.dist(acc[j][i][r], col, rd) : 3.4e38f;
+          ax[r] = in ? epi.aux(col) : 0.f;
+        }
+        if constexpr (Epi::kGroup == 8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Top2 t{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int col = cb + 4 * h + u + 8 * q;
+              if (col < N) top2_take(t, dist[4 * q + u], (uint32_t)col, ax[4 * q + u]);
+            }
+            top2_pair(t);
+            if (cb + 8 * q < N) {  // wave-uniform
+              if (live && h == (q & 1)) epi.group(m, (cb >> 3) + q, rd, t.m1, t.i1, t.m2, t.ax);
+              fold(t);
+            }
+          }
+        } else {
+          Top2 t{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = cb + 4 * h + (r & 3) + 8 * (r >> 2);
+            if (col < N) top2_take(t, dist[r], (uint32_t)col, ax[r]);
+          }
+          top2_pair(t);
+          if (live && h == (j & 1)) epi.group(m, cb >> 5, rd, t.m1, t.i1, t.m2, t.ax);
+          fold(t);
+        }
+      }
+      if (live && h == 0 && n0 + wn * (32 * WNT) < N) epi.slot(m, (n0 + wn * (32 * WNT)) / (32 * WNT), rd, best.m1, best.i1, best.m2, best.ax, run2);
+    }
+  } else {
+  // lane owns row m = l31 of each 32 x 32 tile; register r holds column (r & 3) + 8 (r >> 2) + 4 h
+  const bool full_n = n0 + TN <= N;
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+    const uint64_t m = m0 + wm * (32 * WMT) + i * 32 + l31;
+    if (m < M) {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int nb = n0 + wn * (32 * WNT) + j * 32 + 4 * h;
+        if (full_n) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) epi(m, nb + (r & 3) + 8 * (r >> 2), acc[j][i][r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nb + (r & 3) + 8 * (r >> 2);
+            if (n < N) epi(m, n, acc[j][i][r]);
+          }
+        }
+      }
+    }
+  }
+  }
+}
+
 template <class CF, class Epi>
 __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __restrict__ A, uint64_t M, int K, const bf16x8* __restrict__ B3, int Kp8,
                                                                   int Np, int N, uint32_t nMB, uint32_t nNT, Epi epi) {
@@ -234,88 +322,7 @@ __global__ __launch_bounds__(CF::NT, CF::OCC) void gemm_bf16x3_k(const float* __
     __syncthreads();
   }
 
-  if constexpr (Epi::kGroup != 0) {
-    static_assert(Epi::kGroup == 8 || Epi::kGroup == 32, "group epilogue: groups of 8 or 32 columns");
-#pragma unroll
-    for (int i = 0; i < WMT; ++i) {
-      const uint64_t m = m0 + wm * (32 * WMT) + i * 32 + l31;
-      const bool live = m < M;
-      const float rd = epi.rowdata(live ? m : M - 1);
-      Top2 best{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};  // of this wave's columns (one 64-column slot per 32 WNT columns ... WNT = 2)
-      float run2 = 3.4e38f;                           // smallest distance of the slot's columns other than best.i1
-      auto fold = [&](const Top2& t) {                // groups in ascending order: a tie keeps the earlier group's (lower) column
-        if (t.m1 < best.m1) {
-          run2 = fminf(fminf(run2, best.m1), t.m2);
-          best = t;
-        } else {
-          run2 = fminf(run2, t.m1);
-        }
-      };
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        const int cb = n0 + wn * (32 * WNT) + j * 32;  // first column of the 32 x 32 tile
-        if (cb >= N) continue;                          // wave-uniform
-        float dist[16], ax[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int col = cb + 4 * h + (r & 3) + 8 * (r >> 2);
-          const bool in = col < N;
-          dist[r] = in ? epi.dist(acc[j][i][r], col, rd) : 3.4e38f;
-          ax[r] = in ? epi.aux(col) : 0.f;
-        }
-        if constexpr (Epi::kGroup == 8) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            Top2 t{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int col = cb + 4 * h + u + 8 * q;
-              if (col < N) top2_take(t, dist[4 * q + u], (uint32_t)col, ax[4 * q + u]);
-            }
-            top2_pair(t);
-            if (cb + 8 * q < N) {  // wave-uniform
-              if (live && h == (q & 1)) epi.group(m, (cb >> 3) + q, rd, t.m1, t.i1, t.m2, t.ax);
-              fold(t);
-            }
-          }
-        } else {
-          Top2 t{3.4e38f, 3.4e38f, 0.f, 0xffffffffu};
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int col = cb + 4 * h + (r & 3) + 8 * (r >> 2);
-            if (col < N) top2_take(t, dist[r], (uint32_t)col, ax[r]);
-          }
-          top2_pair(t);
-          if (live && h == (j & 1)) epi.group(m, cb >> 5, rd, t.m1, t.i1, t.m2, t.ax);
-          fold(t);
-        }
-      }
-      if (live && h == 0 && n0 + wn * (32 * WNT) < N) epi.slot(m, (n0 + wn * (32 * WNT)) / (32 * WNT), rd, best.m1, best.i1, best.m2, best.ax, run2);
-    }
-  } else {
-  // lane owns row m = l31 of each 32 x 32 tile; register r holds column (r & 3) + 8 (r >> 2) + 4 h
-  const bool full_n = n0 + TN <= N;
-#pragma unroll
-  for (int i = 0; i < WMT; ++i) {
-    const uint64_t m = m0 + wm * (32 * WMT) + i * 32 + l31;
-    if (m < M) {
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        const int nb = n0 + wn * (32 * WNT) + j * 32 + 4 * h;
-        if (full_n) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) epi(m, nb + (r & 3) + 8 * (r >> 2), acc[j][i][r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int n = nb + (r & 3) + 8 * (r >> 2);
-            if (n < N) epi(m, n, acc[j][i][r]);
-          }
-        }
-      }
-    }
-  }
-  }
+  tile_epilogue<CF, Epi>(acc, m0, n0, wm, wn, l31, h, M, N, epi);
 }
 
 // padded extents of the split B for a tile width TN
@@ -342,6 +349,169 @@ inline hipError_t launch(hipStream_t stream, const float* A, uint64_t M, int K, 
   }
   hipLaunchKernelGGL((gemm_bf16x3_k<CF, Epi>), dim3((uint32_t)(slots * 8)), dim3(CF::NT), CF::LDS_BYTES, stream, A, M, K, reinterpret_cast<const bf16x8*>(B3), Kp8,
                      Np, N, nMB, nNT, epi);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The two-term product with BOTH operands split beforehand and staged by LDS-DMA through a ring of NS stages (round 5).
+// gemm_bf16x3_k<Cfg<..., 16, 2>> stages the next slab through registers (global load -> split -> ds_write) with ONE slab of lookahead: a
+// slab is 12 MFMAs per wave = 1536 matrix-core cycles per SIMD, a loaded slab arrives after an HBM latency of 2000 - 4000 — the kernel
+// runs at the latency, not at the matrix cores (312 of 830 TFLOP/s f32-equivalent; 4100 cycles per slab measured).  Here A (the D x k
+// projection, the same for every call of a k-means phase) is split ONCE into its two bf16 terms, stored as the LDS image of each
+// (row block, slab) — 16 KB contiguous: [term][octet][row] 16-byte units — and a slab is fetched by two global_load_lds_dwordx4 per wave
+// (no VGPRs, no VALU), three slabs ahead: counted s_waitcnt vmcnt(N) and a raw s_barrier (cdna_hip_programming.md, "Pipelining across
+// barriers": __syncthreads() would drain the ring with vmcnt(0)).  Same products in the same order as the register-staged kernel: the
+// accumulators, and with them every distance and bound of the epilogues, are bit-identical.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int NS_, int TK_ = 16>
+struct CfgDma {
+  static constexpr int NS = NS_;  // stages of the ring
+  static constexpr int WMT = 2, WNT = 2, WAVES_M = 4, WAVES_N = 4, TK = TK_, KO = TK_ / 8, NP = 2, OCC = 4;
+  static constexpr int TM = 256, TN = 256, NT = 1024;
+  static constexpr int A_STAGE = NP * KO * TM, B_STAGE = NP * KO * TN, STAGE = A_STAGE + B_STAGE;  // 16-byte units
+  static constexpr int PPW = STAGE / 64 / 16;  // 1-KiB pieces of a slab per wave (A: waves 0 .. 7, B: waves 8 .. 15)
+  static constexpr size_t LDS_BYTES = (size_t)NS * STAGE * 16;
+  static_assert(TK_ == 16 || TK_ == 32, "slabs of 16 or 32");
+};
+inline int nslab_of(int K, int TK) { return (K + TK - 1) / TK; }
+// units of 16 bytes of the split A of an M x K operand (whole row blocks of 256, whole slabs of TK)
+inline size_t a2_units(uint64_t M, int K, int TK = 16) { return (size_t)((M + 255) / 256) * nslab_of(K, TK) * (4 * (TK / 8)) * 256; }
+
+// A (M x K column-major: element (m, k) at A[k * M + m]) -> A2: per (row block mb, slab s) the LDS image [term p][octet oc][row r] of 16-byte
+// units, unit = 8 bf16 = term p of A[256 mb + r][TK s + 8 oc .. + 7] (zero beyond M and K).  grid (row blocks, octets); a thread per row:
+// every read and write of a wave is one contiguous run.
+__global__ __launch_bounds__(256) void gemm2_split_a_k(const float* __restrict__ A, uint64_t M, int K, int nslab, int KO, bf16x8* __restrict__ A2) {
+  const uint64_t mb = blockIdx.x, m = mb * 256 + threadIdx.x;
+  const int q = blockIdx.y;
+  bf16x8 v0, v1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * q + j;
+    const float x = (m < M && k < K) ? A[(uint64_t)k * M + m] : 0.f;
+    const __bf16 x0 = (__bf16)x;
+    v0[j] = x0;
+    v1[j] = (__bf16)(x - (float)x0);
+  }
+  const size_t base = ((mb * nslab + (size_t)(q / KO)) * (2 * KO) + (size_t)(q % KO)) * 256 + threadIdx.x;  // term 0: [p = 0][oc]
+  A2[base] = v0;
+  A2[base + (size_t)KO * 256] = v1;  // term 1: [p = 1][oc]
+}
+inline hipError_t split_a(hipStream_t stream, const float* A, uint64_t M, int K, void* A2, int TK = 16) {
+  const int nslab = nslab_of(K, TK);
+  const uint64_t nMB = (M + 255) / 256;
+  if (nMB == 0) return hipSuccess;
+  if (nMB >= (1ull << 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gemm2_split_a_k, dim3((uint32_t)nMB, (uint32_t)(nslab * (TK / 8))), dim3(256), 0, stream, A, M, K, nslab, TK / 8, reinterpret_cast<bf16x8*>(A2));
+  return hipGetLastError();
+}
+
+template <class CF, class Epi>
+__global__ __launch_bounds__(CF::NT) void gemm_bf16x2_dma_k(const bf16x8* __restrict__ A2, uint64_t M, int K, const bf16x8* __restrict__ B3, int Kp8, int Np,
+                                                             int N, uint32_t nMB, uint32_t nNT, Epi epi) {
+  constexpr int TM = CF::TM, TN = CF::TN, WMT = CF::WMT, WNT = CF::WNT, KO = CF::KO, NP = CF::NP, NS = CF::NS, TK = CF::TK, PPW = CF::PPW;
+  static_assert((NS & (NS - 1)) == 0 && NS >= 2 && NS <= 4, "ring of 2 or 4 stages");
+  extern __shared__ bf16x8 ldsr[];  // [NS][A: NP x KO x TM | B: NP x KO x TN] — ONE array: the DMA ring and the fragment reads share it
+  const uint32_t wg = blockIdx.x, xcd = wg & 7u, slot = wg >> 3;
+  const uint32_t mb = (slot / nNT) * 8u + xcd, nt = slot % nNT;
+  if (mb >= nMB) return;
+  const uint64_t m0 = (uint64_t)mb * TM;
+  const int n0 = (int)nt * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave % CF::WAVES_M, wn = wave / CF::WAVES_M;
+  const int nslab = (K + TK - 1) / TK;
+  // this wave's PPW 1-KiB pieces of a slab: the A stage is walked by waves 0 .. 7, the B stage by waves 8 .. 15
+  const bool mine_a = wave < 8;
+  const int w8 = mine_a ? wave : wave - 8;
+  const bf16x8* ga = A2 + ((size_t)mb * nslab) * CF::A_STAGE + (size_t)(w8 * PPW) * 64 + lane;  // + s * A_STAGE (+ 64 per further piece)
+  // B stage unit u = (w8 * PPW + i) * 64 + lane = [p][oc][n]: p = u / (KO * 256), oc = (u / 256) % KO, n = u % 256
+  const bf16x8* gb[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int u = (w8 * PPW + i) * 64 + lane;
+    gb[i] = B3 + ((size_t)((u / (KO * 256)) * Kp8 + ((u >> 8) % KO))) * Np + n0 + (u & 255);  // + KO s * Np
+  }
+  const uint32_t lpiece = (uint32_t)(((mine_a ? 0 : CF::A_STAGE) + w8 * PPW * 64) * 16);  // byte offset of the wave's first piece in a stage
+  auto issue = [&](int s) {
+    char* l = reinterpret_cast<char*>(ldsr) + (size_t)(s & (NS - 1)) * CF::STAGE * 16 + lpiece;
+    if (mine_a) {
+      const bf16x8* g = ga + (size_t)s * CF::A_STAGE;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 64 * i), (__attribute__((address_space(3))) void*)(l + 1024 * i), 16, 0, 0);
+    } else {
+      const size_t o = (size_t)(KO * s) * Np;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + o), (__attribute__((address_space(3))) void*)(l + 1024 * i), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[WNT][WMT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j)
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nslab) issue(s);
+  for (int s = 0; s < nslab; ++s) {
+    // this wave's pieces of slab s have landed once at most the pieces of the NS - 2 slabs behind it are outstanding (PPW per slab)
+    if (s + NS - 2 < nslab) __builtin_amdgcn_s_waitcnt(0x0f70 | (PPW * (NS - 2)));
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of slab s are in LDS, and everybody is done with slab s - 1: its stage is free
+    if (s + NS - 1 < nslab) issue(s + NS - 1);
+    const bf16x8* st = ldsr + (size_t)(s & (NS - 1)) * CF::STAGE;
+    const bf16x8* a = st + wm * (32 * WMT) + l31;
+    const bf16x8* b = st + CF::A_STAGE + wn * (32 * WNT) + l31;
+#pragma unroll
+    for (int ks = 0; ks < TK / 16; ++ks) {
+      const int oc = 2 * ks + h;  // the lane's octet of this k-step
+      bf16x8 bv[WNT][NP];
+#pragma unroll
+      for (int j = 0; j < WNT; ++j)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bv[j][p] = b[(p * KO + oc) * TN + 32 * j];
+#pragma unroll
+      for (int pa = NP - 1; pa >= 0; --pa) {  // the order of gemm_bf16x3_k: a1 b0; a0 b1, a0 b0
+        bf16x8 av[WMT];
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) av[i] = a[(pa * KO + oc) * TM + 32 * i];
+#pragma unroll
+        for (int pb = NP - 1 - pa; pb >= 0; --pb)
+#pragma unroll
+          for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][pb], av[i], acc[j][i], 0, 0, 0);
+      }
+    }
+  }
+  tile_epilogue<CF, Epi>(acc, m0, n0, wm, wn, l31, h, M, N, epi);
+}
+
+// B3 as for launch<> (three planes' worth of room; the two-term kernel reads planes 0 and 1); A2 from split_a with the same TK
+template <class CF, class Epi>
+inline hipError_t launch_dma(hipStream_t stream, const void* A2, uint64_t M, int K, const float* B, int ldb, int N, void* B3, Epi epi) {
+  const int Kp8 = kp8_of(K), Np = (N + CF::TN - 1) / CF::TN * CF::TN;
+  const size_t nb = (size_t)Kp8 * Np;
+  hipLaunchKernelGGL(gemm3_split_b_k, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, B, ldb, K, N, Kp8, Np, reinterpret_cast<bf16x8*>(B3));
+  const uint32_t nMB = (uint32_t)((M + CF::TM - 1) / CF::TM), nNT = (uint32_t)(Np / CF::TN);
+  const uint64_t slots = (uint64_t)((nMB + 7) / 8) * nNT;
+  static bool lds_attr_set[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !lds_attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x2_dma_k<CF, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) lds_attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16x2_dma_k<CF, Epi>), dim3((uint32_t)(slots * 8)), dim3(CF::NT), CF::LDS_BYTES, stream, reinterpret_cast<const bf16x8*>(A2), M, K,
+                     reinterpret_cast<const bf16x8*>(B3), Kp8, Np, N, nMB, nNT, epi);
   return hipGetLastError();
 }
 

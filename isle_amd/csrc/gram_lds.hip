@@ -44,7 +44,14 @@ namespace {
 constexpr int GL_WAVES = 16;
 constexpr int GL_THREADS = GL_WAVES * 64;
 constexpr int GL_GMAX = 8;  // groups (output items per lane) of a wave: 4 ... 8, GlSide::G; count records are GL_GMAX wide
-constexpr uint32_t GL_RB = 4078;  // source rows per band (even: the half plane is whole float4)
+#ifndef GL_RB_V
+#define GL_RB_V 4078
+#endif
+#ifndef GL_APPLY_WAVES_V
+#define GL_APPLY_WAVES_V 16
+#endif
+constexpr uint32_t GL_RB = GL_RB_V;  // source rows per band (even: the half plane is whole float4)
+constexpr uint32_t GL_APPLY_WAVES = GL_APPLY_WAVES_V;  // most waves of a workgroup of gl_apply_k (experiment builds: 8 with bands of half the height, two workgroups per CU)
 constexpr uint32_t GL_NZ = 16;    // zero rows behind every plane of the band, one per residue class mod 16 (= per 16-byte bank group of the plane):
                                   // a padding slot reads the zero row of a class no real lane of its ds_read_b128 lane group uses in that slot (gl_place_k)
 constexpr uint32_t GL_PS = GL_RB + GL_NZ;   // rows of a plane in LDS
@@ -1220,7 +1227,7 @@ int k_gl_build(isle_ctx* c) {
   // take fewer waves per workgroup so that all CUs stay busy.  The model's figures against the measured ones, pass 1 with 10 columns:
   // C3 shard G = 5: 312 / 313 us; config 3 on one GPU G = 4 / 6 / 8: 2610 / 2530 / 2310 against 2690 / 2490 / 2336 us.
   // ISLE_GL_G1 = 4..8 forces G.
-  const uint32_t maxw = GL_WAVES;
+  const uint32_t maxw = GL_APPLY_WAVES;
   uint32_t wpw = maxw;
   const uint32_t cus = c->knob(KN_GL_TEST_CUS) ? (uint32_t)std::max(1, atoi(c->knob(KN_GL_TEST_CUS))) : (uint32_t)c->num_cus;  // test hook: the geometry of a larger problem on a small one
   {
@@ -1623,6 +1630,12 @@ static int gl_panel_pass(isle_ctx* c, int wcols, int j0, int ld, float* Out) {
   float4* out = (float4*)(Out + j0);
   const uint32_t n2 = (j0 % 4) || half ? (uint32_t)((wcols + 1) / 2) : 0u;  // float2 stores where float4 would be misaligned or too wide
   const float4* in = (const float4*)c->gl_Xs.p;
+#ifdef GL_PWRITE_ABLATE  // timing-only experiment (wrong results): every panel's rows go, whole and in position order, to ONE contiguous scratch
+  if (LPE == 3 && half && ld > 64) {
+    if (c->gl_part.reserve((size_t)c->D * 12 + 64) != hipSuccess) return ISLE_E_HIP;
+    return launch_apply<3, true>(c, c->gl1, in, (float4*)c->gl_part.p, 0, nullptr, 3, 0);
+  }
+#endif
   if (LPE == 1) return half ? launch_apply<1, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<1, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
   if (LPE == 2) return half ? launch_apply<2, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<2, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
   if (LPE == 3 && half) return launch_apply<3, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);

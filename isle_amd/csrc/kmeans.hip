@@ -1010,7 +1010,8 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
       if (k_gemm_assign_fused_ok(c, D, k, k)) {  // distances, tile bounds and candidates formed inside the product: no D x k matrix in memory
         HIPCHK(c, c->cmax_buf.reserve(4));
         ISLECHK(k_max_f32(c, cn, k, c->cmax_buf.p));
-        return k_gemm_assign_tiles(c, c->Pt.p, P, ldk, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ);
+        return k_gemm_assign_tiles(c, c->Pt.p, P, ldk, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ, nullptr,
+                                   c->Pt2_ready && P == c->P.p ? c->Pt2.p : nullptr);
       }
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
       ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));

@@ -680,6 +680,7 @@ int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const floa
     HIPCHK(c, c->P.reserve((size_t)D * ldk));
     c->P_ready = false;
     c->Pt_ready = false;
+    c->Pt2_ready = false;
     ISLECHK(k_gl_wide(c, Mrm, k, ldk, c->P.p));
     return k_dots_assign(c, k, ldk, cn, dn, assign, ub, lb, G);
   }

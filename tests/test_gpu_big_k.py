@@ -151,6 +151,34 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         assert np.array_equal(res[mode][2], res["yinyang"][2])
 
 
+def test_lds_dma_assignment_product_gives_the_bits_of_the_register_staged_one(hp, monkeypatch):
+    """Round 5: the two-term pass of the D x k x k assignment products reads the projection's pre-split copy (two bf16 terms per entry, laid out
+    as the LDS image of every row block and slab) by LDS-DMA through a ring of stages (gemm_bf16x2_dma_k); ISLE_GEMM_DMA=0 splits on the fly
+    and stages through registers (gemm_bf16x3_k).  The same products summed in the same order: partitions, iteration counts and centres of both
+    Lloyd loops must be bit-equal (src/sparseMatrix.cpp:1794-1871, :1494-1572)."""
+    f, B, k = load_case("c3k1000")
+    res = {}
+    for name, env in (("dma", {}), ("registers", {"ISLE_GEMM_DMA": "0"})):
+        for a, b in env.items():
+            monkeypatch.setenv(a, b)
+        upload(hp, B)
+        hp.compute_block_ks(k, seed=3, allow_noconv=True)
+        monkeypatch.setenv("ISLE_KMPP_TRACK", "0")  # so that Lloyd in span(U) opens with a full product as well
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        monkeypatch.delenv("ISLE_KMPP_TRACK")
+        hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = hp.run_lloyds(k)
+        res[name] = (lp, ls)
+        for a in env:
+            monkeypatch.delenv(a)
+    for i in (0, 1):
+        assert res["dma"][i]["iters"] == res["registers"][i]["iters"]
+        assert np.array_equal(res["dma"][i]["assign"], res["registers"][i]["assign"])
+    assert np.array_equal(res["dma"][0]["C_lowd"].view(np.uint32), res["registers"][0]["C_lowd"].view(np.uint32))
+    assert np.array_equal(res["dma"][1]["centers"].view(np.uint32), res["registers"][1]["centers"].view(np.uint32))
+
+
 def test_regrouped_yinyang_groups_give_the_same_partition(hp, monkeypatch):
     """Round 5: the Yinyang groups of the by-group iteration are formed from the centres in the order of their squared norms (slot tables,
     YyMap) instead of eight consecutive labels.  Bounds are bounds whichever centres share a group, labels and ties stay in the centres' own

@@ -65,6 +65,34 @@ static float run_cfg3(hipStream_t st, const S& s, const float* A, const float* B
   return best;
 }
 
+template <class CF>
+static float run_dma(hipStream_t st, const S& s, const float* A, const float* B, float* C, void* B3, void* A2, hipEvent_t e0, hipEvent_t e1, float* split_ms) {
+  float best = 1e30f;
+  hipEventRecord(e0, st);
+  hipError_t e = isle_gemm3::split_a(st, A, (uint64_t)s.M, (int)s.K, A2, CF::TK);
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  hipEventElapsedTime(split_ms, e0, e1);
+  if (e != hipSuccess) {
+    printf("split failed: %s\n", hipGetErrorString(e));
+    return -1.f;
+  }
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0, st);
+    e = isle_gemm3::launch_dma<CF>(st, A2, (uint64_t)s.M, (int)s.K, B, (int)s.ldb, (int)s.N, B3, isle_gemm3::StoreC{C, (uint64_t)s.M});
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    if (e != hipSuccess) {
+      printf("launch failed: %s\n", hipGetErrorString(e));
+      return -1.f;
+    }
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+
 static double check(const S& s, const float* A, const float* B, const float* C) {  // fp64 on 64 random entries + the four corners
   std::vector<float> a(s.K), b(s.K);
   double worst = 0;
@@ -137,6 +165,22 @@ int main(int argc, char** argv) {
   }
     RUN3("bf16 x 3 256x256 1024thr occ4", 2, 2, 4, 4, 4)
     RUN3("bf16 x 2 (3 products) 256x256", 2, 2, 4, 4, 4, 16, 2)
+#define RUND(NAME, NS, TKK)                                                                                                    \
+  {                                                                                                                        \
+    void* A2 = nullptr;                                                                                                    \
+    if (hipMalloc(&A2, isle_gemm3::a2_units((uint64_t)s.M, (int)s.K, TKK) * 16) == hipSuccess) {                               \
+      hipMemsetAsync(C, 0xff, (size_t)s.M * s.N * 4, st);                                                                   \
+      float sp = 0.f;                                                                                                      \
+      const float ms = run_dma<isle_gemm3::CfgDma<NS, TKK>>(st, s, A, B, C, B3, A2, e0, e1, &sp);                                \
+      const double w = zeros ? 0.0 : check(s, A, B, C);                                                                     \
+      printf("    %-34s %8.3f ms %6.1f TFLOP/s  err %.1e%s   (split of A: %.3f ms)\n", NAME, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, w, w < 2e-5 ? "" : "  WRONG", sp); \
+      fflush(stdout);                                                                                                      \
+      hipFree(A2);                                                                                                         \
+    }                                                                                                                      \
+  }
+    RUND("bf16 x 2 LDS-DMA ring of 4", 4, 16)
+    RUND("bf16 x 2 LDS-DMA ring of 2", 2, 16)
+    RUND("bf16 x 2 LDS-DMA ring of 2, TK 32", 2, 32)
     RUN3("bf16 x 2 (3 products) 256x128 occ2", 2, 2, 4, 2, 2, 16, 2)
     RUN3("bf16 x 2 (3 products) 256x256 TK32", 2, 2, 4, 4, 4, 32, 2)
     RUN3("bf16 x 2 (3 products) w128x64 TK32", 4, 2, 2, 4, 2, 32, 2)

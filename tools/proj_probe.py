@@ -28,6 +28,10 @@ for setting in (sys.argv[2:] or [""]):
         if rep == 2:
             os.environ["ISLE_DEBUG_HAMERLY"] = "1"
         g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
+        perm = np.arange(k)
+        if os.environ.get("PROBE_PERM") == "norm":  # the seeds handed over in the order of their squared norms (a relabelling: tiles = 32 consecutive labels)
+            perm = np.argsort((g["C_lowd"].astype(np.float64) ** 2).sum(1), kind="stable")
+            g["C_lowd"] = np.ascontiguousarray(g["C_lowd"][perm])
         hp.timing_enable(True)
         hp.timing_reset()
         t0 = time.perf_counter()
@@ -35,6 +39,7 @@ for setting in (sys.argv[2:] or [""]):
         dt = time.perf_counter() - t0
         t = hp.timing_get()
         hp.timing_enable(False)
+        lp["assign"] = perm[lp["assign"]].astype(np.uint32)
         if ref is None:
             ref = lp["assign"].copy()
         print("%-40s run_lloyds_on_projected_space: %.1f ms wall, %d iterations; device ms lloyd_proj %.1f; partition agreement with the first run %.7f" %
