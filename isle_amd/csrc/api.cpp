@@ -48,6 +48,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_QR_FUSED", "form", "1: panel QR as one persistent launch (bitwise equal to the kernel chain, no faster)"},
     {"ISLE_EVD_JACOBI", "form", "small symmetric EVD by block Jacobi instead of tridiagonalisation"},
     {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},
+    {"ISLE_EVD_SPLIT", "form", "0: with several ranks every rank computes all eigenvectors of the small EVD (default: rank r the vectors [r kc, (r + 1) kc) — eigenvectors of the tridiagonal matrix and their back-transformation — followed by an all-gather; the same bits on every rank)"},
     {"ISLE_KMPP_HOST_DICE", "form", "k-means++ dice scaled and searched through the host round trip (the multi-rank form) on one rank too"},
     {"ISLE_KMPP_SPARSE", "form", "0 / 1: k-means++ rounds on the projection / through thin products of B (default: by cost)"},
     {"ISLE_KMPP_TRACK", "form", "0: Lloyd in span(U) always starts with a full assignment pass (default at k > 224 on a large shard: it starts from the nearest seeds and tile minima the k-means++ rounds kept)"},

@@ -413,13 +413,14 @@ __global__ __launch_bounds__(256) void td_bisect_k(const double* __restrict__ d,
 // interleaved over vectors ([i * nvec + v]: coalesced).  Z row-major n x nvec, unit 2-norm.
 __global__ __launch_bounds__(64) void td_vectors_k(const double* __restrict__ d, const double* __restrict__ e, int n, const double* __restrict__ lam_desc,
                                                     int nvec, double* __restrict__ Dp /*n x nvec*/, double* __restrict__ Lf /*n x nvec*/,
-                                                    double* __restrict__ Z /*n x nvec; also holds U factors during the backward sweep*/) {
+                                                    double* __restrict__ Z /*n x nvec; also holds U factors during the backward sweep*/,
+                                                    int v0, int v1 /*the vectors [v0, v1) of the nvec (several ranks: each takes a range)*/) {
   // One lane per eigenvector; every sweep is a recurrence over the rows.  The operands of a step (d, e, and what an earlier sweep parked
   // in Dp / Lf / Z) do not depend on the recurrence, so they are fetched U rows ahead: fetched inside the step, each row paid a
   // memory latency on top of its division (2.8 ms per call at n = 2010, one wave per CU on 16 CUs).
   constexpr int U = 8;
-  const int v = min(blockIdx.x * 64 + (int)threadIdx.x, nvec - 1);  // lanes beyond the last vector repeat it (the wave max below needs them)
-  const bool live = blockIdx.x * 64 + (int)threadIdx.x < nvec;
+  const int v = min(v0 + (int)blockIdx.x * 64 + (int)threadIdx.x, v1 - 1);  // lanes beyond the last vector repeat it (the wave max below needs them)
+  const bool live = v0 + (int)blockIdx.x * 64 + (int)threadIdx.x < v1;
   const double lam = lam_desc[v];
   double tnorm = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) tnorm = fmax(tnorm, fabs(d[i]) + (i < n - 1 ? fabs(e[i]) : 0.0) + (i > 0 ? fabs(e[i - 1]) : 0.0));
@@ -527,14 +528,14 @@ __global__ __launch_bounds__(64) void td_vectors_k(const double* __restrict__ d,
 constexpr int TD_B_T = 1024;  // threads: per reflector every thread walks (n - j) / (TD_B_T / NC) rows twice, a latency chain (256 threads: 9.6 ms per call at n = 2010)
 template <int NC>  // eigenvectors per workgroup: 8, or 4 when there are too few of them to give every CU a workgroup
 __global__ __launch_bounds__(TD_B_T) void td_back_k(const double* __restrict__ A, const double* __restrict__ tau, int n, const double* __restrict__ Z, int nvec,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int v0, int v1 /*the vectors [v0, v1) of the nvec*/) {
   extern __shared__ double zs[];  // n x NC
   constexpr int NWV = TD_B_T / 64;
   __shared__ double red[NWV][NC];
   constexpr int RL = TD_B_T / NC;  // row lanes
-  const int c0 = blockIdx.x * NC;
+  const int c0 = v0 + (int)blockIdx.x * NC;
   const int t = threadIdx.x, c = t & (NC - 1), rl = t / NC, lane = t & 63, wave = t >> 6;
-  const bool live = c0 + c < nvec;
+  const bool live = c0 + c < v1;
   for (int i = rl; i < n; i += RL) zs[i * NC + c] = live ? Z[(size_t)i * nvec + c0 + c] : 0.0;
   __syncthreads();
   for (int j = n - 3; j >= 0; --j) {
@@ -695,11 +696,33 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   }
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
   hipLaunchKernelGGL(td_bisect_k, dim3((nvec + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, nvec, lam);
-  hipLaunchKernelGGL(td_vectors_k, dim3((nvec + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z);
-  if ((nvec + 7) / 8 > c->num_cus / 2)
-    hipLaunchKernelGGL(td_back_k<8>, dim3((nvec + 7) / 8), dim3(TD_B_T), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
-  else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread (two per workgroup measured no better)
-    hipLaunchKernelGGL(td_back_k<4>, dim3((nvec + 3) / 4), dim3(TD_B_T), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev);
+  // Several ranks (round 5): the eigenvectors are independent of each other from here on — a thread per vector in td_vectors_k, a workgroup per
+  // 8 (4) vectors in td_back_k — so rank r computes the vectors [r kc, (r + 1) kc) only and the columns are all-gathered: every rank
+  // holds the same bits, whoever computed them (the replicated restart decisions stay in step), and the 5 - 8 ms of this stage at n = 2010
+  // divide by the number of ranks.  ISLE_EVD_SPLIT=0 keeps every rank computing every vector.
+  int v0 = 0, v1 = nvec, kc = 0;
+  if (c->multi() && !c->knob_zero(KN_EVD_SPLIT)) {
+    kc = ((nvec + c->world - 1) / c->world + 7) & ~7;
+    if ((size_t)kc * c->world <= (size_t)n) {  // the gathered block fits the caller's n x n array
+      v0 = std::min(nvec, c->rank * kc);
+      v1 = std::min(nvec, v0 + kc);
+    } else {
+      kc = 0;
+    }
+  }
+  const int nv = v1 - v0;
+  if (nv > 0) {
+    hipLaunchKernelGGL(td_vectors_k, dim3((nv + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z, v0, v1);
+    if ((nvec + 7) / 8 > c->num_cus / 2 && !kc)
+      hipLaunchKernelGGL(td_back_k<8>, dim3((nv + 7) / 8), dim3(TD_B_T), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev, v0, v1);
+    else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread (two per workgroup measured no better)
+      hipLaunchKernelGGL(td_back_k<4>, dim3((nv + 3) / 4), dim3(TD_B_T), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev, v0, v1);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (kc) {
+    TimeScope ts(c, ISLE_T_COMM);
+    ISLECHK(isle_allgather(c, vecs_dev + (size_t)c->rank * kc * n, vecs_dev, (size_t)kc * n, ISLE_DT_F32));
+  }
   hipLaunchKernelGGL(td_check_k, dim3(nvec), dim3(256), 0, c->stream, vecs_dev, n, nvec, worst);
   HIPCHK(c, hipGetLastError());
   std::vector<double> ev(n);
