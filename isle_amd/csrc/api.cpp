@@ -16,6 +16,8 @@
 #include <numeric>
 #include <thread>
 
+#include <dlfcn.h>
+
 #include "api_internal.h"
 
 // ------------------------------------------------------------------------------------------
@@ -75,6 +77,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_COMM_TIMEOUT_S", "tuning", "seconds without a completed collective, while collectives are pending, after which the watchdog aborts the RCCL communicator and the call returns ISLE_E_COMM (default 300; 0: no watchdog)"},
     {"ISLE_FORCE_COMM", "test hook", "create a 1-rank RCCL communicator so that every collective call site runs on one GPU"},
     {"ISLE_TEST_STALL_MS", "test hook", "a kernel that spins for this many milliseconds is queued ahead of every RCCL collective (the watchdog's test)"},
+    {"ISLE_ROCTX", "diagnostic", "1: every kernel family's launches are wrapped in a roctx range (isle:gram_pass1, isle:ortho, ...) for rocprofv3 --marker-trace; the roctx library is opened at run time"},
     {"ISLE_HOST_TRACE", "diagnostic", "print host wall time between marks of the control loops"},
     {"ISLE_DEBUG_HAMERLY", "diagnostic", "print active documents / group scans per Lloyd iteration"},
     {"ISLE_DEBUG_EVD", "diagnostic", "print sweeps / orthogonality defect of the small EVD"},
@@ -142,7 +145,43 @@ extern "C" int isle_hip_switch_info(int index, const char** name, const char** k
   return KN_COUNT;
 }
 
+// rocprofv3 markers per kernel family (SURVEY 5.1 "build hook"; the reference's phase timers are include/timer.h:72-85).  ISLE_ROCTX=1:
+// every TimeScope also pushes / pops a roctx range named after its family (host-side API ranges around the launches: `rocprofv3
+// --marker-trace --kernel-trace` shows which kernels belong to which family).  The roctx library is opened at run time — libisle_hip.so
+// itself links RCCL and the HIP runtime only — and a missing library just leaves the markers out.
+static const char* const kFamilyName[ISLE_T_COUNT] = {"isle:gram_pass1", "isle:gram_pass2", "isle:ortho", "isle:panel_qr", "isle:small_evd", "isle:rotate",
+                                                       "isle:project", "isle:kmeanspp", "isle:lloyd_projected", "isle:lloyd_sparse_assign",
+                                                       "isle:lloyd_sparse_update", "isle:operator_build", "isle:collectives", "isle:threshold",
+                                                       "isle:post", "isle:ingest", "isle:infer"};
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static void roctx_load_once() {
+  static bool tried = false;
+  if (tried) return;
+  tried = true;
+  for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+    if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+      g_roctx_push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+      g_roctx_pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+      if (g_roctx_push && g_roctx_pop) return;
+      g_roctx_push = nullptr;
+      g_roctx_pop = nullptr;
+    }
+  }
+  fprintf(stderr, "[isle_hip] ISLE_ROCTX: no roctx library found (librocprofiler-sdk-roctx.so / libroctx64.so): no markers\n");
+}
+
 TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
+  if (fam >= 0 && fam < ISLE_T_COUNT && c->knob_on(KN_ROCTX) && !c->knob_zero(KN_ROCTX) && !c->roctx_open) {
+    roctx_load_once();
+    if (g_roctx_push) {
+      g_roctx_push(kFamilyName[fam]);
+      c->roctx_open = true;
+      marker = true;
+    }
+  }
   if (fam < 0 || !c->timing || !((c->timing_mask >> fam) & 1u)) return;
   if (c->ts_open) return;  // inside another scope (a launcher called by a launcher): the outer one times both, nothing is counted twice
   if (!c->ev_free.empty()) {
@@ -156,6 +195,10 @@ TimeScope::TimeScope(isle_ctx* c_, int fam) : c(c_), on(false) {
   if (on) c->ts_open = true;
 }
 TimeScope::~TimeScope() {
+  if (marker) {
+    g_roctx_pop();
+    c->roctx_open = false;
+  }
   if (!on) return;
   c->ts_open = false;
   (void)hipEventRecord(ep.b, c->stream);

@@ -90,7 +90,7 @@ enum IsleKnob {
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN, KN_EVD_SPLIT,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
-  KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
+  KN_ROCTX, KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
 };
 struct IsleKnobInfo {
@@ -286,6 +286,7 @@ struct isle_ctx {
   DevBuf<float> ga_bn;             // squared norms of the product's columns and their maximum
   DevBuf<float> ga_rows, ga_rown;  // those rows gathered coordinate-major, their squared norms
   bool ts_open = false;       // a TimeScope is open (nested scopes are not timed again)
+  bool roctx_open = false;    // ... and a roctx range (ISLE_ROCTX; nested scopes push no second one)
   uint32_t ga_last_redo = 0;  // their number in the last product (diagnostic: isle_hip_measure)
   DevBuf<float> assign_part;  // per document and 64-column slot the best centre of the slot (16 bytes: k_gemm_assign_yy / _tiles, dense.hip)
   DevBuf<float> lift_C;    // the k x k coefficients the device-resident centres were lifted from (centres = U lift_C^T)
@@ -402,6 +403,7 @@ struct TimeScope {
   isle_ctx* c;
   isle_event_pair ep;
   bool on;
+  bool marker = false;  // a roctx range is open for this scope (ISLE_ROCTX)
   TimeScope(isle_ctx* c_, int fam);
   ~TimeScope();
 };

@@ -652,3 +652,18 @@ def test_kmeanspp_dice_thrown_on_the_device_pick_the_hosts_seeds(hp, small50, mo
     assert (g0["seeds"] == g1["seeds"]).all() and g0["rounds"] == g1["rounds"]
     assert g0["residual"] == g1["residual"]
     assert np.array_equal(g0["C_lowd"], g1["C_lowd"])
+
+
+def test_roctx_family_markers_leave_the_results_alone(hp, tiny10, monkeypatch):
+    """ISLE_ROCTX=1 wraps every kernel family's launches in a roctx range (SURVEY 5.1's build hook; `rocprofv3 --marker-trace` shows them,
+    profiles/r05_roctx_marker_trace_sample.txt).  The markers are host-side API calls: same bits with and without."""
+    B = tiny10
+    upload(hp, B)
+    X = np.random.default_rng(3).standard_normal((B["V"], 10)).astype(np.float32)
+    Z0 = hp.gram_apply(X)
+    monkeypatch.setenv("ISLE_ROCTX", "1")
+    Z1 = hp.gram_apply(X)
+    r = hp.compute_block_ks(10, allow_noconv=True)
+    monkeypatch.delenv("ISLE_ROCTX")
+    assert np.array_equal(Z0.view(np.uint32), Z1.view(np.uint32))
+    assert r["nconv"] == 10
