@@ -109,8 +109,10 @@ int isle_hip_get_A(isle_ctx* ctx, float* counts, uint32_t* rows, int64_t* offset
  * B is built in device memory and becomes the context's matrix exactly as if it had been passed
  * to isle_hip_upload_csc (empty columns removed; its doc_offset / docs_global follow from the
  * shards' surviving column counts).  Thresholds use the GLOBAL corpus (token total, non-empty
- * documents and per-word histograms are all-reduced).  Sampling is single-rank only; its keys
- * are drawn on the host from sample_seed (the reference uses unseeded rand()).
+ * documents and per-word histograms are all-reduced).  Sampling keys are drawn on the host from
+ * sample_seed and the document's GLOBAL number (the reference uses unseeded rand()); with several
+ * ranks all keys are gathered and every rank selects the same pivot, so the shards keep what a
+ * single-rank run keeps.
  * Outputs (any may be NULL): docs_kept / nnz_kept describe this rank's shard of B;
  * entries_above_threshold is the global count before sampling (the reference's log line);
  * avg_doc_sz as computed at src/sparseMatrix.cpp:98. */

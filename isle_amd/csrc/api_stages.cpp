@@ -102,7 +102,6 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
   if (!c->a_ready) return isle_fail(c, ISLE_E_ARG, "threshold: no count matrix uploaded");
   if (num_topics == 0) return isle_fail(c, ISLE_E_ARG, "threshold: num_topics == 0");
   const bool sampling = sample_rate > 0.0 && sample_rate < 1.0;
-  if (sampling && c->world > 1) return isle_fail(c, ISLE_E_ARG, "threshold: document sampling is single-rank only");
   const uint64_t V = c->a_V, D = c->a_D;
 
   // corpus statistics (src/sparseMatrix.cpp:92-99), global
@@ -155,28 +154,61 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
     *entries_above = g;
   }
 
-  if (sampling && D) {  // sampled_threshold_and_copy, src/sparseMatrix.cpp:1383-1415 (keys on the host, like the reference)
+  if (sampling && (D || c->multi())) {  // sampled_threshold_and_copy, src/sparseMatrix.cpp:1383-1415 (keys on the host, like the reference)
+    // Several ranks (round 5): a document's key depends on its GLOBAL number only, the pivot is the (rate x D_global)-th largest key of the
+    // whole corpus — every rank gathers all keys (padded to the largest shard) and selects the same pivot; what a shard keeps is what the
+    // single-rank run keeps of those documents.
     std::vector<float> wgt(D), key(D), dice(D);
-    HIPCHK(c, hipMemcpy(wgt.data(), c->a_wgt.p, D * sizeof(float), hipMemcpyDeviceToHost));
-    for (uint64_t d = 0; d < D; ++d) {
+    if (D) HIPCHK(c, hipMemcpy(wgt.data(), c->a_wgt.p, D * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint64_t dl = 0; dl < D; ++dl) {
+      const uint64_t d = c->a_doc_offset + dl;  // the document's number in the corpus
       uint64_t z = (sample_seed + 1) * 0x9E3779B97F4A7C15ull ^ (d * 0xD1342543DE82EF95ull);
       z += 0x9E3779B97F4A7C15ull;
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
       z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
       z = z ^ (z >> 31);
       const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
-      key[d] = (wgt[d] == 0.f) ? 0.f : (float)std::pow(u, 1.0 / (double)wgt[d]);
-      dice[d] = key[d];
+      key[dl] = (wgt[dl] == 0.f) ? 0.f : (float)std::pow(u, 1.0 / (double)wgt[dl]);
+      dice[dl] = key[dl];
     }
-    const size_t nth = std::min<size_t>((size_t)((float)sample_rate * (float)D), D - 1);
-    std::nth_element(dice.begin(), dice.begin() + nth, dice.end(), std::greater<float>());
-    const float pivot = dice[nth];
-    std::vector<uint8_t> drop(D);
+    uint64_t Dg = D;
+    if (c->multi()) {  // all keys of the corpus on every rank: shards padded with -1 to the largest one
+      uint64_t dmax = D;
+      HIPCHK(c, hipMemcpyAsync(st_dev, &dmax, sizeof(dmax), hipMemcpyHostToDevice, c->stream));
+      ISLECHK(isle_allreduce(c, st_dev, 1, ISLE_DT_U64, true));
+      HIPCHK(c, hipMemcpyAsync(&dmax, st_dev, sizeof(dmax), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (dmax == 0) dmax = 1;
+      DevBuf<float> keys_all;
+      HIPCHK(c, keys_all.reserve((size_t)c->world * dmax));
+      std::vector<float> mine(dmax, -1.f);
+      std::copy(key.begin(), key.end(), mine.begin());
+      HIPCHK(c, hipMemcpy(keys_all.p + (size_t)c->rank * dmax, mine.data(), dmax * sizeof(float), hipMemcpyHostToDevice));
+      {
+        TimeScope ts(c, ISLE_T_COMM);
+        ISLECHK(isle_allgather(c, keys_all.p + (size_t)c->rank * dmax, keys_all.p, dmax, ISLE_DT_F32));
+      }
+      std::vector<float> all((size_t)c->world * dmax);
+      HIPCHK(c, hipMemcpyAsync(all.data(), keys_all.p, all.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      keys_all.release();
+      dice.clear();
+      for (float v : all)
+        if (v >= 0.f) dice.push_back(v);
+      Dg = dice.size();
+    }
+    float pivot = 2.f;  // (an empty corpus keeps nothing)
+    if (Dg) {
+      const size_t nth = std::min<size_t>((size_t)((float)sample_rate * (float)Dg), Dg - 1);
+      std::nth_element(dice.begin(), dice.begin() + nth, dice.end(), std::greater<float>());
+      pivot = dice[nth];
+    }
+    std::vector<uint8_t> drop(D ? D : 1);
     for (uint64_t d = 0; d < D; ++d) drop[d] = !(key[d] >= pivot);
     DevBuf<uint8_t> drop_dev;
-    HIPCHK(c, drop_dev.reserve(D));
-    HIPCHK(c, hipMemcpy(drop_dev.p, drop.data(), D, hipMemcpyHostToDevice));
-    int rc = k_th_drop(c, drop_dev.p);
+    HIPCHK(c, drop_dev.reserve(D ? D : 1));
+    if (D) HIPCHK(c, hipMemcpy(drop_dev.p, drop.data(), D, hipMemcpyHostToDevice));
+    int rc = D ? k_th_drop(c, drop_dev.p) : 0;
     if (rc == 0) rc = k_th_scans(c);
     (void)hipStreamSynchronize(c->stream);
     drop_dev.release();

@@ -46,6 +46,13 @@ Bd = hp.get_B()
 res.update(thr_rows=Bd["rows"], thr_vals=Bd["vals"], thr_offs=Bd["offs"], thr_cols=Bd["original_cols"],
            thr_meta=np.array([hp.doc_offset, hp.D_global, ti["entries_above_threshold"]], np.int64))
 
+# ---- the same with importance sampling of documents (BASELINE configs[3]): keys by global document number, one pivot for the corpus
+hp.upload_counts(Vt, cnt, rows, offs, doc_offset=rank * per, docs_global=Dt)
+ts = hp.threshold(kt, sample_rate=0.3, sample_seed=11)
+Bs = hp.get_B()
+res.update(ths_rows=Bs["rows"], ths_vals=Bs["vals"], ths_offs=Bs["offs"], ths_cols=Bs["original_cols"],
+           ths_meta=np.array([hp.doc_offset, hp.D_global, ts["docs_kept"]], np.int64))
+
 # ---- hot path on a shard of B
 k = 20
 B = corpus(3000, 9000, k, 3)
@@ -150,6 +157,13 @@ def test_n_ranks_reproduce_one_rank(single, world, rowshard):
     assert np.array_equal(np.concatenate([r["thr_cols"] for r in rs]), one["thr_cols"])
     assert np.array_equal(np.concatenate([np.diff(r["thr_offs"]) for r in rs]), np.diff(one["thr_offs"]))
     assert rs[0]["thr_meta"][2] == one["thr_meta"][2]
+    # ... and with importance sampling: the shards keep exactly the documents the single-rank run keeps
+    assert rs[0]["ths_meta"][1] == one["ths_meta"][1] and sum(int(r["ths_meta"][2]) for r in rs) == int(one["ths_meta"][2])
+    assert 0 < one["ths_meta"][2] < one["thr_cols"].shape[0]
+    assert np.array_equal(np.concatenate([r["ths_cols"] for r in rs]), one["ths_cols"])
+    assert np.array_equal(np.concatenate([r["ths_rows"] for r in rs]), one["ths_rows"])
+    assert np.array_equal(np.concatenate([r["ths_vals"] for r in rs]), one["ths_vals"])
+    assert np.array_equal(np.concatenate([np.diff(r["ths_offs"]) for r in rs]), np.diff(one["ths_offs"]))
     # operator and eigensolver
     a = rs[0]
     assert abs(a["fro"][0] - one["fro"][0]) <= 1e-6 * one["fro"][0]
