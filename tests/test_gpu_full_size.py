@@ -30,6 +30,34 @@ def _columns(B, cols):
     return dict(vals=B["vals"][idx], rows=B["rows"][idx], offs=so)
 
 
+def _default_route_against_the_oracle(hp, B, V, k, U, g, lp):
+    """The DEFAULT route at full size against the oracle, step by step (a sample uploaded on its own selects the small-shape routes instead):
+    whatever the library assigns in iteration n + 1 of a loop must be the oracle's arg-min against the centres the library itself returned
+    after n updates — iteration 1 of Lloyd in span(U) is the hand-over from the k-means++ rounds (ISLE_KMPP_TRACK left on), iteration 5 a
+    bounded one (tile bounds, movers, sums kept up to date); iteration 1 of Lloyd on B is the two-term product through the projection (read by
+    LDS-DMA, Yinyang groups by norm).  hp holds B with U installed; g = the k-means++ result, lp = the finished Lloyd in span(U)."""
+    from oracle.oracle import OracleCsc, lift
+    cols_a = np.sort(np.random.default_rng(9).choice(B["D"], min(100_000, B["D"]), replace=False))
+    Ba = _columns(B, cols_a)
+    oa = OracleCsc(V, len(cols_a), Ba["vals"], Ba["rows"], Ba["offs"])
+
+    def projected(n):
+        g_ = hp.kmeans_init_on_projected_space(k, inject_seeds=g["seeds"])  # the rounds' tracked state again
+        assert np.array_equal(g_["C_lowd"].view(np.uint32), g["C_lowd"].view(np.uint32))
+        return hp.run_lloyds_on_projected_space(k, g_["C_lowd"], max_reps=n)
+
+    l1, l4, l5 = projected(1), projected(4), projected(5)
+    for got, cen in ((l1, g["C_lowd"]), (l5, l4["C_lowd"])):
+        want = oa.lloyds_projected(U, cen, max_reps=1)["assign"]
+        agree = float((got["assign"][cols_a] == want).mean())
+        assert agree >= 0.9999, agree
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    s1 = hp.run_lloyds(k, max_reps=1, fetch_centers=False)
+    want = oa.lloyds_sparse(lift(U, lp["C_lowd"]), max_reps=1)["assign"]
+    agree = float((s1["assign"][cols_a] == want).mean())
+    assert agree >= 0.9999, agree
+
+
 def _run(hp, V, D, k, seed, n_pairs, n_sample):
     from oracle.oracle import OracleCsc, lift
     from tools.synth import make_B
@@ -58,30 +86,7 @@ def _run(hp, V, D, k, seed, n_pairs, n_sample):
     np.add.at(maj, (ls["assign"].astype(np.int64), B["planted"].astype(np.int64) % k), 1)
     purity = maj.max(1).sum() / B["D"]
     assert 0.78 <= purity <= 0.95, purity
-    # The DEFAULT route at this size against the oracle, step by step (a sample uploaded on its own selects the small-shape routes instead):
-    # whatever the library assigns in iteration n + 1 of a loop must be the oracle's arg-min against the centres the library itself returned
-    # after n updates — iteration 1 of Lloyd in span(U) is the hand-over from the k-means++ rounds (ISLE_KMPP_TRACK left on), iteration 5 a
-    # bounded one (tile bounds, movers, sums kept up to date); iteration 1 of Lloyd on B is the two-term product through the projection.
-    cols_a = np.sort(np.random.default_rng(9).choice(B["D"], min(100_000, B["D"]), replace=False))
-    Ba = _columns(B, cols_a)
-    oa = OracleCsc(V, len(cols_a), Ba["vals"], Ba["rows"], Ba["offs"])
-
-    def projected(n):
-        g_ = hp.kmeans_init_on_projected_space(k, inject_seeds=g["seeds"])  # the rounds' tracked state again
-        assert np.array_equal(g_["C_lowd"].view(np.uint32), g["C_lowd"].view(np.uint32))
-        return hp.run_lloyds_on_projected_space(k, g_["C_lowd"], max_reps=n)
-
-    l1, l4, l5 = projected(1), projected(4), projected(5)
-    for got, cen in ((l1, g["C_lowd"]), (l5, l4["C_lowd"])):
-        want = oa.lloyds_projected(U, cen, max_reps=1)["assign"]
-        agree = float((got["assign"][cols_a] == want).mean())
-        assert agree >= 0.9999, agree
-    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
-    s1 = hp.run_lloyds(k, max_reps=1, fetch_centers=False)
-    want = oa.lloyds_sparse(lift(U, lp["C_lowd"]), max_reps=1)["assign"]
-    agree = float((s1["assign"][cols_a] == want).mean())
-    assert agree >= 0.9999, agree
-    del oa, Ba
+    _default_route_against_the_oracle(hp, B, V, k, U, g, lp)
     # same-input parity with the oracle on a random sample of the documents
     cols = np.sort(np.random.default_rng(7).choice(B["D"], n_sample, replace=False))
     Bs = _columns(B, cols)
@@ -190,3 +195,5 @@ def test_config3_at_its_own_size(hp, monkeypatch):
     l4b = hp.run_lloyds(k, max_reps=4, fetch_centers=False)
     agree = float((l4b["assign"] == l4["assign"]).mean())
     assert agree >= 0.99999, agree
+    # ... and the default route, step by step, against the oracle's arg-min (the k-means++ hand-over, a bounded iteration, the product through the projection)
+    _default_route_against_the_oracle(hp, B, V, k, U, g, lp)
