@@ -46,16 +46,31 @@ def _default_route_against_the_oracle(hp, B, V, k, U, g, lp):
         assert np.array_equal(g_["C_lowd"].view(np.uint32), g["C_lowd"].view(np.uint32))
         return hp.run_lloyds_on_projected_space(k, g_["C_lowd"], max_reps=n)
 
+    U64 = None
+
+    def only_near_ties(got, want, C_lowd):
+        """Where the two assignments differ, the two centres must be equidistant to the document up to fp32 dot-product noise (distances in fp64
+        from the lifted centres U C^T); at most 3 documents in 10 000 may be such near-ties (measured: 0 - 1.3)."""
+        nonlocal U64
+        bad = np.flatnonzero(got != want)
+        assert len(bad) <= 3e-4 * len(want), len(bad)
+        if U64 is None:
+            U64 = U.astype(np.float64)
+        for i in bad[:40]:
+            lo, hi = Ba["offs"][i], Ba["offs"][i + 1]
+            b = np.zeros(V)
+            b[Ba["rows"][lo:hi]] = Ba["vals"][lo:hi]
+            d = [float(((b - U64 @ C_lowd[c].astype(np.float64)) ** 2).sum()) for c in (int(got[i]), int(want[i]))]
+            assert abs(d[0] - d[1]) <= 2e-5 * max(d), (int(cols_a[i]), d)
+
     l1, l4, l5 = projected(1), projected(4), projected(5)
     for got, cen in ((l1, g["C_lowd"]), (l5, l4["C_lowd"])):
         want = oa.lloyds_projected(U, cen, max_reps=1)["assign"]
-        agree = float((got["assign"][cols_a] == want).mean())
-        assert agree >= 0.9999, agree
+        only_near_ties(got["assign"][cols_a], want, cen)
     hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
     s1 = hp.run_lloyds(k, max_reps=1, fetch_centers=False)
     want = oa.lloyds_sparse(lift(U, lp["C_lowd"]), max_reps=1)["assign"]
-    agree = float((s1["assign"][cols_a] == want).mean())
-    assert agree >= 0.9999, agree
+    only_near_ties(s1["assign"][cols_a], want, lp["C_lowd"])
 
 
 def _run(hp, V, D, k, seed, n_pairs, n_sample):
