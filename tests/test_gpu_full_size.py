@@ -56,12 +56,17 @@ def _default_route_against_the_oracle(hp, B, V, k, U, g, lp):
         assert len(bad) <= 3e-4 * len(want), len(bad)
         if U64 is None:
             U64 = U.astype(np.float64)
+        cmax = float((C_lowd.astype(np.float64) ** 2).sum(1).max())
         for i in bad[:40]:
             lo, hi = Ba["offs"][i], Ba["offs"][i + 1]
             b = np.zeros(V)
             b[Ba["rows"][lo:hi]] = Ba["vals"][lo:hi]
             d = [float(((b - U64 @ C_lowd[c].astype(np.float64)) ** 2).sum()) for c in (int(got[i]), int(want[i]))]
-            assert abs(d[0] - d[1]) <= 2e-5 * max(d), (int(cols_a[i]), d)
+            # E = 1e-4 (|b|^2 + max |c|^2): the error either side's fp32 evaluation of a squared distance is allowed (isle_amd/csrc/hamerly.h).
+            # Measured: up to 2.5e-3 at config 3 with the library's centre the closer one in fp64 — the oracle sums a centre's squared norm
+            # sequentially over 100 000 words in fp32, which shifts all its distances to that centre by up to ~1e-3.
+            tol = 1e-4 * (float((b ** 2).sum()) + cmax)
+            assert abs(d[0] - d[1]) <= tol, (int(cols_a[i]), d, tol)
 
     l1, l4, l5 = projected(1), projected(4), projected(5)
     for got, cen in ((l1, g["C_lowd"]), (l5, l4["C_lowd"])):
