@@ -42,6 +42,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_ROUNDS", "tuning", "0: pass 1 keeps ceil(slices / items per lane) waves in workgroups strided over the length order instead of filling whole rounds of the CUs with workgroups of adjacent waves"},
     {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
     {"ISLE_GL_PANEL", "tuning", "8 | 10: columns per pass of the k-wide / thin products (default 10, 8 at 8 items per lane in pass 1)"},
+    {"ISLE_GL_WIDE_GROUPED", "tuning", "0: every panel pass of the projection writes its 40 bytes straight into the documents' rows of P (default on a large shard: the panels' rows go whole and in position order into a scratch, sixteen at a time, and a second kernel assembles 640-byte pieces of the document-major rows and the rows' squared norms)"},
     {"ISLE_WIDE_GATHER", "form", "k-wide products (projection, first word-space assignment) by the row-gather kernel"},
     {"ISLE_WIDE_LDS", "form", "k-wide products through the LDS-banded pass-1 stream whatever the vocabulary size"},
     {"ISLE_KS_ROWSHARD", "form", "0: every rank orthogonalises the whole Krylov block (default with several ranks: row slices, all-reduced coefficients, all-gathered block)"},

@@ -86,7 +86,7 @@ struct DevBuf {
 // (isle_ctx::knob).  DESIGN.md section "Environment switches" is this table with the measurements behind the defaults.
 // ------------------------------------------------------------------------------------------
 enum IsleKnob {
-  KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_WIDE_GATHER, KN_WIDE_LDS,
+  KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_GL_WIDE_GROUPED, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN, KN_EVD_SPLIT,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
@@ -242,6 +242,8 @@ struct isle_ctx {
   DevBuf<uint32_t> gl_slab0, gl_nch;  // per word block: first partial slab, number of slabs
   uint32_t gl_block_items = 4096;     // words per word block of pass 2 (256 per wave of the block)
   DevBuf<float> gl_Xs, gl_part;       // scaled panel diag(s) X; partial rows of Z per (word block, band chunk)
+  DevBuf<float> gl_pscratch;          // k-wide product, grouped form: up to 16 panels' rows, whole and in position order (D x 12 floats each), and the
+                                      // rows' squared-norm partials per group of panels (k_gl_wide)
   DevBuf<uint32_t> rs_hist;           // radix sort scratch (ingest.hip: k_sort_pairs_u64)
   DevBuf<int64_t> rs_hist_off, rs_scratch;
 
@@ -430,7 +432,7 @@ int k_dots_assign_cm(isle_ctx* c, const float* dotsT, int k, int G, const float*
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
-int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out);
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms = nullptr /*also the rows' squared norms (selects the grouped form)*/);
 int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out);  // Out (D x ld) = B^T W, W V x nc col-major, nc <= 32  // Out (D x ld) = B^T M, LDS-banded form only
 int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm);  // Zcm (V x b col-major) = B (B^T Xcm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip

@@ -1623,19 +1623,20 @@ static inline int gl_panel_cols(int PW, int j0, int k, int ld) { return k - j0 <
 
 // one pass of the pass-1 stream over a packed panel (LPE = ceil(wcols / 4) float4 per row) -> columns [j0, j0 + wcols) of Out
 // (D x ld row-major, document order)
-static int gl_panel_pass(isle_ctx* c, int wcols, int j0, int ld, float* Out) {
+static int gl_panel_pass(isle_ctx* c, int wcols, int j0, int ld, float* Out, float* scratch = nullptr /*grouped form: this panel's D x 12 slab*/) {
   const int LPE = (wcols + 3) / 4;
   const bool half = wcols <= 4 * LPE - 2;  // the last float4 holds at most two columns
+  const float4* in = (const float4*)c->gl_Xs.p;
+  if (scratch) {  // whole float4 rows of 48 bytes, in position order: a wave's 64 rows are one 3 kB run
+    float4* so = (float4*)scratch;
+    if (LPE == 1) return half ? launch_apply<1, true>(c, c->gl1, in, so, 0, nullptr, 3, 0) : launch_apply<1, false>(c, c->gl1, in, so, 0, nullptr, 3, 0);
+    if (LPE == 2) return half ? launch_apply<2, true>(c, c->gl1, in, so, 0, nullptr, 3, 0) : launch_apply<2, false>(c, c->gl1, in, so, 0, nullptr, 3, 0);
+    if (LPE == 3 && half) return launch_apply<3, true>(c, c->gl1, in, so, 0, nullptr, 3, 0);
+    return isle_fail(c, ISLE_E_ARG, "LDS products: a panel of %d stored columns", wcols);
+  }
   const uint32_t ld4 = (uint32_t)(ld / 4);
   float4* out = (float4*)(Out + j0);
   const uint32_t n2 = (j0 % 4) || half ? (uint32_t)((wcols + 1) / 2) : 0u;  // float2 stores where float4 would be misaligned or too wide
-  const float4* in = (const float4*)c->gl_Xs.p;
-#ifdef GL_PWRITE_ABLATE  // timing-only experiment (wrong results): every panel's rows go, whole and in position order, to ONE contiguous scratch
-  if (LPE == 3 && half && ld > 64) {
-    if (c->gl_part.reserve((size_t)c->D * 12 + 64) != hipSuccess) return ISLE_E_HIP;
-    return launch_apply<3, true>(c, c->gl1, in, (float4*)c->gl_part.p, 0, nullptr, 3, 0);
-  }
-#endif
   if (LPE == 1) return half ? launch_apply<1, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<1, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
   if (LPE == 2) return half ? launch_apply<2, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2) : launch_apply<2, false>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
   if (LPE == 3 && half) return launch_apply<3, true>(c, c->gl1, in, out, 0, c->dperm.p, ld4, n2);
@@ -1672,13 +1673,121 @@ int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out) {
 // of FPSparseMatrix::multiply_with (src/sparseMatrix.cpp:1749-1782) as ceil(k / 10) passes of the pass-1 stream, ten
 // columns of diag(s) M staged per pass.  Per gathered nonzero the operand comes from LDS instead of the L2 / Infinity Cache
 // row gather of spmm_wide_k (~2x faster at C2).
-int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
+// Grouped form of the k-wide product (round 5).  A panel pass that writes its 40 bytes straight into the documents' 4 kB rows leaves every row
+// a partial sector or two per pass — 36 ms of read-modify-write traffic per projection at config 3 (profiles/r05_gl_apply_item3_measurements.txt).
+// Here up to GL_WG_PANELS panels write their rows whole and in POSITION order into slabs of their own (48 bytes a row: a wave's store is
+// one 3 kB run), and this kernel turns a group of slabs into the document-major rows: 64 positions per workgroup, the slabs' 3 kB pieces read
+// coalesced into an LDS tile, every row's columns of the group written as one run (640 bytes for sixteen 10-column panels) to row
+// rowmap[position]; the rows' squared norms over the group's columns leave as one partial per (group, document), summed in group order afterwards.
+constexpr int GL_WG_PANELS = 16;
+struct GlWidePanels {
+  int n;                  // panels of the group
+  int j0[GL_WG_PANELS];   // first column of a panel, relative to the group's first column
+  int w[GL_WG_PANELS];    // columns it stores
+  int ncols;              // columns of the group (a multiple of 4 unless it ends the row)
+};
+__global__ __launch_bounds__(256) void gl_wide_assemble_k(const float* __restrict__ scratch, size_t slab /*floats per panel slab*/, uint32_t D,
+                                                           const uint32_t* __restrict__ rowmap, GlWidePanels g, int jg0, int ld,
+                                                           float* __restrict__ Out, float* __restrict__ normpart /*nullable: D floats of this group*/) {
+  extern __shared__ float tl[];  // 64 x tw, tw = ncols + 4 (rows 16-byte aligned: whole float4 leave in the second phase)
+  __shared__ uint32_t rm[64];
+  const int tw = g.ncols + 4;
+  const uint32_t p0 = blockIdx.x * 64;
+  const uint32_t np = min(64u, D - p0);
+  if (threadIdx.x < 64) rm[threadIdx.x] = threadIdx.x < np ? rowmap[p0 + threadIdx.x] : 0u;
+  // phase 1: thread t < 192 owns float4 t of every panel's 3 kB piece (row t / 3, float4 t % 3): all panels' loads in flight together
+  if (threadIdx.x < 192) {
+    const uint32_t r = threadIdx.x / 3, c4 = threadIdx.x - 3 * r;
+    float4 v[GL_WG_PANELS];
+#pragma unroll
+    for (int pi = 0; pi < GL_WG_PANELS; ++pi)
+      if (pi < g.n && r < np) v[pi] = reinterpret_cast<const float4*>(scratch + (size_t)pi * slab + (size_t)p0 * 12)[threadIdx.x];
+#pragma unroll
+    for (int pi = 0; pi < GL_WG_PANELS; ++pi) {
+      if (pi < g.n && r < np) {
+        const int cc = 4 * (int)c4;  // first column of this float4 inside the panel (panels start on even columns: 8-byte aligned pairs)
+        float* t = tl + r * tw + g.j0[pi] + cc;
+        if (cc + 1 < g.w[pi]) *reinterpret_cast<float2*>(t) = make_float2(v[pi].x, v[pi].y);
+        else if (cc < g.w[pi]) t[0] = v[pi].x;
+        if (cc + 3 < g.w[pi]) *reinterpret_cast<float2*>(t + 2) = make_float2(v[pi].z, v[pi].w);
+        else if (cc + 2 < g.w[pi]) t[2] = v[pi].z;
+      }
+    }
+  }
+  __syncthreads();
+  const int nq = g.ncols / 4;  // whole float4 (ld and the groups' first columns are multiples of 4)
+  for (uint32_t i = threadIdx.x; i < np * (uint32_t)nq; i += 256) {
+    const uint32_t r = i / nq, q = i - r * nq;
+    *reinterpret_cast<float4*>(Out + (size_t)rm[r] * ld + jg0 + 4 * q) = *reinterpret_cast<const float4*>(tl + r * tw + 4 * q);
+  }
+  if (normpart) {  // four threads per row, then the row's four partial sums in a fixed order
+    const uint32_t r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float s = 0.f;
+    if (r < np) {
+      const int per = (nq + 3) / 4 * 4;  // columns per part: a multiple of 4
+      const float* t = tl + r * tw;
+      for (int j = part * per; j < min(g.ncols, (int)(part + 1) * per); ++j) s = fmaf(t[j], t[j], s);
+    }
+    const float s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2), s3 = __shfl_down(s, 3);
+    if (part == 0 && r < np) normpart[rm[r]] = (s + s1) + (s2 + s3);
+  }
+}
+__global__ __launch_bounds__(256) void gl_wide_norms_k(const float* __restrict__ normpart, uint32_t D, int ngroups, float* __restrict__ norms) {
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int gi = 0; gi < ngroups; ++gi) s += normpart[(size_t)gi * D + d];  // group order: the same bits run after run
+  norms[d] = s;
+}
+
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms) {
   ISLECHK(k_band_build(c));
   if (c->gl_mode != 1) return isle_fail(c, ISLE_E_ARG, "k_gl_wide needs the LDS-banded form");
   if (ld % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: leading dimension %d not a multiple of 4", ld);
   const uint32_t V = (uint32_t)c->V;
   HIPCHK(c, c->gl_Xs.reserve(gl_packed_floats(V, 3, true)));
   const int PW = gl_panel_width(c);
+  // grouped form: asked for together with the norms (the projection), a wide operand on a large shard, 10-column panels (groups of 16 then
+  // start on multiples of 160 columns), and while the slabs fit (7.7 GB at 10 M documents)
+  const uint64_t D = c->D;
+  const int ngroups = (k + PW * GL_WG_PANELS - 1) / (PW * GL_WG_PANELS);
+  const size_t slab = (size_t)D * 12;
+  if (norms && PW == 10 && k >= 160 && D >= 16384 && !c->knob_zero(KN_GL_WIDE_GROUPED) &&
+      isle_scratch_ok(c, 0, (double)(slab * GL_WG_PANELS + (size_t)ngroups * D) * sizeof(float))) {
+    HIPCHK(c, c->gl_pscratch.reserve(slab * GL_WG_PANELS + (size_t)ngroups * D));
+    float* normpart = c->gl_pscratch.p + slab * GL_WG_PANELS;
+    int gi = 0;
+    for (int jg0 = 0; jg0 < k; ++gi) {
+      GlWidePanels g;
+      g.n = 0;
+      int j0 = jg0;
+      for (int ncol; g.n < GL_WG_PANELS && j0 < k; j0 += ncol) {
+        ncol = gl_panel_cols(PW, j0, k, ld);
+        const int wcols = gl_panel_store_cols(j0, ncol, k, ld);
+        const int LPE = (wcols + 3) / 4;
+        const bool half = wcols <= 4 * LPE - 2;
+        const size_t n4 = (size_t)V * LPE;
+        hipLaunchKernelGGL(gl_pack_panel_k, dim3(cdiv((long)n4, 256)), dim3(256), 0, c->stream, Mrm, ld, j0, ncol, LPE, (int)half, c->rowval.p, n4,
+                           (char*)c->gl_Xs.p);
+        HIPCHK(c, hipGetLastError());
+        ISLECHK(gl_panel_pass(c, wcols, j0, ld, Out, c->gl_pscratch.p + (size_t)g.n * slab));
+        g.j0[g.n] = j0 - jg0;
+        g.w[g.n] = wcols;
+        ++g.n;
+        g.ncols = j0 - jg0 + wcols;
+      }
+      if (g.ncols % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: a panel group of %d columns", g.ncols);
+      const size_t lds = (size_t)64 * (g.ncols + 4) * sizeof(float);
+      ISLECHK(isle_max_lds(c, (const void*)gl_wide_assemble_k, (int)lds));
+      hipLaunchKernelGGL(gl_wide_assemble_k, dim3(cdiv((long)D, 64)), dim3(256), lds, c->stream, c->gl_pscratch.p, slab, (uint32_t)D, c->dperm.p, g, jg0, ld, Out,
+                         normpart + (size_t)gi * D);
+      HIPCHK(c, hipGetLastError());
+      jg0 = j0;
+    }
+    hipLaunchKernelGGL(gl_wide_norms_k, dim3(cdiv((long)D, 256)), dim3(256), 0, c->stream, normpart, (uint32_t)D, gi, norms);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   for (int j0 = 0, ncol; j0 < k; j0 += ncol) {
     ncol = gl_panel_cols(PW, j0, k, ld);
     const int wcols = gl_panel_store_cols(j0, ncol, k, ld);
@@ -1690,5 +1799,6 @@ int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out) {
     HIPCHK(c, hipGetLastError());
     ISLECHK(gl_panel_pass(c, wcols, j0, ld, Out));
   }
+  if (norms) return k_rownorms(c, Out, (int)c->D, k, ld, norms);
   return 0;
 }

@@ -664,8 +664,7 @@ int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P,
   TimeScope ts(c, ISLE_T_PROJECT);
   ISLECHK(k_gl_detect(c));
   if (c->gl_mode == 1 && wide_through_lds(c)) {  // row-constant B: panels of M through LDS (gram_lds.hip)
-    ISLECHK(k_gl_wide(c, Mrm, k, ldk, P));
-    return k_rownorms(c, P, (int)c->D, k, ldk, norms);
+    return k_gl_wide(c, Mrm, k, ldk, P, norms);  // (the grouped form forms the norms on its way; the plain one calls k_rownorms)
   }
   return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr, nullptr);
 }

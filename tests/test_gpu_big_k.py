@@ -151,6 +151,31 @@ def test_bound_modes_agree_at_k1000(hp, monkeypatch):
         assert np.array_equal(res[mode][2], res["yinyang"][2])
 
 
+def test_grouped_projection_writes_give_the_same_projection(hp, monkeypatch):
+    """Round 5: the panel passes of P = U^T B write their rows whole and in position order into slabs, sixteen panels at a time, and a second
+    kernel assembles the document-major rows and their squared norms (k_gl_wide, gl_wide_assemble_k); ISLE_GL_WIDE_GROUPED=0 writes 40-byte
+    pieces straight into P.  The accumulators are the same: the seeds' coordinates (rows of P) must be bit-equal, the k-means++ distances
+    (which use the norms, summed in another order) equal to rounding, and the partitions of Lloyd in span(U) equal up to near-ties
+    (src/sparseMatrix.cpp:1749-1791)."""
+    f, B, k = load_case("c3k1000")
+    upload(hp, B)
+    hp.compute_block_ks(k, seed=2, allow_noconv=True)
+    U = hp.get_U(k)
+    res = {}
+    for name, env in (("grouped", {}), ("direct", {"ISLE_GL_WIDE_GROUPED": "0"})):
+        for a, b in env.items():
+            monkeypatch.setenv(a, b)
+        hp.set_U(U)  # invalidates the projection
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
+        res[name] = (g, hp.get_min_dist(), hp.run_lloyds_on_projected_space(k, g["C_lowd"]))
+        for a in env:
+            monkeypatch.delenv(a)
+    assert np.array_equal(res["grouped"][0]["C_lowd"].view(np.uint32), res["direct"][0]["C_lowd"].view(np.uint32))
+    assert np.abs(res["grouped"][1] - res["direct"][1]).max() <= 1e-5 * res["direct"][1].max()
+    assert res["grouped"][2]["iters"] == res["direct"][2]["iters"]
+    assert (res["grouped"][2]["assign"] == res["direct"][2]["assign"]).mean() >= 0.9999
+
+
 def test_lds_dma_assignment_product_gives_the_bits_of_the_register_staged_one(hp, monkeypatch):
     """Round 5: the two-term pass of the D x k x k assignment products reads the projection's pre-split copy (two bf16 terms per entry, laid out
     as the LDS image of every row block and slab) by LDS-DMA through a ring of stages (gemm_bf16x2_dma_k); ISLE_GEMM_DMA=0 splits on the fly

@@ -667,3 +667,32 @@ def test_roctx_family_markers_leave_the_results_alone(hp, tiny10, monkeypatch):
     monkeypatch.delenv("ISLE_ROCTX")
     assert np.array_equal(Z0.view(np.uint32), Z1.view(np.uint32))
     assert r["nconv"] == 10
+
+
+@pytest.mark.parametrize("k", [163, 250, 321])
+def test_grouped_projection_at_topic_counts_that_end_inside_a_group(hp, small50, monkeypatch, k):
+    """The grouped form of P = U^T B (k_gl_wide: sixteen 10-column panels per group, rows assembled by gl_wide_assemble_k) where the last
+    group is short, ends in an 8-column panel and carries the row's padding columns (ldk = 4 ceil(k / 4)): rows of P against fp64 products,
+    and against the direct form (ISLE_GL_WIDE_GROUPED=0) bit for bit; the norms (summed in another order) through the k-means++ distances."""
+    B = small50
+    rng = np.random.default_rng(k)
+    U = np.asfortranarray(np.linalg.qr(rng.standard_normal((B["V"], k)))[0].astype(np.float32))
+    seeds = np.sort(rng.choice(B["D"], size=k, replace=False)).astype(np.uint64)
+    res = {}
+    for name, env in (("grouped", None), ("direct", "0")):
+        if env:
+            monkeypatch.setenv("ISLE_GL_WIDE_GROUPED", env)
+        upload(hp, B)
+        hp.set_U(U)
+        g = hp.kmeans_init_on_projected_space(k, inject_seeds=seeds)
+        res[name] = (g["C_lowd"], hp.get_min_dist())
+        if env:
+            monkeypatch.delenv("ISLE_GL_WIDE_GROUPED")
+    assert np.array_equal(res["grouped"][0].view(np.uint32), res["direct"][0].view(np.uint32))
+    assert np.abs(res["grouped"][1] - res["direct"][1]).max() <= 1e-5 * res["direct"][1].max()
+    U64 = U.astype(np.float64)
+    for i in range(0, k, 7):
+        d = int(seeds[i])
+        lo, hi = B["offs"][d], B["offs"][d + 1]
+        ref = (B["vals"][lo:hi].astype(np.float64)[:, None] * U64[B["rows"][lo:hi]]).sum(0)
+        assert np.abs(res["grouped"][0][i] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
