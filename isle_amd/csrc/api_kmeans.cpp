@@ -412,7 +412,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
               ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, k, Cm, ldk, mv.n, c->Tmp.p, ISLE_T_LLOYD_PROJ));  // W = U C_m^T  (V x n col-major)
               {
                 TimeScope ts(c, ISLE_T_LLOYD_PROJ);
-                ISLECHK(k_gl_thin(c, c->Tmp.p, mv.n, mv.ld, c->yy_mdots.p));
+                ISLECHK(k_gl_thin(c, c->Tmp.p, mv.n, mv.ld, c->yy_mdots.p, true));  // rows by position: pt_filter_k reads them through dpos
               }
               tmove_use = c->yy_gmax2.p;
             }

@@ -433,7 +433,7 @@ int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (n
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
 int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms = nullptr /*also the rows' squared norms (selects the grouped form)*/);
-int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out);  // Out (D x ld) = B^T W, W V x nc col-major, nc <= 32  // Out (D x ld) = B^T M, LDS-banded form only
+int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out, bool by_position = false);  // Out (D x ld) = B^T W, W V x nc col-major, nc <= 32  // Out (D x ld) = B^T M, LDS-banded form only
 int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm);  // Zcm (V x b col-major) = B (B^T Xcm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip
 int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);

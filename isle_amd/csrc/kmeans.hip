@@ -147,13 +147,14 @@ int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out
 }
 
 // min_dist[d] = min(min_dist[d], max(pn[d] + cn[j] - 2 dots[d][j], 0)) over the nc new seeds
+// (dpos: the thin product left document d's row at dpos[d], k_gl_thin by_position; null: at d)
 __global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__ dots, int ld, const float* __restrict__ pn, const float* __restrict__ cn,
-                                                        int nc, uint32_t D, float* __restrict__ min_dist) {
+                                                        int nc, uint32_t D, float* __restrict__ min_dist, const uint32_t* __restrict__ dpos) {
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
   const float nd = pn[d];
   float m = min_dist[d];
-  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)d * ld);
+  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)(dpos ? dpos[d] : d) * ld);
   for (int q = 0; q < ld / 4; ++q) {
     const float4 v = row[q];
     const float x[4] = {v.x, v.y, v.z, v.w};
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__
 __global__ __launch_bounds__(256) void kmpp_min_dots_track_k(const float* __restrict__ dots, int ld, const float* __restrict__ pn,
                                                               const float* __restrict__ cn, int nc, uint32_t D, float* __restrict__ best,
                                                               uint32_t* __restrict__ arg, float* __restrict__ m2a, float* __restrict__ tmin,
-                                                              uint32_t s_old) {
+                                                              uint32_t s_old, const uint32_t* __restrict__ dpos) {
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
   const float nd = pn[d];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void kmpp_min_dots_track_k(const float* __rest
   float* tm_col = tmin + d;  // tile T of this document at tm_col[T * D]
   uint32_t curT = s_old >> 5;
   float tm = tm_col[(size_t)curT * D];
-  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)d * ld);
+  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)(dpos ? dpos[d] : d) * ld);
   for (int q = 0; q < ld / 4; ++q) {
     const float4 v = row[q];
     const float xs[4] = {v.x, v.y, v.z, v.w};
@@ -282,7 +283,7 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
         HIPCHK(c, c->Tmp.reserve((size_t)c->V * 32));
         HIPCHK(c, c->dotsT.reserve((size_t)D * 32));
         ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, k, newC + (size_t)j0 * ldk, ldk, ncj, c->Tmp.p, ISLE_T_KMPP));  // W = U C_new^T  (V x ncj col-major)
-        ISLECHK(k_gl_thin(c, c->Tmp.p, ncj, ld, c->dotsT.p));
+        ISLECHK(k_gl_thin(c, c->Tmp.p, ncj, ld, c->dotsT.p, true));  // rows by position: the kernels below read them through dpos
         if (track) {  // also the nearest seed and the tile minima (kmpp_min_dots_track_k)
           const int T = (k + 31) / 32;
           if (s_old == 0 && j0 == 0) {
@@ -296,11 +297,11 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
           }
           if (c->kmpp_track)
             hipLaunchKernelGGL(kmpp_min_dots_track_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist,
-                               c->kmpp_arg.p, c->kmpp_m2a.p, c->kmpp_tmin.p, (uint32_t)(s_old + j0));
+                               c->kmpp_arg.p, c->kmpp_m2a.p, c->kmpp_tmin.p, (uint32_t)(s_old + j0), c->dpos.p);
           else
-            hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist);
+            hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist, c->dpos.p);
         } else {
-          hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist);
+          hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist, c->dpos.p);
         }
         HIPCHK(c, hipGetLastError());
       }

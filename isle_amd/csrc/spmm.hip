@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
                                                     float* __restrict__ ub, float* __restrict__ tlb, int T, int TL, const float* __restrict__ delta,
                                                     const float* __restrict__ tmove, uint32_t* __restrict__ need, uint32_t* __restrict__ active,
                                                     uint32_t* __restrict__ nactive, YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: P_d . c_mover*/,
-                                                    const float* __restrict__ cn, const float* __restrict__ pn) {
+                                                    const float* __restrict__ cn, const float* __restrict__ pn, const uint32_t* __restrict__ dpos /*nullable: the movers' products lie by position (k_gl_thin by_position)*/) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const bool in = i < D;
   uint32_t d = 0;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
         ml[jm] = 3.4e38f;
         if (jm < mv.n && mv.id[jm] != a) {  // the assigned centre does not bound its own tile
           const uint32_t cj = mv.id[jm];
-          const float dist = fabsf((-2.0f * mdots[(size_t)d * mv.ld + jm] + cn[cj]) + nd);
+          const float dist = fabsf((-2.0f * mdots[(size_t)(dpos ? dpos[d] : d) * mv.ld + jm] + cn[cj]) + nd);
           float uu, ll;
           hamerly_store_bounds(dist, dist, nd + cn[cj], &uu, &ll);
           ml[jm] = ll;
@@ -981,7 +981,7 @@ int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
   hipLaunchKernelGGL(pt_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, tlb, T, TL, delta_dev, tmove_dev, need, active,
-                     nactive, mv, mdots, cn, pn);
+                     nactive, mv, mdots, cn, pn, mv.n ? c->dpos.p : nullptr);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1363,7 +1363,8 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
                                                              const float* __restrict__ cn, const float* __restrict__ dn, const float* __restrict__ cn_max_p,
                                                              YyRes* __restrict__ own, unsigned long long* __restrict__ need, uint32_t* __restrict__ cnt,
                                                              YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: b_d . c_mover*/, YyMap map,
-                                                             const float* __restrict__ cn_by_id /*the movers' norms (cn is indexed by slot)*/) {
+                                                             const float* __restrict__ cn_by_id /*the movers' norms (cn is indexed by slot)*/,
+                                                             const uint32_t* __restrict__ dpos /*document -> row of mdots (k_gl_thin by_position)*/) {
   extern __shared__ float tile[];  // docs_per_block x G bounds, then docs_per_block local indices of the active documents
   uint32_t* lact = reinterpret_cast<uint32_t*>(tile + (size_t)docs_per_block * G);
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
@@ -1436,7 +1437,7 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
         for (int jm = 0; jm < mv.n; ++jm) {
           const uint32_t cj = mv.id[jm];
           if (cj == a) continue;  // the assigned centre does not bound its own group
-          const float dist = fabsf((-2.0f * mdots[(size_t)d * mv.ld + jm] + cn_by_id[cj]) + dnd);
+          const float dist = fabsf((-2.0f * mdots[(size_t)dpos[d] * mv.ld + jm] + cn_by_id[cj]) + dnd);
           const float l = yy_slack_down_sq(dist, E, sE);
           const uint32_t gj = map.slot(cj) >> 3;
           const uint32_t at = j * (uint32_t)G + gj;
@@ -1627,7 +1628,7 @@ int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assi
     HIPCHK(c, c->yy_mdots.reserve((size_t)D * mv.ld));
     hipLaunchKernelGGL(yy_gather_cols_k, dim3(cdiv((long)((size_t)V * mv.n), 256)), dim3(256), 0, c->stream, Crm, V, ld, mv, c->Tmp.p);
     HIPCHK(c, hipGetLastError());
-    ISLECHK(k_gl_thin(c, c->Tmp.p, mv.n, mv.ld, c->yy_mdots.p));
+    ISLECHK(k_gl_thin(c, c->Tmp.p, mv.n, mv.ld, c->yy_mdots.p, true));  // rows by position: read through dpos
   }
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
@@ -1643,7 +1644,7 @@ int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assi
   ISLECHK(isle_max_lds(c, (const void*)yy2_filter_tighten_k, (int)lds));
   hipLaunchKernelGGL(yy2_filter_tighten_k, dim3(cdiv(D, dpb)), dim3(256), lds, c->stream, D, order, assign, ub, glb, G, delta_dev, gmax_dev, active, nactive, dpb,
                      c->vals.p, c->rows.p, c->offs.p, (const float4*)Cg, V, ld, k, NW, cn, dn, cn_max, (YyRes*)c->yy_own.p, (unsigned long long*)c->yy_need.p,
-                     c->yy_cnt.p, mv, c->yy_mdots.p, map, cn_by_id ? cn_by_id : cn);
+                     c->yy_cnt.p, mv, c->yy_mdots.p, map, cn_by_id ? cn_by_id : cn, c->dpos.p);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
