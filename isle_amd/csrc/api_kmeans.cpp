@@ -44,21 +44,26 @@ static int ensure_P(isle_ctx* c, int k) {
   const size_t D = c->D ? c->D : 1;
   HIPCHK(c, c->P.reserve(D * c->ldk));
   HIPCHK(c, c->pnorm.reserve(D));
-  ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p));
-  c->P_ready = true;
-  c->P_gen++;
   c->Pt_ready = false;
   c->Pt2_ready = false;
-  if (c->D) {  // coordinate-major copy for the register-resident MFMA distance kernels
-    HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
-    ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
-    c->Pt_ready = true;
-    // ... and, where the assignment products run with their epilogues inside (a large shard), its two bf16 terms in the layout the LDS-DMA
-    // product stages (gemm_bf16x2_dma_k): the split is made once per projection instead of in every product's staging path
-    c->Pt2_ready = false;
-    if (k_gemm_assign_fused_ok(c, c->D, k, k) && !c->knob_zero(KN_GEMM_DMA) && !(c->knob(KN_GEMM_TERMS) && atoi(c->knob(KN_GEMM_TERMS)) == 3)) {
-      TimeScope ts(c, ISLE_T_PROJECT);
-      HIPCHK(c, c->Pt2.reserve(k_gemm_split_a_bytes(c->D, k) / sizeof(uint4)));
+  c->Pt2_pos = false;
+  // Where the assignment products run with their epilogues inside (a large shard) they read the projection's two bf16 terms in the layout
+  // the LDS-DMA product stages (gemm_bf16x2_dma_k).  The grouped projection writes that copy on its way, by POSITION (the products map their
+  // rows to documents through dperm): no transposition and no split pass behind the projection (round 5: 15 + 15 ms at config 3).
+  const bool want_a2 = c->D && k_gemm_assign_fused_ok(c, c->D, k, k) && !c->knob_zero(KN_GEMM_DMA) &&
+                       !(c->knob(KN_GEMM_TERMS) && atoi(c->knob(KN_GEMM_TERMS)) == 3);
+  bool a2_done = false;
+  if (want_a2) HIPCHK(c, c->Pt2.reserve(k_gemm_split_a_bytes(c->D, k) / sizeof(uint4)));
+  ISLECHK(k_spmm_wide_project(c, c->Urm.p, k, c->ldk, c->P.p, c->pnorm.p, want_a2 ? c->Pt2.p : nullptr, &a2_done));
+  c->P_ready = true;
+  c->P_gen++;
+  if (a2_done) {
+    c->Pt2_ready = true;
+    c->Pt2_pos = true;  // the f32 coordinate-major copy is made when a route asks for it (k_ensure_pt)
+  } else if (c->D) {
+    TimeScope ts(c, ISLE_T_PROJECT);
+    ISLECHK(k_ensure_pt(c));
+    if (want_a2) {  // the projection took another route than the grouped one: split the transposed copy
       ISLECHK(k_gemm_split_a(c, c->Pt.p, c->D, k, c->Pt2.p));
       c->Pt2_ready = true;
     }
@@ -339,7 +344,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is written again at the end of this call
   isle_host_mark("lloyds_projected: centres uploaded");
   // Hamerly bounds (exact skip of documents whose closest centre provably did not change), as in the sparse Lloyd
-  const bool hamerly = !c->knob_on(KN_NO_HAMERLY) && c->Pt_ready;
+  const bool hamerly = !c->knob_on(KN_NO_HAMERLY) && (c->Pt_ready || c->Pt2_ready);
   if (hamerly) {
     HIPCHK(c, c->hub.reserve(D ? D : 1));
     HIPCHK(c, c->hlb.reserve(D ? D : 1));
@@ -602,7 +607,7 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
   const double t_dense = 2.0 * (double)D * k * k / 130e12, t_sparse = (double)((k + 7) / 8) * (double)c->nnz * 2.8e-12;
   const bool fused_first = yinyang && k_gemm_assign_fused_ok(c, D, k, k);  // the product's epilogue forms the assignment: no D x k scratch
   const bool dense_pays = k <= 384 || (t_dense < t_sparse && (fused_first || isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float))));
-  bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && c->Pt_ready && c->ldk == ld &&
+  bool via_projection = !centers_in && c->lift_valid && c->lift_k == k && c->U_k == k && c->P_ready && (c->Pt_ready || c->Pt2_ready) && c->ldk == ld &&
                         D > 0 && (dense_pays || (fa && !strcmp(fa, "projection"))) && !(fa && !strcmp(fa, "sparse"));
   if (via_projection && !fused_first && c->dotsT.reserve((size_t)D * k) != hipSuccess) {
     // the route is chosen from sizes alone (isle_scratch_ok), but on a device shared with other work the D x k scratch may still not be
@@ -668,17 +673,20 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
           ISLECHK(k_yy_rows_by_slot(c, ymap, k, c->lift_C.p, c->lift_ld, c->yy_liftC.p));
           liftC = c->yy_liftC.p;
         }
-        ISLECHK(k_gemm_assign_yy(c, c->Pt.p, c->P.p, c->ldk, c->pnorm.p, D, k, liftC, c->lift_ld, k, G, cn_grp, c->dnorm.p, cn_max_dev, c->assign.p,
-                                 c->hub.p, c->yglb.p, ISLE_T_SPARSE_ASSIGN, c->Pt2_ready ? c->Pt2.p : nullptr));
+        ISLECHK(k_gemm_assign_yy(c, c->Pt_ready ? c->Pt.p : nullptr, c->P.p, c->ldk, c->pnorm.p, D, k, liftC, c->lift_ld, k, G, cn_grp, c->dnorm.p, cn_max_dev,
+                                 c->assign.p, c->hub.p, c->yglb.p, ISLE_T_SPARSE_ASSIGN, c->Pt2_ready ? c->Pt2.p : nullptr,
+                                 c->Pt2_ready && c->Pt2_pos ? c->dperm.p : nullptr));
         if (regroup) ISLECHK(k_yy_labels_to_ids(c, ymap, c->assign.p, D));  // columns (slots) -> centres
       } else if (yinyang) {  // assignment and group bounds straight from the column-major product (the projection stays valid)
         HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+        ISLECHK(k_ensure_pt(c));
         ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
         float* cn_max_dev = c->Csum.p + 2 * k + 8;
         ISLECHK(k_max_f32(c, c->cnorm.p, k, cn_max_dev));
         ISLECHK(k_dots_assign_cm(c, c->dotsT.p, k, G, c->cnorm.p, c->dnorm.p, cn_max_dev, c->assign.p, c->hub.p, c->yglb.p));
       } else {
         HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+        ISLECHK(k_ensure_pt(c));
         ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, c->lift_C.p, c->lift_ld, k, c->dotsT.p, ISLE_T_SPARSE_ASSIGN));
         c->P_ready = false;  // P now holds the dot products (as with the LDS-banded wide product)
         c->Pt_ready = false;

@@ -296,7 +296,8 @@ struct isle_ctx {
   bool lift_valid = false;
   bool Pt_ready = false;
   DevBuf<uint4> Pt2;       // the coordinate-major copy split in two bf16 terms, as the LDS image of every (row block, slab): the A operand of the
-  bool Pt2_ready = false;  // LDS-DMA assignment products (gemm_bf16x3.h, gemm_bf16x2_dma_k); valid with Pt
+  bool Pt2_ready = false;  // LDS-DMA assignment products (gemm_bf16x3.h, gemm_bf16x2_dma_k)
+  bool Pt2_pos = false;    // its rows are POSITIONS of the length order (row m = document dperm[m]): made by the grouped projection on its way
   DevBuf<float> min_dist;  // D
   DevBuf<double> cum;      // D + 1
   DevBuf<double> scan_blk;
@@ -432,13 +433,15 @@ int k_dots_assign_cm(isle_ctx* c, const float* dotsT, int k, int G, const float*
 int k_gl_detect(isle_ctx* c);            // sets c->gl_mode for the current B (no-op once decided)
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ldk, float* Crm, bool fresh);  // fresh: needs c->members grouped by `assign`
 int k_gl_build(isle_ctx* c);
-int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms = nullptr /*also the rows' squared norms (selects the grouped form)*/);
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms = nullptr /*also the rows' squared norms (selects the grouped form)*/,
+              void* A2pos = nullptr /*grouped form only: also the split copy of Out by POSITION (k_gemm_split_a_bytes(D, k) bytes)*/, bool* a2_done = nullptr);
 int k_gl_thin(isle_ctx* c, const float* Wcm, int nc, int ld, float* Out, bool by_position = false);  // Out (D x ld) = B^T W, W V x nc col-major, nc <= 32  // Out (D x ld) = B^T M, LDS-banded form only
 int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm);  // Zcm (V x b col-major) = B (B^T Xcm), b columns in a panel of BP in {4, 8, 12}
 // ingest.hip
 int k_sort_pairs_u64(isle_ctx* c, uint64_t* key_a, uint32_t* val_a, uint64_t* key_b, uint32_t* val_b, uint64_t n, int key_bits, bool* in_a);
 int k_frobenius(isle_ctx* c, double* out_host);
-int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms);
+int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms, void* A2pos = nullptr, bool* a2_done = nullptr);
+int k_ensure_pt(isle_ctx* c);  // the coordinate-major f32 copy of the projection, made from P when a route asks for it (dense.hip)
 int k_spmm_wide_assign(isle_ctx* c, const float* Mrm, int k, int ldk, const float* cn, const float* dn, uint32_t* assign,
                        const uint32_t* perm /*nullable: slot -> doc*/, const uint32_t* nslots = nullptr /*device slot count*/,
                        float* ub = nullptr, float* lb = nullptr, int G = 0 /*> 0: lb holds G Yinyang group bounds per document*/);
@@ -533,10 +536,11 @@ int k_gemm_nn(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, in
 int k_gemm_nn_assign(isle_ctx* c, const float* A, uint64_t M, int K, const float* B, int ldb, int N, float* C, int family);
 bool k_gemm_assign_fused_ok(isle_ctx* c, uint64_t M, int K, int N);
 int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* an, uint64_t M, int K, const float* B, int ldb, int N, int G,
-                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family, const void* A2 = nullptr);
+                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family, const void* A2 = nullptr,
+                     const uint32_t* map2 = nullptr /*row of A2 -> document when A2 lies by position; A may be null then (made on demand)*/);
 int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
                         const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0 = nullptr,
-                        const void* A2 = nullptr);
+                        const void* A2 = nullptr, const uint32_t* map2 = nullptr);
 // A2 = the two bf16 terms of a coordinate-major M x K operand in the layout gemm_bf16x2_dma_k stages by LDS-DMA (gemm_bf16x3.h); bytes it needs
 int k_gemm_split_a(isle_ctx* c, const float* A, uint64_t M, int K, void* A2);
 size_t k_gemm_split_a_bytes(uint64_t M, int K);

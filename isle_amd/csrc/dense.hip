@@ -817,6 +817,9 @@ struct YyGroupEpi {  // Lloyd on B: Yinyang groups of 8 centres (dots_assign_cm_
   __device__ inline float dist(float dot, int col, float dnd) const { return fabsf((-2.0f * dot + cn[col]) + dnd); }
   __device__ inline float aux(int) const { return 0.f; }
   __device__ inline void group(uint64_t m, int g, float dnd, float m1, uint32_t, float, float) const {
+#ifdef GA_ABLATE_LB  // timing-only experiment: what the 4-byte stores of the group bounds cost
+    if (g >= 0) return;
+#endif
     const float E = ISLE_SLACK_REL * (dnd + *cn_max), sE = sqrtf(E);
     const float eps = eta > 0.f ? eta * (an[doc(m)] + *bmax) : 0.f;
     lb[doc(m) * (uint64_t)G + g] = yy_slack_down_sq(fmaxf(m1 - eps, 0.f), E, sE);
@@ -936,7 +939,16 @@ size_t k_gemm_split_a_bytes(uint64_t M, int K) { return isle_gemm3::a2_units(M, 
 template <class MakeEpi, class Combine>
 static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* rown, uint64_t M, int K, const float* B, int ldb, int N,
                                 MakeEpi make, Combine combine, const uint32_t* map0 = nullptr /*row of A -> document (null: identity)*/,
-                                const void* A2 = nullptr /*A split beforehand (k_gemm_split_a): the first pass reads it by LDS-DMA*/) {
+                                const void* A2 = nullptr /*A split beforehand (k_gemm_split_a): the first pass reads it by LDS-DMA*/,
+                                const uint32_t* map2 = nullptr /*row of A2 -> document (the split copy by position: c->dperm)*/) {
+  // A == nullptr: the operand is the context's projection and its f32 coordinate-major copy has not been made (the default routes read A2):
+  // the passes that need it make it
+  auto need_a = [&]() -> int {
+    if (A) return 0;
+    ISLECHK(k_ensure_pt(c));
+    A = c->Pt.p;
+    return 0;
+  };
   const int nslot = (N + 63) / 64;
   static_assert(sizeof(AssignRec) == 20, "");
   const char* gt = c->knob(KN_GEMM_TERMS);
@@ -945,6 +957,7 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
   HIPCHK(c, c->assign_part.reserve((size_t)M * nslot * 5));
   AssignRec* part = reinterpret_cast<AssignRec*>(c->assign_part.p);
   if (!two) {
+    ISLECHK(need_a());
     HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, 0.f)));
     combine(part, (uint32_t)M, map0, 0.f, nullptr, nullptr);
     HIPCHK(c, hipGetLastError());
@@ -954,11 +967,14 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
   HIPCHK(c, c->ga_redo.reserve(M + 1));
   uint32_t* nredo = c->ga_redo.p + M;
   HIPCHK(c, hipMemsetAsync(nredo, 0, sizeof(uint32_t), c->stream));
-  if (A2 && !c->knob_zero(KN_GEMM_DMA))
-    HIPCHK(c, isle_gemm3::launch_dma<Gemm2Dma>(c->stream, A2, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, eta2)));
-  else
+  if (A2 && !c->knob_zero(KN_GEMM_DMA)) {
+    HIPCHK(c, isle_gemm3::launch_dma<Gemm2Dma>(c->stream, A2, M, K, B, ldb, N, c->gemm_b3.p, make(part, map2 ? map2 : map0, eta2)));
+    combine(part, (uint32_t)M, map2 ? map2 : map0, eta2, c->ga_redo.p, nredo);
+  } else {
+    ISLECHK(need_a());
     HIPCHK(c, isle_gemm3::launch<Gemm2Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, eta2)));
-  combine(part, (uint32_t)M, map0, eta2, c->ga_redo.p, nredo);
+    combine(part, (uint32_t)M, map0, eta2, c->ga_redo.p, nredo);
+  }
   HIPCHK(c, hipGetLastError());
   uint32_t* n_pin = reinterpret_cast<uint32_t*>(c->pin + isle_ctx::PIN_SMALL + (192u << 10) + 192);  // page-locked
   HIPCHK(c, hipMemcpyAsync(n_pin, nredo, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -968,6 +984,7 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
   if (c->knob_on(KN_DEBUG_HAMERLY)) fprintf(stderr, "[assignment product] the two-term pass left %u of %llu rows open\n", n, (unsigned long long)M);
   if (n == 0) return 0;
   if ((uint64_t)n * 4 > M) {  // hardly a saving left: the whole product again with three terms
+    ISLECHK(need_a());
     HIPCHK(c, isle_gemm3::launch<Gemm3Huge>(c->stream, A, M, K, B, ldb, N, c->gemm_b3.p, make(part, map0, 0.f)));
     combine(part, (uint32_t)M, map0, 0.f, nullptr, nullptr);
     HIPCHK(c, hipGetLastError());
@@ -986,7 +1003,8 @@ static int gemm_assign_two_pass(isle_ctx* c, const float* A, const float* Arm, i
 // same rows row-major with leading dimension lda_rm, for the second pass) and the k lifted centres' coordinates B (k x k, leading dimension
 // ldb): dots_assign_cm_k's outputs without the D x k product in memory
 int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, const float* an, uint64_t M, int K, const float* B, int ldb, int N, int G,
-                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family, const void* A2) {
+                     const float* cn, const float* dn, const float* cn_max, uint32_t* assign, float* ub, float* lb, int family, const void* A2,
+                     const uint32_t* map2) {
   TimeScope ts(c, family);
   const int nslot = (N + 63) / 64;
   // largest squared norm of the product's columns (rows of B as stored: centre n's K coordinates)
@@ -1003,11 +1021,12 @@ int k_gemm_assign_yy(isle_ctx* c, const float* A, const float* Arm, int lda_rm, 
         hipLaunchKernelGGL(yy_first_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, G, dn, cn_max, assign, ub, lb, map, eta, an, bmax, redo,
                            nredo);
       },
-      nullptr, A2);
+      nullptr, A2, map2);
 }
 // the same for the full pass of Lloyd in span(U): assign / ub / one lower bound per tile of 32 centres (row stride TL); cmax = max |c|^2 on the device
 int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_rm, uint64_t M, int K, const float* B, int ldb, int N, int TL, const float* cn,
-                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0, const void* A2) {
+                        const float* pn, const float* cmax, uint32_t* assign, float* ub, float* tlb, int family, const uint32_t* map0, const void* A2,
+                        const uint32_t* map2) {
   TimeScope ts(c, family);
   const int nslot = (N + 63) / 64;
   return gemm_assign_two_pass(
@@ -1016,7 +1035,7 @@ int k_gemm_assign_tiles(isle_ctx* c, const float* A, const float* Arm, int lda_r
       [&](const AssignRec* part, uint32_t n, const uint32_t* map, float eta, uint32_t* redo, uint32_t* nredo) {
         hipLaunchKernelGGL(tiles_combine_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, part, nslot, n, TL, pn, cmax, assign, ub, tlb, map, eta, redo, nredo);
       },
-      map0, A2);
+      map0, A2, map2);
 }
 
 // in: element (r, cidx) at in[cidx*ld_in + r], r < rows, cidx < cols.  out[r*ld_out + cidx] = in(r, cidx).
@@ -1046,6 +1065,19 @@ int k_transpose(isle_ctx* c, const float* in, uint64_t rows, uint64_t cols, uint
     hipLaunchKernelGGL(transpose_k, g, blk, 0, c->stream, in + r0, nr, cols, ld_in, out + r0 * ld_out, ld_out);
     HIPCHK(c, hipGetLastError());
   }
+  return 0;
+}
+
+// The coordinate-major f32 copy of the projection (Pt[j * D + d] = P[d][j]).  Until round 5 every projection was followed by this
+// transposition; the default routes of a large shard now read the split copy the grouped projection leaves (c->Pt2, by position), and the
+// routes that still want f32 columns — the register kernels, the three-term whole-product fallbacks, the non-fused products, the small-shape
+// k-means++ pass — ask for it here.
+int k_ensure_pt(isle_ctx* c) {
+  if (c->Pt_ready) return 0;
+  if (!c->P_ready || !c->D) return isle_fail(c, ISLE_E_ARG, "no projection to transpose");
+  HIPCHK(c, c->Pt.reserve((size_t)c->D * c->ldk));
+  ISLECHK(k_transpose(c, c->P.p, c->ldk, c->D, c->ldk, c->Pt.p, c->D));
+  c->Pt_ready = true;
   return 0;
 }
 

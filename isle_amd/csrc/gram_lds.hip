@@ -1693,11 +1693,24 @@ struct GlWidePanels {
 };
 __global__ __launch_bounds__(256) void gl_wide_assemble_k(const float* __restrict__ scratch, size_t slab /*floats per panel slab*/, uint32_t D,
                                                            const uint32_t* __restrict__ rowmap, GlWidePanels g, int jg0, int ld,
-                                                           float* __restrict__ Out, float* __restrict__ normpart /*nullable: D floats of this group*/) {
+                                                           float* __restrict__ Out, float* __restrict__ normpart /*nullable: D floats of this group*/,
+                                                           uint4* __restrict__ A2 /*nullable: the split copy by position (gemm_bf16x3.h a2 layout, slabs of 16)*/,
+                                                           int nslab, int oct_end /*octets [jg0 / 8, oct_end) leave from this group*/) {
   extern __shared__ float tl[];  // 64 x tw, tw = ncols + 4 (rows 16-byte aligned: whole float4 leave in the second phase)
   __shared__ uint32_t rm[64];
   const int tw = g.ncols + 4;
   const uint32_t p0 = blockIdx.x * 64;
+  if (p0 >= D) {  // a chunk of the last row block of 256 behind the last document: its units of the split copy are zeros
+    if (A2) {
+      const uint32_t r = threadIdx.x & 63;
+      const uint64_t pos = (uint64_t)p0 + r, mb = pos >> 8;
+      for (int u = (int)(threadIdx.x >> 6); u < 2 * (oct_end - jg0 / 8); u += 4) {
+        const int oct = jg0 / 8 + (u >> 1), term = u & 1;
+        A2[(((mb * nslab + (uint64_t)(oct >> 1)) * 2 + term) * 2 + (oct & 1)) * 256 + (pos & 255)] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    return;
+  }
   const uint32_t np = min(64u, D - p0);
   if (threadIdx.x < 64) rm[threadIdx.x] = threadIdx.x < np ? rowmap[p0 + threadIdx.x] : 0u;
   // phase 1: thread t < 192 owns float4 t of every panel's 3 kB piece (row t / 3, float4 t % 3): all panels' loads in flight together
@@ -1736,6 +1749,29 @@ __global__ __launch_bounds__(256) void gl_wide_assemble_k(const float* __restric
     const float s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2), s3 = __shfl_down(s, 3);
     if (part == 0 && r < np) normpart[rm[r]] = (s + s1) + (s2 + s3);
   }
+  if (A2) {
+    // the two bf16 terms of the group's columns, by POSITION: unit (row block, slab, term, octet, row) = 8 consecutive coordinates of one
+    // position; a wave writes the 64 positions' units of one (octet, term): one 1 KiB run.  Coordinates beyond the group's columns (the row's
+    // end) and positions beyond D are zeros.
+    const uint32_t r = threadIdx.x & 63;
+    const uint64_t pos = (uint64_t)p0 + r, mb = pos >> 8;
+    const float* t = tl + r * tw;
+    for (int u = (int)(threadIdx.x >> 6); u < 2 * (oct_end - jg0 / 8); u += 4) {
+      const int ol = u >> 1, term = u & 1, oct = jg0 / 8 + ol;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = (r < np && 8 * ol + j < g.ncols) ? t[8 * ol + j] : 0.f;
+      unsigned short h[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 x0 = (__bf16)x[j];
+        const __bf16 v = term ? (__bf16)(x[j] - (float)x0) : x0;
+        h[j] = __builtin_bit_cast(unsigned short, v);
+      }
+      A2[(((mb * nslab + (uint64_t)(oct >> 1)) * 2 + term) * 2 + (oct & 1)) * 256 + (pos & 255)] =
+          make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16), h[4] | ((uint32_t)h[5] << 16), h[6] | ((uint32_t)h[7] << 16));
+    }
+  }
 }
 __global__ __launch_bounds__(256) void gl_wide_norms_k(const float* __restrict__ normpart, uint32_t D, int ngroups, float* __restrict__ norms) {
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
@@ -1745,7 +1781,8 @@ __global__ __launch_bounds__(256) void gl_wide_norms_k(const float* __restrict__
   norms[d] = s;
 }
 
-int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms) {
+int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* norms, void* A2pos, bool* a2_done) {
+  if (a2_done) *a2_done = false;
   ISLECHK(k_band_build(c));
   if (c->gl_mode != 1) return isle_fail(c, ISLE_E_ARG, "k_gl_wide needs the LDS-banded form");
   if (ld % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: leading dimension %d not a multiple of 4", ld);
@@ -1784,11 +1821,18 @@ int k_gl_wide(isle_ctx* c, const float* Mrm, int k, int ld, float* Out, float* n
       if (g.ncols % 4) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: a panel group of %d columns", g.ncols);
       const size_t lds = (size_t)64 * (g.ncols + 4) * sizeof(float);
       ISLECHK(isle_max_lds(c, (const void*)gl_wide_assemble_k, (int)lds));
-      hipLaunchKernelGGL(gl_wide_assemble_k, dim3(cdiv((long)D, 64)), dim3(256), lds, c->stream, c->gl_pscratch.p, slab, (uint32_t)D, c->dperm.p, g, jg0, ld, Out,
-                         normpart + (size_t)gi * D);
+      // the split copy (by position) leaves from the same tile; the last group also writes the zero octets up to the last slab's end, and the
+      // grid covers the whole last row block of 256 positions
+      const int nslab = (k + 15) / 16;
+      const int oct_end = j0 >= k ? 2 * nslab : (jg0 + g.ncols) / 8;
+      if (A2pos && (jg0 % 8 || (j0 < k && g.ncols % 8))) return isle_fail(c, ISLE_E_ARG, "k_gl_wide: a panel group that does not end on an octet");
+      const long nwg = A2pos ? cdiv((long)D, 256) * 4 : cdiv((long)D, 64);
+      hipLaunchKernelGGL(gl_wide_assemble_k, dim3((unsigned)nwg), dim3(256), lds, c->stream, c->gl_pscratch.p, slab, (uint32_t)D, c->dperm.p, g, jg0, ld, Out,
+                         normpart + (size_t)gi * D, (uint4*)A2pos, nslab, oct_end);
       HIPCHK(c, hipGetLastError());
       jg0 = j0;
     }
+    if (A2pos && a2_done) *a2_done = true;
     hipLaunchKernelGGL(gl_wide_norms_k, dim3(cdiv((long)D, 256)), dim3(256), 0, c->stream, normpart, (uint32_t)D, gi, norms);
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -310,7 +310,8 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
     }
   }
   c->kmpp_track = false;  // the routes below do not keep the nearest seed and the tile minima
-  if (nc <= 16 && c->Pt_ready && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024) {
+  if (nc <= 16 && (c->Pt_ready || c->Pt2_ready) && (size_t)k * ((nc + 3) / 4) * sizeof(float4) <= 64 * 1024) {
+    ISLECHK(k_ensure_pt(c));
     // streaming pass over the coordinate-major copy (the centres fit the default 64 KB of dynamic LDS)
     const int nq = (nc + 3) / 4;
     const dim3 g(cdiv(D, 256)), b(256);
@@ -789,8 +790,12 @@ template <int MODE>
 static int launch_proj_reg(isle_ctx* c, uint64_t D, int k, int ldk, const float* C, const float* cn, const float* pn, uint32_t* assign,
                            float* min_dist, bool* done, const float* Pt, const uint32_t* map, float* ub, float* lb, const uint32_t* need, int TL) {
   *done = false;
-  if (!D || !c->Pt_ready) return 0;
-  if (!Pt) Pt = c->Pt.p;
+  if (!D) return 0;
+  if (!Pt) {  // the context's projection, coordinate-major: made from P if the default routes have not needed it yet
+    if (!(c->Pt_ready || c->Pt2_ready)) return 0;
+    ISLECHK(k_ensure_pt(c));
+    Pt = c->Pt.p;
+  }
   const int kpad = (k + 31) & ~31;
   const int ct = kpad / 32;
   const int nslab = cdiv(ldk / 2, PR_SL);
@@ -996,7 +1001,7 @@ int k_kmpp_to_tiles(isle_ctx* c, uint64_t D, int k, const float* pn, const float
 
 bool k_proj_full_by_gemm(isle_ctx* c, uint64_t D, int k) {
   const char* pf = c->knob(KN_PROJ_FULL);
-  return c->Pt_ready && D > 0 && k >= 64 && (k_gemm_assign_fused_ok(c, D, k, k) || isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float))) &&
+  return (c->Pt_ready || c->Pt2_ready) && D > 0 && k >= 64 && (k_gemm_assign_fused_ok(c, D, k, k) || isle_scratch_ok(c, c->dotsT.cap, (double)D * k * sizeof(float))) &&
          ((2.0 * (double)D * k * k >= 2e10 && !(pf && !strcmp(pf, "fused"))) || (pf && !strcmp(pf, "gemm")));
 }
 int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* C, const float* cn, uint32_t* assign,
@@ -1011,10 +1016,12 @@ int k_proj_assign_tiles(isle_ctx* c, const float* P, const float* pn, uint64_t D
       if (k_gemm_assign_fused_ok(c, D, k, k)) {  // distances, tile bounds and candidates formed inside the product: no D x k matrix in memory
         HIPCHK(c, c->cmax_buf.reserve(4));
         ISLECHK(k_max_f32(c, cn, k, c->cmax_buf.p));
-        return k_gemm_assign_tiles(c, c->Pt.p, P, ldk, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ, nullptr,
-                                   c->Pt2_ready && P == c->P.p ? c->Pt2.p : nullptr);
+        const bool a2 = c->Pt2_ready && P == c->P.p;
+        return k_gemm_assign_tiles(c, c->Pt_ready ? c->Pt.p : nullptr, P, ldk, D, k, C, ldk, k, TL, cn, pn, c->cmax_buf.p, assign, ub, tlb, ISLE_T_LLOYD_PROJ, nullptr,
+                                   a2 ? c->Pt2.p : nullptr, a2 && c->Pt2_pos ? c->dperm.p : nullptr);
       }
       HIPCHK(c, c->dotsT.reserve((size_t)D * k));
+      ISLECHK(k_ensure_pt(c));
       ISLECHK(k_gemm_nn_assign(c, c->Pt.p, D, k, C, ldk, k, c->dotsT.p, ISLE_T_LLOYD_PROJ));
       hipLaunchKernelGGL(proj_dots_tiles_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, (uint32_t)D, k, pn, cn, assign, ub, tlb, TL);
       HIPCHK(c, hipGetLastError());

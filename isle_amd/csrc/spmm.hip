@@ -660,11 +660,12 @@ int k_dots_assign(isle_ctx* c, int k, int ldk, const float* cn, const float* dn,
   return 0;
 }
 
-int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms) {
+int k_spmm_wide_project(isle_ctx* c, const float* Mrm, int k, int ldk, float* P, float* norms, void* A2pos, bool* a2_done) {
   TimeScope ts(c, ISLE_T_PROJECT);
+  if (a2_done) *a2_done = false;
   ISLECHK(k_gl_detect(c));
   if (c->gl_mode == 1 && wide_through_lds(c)) {  // row-constant B: panels of M through LDS (gram_lds.hip)
-    return k_gl_wide(c, Mrm, k, ldk, P, norms);  // (the grouped form forms the norms on its way; the plain one calls k_rownorms)
+    return k_gl_wide(c, Mrm, k, ldk, P, norms, A2pos, a2_done);  // (the grouped form forms the norms — and the split copy — on its way; the plain one calls k_rownorms)
   }
   return launch_wide<WIDE_PROJECT>(c, Mrm, k, ldk, P, norms, nullptr, nullptr, nullptr, nullptr);
 }
