@@ -868,8 +868,7 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
   if (in) {
     d = order ? order[i] : i;
     const uint32_t a = assign[d];
-    const float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of the updates
-    ub[d] = u;
+    float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of the updates
     float4* row = reinterpret_cast<float4*>(tlb + (size_t)d * TL);
     uint32_t mask = 0u;
     // movers (see YyMovers): centres left out of their tiles' movements; their exact new distances bound their tiles instead.  The
@@ -880,15 +879,17 @@ __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ 
 #pragma unroll
       for (int jm = 0; jm < 10; ++jm) {
         ml[jm] = 3.4e38f;
-        if (jm < mv.n && mv.id[jm] != a) {  // the assigned centre does not bound its own tile
+        if (jm < mv.n) {
           const uint32_t cj = mv.id[jm];
           const float dist = fabsf((-2.0f * mdots[(size_t)(dpos ? dpos[d] : d) * mv.ld + jm] + cn[cj]) + nd);
           float uu, ll;
           hamerly_store_bounds(dist, dist, nd + cn[cj], &uu, &ll);
-          ml[jm] = ll;
+          if (cj != a) ml[jm] = ll;  // the assigned centre does not bound its own tile:
+          else u = fminf(u, uu);     // its exact new distance replaces the upper bound grown by its movement
         }
       }
     }
+    ub[d] = u;
     for (int q = 0; q < TL / 4; ++q) {
       float4 v = row[q];
       float l[4] = {v.x, v.y, v.z, v.w};
@@ -994,6 +995,67 @@ int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
 // overlaps its upper bound.  A group is 32 bytes of a centre row, so a group scan gathers one 32-byte piece per nonzero
 // of the document instead of the whole k-wide row.
 // ------------------------------------------------------------------------------------------
+// The group bounds of a block of documents lowered by the groups' movements, written back and left in the LDS tile [document][group]: a wave
+// takes NU documents at a time — their rows of G floats (500 bytes at k = 1000) are contiguous runs, in the documents' own order or a visiting
+// order's — with ALL their loads in flight together (NU x NT per lane).  Round 5: the loop used to keep 8 (visiting order) or 1 (document
+// order) load per lane in flight and ran at 1.2 - 1.6 TB/s of its 10 GB; this form is bound by the memory again.
+#ifndef YY_NU2
+#define YY_NU2 8  // documents a wave lowers at a time at 65 - 128 groups: 16 loads per lane in flight (timing builds: tools/build_variant.sh)
+#endif
+template <int NT, int NU>
+__device__ inline void yy_lower_block(float* __restrict__ glb, int G, const float* __restrict__ gmax, const uint32_t* __restrict__ order, uint32_t d0,
+                                      uint32_t nd, float* __restrict__ tile) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  float gm[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) gm[t] = lane + 64 * t < G ? gmax[lane + 64 * t] * 1.000001f : 0.f;
+  for (uint32_t jb = (uint32_t)w * NU; jb < nd; jb += (uint32_t)nw * NU) {
+    uint32_t doc[NU];  // (rows are addressed from the document again when they are written: pointers would double the registers held)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const uint32_t j = min(jb + u, nd - 1);
+      doc[u] = order ? order[d0 + j] : d0 + j;
+    }
+    float v[NU][NT];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[u][t] = lane + 64 * t < G ? glb[(size_t)doc[u] * G + lane + 64 * t] : 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (jb + u < nd) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int g = lane + 64 * t;
+          if (g < G) {
+            float l = v[u][t] - gm[t];
+            l = l > 0.f ? l * 0.999999f : l;
+            glb[(size_t)doc[u] * G + g] = l;
+            tile[(jb + u) * (uint32_t)G + g] = l;
+          }
+        }
+      }
+    }
+  }
+}
+__device__ inline void yy_lower_block_any(float* __restrict__ glb, int G, const float* __restrict__ gmax, const uint32_t* __restrict__ order, uint32_t d0,
+                                          uint32_t nd, float* __restrict__ tile) {
+  if (G <= 64) yy_lower_block<1, 2 * YY_NU2>(glb, G, gmax, order, d0, nd, tile);
+  else if (G <= 128) yy_lower_block<2, YY_NU2>(glb, G, gmax, order, d0, nd, tile);
+  else if (G <= 192) yy_lower_block<3, (YY_NU2 + 1) / 2>(glb, G, gmax, order, d0, nd, tile);
+  else if (G <= 256) yy_lower_block<4, (YY_NU2 + 1) / 2>(glb, G, gmax, order, d0, nd, tile);
+  else {  // beyond 256 groups (k > 2048, the by-document bounds only): element by element
+    const uint32_t nel = nd * (uint32_t)G;
+    for (uint32_t i = threadIdx.x; i < nel; i += blockDim.x) {
+      const uint32_t j = i / (uint32_t)G, g = i - j * (uint32_t)G;
+      float* src = glb + (size_t)(order ? order[d0 + j] : d0 + j) * G + g;
+      float l = *src - gmax[g] * 1.000001f;
+      l = l > 0.f ? l * 0.999999f : l;
+      *src = l;
+      tile[i] = l;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* __restrict__ order /*nullable: visiting order*/,
                                                     const uint32_t* __restrict__ assign, float* __restrict__ ub, float* __restrict__ glb, int G,
                                                     const float* __restrict__ delta, const float* __restrict__ gmax, uint32_t* __restrict__ active,
@@ -1006,57 +1068,7 @@ __global__ __launch_bounds__(256) void yy_filter_k(uint32_t D, const uint32_t* _
   extern __shared__ float tile[];  // docs_per_block x G
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
   const uint32_t nd = min((uint32_t)docs_per_block, D - d0);
-  const uint32_t nel = nd * (uint32_t)G;
-  if (order) {
-    // a wave per document: its G floats are one contiguous run (500 bytes at k = 1000), four documents in flight per wave
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t j0 = (uint32_t)w * 4; j0 < nd; j0 += 16) {
-      float* src[4];
-      float v[4][4];  // up to 256 groups: four per lane
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t j = min(j0 + u, nd - 1);
-        src[u] = glb + (size_t)order[d0 + j] * G;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int g = lane + 64 * t;
-          v[u][t] = g < G ? src[u][g] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (j0 + u < nd) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int g = lane + 64 * t;
-            if (g < G) {
-              float l = v[u][t] - gmax[g] * 1.000001f;
-              l = l > 0.f ? l * 0.999999f : l;
-              src[u][g] = l;
-              tile[(j0 + u) * (uint32_t)G + g] = l;
-            }
-          }
-        }
-      }
-    }
-  } else {
-    // (document j, group g) of element i = threadIdx.x + 256 t, stepped without a division per element
-    uint32_t j = threadIdx.x / (uint32_t)G, g = threadIdx.x - j * (uint32_t)G;
-    const uint32_t sj = 256u / (uint32_t)G, sg = 256u - sj * (uint32_t)G;
-    for (uint32_t i = threadIdx.x; i < nel; i += 256) {
-      float* src = glb + (size_t)(d0 + j) * G + g;
-      float l = *src - gmax[g] * 1.000001f;
-      l = l > 0.f ? l * 0.999999f : l;
-      *src = l;
-      tile[i] = l;
-      j += sj;
-      g += sg;
-      if (g >= (uint32_t)G) {
-        g -= (uint32_t)G;
-        ++j;
-      }
-    }
-  }
+  yy_lower_block_any(glb, G, gmax, order, d0, nd, tile);
   __syncthreads();
   for (uint32_t j0 = 0; j0 < (uint32_t)docs_per_block; j0 += 256) {  // the same trip count for every thread: block_append_slot synchronises
     const uint32_t j = j0 + threadIdx.x;
@@ -1370,55 +1382,8 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
   uint32_t* lact = reinterpret_cast<uint32_t*>(tile + (size_t)docs_per_block * G);
   const uint32_t d0 = blockIdx.x * (uint32_t)docs_per_block;
   const uint32_t nd = min((uint32_t)docs_per_block, D - d0);
-  const uint32_t nel = nd * (uint32_t)G;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (order) {
-    for (uint32_t j0 = (uint32_t)w * 4; j0 < nd; j0 += 16) {
-      float* src[4];
-      float v[4][4];  // up to 256 groups: four per lane
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t j = min(j0 + u, nd - 1);
-        src[u] = glb + (size_t)order[d0 + j] * G;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int g = lane + 64 * t;
-          v[u][t] = g < G ? src[u][g] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (j0 + u < nd) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int g = lane + 64 * t;
-            if (g < G) {
-              float l = v[u][t] - gmax[g] * 1.000001f;
-              l = l > 0.f ? l * 0.999999f : l;
-              src[u][g] = l;
-              tile[(j0 + u) * (uint32_t)G + g] = l;
-            }
-          }
-        }
-      }
-    }
-  } else {
-    uint32_t j = threadIdx.x / (uint32_t)G, g = threadIdx.x - j * (uint32_t)G;
-    const uint32_t sj = 256u / (uint32_t)G, sg = 256u - sj * (uint32_t)G;
-    for (uint32_t i = threadIdx.x; i < nel; i += 256) {
-      float* src = glb + (size_t)(d0 + j) * G + g;
-      float l = *src - gmax[g] * 1.000001f;
-      l = l > 0.f ? l * 0.999999f : l;
-      *src = l;
-      tile[i] = l;
-      j += sj;
-      g += sg;
-      if (g >= (uint32_t)G) {
-        g -= (uint32_t)G;
-        ++j;
-      }
-    }
-  }
+  yy_lower_block_any(glb, G, gmax, order, d0, nd, tile);
   __syncthreads();
   uint32_t base = 0, total = 0;
   for (uint32_t j0 = 0; j0 < (uint32_t)docs_per_block; j0 += 256) {  // one trip (docs_per_block <= 256): the append synchronises
@@ -1437,8 +1402,14 @@ __global__ __launch_bounds__(256) void yy2_filter_tighten_k(uint32_t D, const ui
         const float E = ISLE_SLACK_REL * (dnd + *cn_max_p), sE = sqrtf(E);
         for (int jm = 0; jm < mv.n; ++jm) {
           const uint32_t cj = mv.id[jm];
-          if (cj == a) continue;  // the assigned centre does not bound its own group
           const float dist = fabsf((-2.0f * mdots[(size_t)dpos[d] * mv.ld + jm] + cn_by_id[cj]) + dnd);
+          if (cj == a) {
+            // the assigned centre does not bound its own group; its exact new distance replaces the upper bound grown by its movement
+            // (a cluster of 1.5 M documents whose centre moves by 0.02 per iteration made every one of them active: config 3)
+            const float x = sqrtf(dist);
+            u = fminf(u, x + fminf(sE, E / fmaxf(x, 1e-30f)));
+            continue;
+          }
           const float l = yy_slack_down_sq(dist, E, sE);
           const uint32_t gj = map.slot(cj) >> 3;
           const uint32_t at = j * (uint32_t)G + gj;
@@ -1612,7 +1583,7 @@ int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
   int dpb = 256;
-  while (dpb > 32 && (size_t)dpb * G * sizeof(float) > 64 * 1024) dpb /= 2;  // LDS tile of at most 64 KB
+  while (dpb > 32 && (size_t)dpb * G * sizeof(float) > 32 * 1024) dpb /= 2;  // LDS tile of at most 32 KB: five workgroups per CU
   hipLaunchKernelGGL(yy_filter_k, dim3(cdiv(D, dpb)), dim3(256), (size_t)dpb * G * sizeof(float), c->stream, D, order, assign, ub, glb, G, delta_dev,
                      gmax_dev, active, nactive, dpb);
   HIPCHK(c, hipGetLastError());

@@ -16,6 +16,7 @@ from tools.synth import Corpus  # noqa: E402
 
 SHAPES = {"c2": (50_000, 1_000_000, 200, 2024), "c3shard": (100_000, 1_250_000, 1000, 31337), "c3full": (100_000, 10_000_000, 1000, 31337)}
 V, D, k, seed = SHAPES[sys.argv[1] if len(sys.argv) > 1 else "c3shard"]
+k = int(os.environ.get("PROBE_K", k))  # e.g. 1024: rows of the group bounds are then whole cache lines
 B = Corpus(V, D, k, seed).threshold(k, free_A=True)
 hp = HotPath(0)
 hp.upload_csc(V, B["vals"], B["rows"], B["offs"])
