@@ -963,14 +963,95 @@ __global__ __launch_bounds__(256) void pt_tighten_k(const float* __restrict__ P,
   const uint32_t slot = block_append_slot(flag, nactive);
   if (flag) active[slot] = mydoc;
 }
+// pt_tighten_k with its round trips taken out of the candidates' turns.  There a wave walks cand -> assign -> the two rows for each of
+// its 64 candidates, three round trips a candidate (2.0 ms per call at config 3).  Here lane j fetches candidate j's document, centre and
+// norms up front (one round for the 64), and the rows of the NEXT candidate are asked for before the current one's are summed: a candidate
+// costs one round trip.  Rows of at most 4 x 256 floats (NQ float4 per lane).  Same sums in the same order: same bits.
+template <int NQ>
+__global__ __launch_bounds__(256) void pt_tighten_ahead_k(const float* __restrict__ P, const float* __restrict__ pn, int ldk, const float* __restrict__ C,
+                                                           const float* __restrict__ cn, const uint32_t* __restrict__ assign,
+                                                           const uint32_t* __restrict__ cand, const uint32_t* __restrict__ ncand, float* __restrict__ ub,
+                                                           const float* __restrict__ tlb, int T, int TL, uint32_t* __restrict__ need,
+                                                           uint32_t* __restrict__ active, uint32_t* __restrict__ nactive) {
+  const uint32_t n = *ncand;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t base = blockIdx.x * 256 + (uint32_t)wave * 64;
+  const int cnt = base < n ? (int)min(64u, n - base) : 0;  // wave-uniform
+  bool flag = false;
+  uint32_t mydoc = 0;
+  const int nq = ldk >> 2;
+  uint32_t md = 0, ma = 0;
+  float mnd = 0.f, mcc = 0.f;
+  if (lane < cnt) {
+    md = cand[base + (uint32_t)lane];
+    ma = assign[md];
+    mnd = pn[md];
+    mcc = cn[ma];
+  }
+  struct Rows {
+    float4 x[NQ], y[NQ];
+    float l;
+  };
+  auto fetch = [&](Rows& r, int j) {  // no conditions on the loads (a wait can then count them): past the row's end a lane reads its last float4 again
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)md, j), a = (uint32_t)__builtin_amdgcn_readlane((int)ma, j);
+    const float4* pr = reinterpret_cast<const float4*>(P + (size_t)d * ldk);
+    const float4* cr = reinterpret_cast<const float4*>(C + (size_t)a * ldk);
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      const int q = min(lane + 64 * t, nq - 1);
+      r.x[t] = pr[q];
+      r.y[t] = cr[q];
+    }
+    r.l = tlb[(size_t)d * TL + min(lane, T - 1)];
+  };
+  auto step = [&](const Rows& cur, Rows& nxt, int j) {  // candidate j < cnt
+    fetch(nxt, min(j + 1, cnt - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      if (lane + 64 * t < nq) {
+        const float4 x = cur.x[t], y = cur.y[t];
+        s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)md, j), a = (uint32_t)__builtin_amdgcn_readlane((int)ma, j);
+    const float nd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mnd), j));
+    const float cc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mcc), j));
+    const float dist = fabsf((-2.0f * s + cc) + nd);
+    float uu, ll;
+    hamerly_store_bounds(dist, dist, nd + cc, &uu, &ll);
+    const float l = lane < T ? cur.l : 3.4e38f;
+    const uint32_t mask = (uint32_t)__ballot(uu >= l);
+    if (lane == j) {
+      flag = mask != 0u;
+      mydoc = d;
+    }
+    if (lane == 0) {
+      ub[d] = uu;
+      if (mask) need[d] = mask | (1u << (a >> 5));
+    }
+  };
+  Rows r0, r1;
+  if (cnt) fetch(r0, 0);
+  for (int j = 0; j < cnt; j += 2) {
+    step(r0, r1, j);
+    if (j + 1 < cnt) step(r1, r0, j + 1);
+  }
+  const uint32_t slot = block_append_slot(flag, nactive);
+  if (flag) active[slot] = mydoc;
+}
 int k_pt_tighten(isle_ctx* c, const float* P, const float* pn, int ldk, const float* C, const float* cn, const uint32_t* assign, const uint32_t* cand,
                  const uint32_t* ncand, float* ub, const float* tlb, int T, int TL, uint32_t* need, uint32_t* active, uint32_t* nactive) {
   TimeScope ts(c, ISLE_T_LLOYD_PROJ);
   const uint32_t D = (uint32_t)c->D;
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
-  hipLaunchKernelGGL(pt_tighten_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, P, pn, ldk, C, cn, assign, cand, ncand, ub, tlb, T, TL, need, active,
-                     nactive);
+  const int nq64 = cdiv(ldk >> 2, 64);
+  auto kern = nq64 == 1 ? pt_tighten_ahead_k<1> : nq64 == 2 ? pt_tighten_ahead_k<2> : nq64 == 3 ? pt_tighten_ahead_k<3> : nq64 == 4 ? pt_tighten_ahead_k<4> : pt_tighten_k;
+  hipLaunchKernelGGL(kern, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, P, pn, ldk, C, cn, assign, cand, ncand, ub, tlb, T, TL, need, active, nactive);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
