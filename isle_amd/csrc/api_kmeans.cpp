@@ -746,8 +746,17 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
         ISLECHK(k_yy_filter(c, order, c->assign.p, c->hub.p, c->yglb.p, G, delta_dev, gmax_dev, c->active.p, nact));
       const bool dbg = c->knob_on(KN_DEBUG_HAMERLY);
       unsigned long long* dbg_dev = nullptr;
+      if (dbg && fused) {  // diagnostic only: which bound the active documents reach, and by how much
+        unsigned long long hh[16];
+        ISLECHK(k_yy_dbg_margins(c, c->active.p, nact, c->assign.p, c->hub.p, c->yglb.p, G, ymap, hh));
+        fprintf(stderr, "[yinyang] iter %d active by (ub - smallest group bound) < 1e-6 | 1e-5 | 1e-4 | 1e-3 | 1e-2 | 1e-1 | 1 | more:  own group", it);
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", hh[b]);
+        fprintf(stderr, ";  another group");
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", hh[8 + b]);
+        fprintf(stderr, "\n");
+      }
       if (dbg) {  // diagnostic only: group scans and gathered nonzeros of this iteration
-        HIPCHK(c, c->dbg_cnt.reserve(2));
+        HIPCHK(c, c->dbg_cnt.reserve(18));
         HIPCHK(c, hipMemsetAsync(c->dbg_cnt.p, 0, 16, c->stream));
         dbg_dev = c->dbg_cnt.p;
       }

@@ -474,6 +474,8 @@ int k_yy_rows_by_slot(isle_ctx* c, const YyMap& map, int k, const float* in, int
 int k_yy_labels_to_ids(isle_ctx* c, const YyMap& map, uint32_t* assign, uint64_t D);
 int k_yy_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, float* ub, float* glb, int G, const float* delta_dev, const float* gmax_dev,
                 uint32_t* active, uint32_t* nactive);
+int k_yy_dbg_margins(isle_ctx* c, const uint32_t* active, const uint32_t* nactive, const uint32_t* assign, const float* ub, const float* glb, int G,
+                     const YyMap& map, unsigned long long* hist_host);
 int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G, const YyMap& map = YyMap());  // c->yy_cg = the centres group-major (V x 8 floats per group)
 int k_yy_scan(isle_ctx* c, const float* Crm, const float* Cg /*nullable*/, int k, int ld, int G, const float* cn, const float* dn, const float* cn_max_dev,
               const uint32_t* active, const uint32_t* nactive, uint32_t* assign, float* ub, float* glb, unsigned long long* dbg = nullptr,

@@ -1706,6 +1706,34 @@ int k_yy_filter_tighten(isle_ctx* c, const uint32_t* order, const uint32_t* assi
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// diagnostic (ISLE_DEBUG_HAMERLY): why the active documents are active — the group whose bound the upper bound reaches first (own or another)
+// and by how much: hist[own ? 0 : 1][b], b = decade of (ub - smallest bound): < 1e-6, < 1e-5, ... , < 1e-1, >= 1e-1
+__global__ __launch_bounds__(256) void yy_dbg_margins_k(const uint32_t* __restrict__ active, const uint32_t* __restrict__ nactive,
+                                                         const uint32_t* __restrict__ assign, const float* __restrict__ ub, const float* __restrict__ glb,
+                                                         int G, YyMap map, unsigned long long* __restrict__ hist /*2 x 8*/) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= *nactive) return;
+  const uint32_t d = active[e];
+  const float* row = glb + (size_t)d * G;
+  float lmin = 3.4e38f;
+  int gmin = 0;
+  for (int g = 0; g < G; ++g)
+    if (row[g] < lmin) lmin = row[g], gmin = g;
+  const int ga = (int)(map.slot(assign[d]) / YY_GROUP);
+  const float margin = ub[d] - lmin;
+  int b = 0;
+  for (float t = 1e-6f; b < 7 && margin >= t; t *= 10.f) ++b;
+  atomicAdd(&hist[(gmin == ga ? 0 : 8) + b], 1ull);
+}
+int k_yy_dbg_margins(isle_ctx* c, const uint32_t* active, const uint32_t* nactive, const uint32_t* assign, const float* ub, const float* glb, int G,
+                     const YyMap& map, unsigned long long* hist_host /*16*/) {
+  HIPCHK(c, c->dbg_cnt.reserve(18));
+  HIPCHK(c, hipMemsetAsync(c->dbg_cnt.p + 2, 0, 16 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(yy_dbg_margins_k, dim3(cdiv((long)c->D, 256)), dim3(256), 0, c->stream, active, nactive, assign, ub, glb, G, map, c->dbg_cnt.p + 2);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(hist_host, c->dbg_cnt.p + 2, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
 int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G, const YyMap& map) {
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t V = (uint32_t)c->V;
