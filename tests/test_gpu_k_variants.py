@@ -1,0 +1,41 @@
+"""Topic counts BETWEEN the BASELINE configs' (k = 200 and k = 1000 are held by test_gpu_big_k.py, k = 2048 by the edge test): the kernels of
+the two Lloyd loops are instantiated by k — rows of `pt_tighten_ahead_k` of 1 … 4 x 256 coordinates (and the plain kernel beyond), group-bound
+rows of `yy_lower_block` of 1 … 4 x 64 groups — and every instantiation must give the partition of the unbounded loop
+(src/sparseMatrix.cpp:1494-1585 projected, :1587-1746 sparse) and, for Lloyd on B, the oracle's from the same centres."""
+import numpy as np
+import pytest
+
+from conftest import corpus, upload
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [300, 600, 1200])
+def test_both_lloyd_loops_at_other_topic_counts(hp, monkeypatch, k):
+    B = corpus(4000, 20000, 40, 11)
+    upload(hp, B)
+    hp.compute_block_ks(k, seed=1, allow_noconv=True)
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=5)
+    res = {}
+    for mode in ("bounds", "none"):
+        if mode == "none":
+            monkeypatch.setenv("ISLE_NO_HAMERLY", "1")
+        lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+        cen = hp.left_multiply_by_U(lp["C_lowd"], fetch=True)
+        ls = hp.run_lloyds(k, fetch_centers=False)
+        res[mode] = (lp["assign"], lp["iters"], ls["assign"], ls["iters"], cen)
+    monkeypatch.delenv("ISLE_NO_HAMERLY")
+    assert res["none"][1] == res["bounds"][1] and res["none"][3] == res["bounds"][3], (res["none"][1], res["bounds"][1], res["none"][3], res["bounds"][3])
+    assert np.array_equal(res["none"][0], res["bounds"][0]), float((res["none"][0] == res["bounds"][0]).mean())
+    assert np.array_equal(res["none"][2], res["bounds"][2]), float((res["none"][2] == res["bounds"][2]).mean())
+    # the by-document form of the Yinyang iteration (the by-group form is the default from 32 groups on)
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    monkeypatch.setenv("ISLE_YY_MODE", "doc")
+    ld = hp.run_lloyds(k, fetch_centers=False)
+    monkeypatch.delenv("ISLE_YY_MODE")
+    assert ld["iters"] == res["bounds"][3] and np.array_equal(ld["assign"], res["bounds"][2])
+    # the oracle from the same lifted centres
+    so = B["oracle"].lloyds_sparse(np.asfortranarray(res["bounds"][4]))
+    same = float((so["assign"] == res["bounds"][2]).mean())
+    assert same >= 0.999 and so["iters"] == res["bounds"][3], (same, so["iters"], res["bounds"][3])
