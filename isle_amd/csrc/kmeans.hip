@@ -235,22 +235,32 @@ __global__ __launch_bounds__(256) void kmpp_to_tiles_k(uint32_t D, int k, const 
     tcn[32] = m;
   }
   __syncthreads();
-  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  const float nd = pn[d], b = best[d];
-  const uint32_t a = arg[d], Ta = a >> 5;
-  float* row = tlb + (size_t)d * TL;
-  float uu, ll;
-  for (int t = 0; t < T; ++t) {
-    const float m1 = tmin[(size_t)t * D + d];
-    hamerly_store_bounds(m1, m1, nd + tcn[t], &uu, &ll);
-    row[t] = ll;
+  // The tile minima lie tile-major (a tile's D values in a run), the bounds document-major (rows of TL floats): a thread computes its
+  // document's T bounds into an LDS tile [document][tile] and the workgroup writes its 256 rows as one run (a thread writing its own row
+  // touches a different line per lane and store: 5.5 ms at config 3, round 5)
+  __shared__ float rows_s[256][33];
+  const uint32_t d0 = blockIdx.x * 256, d = d0 + threadIdx.x;
+  if (d < D) {
+    const float nd = pn[d], b = best[d];
+    const uint32_t a = arg[d], Ta = a >> 5;
+    float uu, ll;
+    for (int t = 0; t < T; ++t) {
+      const float m1 = tmin[(size_t)t * D + d];
+      hamerly_store_bounds(m1, m1, nd + tcn[t], &uu, &ll);
+      rows_s[threadIdx.x][t] = ll;
+    }
+    hamerly_store_bounds(b, m2a[d], nd + tcn[Ta], &uu, &ll);
+    rows_s[threadIdx.x][Ta] = ll;  // the assigned centre's tile: closest OTHER centre in it
+    hamerly_store_bounds(b, b, nd + tcn[32], &uu, &ll);
+    ub[d] = uu;
+    assign[d] = a;
   }
-  hamerly_store_bounds(b, m2a[d], nd + tcn[Ta], &uu, &ll);
-  row[Ta] = ll;  // the assigned centre's tile: closest OTHER centre in it
-  hamerly_store_bounds(b, b, nd + tcn[32], &uu, &ll);
-  ub[d] = uu;
-  assign[d] = a;
+  __syncthreads();
+  const uint32_t nd_blk = min(256u, D - d0);
+  for (uint32_t i = threadIdx.x; i < nd_blk * (uint32_t)TL; i += 256) {
+    const uint32_t j = i / (uint32_t)TL, t = i - j * (uint32_t)TL;
+    if ((int)t < T) tlb[(size_t)d0 * TL + i] = rows_s[j][t];  // (the columns T .. TL - 1 stay as they are: nobody reads them)
+  }
 }
 
 int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc,
