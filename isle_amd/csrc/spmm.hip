@@ -856,48 +856,66 @@ int k_hamerly_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign,
 // largest movement INSIDE tile t; a document whose upper bound stays below all of them is skipped, any other re-examines only the
 // tiles whose bound it reaches (plus its own centre's), by matrix-core tiles on the compacted active list.  Exact: the
 // partition is the full scan's (tests: all bound modes identical).  One thread per document, rows of TL floats.
+// (round 5: NQ = TL / 4 is a template parameter — the row's float4 and the movers' products are asked for together, before any of them is
+// used; with a run-time trip count a thread walked its row one dependent load at a time: 1.5 -> see DESIGN 14a)
+template <int NQ>
 __global__ __launch_bounds__(256) void pt_filter_k(const uint32_t* __restrict__ order, uint32_t D, const uint32_t* __restrict__ assign,
-                                                    float* __restrict__ ub, float* __restrict__ tlb, int T, int TL, const float* __restrict__ delta,
+                                                    float* __restrict__ ub, float* __restrict__ tlb, int T, const float* __restrict__ delta,
                                                     const float* __restrict__ tmove, uint32_t* __restrict__ need, uint32_t* __restrict__ active,
                                                     uint32_t* __restrict__ nactive, YyMovers mv, const float* __restrict__ mdots /*D x mv.ld: P_d . c_mover*/,
                                                     const float* __restrict__ cn, const float* __restrict__ pn, const uint32_t* __restrict__ dpos /*nullable: the movers' products lie by position (k_gl_thin by_position)*/) {
+  constexpr int TL = 4 * NQ;
+  __shared__ float tmv[32], mcn[10];
+  if (threadIdx.x < 32) tmv[threadIdx.x] = (int)threadIdx.x < T ? tmove[threadIdx.x] * 1.000001f : 0.f;
+  if ((int)threadIdx.x < mv.n) mcn[threadIdx.x] = cn[mv.id[threadIdx.x]];
+  __syncthreads();
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const bool in = i < D;
   uint32_t d = 0;
   bool act = false;
   if (in) {
     d = order ? order[i] : i;
+    float4* row = reinterpret_cast<float4*>(tlb + (size_t)d * TL);
+    float4 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = row[q];
     const uint32_t a = assign[d];
     float u = (ub[d] + delta[a]) * 1.000001f;  // the factors absorb the rounding of the updates
-    float4* row = reinterpret_cast<float4*>(tlb + (size_t)d * TL);
     uint32_t mask = 0u;
     // movers (see YyMovers): centres left out of their tiles' movements; their exact new distances bound their tiles instead.  The
     // bounds of their tiles are collected first (at most ten), applied while the row is walked.
     float ml[10];
     if (mv.n) {
       const float nd = pn[d];
+      const float4* mrow = reinterpret_cast<const float4*>(mdots + (size_t)(dpos ? dpos[d] : d) * mv.ld);  // mv.ld <= 12 floats, a run
+      float md[12];
+#pragma unroll
+      for (int q4 = 0; q4 < 3; ++q4) {
+        const float4 m4 = 4 * q4 < mv.ld ? mrow[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        md[4 * q4] = m4.x, md[4 * q4 + 1] = m4.y, md[4 * q4 + 2] = m4.z, md[4 * q4 + 3] = m4.w;
+      }
 #pragma unroll
       for (int jm = 0; jm < 10; ++jm) {
         ml[jm] = 3.4e38f;
         if (jm < mv.n) {
           const uint32_t cj = mv.id[jm];
-          const float dist = fabsf((-2.0f * mdots[(size_t)(dpos ? dpos[d] : d) * mv.ld + jm] + cn[cj]) + nd);
+          const float dist = fabsf((-2.0f * md[jm] + mcn[jm]) + nd);
           float uu, ll;
-          hamerly_store_bounds(dist, dist, nd + cn[cj], &uu, &ll);
+          hamerly_store_bounds(dist, dist, nd + mcn[jm], &uu, &ll);
           if (cj != a) ml[jm] = ll;  // the assigned centre does not bound its own tile:
           else u = fminf(u, uu);     // its exact new distance replaces the upper bound grown by its movement
         }
       }
     }
     ub[d] = u;
-    for (int q = 0; q < TL / 4; ++q) {
-      float4 v = row[q];
-      float l[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float l[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int t = 4 * q + e;
         if (t < T) {
-          float x = l[e] - tmove[t] * 1.000001f;
+          float x = l[e] - tmv[t];
           x = x > 0.f ? x * 0.999999f : x;
           if (mv.n) {
 #pragma unroll
@@ -1063,8 +1081,20 @@ int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
   const uint32_t D = (uint32_t)c->D;
   HIPCHK(c, hipMemsetAsync(nactive, 0, sizeof(uint32_t), c->stream));
   if (D == 0) return 0;
-  hipLaunchKernelGGL(pt_filter_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, tlb, T, TL, delta_dev, tmove_dev, need, active,
-                     nactive, mv, mdots, cn, pn, mv.n ? c->dpos.p : nullptr);
+  if (TL < 4 || TL > 32 || (TL & 3) || T > 32) return isle_fail(c, ISLE_E_ARG, "k_pt_filter: rows of %d tile bounds", TL);
+#define PF(N) hipLaunchKernelGGL(pt_filter_k<N>, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, order, D, assign, ub, tlb, T, delta_dev, tmove_dev, need, active, \
+                                 nactive, mv, mdots, cn, pn, mv.n ? c->dpos.p : nullptr)
+  switch (TL / 4) {
+    case 1: PF(1); break;
+    case 2: PF(2); break;
+    case 3: PF(3); break;
+    case 4: PF(4); break;
+    case 5: PF(5); break;
+    case 6: PF(6); break;
+    case 7: PF(7); break;
+    default: PF(8); break;
+  }
+#undef PF
   HIPCHK(c, hipGetLastError());
   return 0;
 }
