@@ -148,15 +148,23 @@ int k_rownorms(isle_ctx* c, const float* M, int rows, int k, int ldk, float* out
 
 // min_dist[d] = min(min_dist[d], max(pn[d] + cn[j] - 2 dots[d][j], 0)) over the nc new seeds
 // (dpos: the thin product left document d's row at dpos[d], k_gl_thin by_position; null: at d)
-__global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__ dots, int ld, const float* __restrict__ pn, const float* __restrict__ cn,
+// (NQ = ld / 4 float4 per row, a template parameter since round 5: the row's loads are all in flight before the first is used — with a
+// run-time trip count a thread walked its row one dependent load at a time)
+template <int NQ>
+__global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__ dots, const float* __restrict__ pn, const float* __restrict__ cn,
                                                         int nc, uint32_t D, float* __restrict__ min_dist, const uint32_t* __restrict__ dpos) {
+  constexpr int ld = 4 * NQ;
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
+  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)(dpos ? dpos[d] : d) * ld);
+  float4 vv[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) vv[q] = row[q];
   const float nd = pn[d];
   float m = min_dist[d];
-  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)(dpos ? dpos[d] : d) * ld);
-  for (int q = 0; q < ld / 4; ++q) {
-    const float4 v = row[q];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float4 v = vv[q];
     const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -173,21 +181,27 @@ __global__ __launch_bounds__(256) void kmpp_min_dots_k(const float* __restrict__
 // produces — nearest centre, runner-up of its tile, minimum of every other tile — and run_lloyds_on_projected_space can start from it
 // instead of a D x k x k pass (kmpp_to_tiles_k).  `best` = the running minimum (min_dist during the rounds; a copy for the last batch,
 // which the reference never folds into min_dist).
-__global__ __launch_bounds__(256) void kmpp_min_dots_track_k(const float* __restrict__ dots, int ld, const float* __restrict__ pn,
+template <int NQ>
+__global__ __launch_bounds__(256) void kmpp_min_dots_track_k(const float* __restrict__ dots, const float* __restrict__ pn,
                                                               const float* __restrict__ cn, int nc, uint32_t D, float* __restrict__ best,
                                                               uint32_t* __restrict__ arg, float* __restrict__ m2a, float* __restrict__ tmin,
                                                               uint32_t s_old, const uint32_t* __restrict__ dpos) {
+  constexpr int ld = 4 * NQ;
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
+  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)(dpos ? dpos[d] : d) * ld);
+  float4 vv[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) vv[q] = row[q];
   const float nd = pn[d];
   float m = best[d], m2 = m2a[d];
   uint32_t a = arg[d];  // meaningless while m is FP_MAX (no seed seen): the first seed replaces it
   float* tm_col = tmin + d;  // tile T of this document at tm_col[T * D]
   uint32_t curT = s_old >> 5;
   float tm = tm_col[(size_t)curT * D];
-  const float4* row = reinterpret_cast<const float4*>(dots + (size_t)(dpos ? dpos[d] : d) * ld);
-  for (int q = 0; q < ld / 4; ++q) {
-    const float4 v = row[q];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float4 v = vv[q];
     const float xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -263,6 +277,27 @@ __global__ __launch_bounds__(256) void kmpp_to_tiles_k(uint32_t D, int k, const 
   }
 }
 
+// the rows of the thin product (c->dotsT, ld = 4 .. 32 floats, by position) folded into the running minima (and, tracked, the nearest seed and tile minima)
+static void launch_min_dots(isle_ctx* c, bool track, int ld, const float* pn, const float* cn, int ncj, uint64_t D, float* min_dist, uint32_t s0) {
+  const dim3 g(cdiv(D, 256)), b(256);
+#define MD(N)                                                                                                                                     \
+  if (track)                                                                                                                                      \
+    hipLaunchKernelGGL(kmpp_min_dots_track_k<N>, g, b, 0, c->stream, c->dotsT.p, pn, cn, ncj, (uint32_t)D, min_dist, c->kmpp_arg.p, c->kmpp_m2a.p, \
+                       c->kmpp_tmin.p, s0, c->dpos.p);                                                                                            \
+  else                                                                                                                                            \
+    hipLaunchKernelGGL(kmpp_min_dots_k<N>, g, b, 0, c->stream, c->dotsT.p, pn, cn, ncj, (uint32_t)D, min_dist, c->dpos.p)
+  switch (ld / 4) {
+    case 1: MD(1); break;
+    case 2: MD(2); break;
+    case 3: MD(3); break;
+    case 4: MD(4); break;
+    case 5: MD(5); break;
+    case 6: MD(6); break;
+    case 7: MD(7); break;
+    default: MD(8); break;
+  }
+#undef MD
+}
 int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int k, int ldk, const float* newC, int nc,
                   float* min_dist, int s_old, bool track) {
   TimeScope ts(c, ISLE_T_KMPP);
@@ -305,13 +340,10 @@ int k_kmpp_update(isle_ctx* c, const float* P, const float* pn, uint64_t D, int 
             HIPCHK(c, hipMemsetAsync(c->kmpp_arg.p, 0, D * sizeof(uint32_t), c->stream));
             c->kmpp_track = true;
           }
-          if (c->kmpp_track)
-            hipLaunchKernelGGL(kmpp_min_dots_track_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist,
-                               c->kmpp_arg.p, c->kmpp_m2a.p, c->kmpp_tmin.p, (uint32_t)(s_old + j0), c->dpos.p);
-          else
-            hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist, c->dpos.p);
+          if (c->kmpp_track) launch_min_dots(c, true, ld, pn, c->cnorm.p + j0, ncj, D, min_dist, (uint32_t)(s_old + j0));
+          else launch_min_dots(c, false, ld, pn, c->cnorm.p + j0, ncj, D, min_dist, 0u);
         } else {
-          hipLaunchKernelGGL(kmpp_min_dots_k, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dotsT.p, ld, pn, c->cnorm.p + j0, ncj, (uint32_t)D, min_dist, c->dpos.p);
+          launch_min_dots(c, false, ld, pn, c->cnorm.p + j0, ncj, D, min_dist, 0u);
         }
         HIPCHK(c, hipGetLastError());
       }
