@@ -835,16 +835,24 @@ struct AssignPick {
 };
 __device__ inline AssignPick assign_pick(const AssignRec* __restrict__ part, size_t row, int nslot) {
   AssignPick p{3.4e38f, 3.4e38f, 0.f, 3.4e38f, 0xffffffffu};
-  for (int sl = 0; sl < nslot; ++sl) {  // ascending columns: a tie keeps the earlier centre
-    const AssignRec r = part[row * nslot + sl];
-    if (r.m1 < p.best) {
-      p.run2 = fminf(fminf(p.run2, p.best), r.r2);
-      p.best = r.m1;
-      p.bidx = r.i1;
-      p.m2 = r.m2;
-      p.ax = r.ax;
-    } else {
-      p.run2 = fminf(p.run2, r.m1);
+  for (int sl0 = 0; sl0 < nslot; sl0 += 8) {  // eight records asked for together (one at a time, the comparison chain waited for every load)
+    AssignRec rr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rr[u] = part[row * nslot + min(sl0 + u, nslot - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // ascending columns: a tie keeps the earlier centre
+      if (sl0 + u < nslot) {
+        const AssignRec r = rr[u];
+        if (r.m1 < p.best) {
+          p.run2 = fminf(fminf(p.run2, p.best), r.r2);
+          p.best = r.m1;
+          p.bidx = r.i1;
+          p.m2 = r.m2;
+          p.ax = r.ax;
+        } else {
+          p.run2 = fminf(p.run2, r.m1);
+        }
+      }
     }
   }
   return p;
