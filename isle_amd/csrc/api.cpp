@@ -48,6 +48,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_KS_ROWSHARD", "form", "0: every rank orthogonalises the whole Krylov block (default with several ranks: row slices, all-reduced coefficients, all-gathered block)"},
     {"ISLE_KS_SYNC", "form", "expand loop without the speculative pipeline (one host synchronisation per step)"},
     {"ISLE_KS_ORTHO_PASSES", "form", "3: the reference's three Gram-Schmidt passes per Krylov step instead of two"},
+    {"ISLE_UPDATE_MFMA", "form", "0: the orthogonalisation's update F -= V H by FMA chains with the coefficients read from LDS (update_k) instead of on the matrix cores (same sums in another order)"},
     {"ISLE_QR_FUSED", "form", "1: panel QR as one persistent launch (bitwise equal to the kernel chain, no faster)"},
     {"ISLE_EVD_JACOBI", "form", "small symmetric EVD by block Jacobi instead of tridiagonalisation"},
     {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},

@@ -226,12 +226,73 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
   }
 }
 
+// The same update on the matrix cores (round 5; b <= 16, columns 16-byte aligned).  update_k reads three ds_read_b128 of coefficients for
+// every float of the basis it loads (137 us a call at config 3, 4.4 TB/s of a basis of 1500 columns on average); here (128 us) a wave takes 64 rows: a lane loads FOUR consecutive rows of a
+// basis column as one float4 (a wave instruction = 4 columns x 256 bytes), component c of the 16 lanes of a quarter is the A operand of
+// tile c (rows r0 + 4 i + c, i < 16), the coefficient tile is the B operand (one ds_read_b32 per four MFMAs), v_mfma_f32_16x16x4_f32 (exact
+// f32 products and sums).  The four waves of a workgroup take the basis columns i = 32 q .. 32 q + 31 of every 128-column tile, eight
+// float4 loads in flight each, and their sums are added in the order q = 0 .. 3: deterministic, other rounding than update_k's chains.
+constexpr int UM_TILE = 128;
+__global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint64_t n, uint64_t ld, int b, const float* __restrict__ Vb, int m,
+                                                      const float* __restrict__ coef /*m x b col-major*/) {
+  __shared__ float Cs[UM_TILE][16];
+  __shared__ float red[4][64][17];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const uint64_t r0 = (uint64_t)blockIdx.x * 64;
+  // (ld is a multiple of 4 and n <= ld: a float4 that starts on a row below n stays inside its column's stride)
+  const uint64_t rb = min(r0 + 4 * (uint64_t)l15, (n - 1) & ~(uint64_t)3);
+  floatx4 acc[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) acc[c4] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int i0 = 0; i0 < m; i0 += UM_TILE) {
+    const int cnt = min(UM_TILE, m - i0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < UM_TILE * 16; idx += 256) {
+      const int ii = idx >> 4, j = idx & 15;
+      Cs[ii][j] = (ii < cnt && j < b) ? coef[(size_t)j * m + i0 + ii] : 0.f;  // zeros beyond the basis and the block: their products vanish
+    }
+    __syncthreads();
+    const int kb = q * (UM_TILE / 4);
+    if (kb < cnt) {  // wave-uniform
+      float4 av[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const int kk = min(i0 + kb + 4 * s8 + g, m - 1);  // clamped: a column past the basis meets a zero coefficient
+        av[s8] = *reinterpret_cast<const float4*>(Vb + (uint64_t)kk * ld + rb);
+      }
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const float bq = Cs[kb + 4 * s8 + g][l15];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].x, bq, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].y, bq, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].z, bq, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].w, bq, acc[3], 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout of a 16 x 16 tile: column j = lane & 15, row i = 4 (lane >> 4) + reg; tile c's row i is row r0 + 4 i + c of the block
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[q][16 * g + 4 * reg + c4][l15] = acc[c4][reg];
+  __syncthreads();
+  const uint64_t r = r0 + lane;
+  if (r < n)
+    for (int j = q; j < b; j += 4) F[(uint64_t)j * ld + r] -= ((red[0][lane][j] + red[1][lane][j]) + red[2][lane][j]) + red[3][lane][j];
+}
+
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef, uint64_t ld) {
   TimeScope ts(c, ISLE_T_ORTHO);
   if (ld == 0) ld = n;
   if (n == 0) return 0;
   const int BT = bt_of(b);
   dim3 g(cdiv(n, 64)), blk(256);
+  if (b <= 16 && m >= 32 && (ld & 3) == 0 && (((uintptr_t)Vb | (uintptr_t)F) & 15) == 0 && !c->knob_zero(KN_UPDATE_MFMA)) {
+    hipLaunchKernelGGL(update_mfma_k, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   switch (BT) {
     case 4: hipLaunchKernelGGL(update_k<4>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;
     case 8: hipLaunchKernelGGL(update_k<8>, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef); break;

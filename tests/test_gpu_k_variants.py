@@ -39,3 +39,27 @@ def test_both_lloyd_loops_at_other_topic_counts(hp, monkeypatch, k):
     so = B["oracle"].lloyds_sparse(np.asfortranarray(res["bounds"][4]))
     same = float((so["assign"] == res["bounds"][2]).mean())
     assert same >= 0.999 and so["iters"] == res["bounds"][3], (same, so["iters"], res["bounds"][3])
+
+
+@pytest.mark.parametrize("k", [20, 300])
+def test_orthogonalisation_update_on_the_matrix_cores_agrees_with_the_fma_chains(hp, monkeypatch, k):
+    """`F -= V H` (block-ks/ks_utils.h:129-175, the Gram-Schmidt passes of an expand step) runs on the matrix cores by default
+    (`update_mfma_k`); `ISLE_UPDATE_MFMA=0` keeps the FMA chains of `update_k`.  Same sums in another order: the singular values agree to
+    1e-5 (the contract is 1e-4 against the truth), the subspaces to 1e-3 in every principal angle, and both bases are orthonormal."""
+    B = corpus(4000, 20000, 40, 11)
+    upload(hp, B)
+    r1 = hp.compute_block_ks(k, seed=1, allow_noconv=True)
+    U1 = hp.get_U(k).astype(np.float64)
+    monkeypatch.setenv("ISLE_UPDATE_MFMA", "0")
+    r0 = hp.compute_block_ks(k, seed=1, allow_noconv=True)
+    U0 = hp.get_U(k).astype(np.float64)
+    monkeypatch.delenv("ISLE_UPDATE_MFMA")
+    s1, s0 = np.asarray(r1["evals"], np.float64), np.asarray(r0["evals"], np.float64)  # eigenvalues of B B^T, descending
+    assert np.max(np.abs(s1 - s0) / s0) < 2e-5, float(np.max(np.abs(s1 - s0) / s0))
+    for U in (U1, U0):
+        assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-5
+    # clusters of nearly equal singular values rotate freely: compare the leading subspace below a gap
+    gaps = (s0[:-1] - s0[1:]) / s0[:-1]
+    cut = int(np.argmax(gaps[: max(k // 2, 2)])) + 1
+    sv = np.linalg.svd(U1[:, :cut].T @ U0[:, :cut], compute_uv=False)
+    assert sv.min() > 1.0 - 1e-3, (cut, float(sv.min()))
