@@ -152,10 +152,10 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_cnt_k(const uint32_t* __restr
   const uint64_t pos = (uint64_t)sl * 64 + lane;
   const bool live = sl != GL_NONE && pos < n_out;
   size_t base = 0;
-  if (live) base = PASS == 1 ? (size_t)pos * (NB + 1) : (size_t)wperm[pos] * NB;
+  if (live) base = PASS == 1 ? (size_t)pos * (NB + 1) : (size_t)wperm[pos];
   for (uint32_t band = 0; band < NB; ++band) {
     uint32_t n = 0;
-    if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[base + band];
+    if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[(size_t)band * n_out + base];  // (pass 2: n_out = V)
     const uint32_t sr = (wave_max_u32(n) + 3) >> 2;
     if (lane == 0) {
       if (sr > 0x7fffu) *overflow = 1;  // bit 15 marks a half last super-round (gl_place_k)
@@ -177,9 +177,16 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_cnt_k(const uint32_t* __restr
 __global__ __launch_bounds__(64 * GL_GMAX) void gl_fill1_k(const uint32_t* __restrict__ slice_of, int G, uint32_t D, uint32_t NB,
                                                             const uint32_t* __restrict__ bst, const uint32_t* __restrict__ dperm,
                                                             const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs, uint64_t nnz,
-                                                            const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids) {
+                                                            const uint16_t* __restrict__ cnt, const int64_t* __restrict__ roff, uint2* __restrict__ ids,
+                                                            size_t nwb) {
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const size_t wb = blockIdx.x;  // wv * NB + band
+  // wb = wv * NB + band.  Consecutive workgroups go to the eight XCDs in turn; the 25 bands of one slice of 64 documents read the SAME
+  // lines of `rows` and `bst` (a document's entries of consecutive bands follow each other: ~3 entries a band, 32 a line), so XCD x takes the
+  // x-th eighth of the (wave, band) pairs and a line is fetched once into one L2 instead of once per band into all eight (round 5: the
+  // counters showed 29.8 GB fetched for 2.4 GB of ids; the grid has 8 ceil(nwb / 8) workgroups)
+  const size_t per = gridDim.x >> 3;
+  const size_t wb = (size_t)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if (wb >= nwb) return;
   const size_t wv = wb / NB;
   const uint32_t band = (uint32_t)(wb - wv * NB);
   const uint16_t* cc = cnt + wb * GL_GMAX;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_fill1_k(const uint32_t* __res
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GL_THREADS) void gl_hist_count_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                                const uint32_t* __restrict__ dperm, uint32_t D, uint32_t V, uint32_t NB,
-                                                               uint16_t* __restrict__ cellcnt /* V x NB */) {
+                                                               uint16_t* __restrict__ cellcnt /* NB x V: a band's counts are a run (round 5; word-major, the 2-byte stores below each touched a line of their own: 8.8 GB written for 0.5 GB) */) {
   extern __shared__ uint32_t hist[];  // GL_VP / 2 dwords, two u16 counters each (a cell holds <= GL_RB entries)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t band = blockIdx.x;
@@ -248,8 +255,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_count_k(const uint32_t* __
   for (uint32_t j = threadIdx.x; j < (w1 - w0 + 1) / 2; j += GL_THREADS) {
     const uint32_t v = hist[j];
     const uint32_t w = w0 + 2 * j;
-    cellcnt[(size_t)w * NB + band] = (uint16_t)(v & 0xffffu);
-    if (w + 1 < w1) cellcnt[(size_t)(w + 1) * NB + band] = (uint16_t)(v >> 16);
+    cellcnt[(size_t)band * V + w] = (uint16_t)(v & 0xffffu);
+    if (w + 1 < w1) cellcnt[(size_t)band * V + w + 1] = (uint16_t)(v >> 16);
   }
 }
 
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void gl_rowlen_key_k(const uint16_t* __restric
   const uint32_t w = blockIdx.x * 256 + threadIdx.x;
   if (w >= V) return;
   uint64_t len = 0;
-  for (uint32_t b = 0; b < NB; ++b) len += cellcnt[(size_t)w * NB + b];
+  for (uint32_t b = 0; b < NB; ++b) len += cellcnt[(size_t)b * V + w];
   key[w] = maxkey - (len < maxkey ? len : maxkey);
   val[w] = w;
 }
@@ -1090,8 +1097,8 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   if (PASS == 1) {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)(ids16 + n16_body), (unsigned short)GL_RB, n16_all - n16_body, c->stream));
     if (nwb)
-      hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)nwb), dim3(64 * s.G), 0, c->stream, s.slice_of.p, s.G, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
-                         c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p);
+      hipLaunchKernelGGL(gl_fill1_k, dim3((unsigned)(8 * cdiv((long)nwb, 8))), dim3(64 * s.G), 0, c->stream, s.slice_of.p, s.G, s.n_out, s.NB, c->gl_bst.p, c->dperm.p,
+                         c->rows.p, c->offs.p, c->nnz, s.cnt.p, s.roff.p, s.ids.p, (size_t)nwb);
     HIPCHK(c, hipGetLastError());
   } else {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
