@@ -1113,6 +1113,18 @@ int k_pt_filter(isle_ctx* c, const uint32_t* order, const uint32_t* assign, floa
 #ifndef YY_NU2
 #define YY_NU2 8  // documents a wave lowers at a time at 65 - 128 groups: 16 loads per lane in flight (timing builds: tools/build_variant.sh)
 #endif
+// The bounds are a stream (each row is read and written once per iteration): non-temporal accesses keep them from pushing the group-major
+// centre table — which the tightening phase of the same kernel gathers from — out of the L2
+#ifndef YY_NT
+#define YY_NT 1
+#endif
+#if YY_NT
+#define YY_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define YY_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define YY_NT_LOAD(p) (*(p))
+#define YY_NT_STORE(v, p) (*(p) = (v))
+#endif
 template <int NT, int NU>
 __device__ inline void yy_lower_block(float* __restrict__ glb, int G, const float* __restrict__ gmax, const uint32_t* __restrict__ order, uint32_t d0,
                                       uint32_t nd, float* __restrict__ tile) {
@@ -1131,7 +1143,7 @@ __device__ inline void yy_lower_block(float* __restrict__ glb, int G, const floa
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) v[u][t] = lane + 64 * t < G ? glb[(size_t)doc[u] * G + lane + 64 * t] : 0.f;
+      for (int t = 0; t < NT; ++t) v[u][t] = lane + 64 * t < G ? YY_NT_LOAD(&glb[(size_t)doc[u] * G + lane + 64 * t]) : 0.f;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       if (jb + u < nd) {
@@ -1141,7 +1153,7 @@ __device__ inline void yy_lower_block(float* __restrict__ glb, int G, const floa
           if (g < G) {
             float l = v[u][t] - gm[t];
             l = l > 0.f ? l * 0.999999f : l;
-            glb[(size_t)doc[u] * G + g] = l;
+            YY_NT_STORE(l, &glb[(size_t)doc[u] * G + g]);
             tile[(jb + u) * (uint32_t)G + g] = l;
           }
         }
