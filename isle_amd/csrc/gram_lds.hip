@@ -145,7 +145,10 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_cnt_k(const uint32_t* __restr
                                                           const uint32_t* __restrict__ bst, const uint16_t* __restrict__ cellcnt,
                                                           const uint32_t* __restrict__ wperm, uint16_t* __restrict__ cnt, uint32_t* __restrict__ srsum,
                                                           int* __restrict__ overflow) {
-  __shared__ uint32_t sh[GL_GMAX];
+  // sixteen bands per step: their counts are asked for together and the workgroup meets twice per step (a band at a time, the 2453
+  // document bands of pass 2 at config 3 were a chain of 2453 loads and 4906 barriers: 3.1 ms)
+  constexpr int CB = 16;
+  __shared__ uint32_t sh[GL_GMAX][CB];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const size_t wv = blockIdx.x;
   const uint32_t sl = slice_of[wv * G + g];
@@ -153,19 +156,28 @@ __global__ __launch_bounds__(64 * GL_GMAX) void gl_cnt_k(const uint32_t* __restr
   const bool live = sl != GL_NONE && pos < n_out;
   size_t base = 0;
   if (live) base = PASS == 1 ? (size_t)pos * (NB + 1) : (size_t)wperm[pos];
-  for (uint32_t band = 0; band < NB; ++band) {
-    uint32_t n = 0;
-    if (live) n = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[(size_t)band * n_out + base];  // (pass 2: n_out = V)
-    const uint32_t sr = (wave_max_u32(n) + 3) >> 2;
-    if (lane == 0) {
-      if (sr > 0x7fffu) *overflow = 1;  // bit 15 marks a half last super-round (gl_place_k)
-      cnt[(wv * NB + band) * GL_GMAX + g] = (uint16_t)sr;
-      sh[g] = sr;
+  for (uint32_t b0 = 0; b0 < NB; b0 += CB) {
+    uint32_t n[CB];
+#pragma unroll
+    for (int t = 0; t < CB; ++t) {
+      const uint32_t band = min(b0 + (uint32_t)t, NB - 1);  // clamped: the loads stay unconditional
+      n[t] = 0;
+      if (live) n[t] = PASS == 1 ? bst[base + band + 1] - bst[base + band] : (uint32_t)cellcnt[(size_t)band * n_out + base];  // (pass 2: n_out = V)
+    }
+#pragma unroll
+    for (int t = 0; t < CB; ++t) {
+      const uint32_t sr = (wave_max_u32(n[t]) + 3) >> 2;
+      if (lane == 0 && b0 + t < NB) {
+        if (sr > 0x7fffu) *overflow = 1;  // bit 15 marks a half last super-round (gl_place_k)
+        cnt[(wv * NB + b0 + t) * GL_GMAX + g] = (uint16_t)sr;
+        sh[g][t] = sr;
+      }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < CB && b0 + threadIdx.x < NB) {
+      const uint32_t band = b0 + threadIdx.x;
       uint32_t t = 0;
-      for (int j = 0; j < G; ++j) t += sh[j];
+      for (int j = 0; j < G; ++j) t += sh[j][threadIdx.x];
       srsum[wv * NB + band] = t;
       for (int j = G; j < GL_GMAX; ++j) cnt[(wv * NB + band) * GL_GMAX + j] = 0;
     }
