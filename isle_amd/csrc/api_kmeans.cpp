@@ -12,6 +12,13 @@
 
 #include "api_internal.h"
 
+#ifndef ISLE_PROJ_FULL_NUM
+// Lloyd in span(U): a full pass instead of the active rows' products when more than NUM / DEN of the documents are active.  A third since round 5
+// (a half before): at config 3 the loop takes 187 ms with 1/2, 166 with 1/3 and 1/4, 199 with 1/6, 214 with 1/10 (the full product costs
+// 5.5 ns a document, the compaction + tile products of the active rows 15 - 20 ns an active document, and a full pass refreshes every bound)
+#define ISLE_PROJ_FULL_NUM 1
+#define ISLE_PROJ_FULL_DEN 3
+#endif
 // ------------------------------------------------------------------------------------------
 // k-means in the projected space
 // ------------------------------------------------------------------------------------------
@@ -451,7 +458,7 @@ extern "C" int isle_hip_lloyds_projected(isle_ctx* c, int k, float* C_lowd, int 
         }
         // (measured with the product on the gathered rows of the active documents: handing the full pass over only beyond 3/4 of the documents
         // is slower, 222 against 187 ms at config 3 — gathering 5.4 M rows costs what the product saves, and the full pass refreshes every bound)
-        if ((uint64_t)na * 2 > D && k_proj_full_by_gemm(c, D, k))  // most documents are up for re-examination: the full GEMM pass costs less than
+        if ((uint64_t)na * ISLE_PROJ_FULL_DEN > (uint64_t)D * ISLE_PROJ_FULL_NUM && k_proj_full_by_gemm(c, D, k))  // most documents are up for re-examination: the full GEMM pass costs less than
           ISLECHK(k_proj_assign_tiles(c, c->P.p, c->pnorm.p, D, k, ldk, c->Cdev.p, c->cnorm.p, c->assign.p, c->hub.p, c->ptlb.p, TL, nullptr, 0,
                                       nullptr, nullptr, nullptr));  // compacting them and walking their tiles, and refreshes every bound
         else
