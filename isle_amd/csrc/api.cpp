@@ -69,7 +69,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_YY_FUSED", "form", "0: the by-group Yinyang iteration lowers the bounds (yy_filter_k) and tightens the active documents (yy2_tighten_k) in two launches instead of one (same bits)"},
     {"ISLE_YY_MOVERS", "form", "0: every centre's movement lowers its Yinyang group's bound (default: up to ten centres that moved far beyond the rest are bounded by their exact new distances instead)"},
     {"ISLE_YY_REGROUP", "form", "0: a Yinyang group is eight consecutive centres (default at k >= 256 behind the product's first assignment: the centres in the order of their squared norms, so that the few centres every far-off document is near share groups; same partitions, a third of the (document, group) pairs)"},
-    {"ISLE_YY_ORDER", "form", "doc: the by-group Yinyang iteration visits the documents in their own order instead of the member lists' (same bits)"},
+    {"ISLE_YY_ORDER", "form", "doc | member: the Yinyang filter visits the documents in their own order or in the member lists' (default: doc for the fused by-group launch, member otherwise; same bits)"},
     {"ISLE_PT_SORT", "form", "0: the active documents of a projected Lloyd iteration keep the order of the member lists (default: ordered by the set of tiles they have to re-examine, so that a workgroup's documents ask for the same tiles; same partitions)"},
     {"ISLE_PROJ_ACTIVE", "form", "tiles: the active documents of a projected Lloyd iteration re-examine only the tiles their bounds name (register kernel, f32 matrix cores); default gemm: all centres through the assignment product on their gathered rows wherever that product is taken (every tile bound refreshed, the arithmetic of the full passes)"},
     {"ISLE_PROJ_SUMS", "form", "fresh: the centroid sums of Lloyd in span(U) are formed from all member rows every iteration (default: kept up to date by the documents that changed centre; both bitwise reproducible, the two differ in rounding)"},

@@ -720,8 +720,13 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       // (the member lists), so that waves running together gather from one table in L2; ISLE_YY_MODE = doc | docg | group picks the form
       // (measured, Lloyd on B per step: C3 shard 176 ms by document -> 112 ms by group, all of config 3 on one GPU 825 -> 588 ms; at C2,
       // G = 25 and a 40 MB table, the three forms are within 10 % of each other and the plain one stays)
+      // Visiting order of the filter.  The fused by-group launch takes the documents in their own order since the end of round 5 (its first
+      // phase then streams the bounds as one run per workgroup; once that phase kept sixteen loads in flight the member order's gain in the
+      // second phase — neighbours share the own group's table — no longer paid for its scattered rows: sparse_assign 177 -> 170 ms at
+      // config 3); the other forms keep the member lists' order.  ISLE_YY_ORDER = doc | member forces either.
       const char* yord = c->knob(KN_YY_ORDER);
-      const uint32_t* order = yy_mode && c->members_valid && !(yord && !strcmp(yord, "doc")) ? c->members.p : nullptr;
+      const bool by_members = yord ? strcmp(yord, "doc") != 0 : !(yy_mode == 2 && !c->knob_zero(KN_YY_FUSED));
+      const uint32_t* order = yy_mode && c->members_valid && by_members ? c->members.p : nullptr;
       if (yy_mode) ISLECHK(k_yy_pack_groups(c, c->centers_rm.p, ld, G, ymap));
       // by group: the bounds are lowered and the active documents tightened in one launch (the D x G bounds read once), ISLE_YY_FUSED=0: in two
       const bool fused = yy_mode == 2 && !c->knob_zero(KN_YY_FUSED);

@@ -264,14 +264,16 @@ def test_fused_filter_and_tightening_give_the_bits_of_the_two_kernel_form(hp, mo
     g = hp.kmeans_init_on_projected_space(k, inject_seeds=f["seeds"])
     lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
     out = {}
-    for name, env in (("fused", {}), ("two", {"ISLE_YY_FUSED": "0"}), ("doc", {"ISLE_YY_MODE": "doc"})):
+    # (the fused launch visits the documents in their own order by default, the two-kernel form in the member lists'; ISLE_YY_ORDER forces either)
+    for name, env in (("fused", {}), ("two", {"ISLE_YY_FUSED": "0"}), ("doc", {"ISLE_YY_MODE": "doc"}), ("fused_by_members", {"ISLE_YY_ORDER": "member"}),
+                      ("two_in_document_order", {"ISLE_YY_FUSED": "0", "ISLE_YY_ORDER": "doc"})):
         for a, b in env.items():
             monkeypatch.setenv(a, b)
         hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
         out[name] = hp.run_lloyds(k)
         for a in env:
             monkeypatch.delenv(a)
-    for name in ("two", "doc"):
+    for name in ("two", "doc", "fused_by_members", "two_in_document_order"):
         assert out[name]["iters"] == out["fused"]["iters"], name
         assert np.array_equal(out[name]["assign"], out["fused"]["assign"]), name
         assert np.array_equal(out[name]["centers"].view(np.uint32), out["fused"]["centers"].view(np.uint32)), name
