@@ -837,9 +837,17 @@ extern "C" int isle_hip_lloyds_sparse(isle_ctx* c, int k, const float* centers_i
       }
     }
     ISLECHK(k_count_sizes(c, c->assign.p, D, k, c->counts.p));
-    {  // documents grouped by centre: visiting order of the next assignment, and what the counting centroid update walks
-      TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
-      ISLECHK(k_member_lists_dev(c, c->assign.p, D, k, c->counts.p));
+    {  // documents grouped by centre: visiting order of the next assignment, and what the FRESH counting centroid update walks (the
+       // first of a run; later ones go by the documents that changed centre).  The fused by-group launch visits the documents in their
+       // own order: nothing reads the lists then, and they are not made (a sort of D keys per iteration)
+      const char* yord = c->knob(KN_YY_ORDER);
+      const bool lists_as_order = !yinyang || !yy_mode || (yord ? strcmp(yord, "doc") != 0 : !(yy_mode == 2 && !c->knob_zero(KN_YY_FUSED)));
+      if (it == 0 || lists_as_order || c->gl_mode != 1 || c->knob_on(KN_CENTERS_FRESH)) {
+        TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
+        ISLECHK(k_member_lists_dev(c, c->assign.p, D, k, c->counts.p));
+      } else {
+        c->members_valid = false;  // the lists are those of an earlier assignment
+      }
     }
     if (hamerly) HIPCHK(c, hipMemcpyAsync(c->centers_old.p, c->centers_rm.p, (size_t)V * ld * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     ISLECHK(k_centers_from_rows(c, c->assign.p, k, ld, c->centers_rm.p, it == 0));                 // :1613-1638
