@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the full-pass threshold of Lloyd in span(U) (ISLE_PROJ_FULL_NUM / _DEN, api_kmeans.cpp) under variant builds
+# (tools/build_variant.sh <name> "-DISLE_PROJ_FULL_NUM=a -DISLE_PROJ_FULL_DEN=b" api_kmeans.cpp), bench lines side by side on one box
 set -o pipefail
 O=gpurun_out/r05_pf; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
