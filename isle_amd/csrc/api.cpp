@@ -39,6 +39,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_G1", "tuning", "4..8: output items per lane in pass 1 of the LDS-banded form (default: makespan model, gram_lds.hip)"},
     {"ISLE_GL_G2", "tuning", "4..8: output items per lane in pass 2 (default 4, 6 beyond 1024 document bands)"},
     {"ISLE_GL_PLACE", "tuning", "0: a lane's entries stay packed at the front of its slots in ascending order instead of the bank-aware placement (gl_place_k)"},
+    {"ISLE_GL_FILL_BUCKETS", "tuning", "0: the pass-2 id stream is filled by one scatter over a band's whole region (gl_hist_fill_k) instead of by buckets of word positions (same stream)"},
     {"ISLE_GL_ROUNDS", "tuning", "0: pass 1 keeps ceil(slices / items per lane) waves in workgroups strided over the length order instead of filling whole rounds of the CUs with workgroups of adjacent waves"},
     {"ISLE_GL_COLUMNS", "tuning", "0: pass 2 chunks its document bands per word block instead of walking band columns shared through one XCD's L2"},
     {"ISLE_GL_PANEL", "tuning", "8 | 10: columns per pass of the k-wide / thin products (default 10, 8 at 8 items per lane in pass 1)"},

@@ -86,7 +86,7 @@ struct DevBuf {
 // (isle_ctx::knob).  DESIGN.md section "Environment switches" is this table with the measurements behind the defaults.
 // ------------------------------------------------------------------------------------------
 enum IsleKnob {
-  KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_GL_WIDE_GROUPED, KN_WIDE_GATHER, KN_WIDE_LDS,
+  KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_FILL_BUCKETS, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_GL_WIDE_GROUPED, KN_WIDE_GATHER, KN_WIDE_LDS,
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_UPDATE_MFMA, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN, KN_EVD_SPLIT,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
@@ -234,6 +234,9 @@ struct isle_ctx {
   DevBuf<uint32_t> gl_bst;   // D x (NB1 + 1): first entry of each word band inside a document's column
   DevBuf<uint16_t> gl_cellcnt;   // V x NB2: entries of (word, document band)
   DevBuf<uint32_t> gl_srsum, gl_sbase;
+  DevBuf<uint32_t> gl_fb_cnt, gl_fb_tmp;  // pass-2 fill by buckets of word positions: entries per (band, bucket); the packed entries (nnz words, released behind the build)
+  DevBuf<int64_t> gl_fb_off;
+  DevBuf<uint16_t> gl_scnt;  // super-rounds of (slice, band) of pass 2 (gl_sbase's indexing)
   DevBuf<uint32_t> gl_biglist;   // [count | (wave, band, group) triples whose pass-2 cells are too long for the register sort]
   DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)
   DevBuf<uint32_t> ccounted;     // D: the centre under which document d is counted in ccount

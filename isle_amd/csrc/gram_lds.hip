@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void gl_rowlen_key_k(const uint16_t* __restric
 
 // sbase[slice * NB + band] = first super-round of (slice, band) in the stream
 __global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ slice_of, int G, const uint16_t* __restrict__ cnt,
-                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase) {
+                                                   const int64_t* __restrict__ roff, size_t nwb, uint32_t NB, uint32_t* __restrict__ sbase,
+                                                   uint16_t* __restrict__ scnt /*nullable: super-rounds of (slice, band), same indexing*/) {
   const size_t wb = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (wb >= nwb) return;
   const size_t wv = wb / NB;
@@ -293,7 +294,10 @@ __global__ __launch_bounds__(256) void gl_sbase_k(const uint32_t* __restrict__ s
   uint32_t base = (uint32_t)roff[wb];
   for (int g = 0; g < G; ++g) {
     const uint32_t sl = slice_of[wv * G + g];
-    if (sl != GL_NONE) sbase[(size_t)sl * NB + band] = base;
+    if (sl != GL_NONE) {
+      sbase[(size_t)sl * NB + band] = base;
+      if (scnt) scnt[(size_t)sl * NB + band] = cnt[wb * GL_GMAX + g];
+    }
     base += cnt[wb * GL_GMAX + g];
   }
 }
@@ -342,6 +346,127 @@ __global__ __launch_bounds__(GL_THREADS) void gl_hist_fill_k(const uint32_t* __r
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 2 fill in two steps (round 5).  gl_hist_fill_k scatters 2-byte ids over a band's whole stream region (1.3 MB at config 3); with one
+// workgroup per CU the regions in flight on an XCD are ten times its L2, every line leaves half written and comes back: 29.6 GB written and
+// 19.4 GB fetched for 2.6 GB of ids.  Here the band's entries are first dealt into BUCKETS of word positions (gl_fb_scatter_k: a packed word
+// per entry, position << 12 | document, appended to one of NBK runs per band — few open lines per workgroup, the L2 combines them), then one
+// small workgroup per (band, bucket) hands out the slots (gl_fb_fill_k: cursors of <= 8192 words and the bucket's slice bases in LDS) and
+// writes the ids into a region of 1 / NBK of the band's: the regions in flight fit the L2.  The bucket sizes come from the cell counts
+// (gl_fb_count_k), their offsets from a scan.  The slots of a cell are handed out in arrival order as before; gl_sort2_k orders them.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(GL_THREADS) void gl_fb_count_k(const uint16_t* __restrict__ cellcnt /*NB x V, by word id*/, const uint32_t* __restrict__ wperm,
+                                                             uint32_t V, uint32_t W, uint32_t NBK, uint32_t* __restrict__ bcnt /*NB x NBK*/) {
+  // one workgroup per band (its 2 V bytes of counts are gathered by word position: fetched once and found in the caches by all sixteen waves;
+  // a workgroup per (band, bucket) fetched 14 GB for the 0.5 GB table), a wave per bucket in turn
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t band = blockIdx.x;
+  for (uint32_t bk = wave; bk < NBK; bk += GL_WAVES) {
+    const uint32_t q0 = bk * W, q1 = min(V, q0 + W);
+    uint32_t t = 0;
+    for (uint32_t q = q0 + lane; q < q1; q += 64) t += cellcnt[(size_t)band * V + wperm[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += (uint32_t)__shfl_xor((int)t, o);
+    if (lane == 0) bcnt[(size_t)band * NBK + bk] = t;
+  }
+}
+__global__ __launch_bounds__(GL_THREADS) void gl_fb_scatter_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
+                                                               const uint32_t* __restrict__ dperm, uint32_t D, const uint32_t* __restrict__ wpos,
+                                                               uint32_t W, uint32_t NBK, const int64_t* __restrict__ boff /*NB x NBK + 1*/,
+                                                               uint32_t* __restrict__ tmp) {
+  __shared__ uint32_t cur[128];  // NBK <= 128: cursors relative to the band's first entry
+  constexpr int NU = 8;          // entries in flight per lane
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
+  const uint32_t band = blockIdx.x;
+  const int64_t base = boff[(size_t)band * NBK];
+  if (threadIdx.x < NBK) cur[threadIdx.x] = (uint32_t)(boff[(size_t)band * NBK + threadIdx.x] - base);
+  __syncthreads();
+  const uint32_t p0 = band * GL_RB, p1 = min(D, p0 + GL_RB);
+  for (uint32_t p = p0 + wave * (64 / GL_SUB) + sub; p < p1; p += GL_WAVES * (64 / GL_SUB)) {
+    const uint32_t d = dperm[p];
+    const int64_t iend = offs[d + 1];
+    for (int64_t i = offs[d] + sl; i < iend; i += NU * GL_SUB) {
+      uint32_t w[NU], q[NU];
+      bool in[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int64_t iu = i + (int64_t)u * GL_SUB;
+        in[u] = iu < iend;
+        w[u] = rows[in[u] ? iu : iend - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) q[u] = wpos[w[u]];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (in[u]) {
+          const uint32_t at = atomicAdd(&cur[q[u] / W], 1u);
+          tmp[base + at] = (q[u] << 12) | (p - p0);
+        }
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void gl_fb_fill_k(const uint32_t* __restrict__ tmp, const int64_t* __restrict__ boff, uint32_t V, uint32_t NB, uint32_t W,
+                                                     uint32_t NBK, const uint32_t* __restrict__ sbase, const uint16_t* __restrict__ scnt,
+                                                     uint16_t* __restrict__ ids16, uint32_t lds_sr /*super-rounds the LDS image holds*/) {
+  // LDS: W cursors | the bucket's slice bases | their super-round offsets inside the image | the image: the bucket's super-rounds of this band
+  // (512 bytes each), assembled here with their padding ids and written out as whole lines — a 2-byte store per id straight into the stream
+  // leaves every 32-byte sector partly written (the slots no entry lands in), and the memory pays a read-modify-write for it: 15.6 GB written
+  // for a 3.2 GB stream.  A bucket whose super-rounds do not fit (a very frequent word) scatters into the stream as gl_hist_fill_k does.
+  extern __shared__ uint32_t fb_lds[];
+  const uint32_t NSL = W / 64 + 2;
+  uint32_t* cur = fb_lds;
+  uint32_t* sb = cur + W;
+  uint32_t* loff = sb + NSL;
+  uint16_t* img = reinterpret_cast<uint16_t*>(fb_lds + ((W + 2 * NSL + 1 + 3) & ~3u));  // 16-byte aligned: read back as uint4
+  const uint32_t band = blockIdx.x, bk = blockIdx.y;
+  const uint32_t q0 = bk * W, q1 = min(V, q0 + W);
+  if (q0 >= q1) return;
+  const uint32_t s0 = q0 >> 6, ns = ((q1 - 1) >> 6) - s0 + 1;
+  for (uint32_t j = threadIdx.x; j < q1 - q0; j += 256) cur[j] = 0;
+  for (uint32_t j = threadIdx.x; j < ns; j += 256) {
+    sb[j] = sbase[(size_t)(s0 + j) * NB + band];
+    loff[j + 1] = scnt[(size_t)(s0 + j) * NB + band] & 0x7fffu;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loff[0] = 0;
+    for (uint32_t j = 0; j < ns; ++j) loff[j + 1] += loff[j];
+  }
+  __syncthreads();
+  const uint32_t total = loff[ns];
+  const bool in_lds = total <= lds_sr;  // uniform
+  if (in_lds) {
+    uint32_t* img32 = reinterpret_cast<uint32_t*>(img);
+    for (uint32_t i = threadIdx.x; i < total * 128; i += 256) img32[i] = GL_RB | (GL_RB << 16);
+  }
+  __syncthreads();
+  const int64_t e0 = boff[(size_t)band * NBK + bk], e1 = boff[(size_t)band * NBK + bk + 1];
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 4 * 256) {  // four entries in flight per thread
+    uint32_t x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = __builtin_nontemporal_load(&tmp[min(e + (int64_t)u * 256, e1 - 1)]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e + (int64_t)u * 256 < e1) {
+        const uint32_t q = x[u] >> 12, sl = (q >> 6) - s0;
+        const uint32_t j = atomicAdd(&cur[q - q0], 1u);
+        if (in_lds) img[((size_t)(loff[sl] + (j >> 2)) * 64 + (q & 63u)) * 4 + (j & 3u)] = (uint16_t)(x[u] & 0xfffu);
+        else ids16[((size_t)(sb[sl] + (j >> 2)) * 64 + (q & 63u)) * 4 + (j & 3u)] = (uint16_t)(x[u] & 0xfffu);
+      }
+    }
+  }
+  if (!in_lds) return;
+  __syncthreads();
+  const uint4* src = reinterpret_cast<const uint4*>(img);
+  for (uint32_t j = 0; j < ns; ++j) {  // a slice's super-rounds are one run of the stream
+    const uint32_t n4 = (loff[j + 1] - loff[j]) * 32;  // uint4 per super-round: 32
+    uint4* dst = reinterpret_cast<uint4*>(ids16) + (size_t)sb[j] * 32;
+    for (uint32_t t = threadIdx.x; t < n4; t += 256) dst[t] = src[(size_t)loff[j] * 32 + t];
   }
 }
 
@@ -1115,13 +1240,40 @@ int build_side(isle_ctx* c, GlSide& s, const std::vector<uint32_t>& slice_of_hos
   } else {
     HIPCHK(c, hipMemsetD16Async((hipDeviceptr_t)ids16, (unsigned short)GL_RB, n16_all, c->stream));
     HIPCHK(c, c->gl_sbase.reserve((size_t)s.nslice * s.NB));
+    HIPCHK(c, c->gl_scnt.reserve((size_t)s.nslice * s.NB));
     if (nwb) hipLaunchKernelGGL(gl_sbase_k, dim3(cdiv((long)nwb, 256)), dim3(256), 0, c->stream, s.slice_of.p, s.G, s.cnt.p, s.roff.p, nwb, s.NB,
-                                c->gl_sbase.p);
+                                c->gl_sbase.p, c->gl_scnt.p);
     HIPCHK(c, hipGetLastError());
-    const uint32_t nvp = (s.n_out + GL_VP - 1) / GL_VP;
-    hipLaunchKernelGGL(gl_hist_fill_k, dim3(s.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, s.n_out,
-                       s.NB, c->wpos.p, c->gl_sbase.p, ids16);
-    HIPCHK(c, hipGetLastError());
+    static_assert(GL_RB <= 4096, "the packed entries of the bucketed fill hold the document in 12 bits");
+    if (s.n_out <= (1u << 20) && c->nnz && !c->knob_zero(KN_GL_FILL_BUCKETS)) {  // (word positions in 20 bits)
+      const uint32_t V = s.n_out;
+      // buckets of about 1024 word positions, 16 ... 128 of them (W <= 8192 while V <= 2^20): at config 3 a bucket's part of a band's stream
+      // region is 13 KB, and the 256 workgroups in flight on an XCD write into 3.4 MB — with 16 buckets (81 KB each) they thrashed the L2 as
+      // the direct scatter does (gl_fb_fill_k 14.9 ms)
+      // (W a multiple of 64: a bucket holds whole slices — gl_fb_fill_k writes a slice's super-rounds as one run)
+      const uint32_t NBK0 = std::min<uint32_t>(128u, std::max<uint32_t>(16u, (V + 1023) / 1024)), W = ((V + NBK0 - 1) / NBK0 + 63) / 64 * 64, NBK = (V + W - 1) / W;
+      const size_t nbb = (size_t)s.NB * NBK;
+      HIPCHK(c, c->gl_fb_cnt.reserve(nbb));
+      HIPCHK(c, c->gl_fb_off.reserve(nbb + 1));
+      HIPCHK(c, c->gl_scan.reserve(isle_scan::scan_scratch_elems(nbb) + 8));
+      HIPCHK(c, c->gl_fb_tmp.reserve(c->nnz));
+      hipLaunchKernelGGL(gl_fb_count_k, dim3(s.NB), dim3(GL_THREADS), 0, c->stream, c->gl_cellcnt.p, c->wperm.p, V, W, NBK, c->gl_fb_cnt.p);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, (isle_scan::exclusive_scan<uint32_t, int64_t>(c->stream, c->gl_fb_cnt.p, nbb, c->gl_fb_off.p, c->gl_scan.p)));
+      hipLaunchKernelGGL(gl_fb_scatter_k, dim3(s.NB), dim3(GL_THREADS), 0, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, c->wpos.p, W, NBK,
+                         c->gl_fb_off.p, c->gl_fb_tmp.p);
+      const size_t fb_head = ((size_t)W + 2 * (W / 64 + 2) + 1 + 3) / 4 * 4 * sizeof(uint32_t);  // cursors, slice bases, offsets: a multiple of 16 bytes
+      const size_t fb_lds = std::max<size_t>(32u << 10, fb_head + 8 * 512);                          // 32 KB: five workgroups per CU
+      ISLECHK(isle_max_lds(c, (const void*)gl_fb_fill_k, (int)fb_lds));
+      hipLaunchKernelGGL(gl_fb_fill_k, dim3(s.NB, NBK), dim3(256), fb_lds, c->stream, c->gl_fb_tmp.p, c->gl_fb_off.p, V, s.NB, W, NBK, c->gl_sbase.p,
+                         c->gl_scnt.p, ids16, (uint32_t)((fb_lds - fb_head) / 512));
+      HIPCHK(c, hipGetLastError());
+    } else {
+      const uint32_t nvp = (s.n_out + GL_VP - 1) / GL_VP;
+      hipLaunchKernelGGL(gl_hist_fill_k, dim3(s.NB, nvp), dim3(GL_THREADS), GL_HLDS, c->stream, c->rows.p, c->offs.p, c->dperm.p, s.n_src, s.n_out,
+                         s.NB, c->wpos.p, c->gl_sbase.p, ids16);
+      HIPCHK(c, hipGetLastError());
+    }
     if (nwb) {
       HIPCHK(c, c->gl_biglist.reserve(nwb * GL_GMAX + 1));
       HIPCHK(c, hipMemsetAsync(c->gl_biglist.p, 0, sizeof(uint32_t), c->stream));

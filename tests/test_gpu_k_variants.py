@@ -63,3 +63,25 @@ def test_orthogonalisation_update_on_the_matrix_cores_agrees_with_the_fma_chains
     cut = int(np.argmax(gaps[: max(k // 2, 2)])) + 1
     sv = np.linalg.svd(U1[:, :cut].T @ U0[:, :cut], compute_uv=False)
     assert sv.min() > 1.0 - 1e-3, (cut, float(sv.min()))
+
+
+def test_pass2_stream_filled_by_buckets_is_the_stream_of_the_direct_scatter(hp, monkeypatch):
+    """The pass-2 id stream of the LDS-banded Gram apply (stands for the MKL_SpSpTrProd constructor, include/matUtils.h:52-273) is filled by
+    buckets of word positions with whole lines assembled in LDS (round 5); `ISLE_GL_FILL_BUCKETS=0` keeps the direct 2-byte scatter.  Both put
+    the same ids into the same cells and every cell is sorted afterwards: `Z = B (B^T X)` must be bit-identical, for panels of 1, 10 and 25
+    columns, on a corpus whose vocabulary is not a multiple of the bucket width."""
+    B = corpus(4000, 20000, 40, 11)
+    rng = np.random.default_rng(2)
+    Xs = [rng.standard_normal((B["V"], b)).astype(np.float32) for b in (1, 10, 25)]
+    upload(hp, B)
+    assert hp.operator_form() in (-1, 1)
+    Z1 = [hp.gram_apply(X) for X in Xs]
+    assert hp.operator_form() == 1
+    monkeypatch.setenv("ISLE_GL_FILL_BUCKETS", "0")
+    upload(hp, B)  # a new upload: the operator is built again
+    Z0 = [hp.gram_apply(X) for X in Xs]
+    monkeypatch.delenv("ISLE_GL_FILL_BUCKETS")
+    for a, b in zip(Z1, Z0):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    Zo = B["oracle"].gram_apply(Xs[1])
+    assert np.linalg.norm(Z1[1] - Zo) / np.linalg.norm(Zo) <= 1e-5
