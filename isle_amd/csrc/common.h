@@ -238,7 +238,7 @@ struct isle_ctx {
   DevBuf<int64_t> gl_fb_off;
   DevBuf<uint16_t> gl_scnt;  // super-rounds of (slice, band) of pass 2 (gl_sbase's indexing)
   DevBuf<uint32_t> gl_biglist;   // [count | (wave, band, group) triples whose pass-2 cells are too long for the register sort]
-  DevBuf<uint32_t> ccount;       // V x ld: members of centre c that contain word w (sparse Lloyd centroid update)
+  DevBuf<uint32_t> ccount;       // k x V, centre-major: members of centre c that contain word w (sparse Lloyd centroid update)
   DevBuf<uint32_t> ccounted;     // D: the centre under which document d is counted in ccount
   DevBuf<int64_t> gl_scan;
   DevBuf<unsigned long long> gl_blocktot;

@@ -1114,7 +1114,7 @@ constexpr uint32_t CC_CH = 2048;
 __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                          const uint32_t* __restrict__ members, const int* __restrict__ moff,
                                                          const uint32_t* __restrict__ assign, uint32_t D, uint32_t V, int ld,
-                                                         uint32_t* __restrict__ cnt /* V x ld */) {
+                                                         uint32_t* __restrict__ cnt /* k x V, centre-major */) {
   extern __shared__ uint32_t hist[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / GL_SUB, sl = lane % GL_SUB;
   const uint32_t w0 = blockIdx.y * GL_VP, w1 = min(V, w0 + GL_VP);
@@ -1148,9 +1148,9 @@ __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restri
     for (uint32_t j = threadIdx.x; j < nh; j += GL_THREADS) {
       const uint32_t v = hist[j];
       if (v) {
-        const size_t w = (size_t)w0 + 2 * j;
-        if (v & 0xffffu) atomicAdd(&cnt[w * ld + cc], v & 0xffffu);
-        if (v >> 16) atomicAdd(&cnt[(w + 1) * ld + cc], v >> 16);
+        const size_t w = (size_t)w0 + 2 * j;  // (centre-major counts: a centre's words are a run — word-major, every atomic touched a line of its own)
+        if (v & 0xffffu) atomicAdd(&cnt[(size_t)cc * V + w], v & 0xffffu);
+        if (v >> 16) atomicAdd(&cnt[(size_t)cc * V + w + 1], v >> 16);
         hist[j] = 0;
       }
     }
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(GL_THREADS) void cc_hist_k(const uint32_t* __restri
 // exact, so add / subtract leaves precisely what a fresh count would give).  GL_SUB lanes per document.
 __global__ __launch_bounds__(256) void cc_moved_k(const uint32_t* __restrict__ rows, const int64_t* __restrict__ offs,
                                                    const uint32_t* __restrict__ assign, uint32_t* __restrict__ counted /*D: centre the counts hold*/,
-                                                   uint32_t D, int ld, uint32_t* __restrict__ cnt) {
+                                                   uint32_t D, uint32_t V, uint32_t* __restrict__ cnt /*k x V*/) {
   const int sub = (threadIdx.x & 63) / GL_SUB, sl = threadIdx.x % GL_SUB;
   const uint32_t d = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / GL_SUB) + sub;
   if (d >= D) return;
@@ -1170,15 +1170,28 @@ __global__ __launch_bounds__(256) void cc_moved_k(const uint32_t* __restrict__ r
   if (a == o) return;
   for (int64_t i = offs[d] + sl; i < offs[d + 1]; i += GL_SUB) {
     const size_t w = rows[i];
-    atomicAdd(&cnt[w * ld + a], 1u);
-    atomicSub(&cnt[w * ld + o], 1u);
+    atomicAdd(&cnt[(size_t)a * V + w], 1u);
+    atomicSub(&cnt[(size_t)o * V + w], 1u);
   }
   if (sl == 0) counted[d] = a;
 }
-__global__ __launch_bounds__(256) void cc_centers_k(const uint32_t* __restrict__ cnt, const float* __restrict__ rowval, size_t n, int ld,
-                                                     float* __restrict__ Crm) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) Crm[i] = rowval[i / ld] * (float)cnt[i];
+// Crm[w][c] = rowval[w] * cnt[c][w] for c < k, 0 in the padding columns: 32 x 32 tiles through LDS (the counts lie centre-major)
+__global__ __launch_bounds__(256) void cc_centers_k(const uint32_t* __restrict__ cnt /*k x V*/, const float* __restrict__ rowval, uint32_t V, int k, int ld,
+                                                     float* __restrict__ Crm /*V x ld*/) {
+  __shared__ uint32_t t[32][33];
+  const uint32_t w0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const uint32_t cc = c0 + r, w = w0 + tx;
+    t[r][tx] = (cc < (uint32_t)k && w < V) ? cnt[(size_t)cc * V + w] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const uint32_t w = w0 + r, cc = c0 + tx;
+    if (w < V && cc < (uint32_t)ld) Crm[(size_t)w * ld + cc] = rowval[w] * (float)t[tx][r];
+  }
 }
 
 int bits_for(uint64_t n) {
@@ -1749,10 +1762,9 @@ int k_gl_apply_cm(isle_ctx* c, const float* Xcm, int b, int BP, float* Zcm) {
 // otherwise the counts of the previous call (same k, ld, B) are updated by the documents that changed centre.
 int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* Crm, bool fresh) {
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
-  (void)k;
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
   ISLECHK(isle_max_lds(c, (const void*)cc_hist_k, GL_HLDS));
-  const size_t n = (size_t)V * ld;
+  const size_t n = (size_t)V * k;
   HIPCHK(c, c->ccount.reserve(n));
   HIPCHK(c, c->ccounted.reserve(D ? D : 1));
   if (fresh) {
@@ -1765,11 +1777,11 @@ int k_centers_counts(isle_ctx* c, const uint32_t* assign, int k, int ld, float* 
       HIPCHK(c, hipMemcpyAsync(c->ccounted.p, assign, (size_t)D * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     }
   } else if (D) {
-    hipLaunchKernelGGL(cc_moved_k, dim3(cdiv(D, 4 * (64 / GL_SUB))), dim3(256), 0, c->stream, c->rows.p, c->offs.p, assign, c->ccounted.p, D, ld,
+    hipLaunchKernelGGL(cc_moved_k, dim3(cdiv(D, 4 * (64 / GL_SUB))), dim3(256), 0, c->stream, c->rows.p, c->offs.p, assign, c->ccounted.p, D, V,
                        c->ccount.p);
     HIPCHK(c, hipGetLastError());
   }
-  hipLaunchKernelGGL(cc_centers_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, c->ccount.p, c->rowval.p, n, ld, Crm);
+  hipLaunchKernelGGL(cc_centers_k, dim3(cdiv(V, 32), cdiv(ld, 32)), dim3(256), 0, c->stream, c->ccount.p, c->rowval.p, V, k, ld, Crm);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -11,7 +11,7 @@ for v in ${VARIANTS:-new}; do
   python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if r["Name"].startswith(("yy_filter_k","yy2_","void yy2_","yy_scan","pt_","void pt_","kmpp_","void kmpp_","tiles_comb","yy_first")): print("   %-34s calls %4s avg_us %9.1f" % (r["Name"][:34], r["Calls"], float(r["AverageNs"])/1e3))
+    if r["Name"].startswith(("yy_filter_k","yy2_","void yy2_","yy_scan","pt_","void pt_","kmpp_","void kmpp_","tiles_comb","yy_first","cc_")): print("   %-34s calls %4s avg_us %9.1f" % (r["Name"][:34], r["Calls"], float(r["AverageNs"])/1e3))
 PY
   find $O -name "*kernel_trace.csv" -delete
 done
