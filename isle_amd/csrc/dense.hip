@@ -227,47 +227,46 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
 }
 
 // The same update on the matrix cores (round 5; b <= 16, columns 16-byte aligned).  update_k reads three ds_read_b128 of coefficients for
-// every float of the basis it loads (137 us a call at config 3, 4.4 TB/s of a basis of 1500 columns on average); here (128 us) a wave takes 64 rows: a lane loads FOUR consecutive rows of a
+// every float of the basis it loads (137 us a call at config 3); here (94 us) a wave takes 64 rows: a lane loads FOUR consecutive rows of a
 // basis column as one float4 (a wave instruction = 4 columns x 256 bytes), component c of the 16 lanes of a quarter is the A operand of
-// tile c (rows r0 + 4 i + c, i < 16), the coefficient tile is the B operand (one ds_read_b32 per four MFMAs), v_mfma_f32_16x16x4_f32 (exact
+// tile c (rows r0 + 4 i + c, i < 16), the coefficients are the B operand (one cached 4-byte load per four MFMAs), v_mfma_f32_16x16x4_f32 (exact
 // f32 products and sums).  The four waves of a workgroup take the basis columns i = 32 q .. 32 q + 31 of every 128-column tile, eight
 // float4 loads in flight each, and their sums are added in the order q = 0 .. 3: deterministic, other rounding than update_k's chains.
 constexpr int UM_TILE = 128;
 __global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint64_t n, uint64_t ld, int b, const float* __restrict__ Vb, int m,
                                                       const float* __restrict__ coef /*m x b col-major*/) {
-  __shared__ float Cs[UM_TILE][16];
   __shared__ float red[4][64][17];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const uint64_t r0 = (uint64_t)blockIdx.x * 64;
   // (ld is a multiple of 4 and n <= ld: a float4 that starts on a row below n stays inside its column's stride)
   const uint64_t rb = min(r0 + 4 * (uint64_t)l15, (n - 1) & ~(uint64_t)3);
+  // the coefficients are the B operand, one float per lane and MFMA group (row k0 + g of column l15): read straight from the cached
+  // m x b block — no staging in LDS, no barrier in the loop, the waves run free like vtf_mfma_k's (with the coefficients staged per 128 columns behind two barriers:
+  // 128 us a call at config 3; this form: 94)
+  const float* cf = coef + (size_t)min(l15, b - 1) * m;
+  const float bmask = l15 < b ? 1.f : 0.f;
   floatx4 acc[4];
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) acc[c4] = floatx4{0.f, 0.f, 0.f, 0.f};
   for (int i0 = 0; i0 < m; i0 += UM_TILE) {
-    const int cnt = min(UM_TILE, m - i0);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < UM_TILE * 16; idx += 256) {
-      const int ii = idx >> 4, j = idx & 15;
-      Cs[ii][j] = (ii < cnt && j < b) ? coef[(size_t)j * m + i0 + ii] : 0.f;  // zeros beyond the basis and the block: their products vanish
-    }
-    __syncthreads();
-    const int kb = q * (UM_TILE / 4);
-    if (kb < cnt) {  // wave-uniform
+    const int kb = i0 + q * (UM_TILE / 4);
+    if (kb < m) {  // wave-uniform
       float4 av[8];
+      float bq[8];
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        const int kk = min(i0 + kb + 4 * s8 + g, m - 1);  // clamped: a column past the basis meets a zero coefficient
+        const int kk = min(kb + 4 * s8 + g, m - 1);  // clamped: a column past the basis meets a zero coefficient
         av[s8] = *reinterpret_cast<const float4*>(Vb + (uint64_t)kk * ld + rb);
+        bq[s8] = cf[kk];
       }
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) {
-        const float bq = Cs[kb + 4 * s8 + g][l15];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].x, bq, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].y, bq, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].z, bq, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].w, bq, acc[3], 0, 0, 0);
+        const float bb = kb + 4 * s8 + g < m ? bq[s8] * bmask : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].x, bb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].y, bb, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].z, bb, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].w, bb, acc[3], 0, 0, 0);
       }
     }
   }
