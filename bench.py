@@ -41,11 +41,19 @@ WORKLOADS = {
     "c3": (100_000, 10_000_000, 1000, 31337),      # configs[2], column-sharded over all ranks (strong scaling)  <- bench default, every N
     "c3shard": (100_000, 1_250_000, 1000, 31337),  # one GPU's share of configs[2] at N = 8
     "c3full": (100_000, 10_000_000, 1000, 31337),  # = c3 (the name earlier rounds' profiles use for the one-GPU run)
+    "c4": (100_000, 10_000_000, 1000, 31337),      # configs[3]: importance sampling, sample_rate 0.1 (A on the device -> sampled B -> hot path)
+    "c5": (100_000, 10_000_000, 1000, 31337),      # configs[4]: config 3 + catchwords + topic model + 5000 edge topics behind the hot path
+    "c4small": (20_000, 200_000, 100, 7),          # the c4 / c5 flows at a size a test can run (tests/test_gpu_bench_contract.py)
+    "c5small": (20_000, 200_000, 100, 7),
     "tiny": (2_000, 5_000, 10, 0),
 }
-CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c3full": 2, "c3shard": 2}
+CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c3full": 2, "c3shard": 2, "c4": 3, "c5": 4, "c4small": 3, "c5small": 4}
+# workloads whose A goes to the device and is thresholded there (isle_hip_threshold), the CPU port's B being the checker:
+# sample_rate = sampled_threshold_and_copy (src/sparseMatrix.cpp:1365-1435), edge_topics = max_edge_topics of train_edge_topics (src/trainer.cpp:673-685)
+WORKLOAD_OPTS = {"c4": {"sample_rate": 0.1}, "c5": {"edge_topics": 5000}, "c4small": {"sample_rate": 0.1}, "c5small": {"edge_topics": 300}}
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix-core peak (v_mfma_f32_32x32x2_f32 ...); SURVEY 8(d) prices the dense contractions against it
 SIGMA_GATE = 1e-4        # north_star: top-k singular values within 1e-4 relative error
 PARTITION_GATE = 0.999   # k-means against the oracle from the same U and seeds (SURVEY 8c asks >= 0.99; near-ties are all that may differ)
 BIG_NNZ = 400_000_000  # above this the CPU legs (accuracy, k-means sample, cpu_baseline) run on bounded samples
@@ -65,37 +73,175 @@ def csc_columns(B, cols):
     return dict(vals=B["vals"][idx], rows=B["rows"][idx], offs=so)
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def kmpp_draws(k):
+    """Draws per k-means++ round (src/sparseMatrix.cpp:2183: 1 + ceil(sqrt(max(s - 5, 0))) draws when s seeds exist; the first seed is
+    round-less).  Duplicate draws are skipped by the reference, so a round may add fewer centres than it draws: an upper bound per round."""
+    s_, out = 1, []
+    while s_ < k:
+        c = 0
+        while c < 1 + max(s_ - 5, 0) ** 0.5 and s_ + c < k:
+            c += 1
+        out.append(c)
+        s_ += c
+    return out
+
+
+def family_rooflines(V, D, nnz, k, b, ncv, restarts, applies, kmpp_rounds, lp_iters, ls_iters, device_ms):
+    """SURVEY 8(d)'s algorithmic bytes / flops of every kernel family of the step x the counts THIS run executed, over the family's
+    device time (events around every launch, the untimed extra pass) and the bounding peak.  All figures are per step on this rank's
+    shard.  `frac` = achieved / peak.  Families without a device time in this run are left out."""
+    out = {}
+
+    def put(name, bound, alg, ms, what):
+        if not ms or ms <= 0:
+            return
+        if bound == "hbm":
+            ach, peak, unit = alg / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = alg / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        out[name] = {"bound": bound, "algorithmic_%s_per_step" % ("bytes" if bound == "hbm" else "flops"): alg, "device_ms_per_step": round(ms, 3),
+                     "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "what": what}
+
+    g = device_ms.get("gram_pass1", 0.0) + device_ms.get("gram_pass2", 0.0)
+    put("gram", "hbm", applies * (8.0 * nnz + 8.0 * (D + 1) + 8.0 * V * b), g,
+        "%d applications x (8 nnz + 8 (D+1) + 2*4 V b)" % applies)
+    # expand steps: the first sweep orthogonalises against m = 2b, 3b, ... ncv - b basis columns, every restart sweep against k + b ... ncv - b
+    ms_ = list(range(2 * b, ncv, b)) + restarts * list(range(k + b, ncv, b)) if k > b else []
+    if len(ms_) + 1 != applies:  # a run that stopped early / ran extra sweeps: price the expands it made at the mean width
+        ms_ = [sum(ms_) / max(len(ms_), 1)] * max(applies - 1, 0)
+    put("ortho", "hbm", sum(16.0 * V * m + 16.0 * V * b for m in ms_), device_ms.get("ortho", 0.0),
+        "%d expand steps x (4 (4 V m) + 16 V b), CGS2, m = basis width of the step" % len(ms_))
+    put("project", "hbm", 8.0 * nnz + 4.0 * V * k + 4.0 * k * D, device_ms.get("project", 0.0), "P = U^T B once: 8 nnz + 4 V k + 4 k D")
+    draws = kmpp_draws(k)[:kmpp_rounds] if kmpp_rounds > 0 else []
+    put("kmpp", "hbm", sum(min(4.0 * k * D, 8.0 * nnz + 8.0 * (D + 1) + 4.0 * V * c) + 8.0 * D for c in draws), device_ms.get("kmpp", 0.0),
+        "%d rounds x (min(4 k D, 8 nnz + 8 (D+1) + 4 V c) + 8 D), c = the round's draws" % len(draws))
+    put("lloyd_proj", "mfma", lp_iters * 2.0 * D * k * k, device_ms.get("lloyd_proj", 0.0),
+        "%d iterations x 2 D k^2 (the dense formulation SURVEY 8(d) scores; bounded iterations skip part of it)" % lp_iters)
+    put("sparse", "hbm", ls_iters * (16.0 * nnz + 8.0 * V * k), device_ms.get("sparse_assign", 0.0) + device_ms.get("sparse_update", 0.0),
+        "%d iterations of Lloyd on B x (2 (8 nnz) + 2*4 V k)" % ls_iters)
+    put("rotate", "mfma", (restarts + 1) * 2.0 * V * (ncv - b) * k, device_ms.get("rotate", 0.0),
+        "%d Ritz rotations (every restart + the final extraction) x 2 V (ncv - b) k" % (restarts + 1))
+    put("lift", "mfma", 2.0 * V * k * k, device_ms.get("lift", 0.0), "centres = U C: 2 V k^2")
+    return out
+
+
+def gram_kernel_sha16():
+    """sha256 (first 16 hex digits) of the Gram-apply kernel's source text — isle_amd/csrc/gram_lds.hip from the banner of the apply kernel
+    to the end of gl_apply_k — the key under which a counter pass in profiles/pmc_traffic.json stays valid."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "isle_amd", "csrc", "gram_lds.hip")) as f:
+            t = f.read()
+        a, z = t.index("// the apply kernel (both passes)"), t.index("#undef GL_ROWS_N")
+        return hashlib.sha256(t[a:z].encode()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher's environment: start N fresh rank processes of this script (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1) and wait for them.  The parent makes no torch or HIP
     call, before or after: the children are new processes, nothing is exec'ed from a process that holds the GPU.  Rank 0 inherits this
-    process's stdout (its one JSON line is the result), the other ranks' stdout goes to stderr.  Returns the worst exit status; when one
-    rank fails the others are given 30 s to notice (their collectives would wait for ever) and are then ended by PID."""
+    process's stdout (its one JSON line is the result), the other ranks' stdout goes to stderr.  Returns the worst exit status.  No rank
+    outlives the launcher: when one rank fails the others are given 30 s to notice (their collectives would wait for ever), a SIGTERM /
+    SIGINT / SIGHUP that reaches only this process, an exception, or the overall deadline (ISLE_BENCH_DEADLINE_S, default 3300 s) end
+    every live child by PID — terminate, then kill after 10 s."""
+    import signal
     import socket
     import subprocess
+    procs = []
+
+    def end_children(grace=10.0):
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    p.kill()
+                except OSError:
+                    pass
+        for p in live:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+
+    class _Signalled(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Signalled(signum)
+
+    old_handlers = {}
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            old_handlers[sg] = signal.signal(sg, on_signal)
+        except (ValueError, OSError):
+            pass
+    deadline = time.time() + float(os.environ.get("ISLE_BENCH_DEADLINE_S", "3300"))
+    # the rendezvous port: the listening socket stays open (SO_REUSEADDR on both sides lets rank 0's store bind the same port) until every
+    # rank has been started, so that no other process can be handed the port in between
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr.fileno()))
-    log("bench.py launcher: started %d ranks (pids %s), rendezvous 127.0.0.1:%d" % (n, [p.pid for p in procs], port))
-    worst, first_failure = 0, None
-    while any(p.poll() is None for p in procs):
-        for r, p in enumerate(procs):
-            rc = p.poll()
-            if rc not in (None, 0) and first_failure is None:
-                first_failure = time.time()
-                log("bench.py launcher: rank %d exited with status %d" % (r, rc))
-        if first_failure is not None and time.time() - first_failure > 30:
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-        time.sleep(0.2)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else sys.stderr.fileno()))
+        s.close()
+        s = None
+        log("bench.py launcher: started %d ranks (pids %s), rendezvous 127.0.0.1:%d" % (n, [p.pid for p in procs], port))
+        first_failure = None
+        while any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                rc = p.poll()
+                if rc not in (None, 0) and first_failure is None:
+                    first_failure = time.time()
+                    log("bench.py launcher: rank %d exited with status %d" % (r, rc))
+            if first_failure is not None and time.time() - first_failure > 30:
+                log("bench.py launcher: ending the remaining ranks 30 s after the first failure")
+                end_children()
+                break
+            if time.time() > deadline:
+                log("bench.py launcher: overall deadline reached (ISLE_BENCH_DEADLINE_S): ending all ranks")
+                end_children()
+                return 124
+            time.sleep(0.2)
+    except _Signalled as e:
+        log("bench.py launcher: signal %d: ending all ranks" % e.args[0])
+        end_children()
+        return 128 + int(e.args[0])
+    finally:
+        if s is not None:
+            s.close()
+        end_children(grace=5.0)  # no-op when every rank has exited; an exception above must not leave ranks holding their GPUs
+        for sg, h in old_handlers.items():
+            try:
+                signal.signal(sg, h)
+            except (ValueError, OSError):
+                pass
+    worst = 0
     for p in procs:
         rc = p.returncode
         worst = max(worst, rc if rc >= 0 else 128 - rc)
@@ -128,6 +274,8 @@ def main():
         sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("ISLE_BENCH_HOLD_S"):  # tests/test_bench_launcher_cpu.py: ranks that stay alive until their launcher ends them
+        time.sleep(float(os.environ["ISLE_BENCH_HOLD_S"]))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
@@ -162,6 +310,17 @@ def main():
         except Exception as e:  # the headline line must not depend on the secondary run
             out["secondary_c2"] = {"error": repr(e)[:300]}
     if out is not None and defaulted and world == 1 and not args.no_secondary:
+        # one GPU's share of configs[2] at N = 8 — the unit an 8-GPU step actually runs (1.25 M documents, the full vocabulary and k): its
+        # step, its Gram apply and its latency chains (QR, EVD) are what the scaling curve is made of, so they are reported next to the headline
+        try:
+            sec = run(args, "c3shard", rank, world, local_rank, dist, torch, 3, 1, full=False)
+            out["secondary_c3shard"] = {"workload": sec["config"]["workload"], "ms_per_step": sec["ms_per_step"], "value": sec["value"],
+                                        "unit": "docs/sec", "steps": 3, "warmup": 1, "roofline_frac": sec["roofline"]["frac"],
+                                        "avg_gram_apply_ms": sec["roofline"]["avg_launch_ms"], "device_ms_per_step": sec["device_ms_per_step"],
+                                        "roofline_frac_by_family": {f: v["frac"] for f, v in sec["roofline_by_family"].items()}}
+        except Exception as e:
+            out["secondary_c3shard"] = {"error": repr(e)[:300]}
+    if out is not None and defaulted and world == 1 and not args.no_secondary:
         # SURVEY 8(d)'s second figure: full ISLETrain wall time, tdf text in -> M_hat_catch_sparse out, at BASELINE configs[1]
         try:
             out["full_cli_c2"] = full_cli_leg("c2")
@@ -170,10 +329,17 @@ def main():
     if out is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    failed_gate = None
+    if out is not None:
         gate = out.get("accuracy", {}).get("gate")
         if gate is not None and not gate["passed"]:
-            log("bench.py: ACCURACY GATE FAILED: " + "; ".join(gate["failed"]))
-            sys.exit(3)
+            failed_gate = gate["failed"]
+    if dist is not None:  # every rank leaves the same way: contexts closed (run), one last barrier, the process group torn down
+        dist.barrier()
+        dist.destroy_process_group()
+    if failed_gate:
+        log("bench.py: ACCURACY GATE FAILED: " + "; ".join(failed_gate))
+        sys.exit(3)
 
 
 def full_cli_leg(workload):
@@ -240,7 +406,10 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     from tools.synth import Corpus, effective_cpus
 
     V, D_per, k, seed = WORKLOADS[workload]
-    strong = workload in ("c3", "c3full")
+    opts = WORKLOAD_OPTS.get(workload, {})
+    sample_rate, edge_topics = float(opts.get("sample_rate", 0.0)), int(opts.get("edge_topics", 0))
+    device_stage = bool(opts)
+    strong = workload in ("c3", "c3full", "c4", "c5", "c4small", "c5small")
     doc_base = rank * D_per
     if strong:  # one corpus, documents [doc_base, doc_base + D_per) on this rank (the generator seeds every document by its global id)
         D_total = D_per
@@ -260,12 +429,60 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     big = nnz_A > BIG_NNZ
     # stages either side of the path: run (outside the timed region) where the tdf text of the corpus is a sensible object — a
     # 1 B-line file is 15 GB of text (SURVEY §8d generates C3-C5 directly as CSC)
-    upstream = full and world == 1 and not args.no_upstream and not big
+    upstream = full and world == 1 and not args.no_upstream and not big and not device_stage
     A_host = corp.A() if upstream else None
     tdf_text = corp.tdf_bytes() if upstream else None
     t_thr0 = time.time()
     planted_all = corp.planted()
-    B = corp.threshold(k, free_A=True, allreduce=allreduce_np if dist is not None else None)
+
+    # ISLE_BENCH_REHEARSE=1: all ranks on GPU 0 with the host-staged test transport (RCCL refuses two ranks on one device).
+    # For checking this script's N > 1 control flow on a one-GPU box only: the line it prints is marked and is not a measurement.
+    rehearse = world > 1 and os.environ.get("ISLE_BENCH_REHEARSE") == "1"
+    hp = HotPath(0 if rehearse else local_rank)
+    if rehearse:
+        hp.comm_init_host(world, rank, HotPath.gloo_exchange(dist, world, rank))
+    elif world > 1:
+        uid = [HotPath.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        hp.comm_init(world, rank, uid[0])
+
+    stage_in = None
+    D_A_total = WORKLOADS[workload][1] * (1 if strong else world)  # documents of A over all ranks (the metric's numerator)
+    if device_stage:
+        # configs[3] / [4]: the count matrix A goes to the device (views, no second host copy), normalize_docs + compute_thresholds +
+        # (sampled_)threshold_and_copy run there (src/trainer.cpp:430-485), and the hot path runs on THAT B.  One rank: the CPU port of the
+        # same stage (tools/synth_corpus.cpp) is the checker — B, the kept-document map and the thresholds must agree bit for bit.
+        cntA, rowsA, offsA = corp.A_views()
+        t1 = time.perf_counter()
+        hp.upload_counts(V, cntA, rowsA, offsA, doc_offset=doc_base, docs_global=D_A_total)
+        t_h2d = time.perf_counter() - t1
+        hp.timing_enable(True)
+        hp.timing_reset()
+        t1 = time.perf_counter()
+        info = hp.threshold(k, sample_rate=sample_rate, sample_seed=seed)
+        hp.synchronize()
+        t_thr_dev = time.perf_counter() - t1
+        thr_dev_ms = hp.timing_get()["threshold"][0]
+        hp.timing_enable(False)
+        B = hp.get_B()
+        B["D"], B["nnz"] = int(B["D"]), int(B["nnz"])
+        stage_in = {"stage": "A on the device -> B (normalize_docs + compute_thresholds + %s, src/trainer.cpp:430-485)"
+                             % ("sampled_threshold_and_copy, sample_rate %.2f" % sample_rate if sample_rate else "threshold_and_copy"),
+                    "docs_A": int(D_per), "nnz_A": int(nnz_A), "docs_kept": info["docs_kept"], "nnz_kept": info["nnz_kept"],
+                    "upload_A_wall_ms": round(t_h2d * 1e3, 1), "wall_ms": round(t_thr_dev * 1e3, 1), "device_ms": round(thr_dev_ms, 3)}
+        if world == 1:
+            t1 = time.time()
+            Bc = corp.threshold(k, free_A=True, sample_rate=sample_rate, sample_seed=seed)
+            stage_in["cpu_port_ms"] = round((time.time() - t1) * 1e3, 1)
+            stage_in["cpu_cores"] = effective_cpus()
+            same = {x: bool(np.array_equal(B[x], Bc[x])) for x in ("vals", "rows", "offs", "original_cols", "zetas")}
+            stage_in["identical_to_cpu_port"] = same
+            del Bc
+            if not all(same.values()):
+                raise SystemExit("bench.py: the device's thresholded / sampled B differs from the CPU port's: %s" % same)
+        del cntA, rowsA, offsA
+    else:
+        B = corp.threshold(k, free_A=True, allreduce=allreduce_np if dist is not None else None)
     planted = planted_all[B["original_cols"].astype(np.int64)]  # dominant planted topic of every column of B (local numbering)
     t_thr_cpu = time.time() - t_thr0
     del corp, planted_all
@@ -279,20 +496,12 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     tot = np.array([nnz_loc, nnz_A], np.int64)
     allreduce_np(tot)
     nnz_glob = int(tot[0])
+    docs_metric = D_A_total if device_stage else D_glob  # docs/sec counts the documents of the INPUT (config 4 keeps a tenth of them in B)
     log("[rank %d] %s corpus: V=%d docs=%d (global %d) nnz(A)=%d nnz(B)=%d  generated in %.1fs" %
         (rank, workload, V, D_loc, D_glob, nnz_A, nnz_loc, t_gen))
 
-    # ISLE_BENCH_REHEARSE=1: all ranks on GPU 0 with the host-staged test transport (RCCL refuses two ranks on one device).
-    # For checking this script's N > 1 control flow on a one-GPU box only: the line it prints is marked and is not a measurement.
-    rehearse = world > 1 and os.environ.get("ISLE_BENCH_REHEARSE") == "1"
-    hp = HotPath(0 if rehearse else local_rank)
-    if rehearse:
-        hp.comm_init_host(world, rank, HotPath.gloo_exchange(dist, world, rank))
-    elif world > 1:
-        uid = [HotPath.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        hp.comm_init(world, rank, uid[0])
-    hp.upload_csc(V, B["vals"], B["rows"], B["offs"], doc_offset=doc_offset, docs_global=D_glob)
+    if not device_stage:
+        hp.upload_csc(V, B["vals"], B["rows"], B["offs"], doc_offset=doc_offset, docs_global=D_glob)
 
     phase_wall = {"block_ks": 0.0, "kmeanspp": 0.0, "lloyd_projected": 0.0, "lift": 0.0, "lloyd_sparse": 0.0}
 
@@ -368,7 +577,7 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(dtt[0])
     ms_per_step = 1e3 * dt / steps
-    value = D_glob * steps / dt
+    value = docs_metric * steps / dt
 
     # ---------------- roofline of the dominant sparse kernel family (Gram apply) --------------------------
     b = (args.blk or 10) if k > 10 else 1
@@ -389,18 +598,26 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     elif form != 1:
         traffic_note = "profiles/pmc_traffic.json holds the LDS-banded form's counters; this run used the gather form"
     else:
+        sha = gram_kernel_sha16()
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(pmc_key, {}).get("gram_apply_hbm_bytes_per_launch")
+                ent = json.load(f).get(pmc_key, {})
+            traffic = ent.get("gram_apply_hbm_bytes_per_launch")
+            if traffic is not None and ent.get("kernel_source_sha16") != sha:
+                traffic, traffic_note = None, ("profiles/pmc_traffic.json['%s'] was collected on kernel source %s, this build's gl_apply_k is %s: stale, "
+                                               "not reported" % (pmc_key, ent.get("kernel_source_sha16"), sha))
         except Exception:
             pass
-        traffic_note = ("profiles/pmc_traffic.json['%s']: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py at this size"
-                        % pmc_key if traffic is not None else "no counter pass committed for workload '%s'" % pmc_key)
+        if traffic_note is None:
+            traffic_note = ("profiles/pmc_traffic.json['%s'] (kernel source %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py at "
+                            "this size" % (pmc_key, sha) if traffic is not None else "no counter pass committed for workload '%s'" % pmc_key)
     roofline = {"bound": "hbm", "kernel": "gram_apply (Z = B(B^T X), b=%d) = %s" % (b, form_kernels),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_apply_ms, 4), "launches": n_apply}
     device_ms = {f: round(v[0], 3) for f, v in tm.items() if v[1]}  # the one untimed pass with events around every launch
+    by_family = family_rooflines(V, D_loc, nnz_loc, k, b, (2 * k + b) if k > 10 else 2 * k + 10, last["ks"]["restarts"], last["ks"]["napplies"],
+                                 last["kmpp_rounds"], last["lp_iters"], last["ls_iters"], device_ms)
     scopes_per_step = int(sum(v[1] for v in tm.values()))  # event-bracketed scopes (a scope may hold several launches; rocprof has the launch count)
 
     sizes = np.bincount(last["assign"], minlength=k).astype(np.int64)
@@ -410,9 +627,13 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
                          % (min(step_nonempty), k, max(step_largest), D_glob))
     cfg = {
         "workload": "synthetic planted-topic Zipf corpus (%s = BASELINE.json configs[%d]%s): vocab=%d, docs=%d (%d on rank 0), nnz(A)=%d, "
-                    "nnz(B)=%d, num_topics=%d, sample=0; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)"
+                    "nnz(B)=%d, num_topics=%d, %s; hot path = block-KS SVD + k-means++ + Lloyd(projected) + lift + Lloyd(sparse)%s"
                     % (workload, CONFIG_INDEX.get(workload, -1), ", all of it on one GPU" if strong and world == 1 else "", V, D_glob,
-                       D_loc, int(tot[1]), nnz_glob, k),
+                       D_loc, int(tot[1]), nnz_glob, k,
+                       "sample=1 sample_rate=%.2f: B keeps %d of the %d documents of A, docs/sec counts the %d" % (sample_rate, D_glob, D_A_total, D_A_total)
+                       if sample_rate else "sample=0",
+                       "; edge_topics=1 max_edge_topics=%d (catchwords + topic model + edge topics run behind the timed region: other_stages)" % edge_topics
+                       if edge_topics else ""),
         "block_ks": {"nev": k, "ncv": 2 * k + 10, "blk": b, "tol": 1e-4, "maxit": 100,
                      "restarts": last["ks"]["restarts"], "applies": last["ks"]["napplies"], "nconv": last["ks"]["nconv"],
                      "converged": bool(last["ks"]["rc"] == 0 and last["ks"]["nconv"] == k)},
@@ -450,10 +671,13 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         "data": "synthetic",
         "config": cfg,
         "roofline": roofline,
+        "roofline_by_family": by_family,
         "device_ms_per_step": device_ms,
         "timed_scopes_per_step": scopes_per_step,
         "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
     }
+    if stage_in is not None:
+        out["other_stages"] = {"note": "stage upstream of the hot path, run on the device OUTSIDE the timed region at the workload's own size", "input": stage_in}
     if not full:
         hp.close()
         return out if rank == 0 else None
@@ -491,6 +715,7 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     purity = float(maj.max(1).sum() / max(D_glob, 1))
 
     if rank != 0:
+        hp.close()  # the communicator and the device memory go here, not whenever the interpreter gets to it
         return None
 
     # ---------------- k-means parity on a sub-sample: the HIP path and the CPU oracle from the same U and the same injected seeds ------
@@ -588,18 +813,56 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         o.lloyds_sparse(cen, max_reps=2)
         t_ls_cpu = max(time.time() - t1 - ta, 1e-9)
         n_app = last["ks"]["napplies"]
+        # The dense half of the CPU eigensolver (BlockKs::expand / compute_qr / truncate, block-ks/restarted_block_ks.h:62-187): its cost
+        # depends on V, k and the block size, not on the number of documents, so it is measured at full V and NOT scaled by `frac`.
+        # One CGS2 step (two rounds of H = V_m^T F, F -= V_m H) and one Ritz rotation as BLAS products on these cores (numpy: what the
+        # reference does through Armadillo / MKL), one fp64-MGS panel QR and one eig_sym by the oracle; the EVD at n <= 640 and scaled by n^3.
+        ncv_ = 2 * k + b if k > 10 else 2 * k + 10
+        rst = last["ks"]["restarts"]
+        widths = list(range(2 * b, ncv_, b)) + rst * list(range(k + b, ncv_, b)) if k > b else [b] * max(n_app - 1, 0)
+        rngd = np.random.default_rng(1)
+        m_mid = max(b, min(ncv_ - b, int(np.mean(widths)) if widths else b))
+        Vm = rngd.standard_normal((V, m_mid), dtype=np.float32)
+        Fb = rngd.standard_normal((V, b), dtype=np.float32)
+        t1 = time.time()
+        for _ in range(2):
+            Hc = Vm.T @ Fb
+            Fb -= Vm @ Hc
+        t_cgs2_mid = time.time() - t1
+        t_ortho_cpu = t_cgs2_mid * (sum(widths) / m_mid) if widths else 0.0
+        from oracle import oracle as orc_d
+        t1 = time.time()
+        orc_d.qr(np.asfortranarray(Fb))
+        t_qr_cpu = (time.time() - t1) * n_app
+        n_evd = ncv_ - b
+        n_meas = min(n_evd, 640)
+        Sm = rngd.standard_normal((n_meas, n_meas)).astype(np.float32)
+        t1 = time.time()
+        orc_d.eig_sym((Sm + Sm.T) / 2)
+        t_evd_cpu = (time.time() - t1) * (n_evd / n_meas) ** 3 * (rst + 1)
+        kc = max(1, k // 8)
+        Wr = rngd.standard_normal((n_evd if n_evd <= Vm.shape[1] else Vm.shape[1], kc), dtype=np.float32)
+        t1 = time.time()
+        _ = Vm[:, :Wr.shape[0]] @ Wr
+        t_rot_cpu = (time.time() - t1) * (n_evd / Wr.shape[0]) * (k / kc) * (rst + 1)
+        t_dense_cpu = t_ortho_cpu + t_qr_cpu + t_evd_cpu + t_rot_cpu
+        del Vm, Fb
         est = frac * (n_app * t_apply_cpu + last["kmpp_rounds"] * t_round_cpu + last["lp_iters"] * t_lp_cpu +
-                      last["ls_iters"] * t_ls_cpu)
+                      last["ls_iters"] * t_ls_cpu) + t_dense_cpu
         cpu = {
-            "value": round(D_loc / est, 1), "unit": "docs/sec", "cores": cores, "kind": "port",
+            "value": round((docs_metric if world == 1 else D_loc) / est, 1), "unit": "docs/sec", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_name(), "cpus_online": os.cpu_count(),
             "sample": ("same-work extrapolation on %s: measured 1 Gram-apply (%.3fs), 1 k-means++ round "
                        "(%.3fs), 1 projected-Lloyd iteration (%.3fs), 1 sparse-Lloyd iteration (%.3fs) of oracle/ "
                        "(OpenMP, %d threads), scaled by the counts the GPU run executed (%d applies, %d rounds, %d+%d "
-                       "iterations)%s; orthogonalisation/QR/EVD time of the CPU eigensolver NOT included (upper bound on CPU "
-                       "docs/s); sampling took %.0fs" %
+                       "iterations)%s; plus the dense half of the CPU eigensolver at full V, not scaled by the sample: orthogonalisation %.1fs (one CGS2 "
+                       "step at basis width %d as BLAS products, scaled by the sum of the widths), panel QR %.1fs (oracle's fp64 MGS x %d), "
+                       "small EVD %.1fs (oracle's eig_sym at n = %d, scaled by n^3 to %d, x %d), Ritz rotation %.1fs; sampling took %.0fs" %
                        ("the full-size matrix" if frac == 1 else "the first 1/%d of the columns (%d documents, all %d words, k = %d)" % (frac, n_o, V, k),
                         t_apply_cpu, t_round_cpu, t_lp_cpu, t_ls_cpu, cores, n_app, last["kmpp_rounds"], last["lp_iters"],
-                        last["ls_iters"], "" if frac == 1 else " and by %d for the size" % frac, time.time() - tc0)),
+                        last["ls_iters"], "" if frac == 1 else " and by %d for the size" % frac, t_ortho_cpu, m_mid, t_qr_cpu, n_app,
+                        t_evd_cpu, n_meas, n_evd, rst + 1, t_rot_cpu, time.time() - tc0)),
+            "dense_eigensolver_seconds": {"ortho": round(t_ortho_cpu, 2), "qr": round(t_qr_cpu, 2), "evd": round(t_evd_cpu, 2), "rotate": round(t_rot_cpu, 2)},
         }
         try:  # the port's speed against the reference's own MKL path, unit by unit (tools/cpu_calibration.py, run in the build container)
             with open(os.path.join(ROOT, "profiles", "cpu_port_calibration.json")) as f:
@@ -686,6 +949,55 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         up = {"note": "stages either side of the hot path, run OUTSIDE the timed region at the same size, each checked at full size",
               "ingest": ingest, "threshold": up, "downstream": down, "inference": infer_stage}
         del A_host
+    elif device_stage:
+        up = {"note": "stages either side of the hot path, run on the device OUTSIDE the timed region at the workload's own size", "input": stage_in}
+        if edge_topics and world == 1:
+            # configs[4]: what train_edge_topics adds behind a config-3 hot path (src/trainer.cpp:577-685, :1116-1167) — catchwords and the topic
+            # model from the partition the last timed step left on the device, the pair selection on the host (as fpsparse_hip.h does it), the
+            # two FPaxpy per edge topic on the device, the V x #edge model back on the host.  Checker: oracle/isle_post_oracle.cpp for the pair
+            # selection (all pairs) and for a sample of the edge columns.
+            from isle_amd.hot_path import EDGE_TOPIC_PRIMARY_RATIO, catchword_rank, model_rank_threshold, select_edge_pairs
+            from oracle import oracle as orc
+            D_A = int(WORKLOADS[workload][1])
+            hp.timing_enable(True)
+            hp.timing_reset()
+            t1 = time.perf_counter()
+            cw = hp.find_catchwords(k, catchword_rank(D_A, k), fetch_thresholds=False)
+            t_cw = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            tmo = hp.construct_topic_model(k, model_rank_threshold(D_A, k), D_A, fetch_sums=False)
+            t_tm = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            pairs = select_edge_pairs(tmo["top1"], tmo["top2"], edge_topics)
+            t_sel = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            E = hp.edge_topics(pairs[:, :2])
+            t_edge = time.perf_counter() - t1
+            post_ms = hp.timing_get()["post"][0]
+            hp.timing_enable(False)
+            model = tmo["model"]
+            ref_pairs, _ = orc.post_edge_topics(model, tmo["top1"], tmo["top2"], edge_topics, want_edge=False)
+            pick_e = np.unique(np.linspace(0, max(len(pairs) - 1, 0), 64).astype(np.int64)) if len(pairs) else np.zeros(0, np.int64)
+            worst = 0.0
+            for t_ in pick_e:
+                want = (np.float32(EDGE_TOPIC_PRIMARY_RATIO) * model[:, pairs[t_, 0]].astype(np.float64)
+                        + np.float32(1.0 - EDGE_TOPIC_PRIMARY_RATIO) * model[:, pairs[t_, 1]].astype(np.float64))
+                okc = np.isfinite(want)
+                if okc.any():
+                    worst = max(worst, float(np.max(np.abs(E[okc, t_] - want[okc]) / np.maximum(np.abs(want[okc]), 1e-12))))
+            up["edge_topics"] = {"stage": "catchwords + topic model + edge topics (src/trainer.cpp:577-685, construct_edge_topics_v2 :1116-1167), max_edge_topics=%d"
+                                          % edge_topics,
+                                 "catchwords_wall_ms": round(t_cw * 1e3, 1), "topic_model_wall_ms": round(t_tm * 1e3, 1),
+                                 "pair_selection_host_ms": round(t_sel * 1e3, 1), "edge_model_wall_ms_incl_d2h": round(t_edge * 1e3, 1),
+                                 "device_ms": round(post_ms, 3), "num_catchwords": cw["num_catchwords"],
+                                 "documents_with_two_topics": int(((tmo["top1"] >= 0) & (tmo["top2"] >= 0)).sum()),
+                                 "num_edge_topics": int(len(pairs)), "edge_model_bytes": int(E.nbytes),
+                                 "pairs_identical_to_oracle": bool(np.array_equal(pairs, ref_pairs)),
+                                 "edge_columns_checked": int(len(pick_e)), "edge_columns_worst_rel_err": worst,
+                                 "model_columns_sum_to_one": bool(np.allclose(np.nansum(np.abs(model), 0)[np.isfinite(model).all(0)], 1.0, rtol=1e-3))}
+            if not up["edge_topics"]["pairs_identical_to_oracle"] or worst > 1e-5:
+                raise SystemExit("bench.py: edge-topic stage differs from the CPU restatement: %s" % up["edge_topics"])
+            del E, model, tmo
     elif full and world == 1 and big and not args.no_upstream:
         up = {"note": "not run at this size: the corpus is generated directly as CSC (a 1.1 B-line tdf file is 15 GB of text, SURVEY §8d); "
                       "`--workload c2` runs ingest, thresholding, catchwords + topic model and inference at 1 M documents, each checked at "

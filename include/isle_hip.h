@@ -287,7 +287,7 @@ enum {
   ISLE_T_ORTHO = 2,        /* V^T F, F -= V H                      */
   ISLE_T_QR = 3,           /* panel QR (Gram, apply)               */
   ISLE_T_EVD = 4,          /* small symmetric EVD                  */
-  ISLE_T_ROTATE = 5,       /* Ritz rotation / lift GEMM            */
+  ISLE_T_ROTATE = 5,       /* Ritz rotation (every restart + the final extraction of U) */
   ISLE_T_PROJECT = 6,      /* P = U^T B                            */
   ISLE_T_KMPP = 7,         /* k-means++ rounds                     */
   ISLE_T_LLOYD_PROJ = 8,   /* projected Lloyd assign + update      */
@@ -299,7 +299,8 @@ enum {
   ISLE_T_POST = 14,        /* catchwords / topic model / edge topics (downstream stage) */
   ISLE_T_INGEST = 15,      /* tdf text -> count matrix */
   ISLE_T_INFER = 16,       /* ISLEInfer: multiplicative-weights inference */
-  ISLE_T_COUNT = 17
+  ISLE_T_LIFT = 17,        /* centres = U C_lowd (left_multiply_by_U_Spectra)  */
+  ISLE_T_COUNT = 18
 };
 /* on: 0 = off, 1 = events around every launch, 2 = around the Gram applications only (what bench.py's timed region uses): the
  * LDS-banded form then books one event pair per application — both passes and the gap between them — under ISLE_T_GRAM_PASS1. */

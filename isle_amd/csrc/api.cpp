@@ -50,9 +50,9 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_KS_SYNC", "form", "expand loop without the speculative pipeline (one host synchronisation per step)"},
     {"ISLE_KS_ORTHO_PASSES", "form", "3: the reference's three Gram-Schmidt passes per Krylov step instead of two"},
     {"ISLE_UPDATE_MFMA", "form", "0: the orthogonalisation's update F -= V H by FMA chains with the coefficients read from LDS (update_k) instead of on the matrix cores (same sums in another order)"},
-    {"ISLE_QR_FUSED", "form", "1: panel QR as one persistent launch (bitwise equal to the kernel chain, no faster)"},
     {"ISLE_EVD_JACOBI", "form", "small symmetric EVD by block Jacobi instead of tridiagonalisation"},
     {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},
+    {"ISLE_TD_FLATBAR", "tuning", "1: the persistent tridiagonalisation crosses its grid barriers on one counter (gb_barrier) instead of the hierarchical barrier (gbh_barrier, gridbar.h); same bits"},
     {"ISLE_EVD_SPLIT", "form", "0: with several ranks every rank computes all eigenvectors of the small EVD (default: rank r the vectors [r kc, (r + 1) kc) — eigenvectors of the tridiagonal matrix and their back-transformation — followed by an all-gather; the same bits on every rank)"},
     {"ISLE_KMPP_HOST_DICE", "form", "k-means++ dice scaled and searched through the host round trip (the multi-rank form) on one rank too"},
     {"ISLE_KMPP_SPARSE", "form", "0 / 1: k-means++ rounds on the projection / through thin products of B (default: by cost)"},
@@ -78,6 +78,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_INFER_CAP_ROWS", "form", "inference: stage at most this many model rows per document in LDS (default 0: rows read through L2)"},
     {"ISLE_CHUNK_COLS", "tuning", "gather form: rows per chunk of the chunked-CSR copy"},
     {"ISLE_COMM_TIMEOUT_S", "tuning", "seconds without a completed collective, while collectives are pending, after which the watchdog aborts the RCCL communicator and the call returns ISLE_E_COMM (default 300; 0: no watchdog)"},
+    {"ISLE_COMM_SELFTEST", "diagnostic", "0 / 1: behind the communicator's creation every rank runs one all-reduce (sum, max) and one all-gather of every (datatype, size class) the step issues on patterns with known results, and logs its rank, device and PCI bus id (default: on with an RCCL communicator of more than one rank, off for the host-staged test transport and the forced 1-rank communicator)"},
     {"ISLE_FORCE_COMM", "test hook", "create a 1-rank RCCL communicator so that every collective call site runs on one GPU"},
     {"ISLE_TEST_STALL_MS", "test hook", "a kernel that spins for this many milliseconds is queued ahead of every RCCL collective (the watchdog's test)"},
     {"ISLE_ROCTX", "diagnostic", "1: every kernel family's launches are wrapped in a roctx range (isle:gram_pass1, isle:ortho, ...) for rocprofv3 --marker-trace; the roctx library is opened at run time"},
@@ -155,7 +156,7 @@ extern "C" int isle_hip_switch_info(int index, const char** name, const char** k
 static const char* const kFamilyName[ISLE_T_COUNT] = {"isle:gram_pass1", "isle:gram_pass2", "isle:ortho", "isle:panel_qr", "isle:small_evd", "isle:rotate",
                                                        "isle:project", "isle:kmeanspp", "isle:lloyd_projected", "isle:lloyd_sparse_assign",
                                                        "isle:lloyd_sparse_update", "isle:operator_build", "isle:collectives", "isle:threshold",
-                                                       "isle:post", "isle:ingest", "isle:infer"};
+                                                       "isle:post", "isle:ingest", "isle:infer", "isle:lift"};
 typedef int (*roctx_push_fn)(const char*);
 typedef int (*roctx_pop_fn)(void);
 static roctx_push_fn g_roctx_push = nullptr;
@@ -439,6 +440,70 @@ extern "C" int isle_hip_comm_unique_id(void* out128) {
   return 0;
 }
 
+// ---- communicator self-test (ISLE_COMM_SELFTEST; default on behind ncclCommInitRank with more than one rank) ----
+// One all-reduce (sum), one all-reduce (max) and one all-gather of every (datatype, size class) the step issues — scalars and flag pairs,
+// coefficient blocks, the 4 MB Gram panel / k x k centroid sums, a 64 MB piece of the V x k centre sums — on patterns whose results are known
+// in closed form, checked element by element on the host.  A rank on the wrong device, a transport that does not come up, a datatype or
+// count that one build disagrees on, surface here, within seconds and with a message that names the operation, instead of as a hang or
+// a wrong eigenvalue inside the first step.  It also takes RCCL's connection set-up out of the first timed collective.
+template <typename T>
+static int selftest_type(isle_ctx* c, int dtype, const char* tname, const std::vector<size_t>& counts, int* ncoll) {
+  const int W = c->world, r = c->rank;
+  for (size_t n : counts) {
+    std::vector<T> h(n * (size_t)W);
+    DevBuf<T> d;
+    HIPCHK(c, d.reserve(n * (size_t)W));
+    for (int op = 0; op < 3; ++op) {  // 0 sum, 1 max, 2 all-gather
+      const size_t nsend = n;
+      if (op < 2) for (size_t i = 0; i < n; ++i) h[i] = (T)((r + 1) * (int)(i % 251 + 1));
+      else for (size_t i = 0; i < n; ++i) h[(size_t)r * n + i] = (T)(r * 131 + (int)(i % 127));
+      HIPCHK(c, hipMemcpyAsync(op < 2 ? d.p : d.p + (size_t)r * n, op < 2 ? h.data() : h.data() + (size_t)r * n, nsend * sizeof(T), hipMemcpyHostToDevice, c->stream));
+      if (op < 2) ISLECHK(isle_allreduce(c, d.p, n, dtype, op == 1));
+      else ISLECHK(isle_allgather(c, d.p + (size_t)r * n, d.p, n, dtype));
+      const size_t nback = op < 2 ? n : n * (size_t)W;
+      HIPCHK(c, hipMemcpyAsync(h.data(), d.p, nback * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (c->comm_dead.load()) return isle_fail(c, ISLE_E_COMM, "communicator self-test: the %s of %zu %s did not complete (communicator aborted)",
+                                                op == 0 ? "all-reduce(sum)" : op == 1 ? "all-reduce(max)" : "all-gather", n, tname);
+      for (size_t i = 0; i < nback; ++i) {
+        T want;
+        if (op == 0) want = (T)((W * (W + 1) / 2) * (int)(i % 251 + 1));
+        else if (op == 1) want = (T)(W * (int)(i % 251 + 1));
+        else want = (T)((int)(i / n) * 131 + (int)((i % n) % 127));
+        if (h[i] != want)
+          return isle_fail(c, ISLE_E_COMM, "communicator self-test FAILED on rank %d of %d: %s of %zu %s, element %zu is %.17g, expected %.17g", r, W,
+                           op == 0 ? "all-reduce(sum)" : op == 1 ? "all-reduce(max)" : "all-gather", n, tname, i, (double)h[i], (double)want);
+      }
+      ++*ncoll;
+    }
+  }
+  return 0;
+}
+static int comm_selftest(isle_ctx* c) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int ncoll = 0;
+  const std::vector<size_t> small = {1, 2, 16, 1000}, panel = {1, 2, 100, 20100, (size_t)1 << 20};
+  std::vector<size_t> f32 = panel;
+  f32.push_back((size_t)1 << 24);
+  ISLECHK(selftest_type<float>(c, ISLE_DT_F32, "f32", f32, &ncoll));
+  ISLECHK(selftest_type<double>(c, ISLE_DT_F64, "f64", panel, &ncoll));
+  ISLECHK(selftest_type<int32_t>(c, ISLE_DT_I32, "i32", small, &ncoll));
+  ISLECHK(selftest_type<uint32_t>(c, ISLE_DT_U32, "u32", panel, &ncoll));
+  ISLECHK(selftest_type<uint64_t>(c, ISLE_DT_U64, "u64", small, &ncoll));
+  char bus[64] = "?";
+  (void)hipDeviceGetPCIBusId(bus, sizeof bus, c->device);
+  int ver = 0;
+  if (c->comm) (void)ncclGetVersion(&ver);
+  fprintf(stderr, "[isle_hip] rank %d of %d: device %d (PCI %s), %s; communicator self-test: %d collectives (sum / max / all-gather x f32 f64 i32 u32 u64, 1 ... 16 M elements) correct in %.0f ms\n",
+          c->rank, c->world, c->device, bus, c->host_xchg ? "host-staged test transport" : ("RCCL " + std::to_string(ver)).c_str(), ncoll,
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  return 0;
+}
+static bool comm_selftest_wanted(isle_ctx* c, bool dflt) {
+  if (c->knob_on(KN_COMM_SELFTEST)) return !c->knob_zero(KN_COMM_SELFTEST);
+  return dflt;
+}
+
 extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* uid) {
   if (!c || world < 1 || rank < 0 || rank >= world) return isle_fail(c, ISLE_E_ARG, "bad world/rank");
   c->world = world;
@@ -451,7 +516,9 @@ extern "C" int isle_hip_comm_init(isle_ctx* c, int world, int rank, const void* 
   ncclUniqueId id;
   memcpy(&id, uid, sizeof id);
   NCCLCHK(c, ncclCommInitRank(&c->comm, world, id, rank));
-  return wd_start(c);
+  ISLECHK(wd_start(c));
+  if (comm_selftest_wanted(c, world > 1)) return comm_selftest(c);  // (a forced 1-rank communicator: the collectives are the identity)
+  return 0;
 }
 
 extern "C" int isle_hip_comm_init_host(isle_ctx* c, int world, int rank, isle_host_exchange_fn fn, void* user) {
@@ -461,6 +528,10 @@ extern "C" int isle_hip_comm_init_host(isle_ctx* c, int world, int rank, isle_ho
   c->rank = rank;
   c->host_xchg = fn;
   c->host_xchg_user = user;
+  if (comm_selftest_wanted(c, false)) {
+    ISLECHK(isle_enter(c));
+    return comm_selftest(c);
+  }
   return 0;
 }
 

@@ -550,7 +550,7 @@ extern "C" int isle_hip_lift_centers(isle_ctx* c, const float* in, int ld_in, in
     HIPCHK(c, hipMemcpyAsync(c->Csum.p, c->pin_stage, in_bytes, hipMemcpyHostToDevice, c->stream));  // the call synchronises before it returns
   }
   HIPCHK(c, c->centers_cm.reserve((size_t)c->V * ncols));
-  ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, c->U_k, c->Csum.p, ld_in, ncols, c->centers_cm.p));
+  ISLECHK(k_gemm_nn(c, c->Ucm.p, c->V, c->U_k, c->Csum.p, ld_in, ncols, c->centers_cm.p, ISLE_T_LIFT));
   ISLECHK(install_centers(c, ncols));
   // the centres lie in span(U): Lloyd on B can take its first assignment from the projection (isle_hip_lloyds_sparse)
   HIPCHK(c, c->lift_C.reserve((size_t)ld_in * ncols));

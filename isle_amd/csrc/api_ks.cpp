@@ -255,10 +255,6 @@ struct Ks {
       if (c->multi() && meta[KS_AGREE] != -meta[KS_AGREE + 1])
         return isle_fail(c, ISLE_E_COMM, "ranks disagree on the rank of a Krylov block (min %d, max %d): replicated state diverged",
                          -meta[KS_AGREE + 1], meta[KS_AGREE]);
-      if (meta[1] == 2) {  // the speculative next step has already overwritten the block: give up on this solve, the next one runs the five kernels
-        ISLECHK(k_panel_qr_fused_lost(c));
-        return isle_fail(c, ISLE_E_NUMERIC, "panel QR: the persistent kernel lost residency at a grid barrier; this context now uses the five-kernel form");
-      }
       if (meta[1] || (c->multi() && meta[KS_AGREE + 2]))
         return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
       const int rk = meta[0];

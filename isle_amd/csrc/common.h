@@ -87,9 +87,9 @@ struct DevBuf {
 // ------------------------------------------------------------------------------------------
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_FILL_BUCKETS, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_GL_WIDE_GROUPED, KN_WIDE_GATHER, KN_WIDE_LDS,
-  KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_UPDATE_MFMA, KN_QR_FUSED, KN_EVD_JACOBI, KN_TD_CHAIN, KN_EVD_SPLIT,
+  KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_UPDATE_MFMA, KN_EVD_JACOBI, KN_TD_CHAIN, KN_TD_FLATBAR, KN_EVD_SPLIT,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
-  KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_FORCE_COMM, KN_TEST_STALL_MS,
+  KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_COMM_SELFTEST, KN_FORCE_COMM, KN_TEST_STALL_MS,
   KN_ROCTX, KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
   KN_COUNT
 };
@@ -264,9 +264,6 @@ struct isle_ctx {
   DevBuf<double> pq_part, pq_R1;  // panel QR: partial Gram matrices, first triangular factor
   DevBuf<float> pq_T;             // panel QR: T (32 x 32) and R (32 x 32)
   DevBuf<int> pq_meta;            // panel QR: rank, status, pivots
-  DevBuf<unsigned int> pq_bar;    // persistent panel QR: [grid-barrier counter | abort flag]
-  unsigned int pq_bar_count = 0;  // arrivals counted so far (the next launch's base)
-  bool pq_fused_failed = false;   // the persistent form lost residency once: five-kernel form from then on
   DevBuf<float> small;     // misc small device scratch
   DevBuf<double> jacW, jacV;  // n x n each
   DevBuf<double> jacS;        // per-pair Gram / rotation scratch
@@ -532,7 +529,6 @@ int k_post_edge(isle_ctx* c, const int64_t* pairs_dev, int n, float a, float b, 
 // dense.hip
 int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b, float* coef /*m x b col-major dev*/, uint64_t ld = 0);
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef, uint64_t ld = 0);
-int k_panel_qr_fused_lost(isle_ctx* c);
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host /*w*w*/, int* rank_out);
 int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, int* meta_dev /*2 + 32*/, float* Rout_dev /*w*w*/);
 int k_randu(isle_ctx* c, float* F, uint64_t count, uint64_t seed);

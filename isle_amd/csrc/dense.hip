@@ -357,20 +357,33 @@ __global__ __launch_bounds__(256) void pqr_gram_k(const float* __restrict__ F, u
   }
 }
 
-// meta: [0] rank, [1] status (0 ok, 1 second Gram matrix not positive definite, 2 the persistent form lost residency), [2..2+PQ_W) pivots
+// meta: [0] rank, [1] status (0 ok, 1 second Gram matrix not positive definite), [2..2+PQ_W) pivots
+constexpr int PQ_NSEG = 4;                      // the partial Gram matrices are summed in four runs of consecutive slabs, combined (0 + 1) + (2 + 3)
+constexpr int PQ_NE = PQ_W * (PQ_W + 1) / 2;   // entries of the upper triangle at the widest panel
 struct PqFactorLds {
   double G[PQ_W][PQ_W + 1];
-  double Rm[PQ_W][PQ_W + 1];  // Rm[r][col]: row r of the triangular factor
-  double X[PQ_W][PQ_W + 1];
+  union {
+    struct {
+      double Rm[PQ_W][PQ_W + 1];  // Rm[r][col]: row r of the triangular factor
+      double X[PQ_W][PQ_W + 1];
+    };
+    double S[PQ_NSEG][PQ_NE];     // the four runs' sums, before Rm and X are in use
+  };
   int piv[PQ_W];
   int sh_rk, sh_bad;
   double sh_nrm;
 };
-// The factor step of one CholQR pass for a workgroup of 256 threads.  R1g, meta, T, Rout may live in global memory (pqr_factor_k)
-// or in the workgroup's LDS (pqr_fused_k, where every workgroup repeats the step): the arithmetic is the same either way.
-template <bool COH>  // COH: the partial sums were stored by other workgroups of this launch (agent-scope loads, see gridbar.h)
+// The factor step of one CholQR pass for a workgroup of 256 threads.
+template <bool COH>  // COH: the partial sums were stored by other workgroups of this launch (agent-scope loads, see gridbar.h); unused since round 6
 __device__ inline double pq_ld(const double* p) {
   return COH ? gb_ld(p) : *p;
+}
+// the LDS stores of this wave's earlier instructions are visible to its later loads (one wave's LDS accesses execute in order); the
+// fences keep the compiler from moving accesses across the point
+__device__ inline void pq_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <bool COH>
 __device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts, int wmax, int pass, double* R1g /*PQ_W*PQ_W*/, int* meta,
@@ -381,38 +394,50 @@ __device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts,
   auto& piv = L.piv;
   int& sh_rk = L.sh_rk;
   int& sh_bad = L.sh_bad;
-  double& sh_nrm = L.sh_nrm;
   const int t = threadIdx.x;
   const int w = (pass == 1) ? wmax : meta[0];
   {
-    // sum of the partial Gram matrices in index order, two threads per entry (first and second half of the slabs, combined
-    // first + second): the 98-way sum is a chain of dependent load batches, most of this kernel's time
-    const int half = t >> 7, p0 = half ? nparts / 2 : 0, p1 = half ? nparts : nparts / 2;
-    for (int o = t & 127; o < w * w; o += 128) {
-      const int i = o / w, j = o - i * w;  // G(i, j), upper triangle stored at [j*w + i]
-      const int u = (i <= j) ? j * w + i : i * w + j;
-      double s = 0.0;
+    // Sum of the partial Gram matrices: only the upper triangle (the slabs store nothing else), the slabs cut into PQ_NSEG runs of
+    // consecutive indices, a thread per (run, entry) with up to 32 loads in flight, each run summed in index order and the runs combined
+    // in a fixed order — a function of (nparts, w) alone, so every workgroup of the fused form and every rank gets the same bits.  (Until
+    // round 6: all w x w entries, two runs, 16 loads in flight: a chain of seven dependent load batches at 196 slabs, most of the kernel.)
+    const int ne = w * (w + 1) / 2;
+    for (int it = t; it < ne * PQ_NSEG; it += 256) {
+      const int seg = it / ne, en = it - seg * ne;
+      // entry en of the upper triangle in column-major order: column j holds rows 0 .. j
+      int j = 0;
+      while ((j + 1) * (j + 2) / 2 <= en) ++j;
+      const int i = en - j * (j + 1) / 2;
+      const int u = j * w + i;
+      const int p0 = (int)((long)nparts * seg / PQ_NSEG), p1 = (int)((long)nparts * (seg + 1) / PQ_NSEG);
+      double sacc = 0.0;
       int p = p0;
-      for (; p + 16 <= p1; p += 16) {  // sixteen loads in flight, summed in index order
-        double v[16];
+      for (; p + 32 <= p1; p += 32) {
+        double v[32];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
+        for (int q = 0; q < 32; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s += v[q];
+        for (int q = 0; q < 32; ++q) sacc += v[q];
       }
-      for (; p + 4 <= p1; p += 4) {
-        double v[4];
+      for (; p + 8 <= p1; p += 8) {
+        double v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
+        for (int q = 0; q < 8; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s += v[q];
+        for (int q = 0; q < 8; ++q) sacc += v[q];
       }
-      for (; p < p1; ++p) s += pq_ld<COH>(&part[(size_t)p * (PQ_W * PQ_W) + u]);
-      if (half) X[i][j] = s;  // X is free until the inverse below
-      else G[i][j] = s;
+      for (; p < p1; ++p) sacc += pq_ld<COH>(&part[(size_t)p * (PQ_W * PQ_W) + u]);
+      L.S[seg][en] = sacc;
     }
     __syncthreads();
-    for (int o = t; o < w * w; o += 256) G[o / w][o % w] += X[o / w][o % w];
+    for (int en = t; en < ne; en += 256) {
+      int j = 0;
+      while ((j + 1) * (j + 2) / 2 <= en) ++j;
+      const int i = en - j * (j + 1) / 2;
+      const double g = (L.S[0][en] + L.S[1][en]) + (L.S[2][en] + L.S[3][en]);
+      G[i][j] = g;
+      G[j][i] = g;
+    }
     __syncthreads();
   }
   for (int o = t; o < PQ_W * PQ_W; o += 256) {
@@ -425,15 +450,18 @@ __device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts,
     sh_bad = 0;
   }
   __syncthreads();
-  for (int i = 0; i < w; ++i) {
-    const int rk = sh_rk;
-    double tj = 0.0;
-    if (t < w) {
-      tj = G[i][t];
-      for (int r = 0; r < rk; ++r) tj -= Rm[r][i] * Rm[r][t];
-    }
-    if (t == i) {
-      const double s = tj;
+  // Cholesky with column dropping and the triangular inverse: 2 w dependent steps, by wave 0 ALONE (w <= 32 columns = lanes) — the steps
+  // hand their values on through readlane and wave-ordered LDS accesses instead of two workgroup barriers each (round 6; the arithmetic and
+  // its order are those of rounds 1 - 5)
+  if (t < 64) {
+    int rk = 0, bad = 0;
+    for (int i = 0; i < w; ++i) {
+      double tj = 0.0;
+      if (t < w) {
+        tj = G[i][t];
+        for (int r = 0; r < rk; ++r) tj -= Rm[r][i] * Rm[r][t];
+      }
+      const double s = __shfl(tj, i);  // the pivot candidate: lane i's value, known to every lane
       double nrm = s > 0.0 ? sqrt(s) : 0.0;
       bool drop;
       if (pass == 1) {
@@ -442,35 +470,34 @@ __device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts,
       } else {
         drop = false;
         if (!(s > 0.0)) {
-          sh_bad = 1;
+          bad = 1;
           nrm = 1.0;
         }
       }
-      sh_nrm = drop ? 0.0 : nrm;
-    }
-    __syncthreads();
-    const double nrm = sh_nrm;
-    if (nrm != 0.0) {
-      if (t < w) Rm[rk][t] = (t >= i) ? tj / nrm : 0.0;
-      if (t == 0) {
-        piv[rk] = i;
-        sh_rk = rk + 1;
+      if (!drop && nrm != 0.0) {
+        if (t < w) Rm[rk][t] = (t >= i) ? tj / nrm : 0.0;
+        if (t == 0) piv[rk] = i;
+        ++rk;
       }
+      pq_wave_sync();
     }
-    __syncthreads();
-  }
-  const int rk = sh_rk;
-  // X = inverse of the rk x rk upper-triangular U(a, b) = Rm[a][piv[b]]; lane = column
-  if (t < rk) {
-    const int j = t;
-    X[j][j] = 1.0 / Rm[j][piv[j]];
-    for (int i = j - 1; i >= 0; --i) {
-      double s = 0.0;
-      for (int q = i + 1; q <= j; ++q) s += Rm[i][piv[q]] * X[q][j];
-      X[i][j] = -s / Rm[i][piv[i]];
+    if (t == 0) {
+      sh_rk = rk;
+      sh_bad = bad;
+    }
+    // X = inverse of the rk x rk upper-triangular U(a, b) = Rm[a][piv[b]]; lane = column
+    if (t < rk) {
+      const int j = t;
+      X[j][j] = 1.0 / Rm[j][piv[j]];
+      for (int i = j - 1; i >= 0; --i) {
+        double sacc = 0.0;
+        for (int q = i + 1; q <= j; ++q) sacc += Rm[i][piv[q]] * X[q][j];
+        X[i][j] = -sacc / Rm[i][piv[i]];
+      }
     }
   }
   __syncthreads();
+  const int rk = sh_rk;
   // T (w x rk, col-major): rows at the pivot columns hold X
   for (int o = t; o < rk * rk; o += 256) {
     const int cc = o / rk, a = o - cc * rk;
@@ -578,131 +605,6 @@ __global__ __launch_bounds__(256) void pqr_apply_gram_k(const float* F, uint64_t
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// The whole CholQR2 of a panel in ONE launch (n <= 512 x number of CUs rows; opt-in, see k_panel_qr_kernels).  One workgroup per 512 rows keeps its rows in LDS from the first read to the last write;
-// the two all-to-all dependencies (the summed Gram matrices) are grid barriers (gridbar.h), after which EVERY workgroup repeats the
-// small factor step on the same partial sums in the same order — cheaper than a third barrier to broadcast it.  Slab partition,
-// summation orders and formulas are those of the kernels above, so both forms give the same bits (the ranks of a multi-GPU job
-// may fall back independently).  Workgroup 0 also writes the side outputs (rank, status, pivots, T, R).
-// ------------------------------------------------------------------------------------------
-struct PqFusedLds {
-  float Ft[PQ_SUB][PQ_W][PQ_ROWS + 1];
-  PqFactorLds fac;
-  double R1[PQ_W * PQ_W];
-  float T[PQ_W * PQ_W];
-  float Rout[PQ_W * PQ_W];
-  int meta[2 + PQ_W];
-};
-__device__ inline void pq_gram_slab(const float (*Ft)[PQ_ROWS + 1], int w, double acc[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int o = threadIdx.x + 256 * q;
-    if (o >= w * w) break;
-    const int i = o / w, j = o - i * w;
-    if (j < i) continue;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains, combined in a fixed order (as pqr_gram_k)
-#pragma unroll 4
-    for (int r = 0; r < PQ_ROWS; r += 4) {
-      s0 = fma((double)Ft[i][r], (double)Ft[j][r], s0);
-      s1 = fma((double)Ft[i][r + 1], (double)Ft[j][r + 1], s1);
-      s2 = fma((double)Ft[i][r + 2], (double)Ft[j][r + 2], s2);
-      s3 = fma((double)Ft[i][r + 3], (double)Ft[j][r + 3], s3);
-    }
-    acc[q] += (s0 + s1) + (s2 + s3);
-  }
-}
-__device__ inline void pq_store_part(double* out, int w, const double acc[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int o = threadIdx.x + 256 * q;
-    if (o >= w * w) break;
-    const int i = o / w, j = o - i * w;
-    if (j >= i) __hip_atomic_store(&out[j * w + i], acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by other workgroups after the barrier
-  }
-}
-__global__ __launch_bounds__(256) void pqr_fused_k(const float* __restrict__ F, uint64_t n, int w, float* __restrict__ Q,
-                                                    double* part /*2 x nparts x PQ_W*PQ_W*/, int nparts, double* __restrict__ R1g,
-                                                    int* __restrict__ meta_g, float* __restrict__ Tg, float* __restrict__ Rout_g,
-                                                    unsigned int* __restrict__ bar, unsigned int bar_base, unsigned int* __restrict__ abort) {
-  extern __shared__ __align__(16) unsigned char pqf_raw[];
-  PqFusedLds& L = *reinterpret_cast<PqFusedLds*>(pqf_raw);
-  const int t = threadIdx.x;
-  const unsigned int G = gridDim.x;
-  // ---- pass 1: this workgroup's slabs into LDS, their partial Gram matrix
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int sub = 0; sub < PQ_SUB; ++sub) {
-    const uint64_t r0 = ((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS;
-    const int rc = r0 < n ? (int)min((uint64_t)PQ_ROWS, n - r0) : 0;
-    for (int idx = t; idx < w * PQ_ROWS; idx += 256) {
-      const int j = idx / PQ_ROWS, r = idx - j * PQ_ROWS;
-      L.Ft[sub][j][r] = (r < rc) ? F[(uint64_t)j * n + r0 + r] : 0.f;
-    }
-  }
-  __syncthreads();
-  for (int sub = 0; sub < PQ_SUB; ++sub)
-    if (((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS < n) pq_gram_slab(L.Ft[sub], w, acc);
-  pq_store_part(part + (size_t)blockIdx.x * (PQ_W * PQ_W), w, acc);
-  if (!gb_barrier(bar, bar_base + G, abort)) {
-    if (blockIdx.x == 0 && t == 0) meta_g[1] = 2;
-    return;
-  }
-  pq_factor<true>(L.fac, part, nparts, w, 1, L.R1, L.meta, L.T, L.Rout);
-  __syncthreads();
-  const int rk = L.meta[0];
-  // ---- Q1 = F T in place (a thread owns one row of each slab), partial Gram matrix of Q1
-  acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-  for (int sub = 0; sub < PQ_SUB; ++sub) {
-    if (((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS >= n) break;
-    float f[PQ_W];
-#pragma unroll
-    for (int j = 0; j < PQ_W; ++j) f[j] = (j < w) ? L.Ft[sub][j][t] : 0.f;
-    for (int cc = 0; cc < rk; ++cc) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int j = 0; j < PQ_W; ++j)
-        if (j < w) sacc = fmaf(f[j], L.T[cc * w + j], sacc);
-      L.Ft[sub][cc][t] = sacc;  // rows beyond n were zero and stay zero
-    }
-  }
-  __syncthreads();
-  for (int sub = 0; sub < PQ_SUB; ++sub)
-    if (((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS < n) pq_gram_slab(L.Ft[sub], rk, acc);
-  double* part2 = part + (size_t)nparts * (PQ_W * PQ_W);
-  pq_store_part(part2 + (size_t)blockIdx.x * (PQ_W * PQ_W), rk, acc);
-  if (blockIdx.x == 0) {  // side outputs of pass 1 (the unfused form leaves them in global memory too)
-    for (int o = t; o < PQ_W * PQ_W; o += 256) R1g[o] = L.R1[o];
-    if (t < 2 + PQ_W) meta_g[t] = L.meta[t];
-  }
-  if (!gb_barrier(bar, bar_base + 2 * G, abort)) {
-    if (blockIdx.x == 0 && t == 0) meta_g[1] = 2;
-    return;
-  }
-  // ---- pass 2
-  pq_factor<true>(L.fac, part2, nparts, w, 2, L.R1, L.meta, L.T, L.Rout);
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    for (int o = t; o < PQ_W * PQ_W; o += 256) {
-      Tg[o] = L.T[o];
-      if (o < rk * w) Rout_g[o] = L.Rout[o];
-    }
-    if (t == 0) meta_g[1] = L.meta[1];
-  }
-  for (int sub = 0; sub < PQ_SUB; ++sub) {
-    const uint64_t r = ((uint64_t)blockIdx.x * PQ_SUB + sub) * PQ_ROWS + t;
-    if (r >= n) break;
-    float f[PQ_W];
-#pragma unroll
-    for (int j = 0; j < PQ_W; ++j) f[j] = (j < rk) ? L.Ft[sub][j][t] : 0.f;
-    for (int cc = 0; cc < rk; ++cc) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int j = 0; j < PQ_W; ++j)
-        if (j < rk) sacc = fmaf(f[j], L.T[cc * rk + j], sacc);
-      Q[(uint64_t)cc * n + r] = sacc;
-    }
-  }
-}
-
 // F: n x w (device, destroyed).  Q: n x rank at Qdst.  R_host: room for w*w floats, rank x w as [j*rank + r].
 // Kernels only.  meta_dev (2 + PQ_W ints: rank, status, pivots) and Rout_dev (rank x w, leading dimension rank) are device
 // buffers of the caller's choice, so that a pipelined caller can fetch them, together with whatever else it needs from the
@@ -714,25 +616,9 @@ int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, in
   HIPCHK(c, c->pq_part.reserve((size_t)2 * nparts * PQ_W * PQ_W));
   HIPCHK(c, c->pq_R1.reserve(PQ_W * PQ_W));
   HIPCHK(c, c->pq_T.reserve(2 * PQ_W * PQ_W));
-  // Opt-in (ISLE_QR_FUSED=1): measured at C2 / C3 shard the one launch takes as long as the five (79 against 75 us of kernel time plus
-  // four 5-us gaps) — the chain is not launch latency but the two serial factor steps (15 us each: a 98- to 196-way sum of partial
-  // Gram matrices and a 10-step fp64 Cholesky), which every workgroup now repeats behind agent-scope loads.  It saves 240 launches per
-  // C2 step and no time, so the form without grid barriers stays the default.  Read per call: the parity test switches forms.
-  const char* fq = c->knob(KN_QR_FUSED);
-  const bool fused_on = fq && atoi(fq) != 0;
-  if (fused_on && !c->pq_fused_failed && nparts <= c->num_cus) {  // every workgroup resident: one per CU
-    if (!c->pq_bar.p) {
-      HIPCHK(c, c->pq_bar.reserve(2));
-      HIPCHK(c, hipMemsetAsync(c->pq_bar.p, 0, 2 * sizeof(unsigned int), c->stream));
-      c->pq_bar_count = 0;
-    }
-    ISLECHK(isle_max_lds(c, (const void*)pqr_fused_k, (int)sizeof(PqFusedLds)));
-    hipLaunchKernelGGL(pqr_fused_k, dim3(nparts), dim3(256), sizeof(PqFusedLds), c->stream, F, n, w, Qdst, c->pq_part.p, nparts, c->pq_R1.p, meta_dev,
-                       c->pq_T.p, Rout_dev, c->pq_bar.p, c->pq_bar_count, c->pq_bar.p + 1);
-    HIPCHK(c, hipGetLastError());
-    c->pq_bar_count += 2u * (unsigned int)nparts;  // the counter only grows (wraps with the kernel's signed comparison)
-    return 0;
-  }
+  // (A one-launch form of the whole CholQR2 — rows resident in LDS, two grid barriers, every workgroup repeating the factor step — was
+  // measured in rounds 1, 2 and 6: 83 / 79 / 91 us per QR against 78 / 75 / 76 for this chain, whose launches follow each other without
+  // gaps; removed in round 6.)
   const dim3 rows(cdiv((long)n, 256));
   hipLaunchKernelGGL(pqr_gram_k, dim3(nparts), dim3(256), 0, c->stream, F, n, w, (const int*)nullptr, c->pq_part.p);
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 1, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
@@ -740,13 +626,6 @@ int k_panel_qr_kernels(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, in
   hipLaunchKernelGGL(pqr_factor_k, dim3(1), dim3(256), 0, c->stream, c->pq_part.p, nparts, w, 2, c->pq_R1.p, meta_dev, c->pq_T.p, Rout_dev);
   hipLaunchKernelGGL(pqr_apply_k, rows, dim3(256), 0, c->stream, Qdst, n, w, 2, c->pq_T.p, meta_dev, Qdst);
   HIPCHK(c, hipGetLastError());
-  return 0;
-}
-// The persistent form gave up at a grid barrier (a workgroup not resident within the spin limit): nothing was written but the status.
-// Clears the abort flag and switches this context to the five-kernel form.
-int k_panel_qr_fused_lost(isle_ctx* c) {
-  c->pq_fused_failed = true;
-  if (c->pq_bar.p) HIPCHK(c, hipMemsetAsync(c->pq_bar.p + 1, 0, sizeof(unsigned int), c->stream));
   return 0;
 }
 int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_host, int* rank_out) {
@@ -758,13 +637,6 @@ int k_panel_qr(isle_ctx* c, float* F, uint64_t n, int w, float* Qdst, float* R_h
   HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (meta[1] == 2) {  // F is untouched: once more with the five kernels
-    ISLECHK(k_panel_qr_fused_lost(c));
-    ISLECHK(k_panel_qr_kernels(c, F, n, w, Qdst, c->pq_meta.p, Rout));
-    HIPCHK(c, hipMemcpyAsync(meta, c->pq_meta.p, sizeof(meta), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(R_host, Rout, (size_t)w * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
   if (meta[1]) return isle_fail(c, ISLE_E_NUMERIC, "CholQR2: second Gram matrix not positive definite");
   *rank_out = meta[0];
   return 0;

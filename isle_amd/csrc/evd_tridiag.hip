@@ -223,7 +223,6 @@ constexpr size_t TD_P_LDS = 160 * 1024 - 512;  // dynamic part: the kernel also 
 
 __device__ inline double td_ld(const double* p) { return gb_ld(p); }
 __device__ inline void td_st(double* p, double v) { gb_st(p, v); }
-__device__ inline bool td_grid_barrier(unsigned int* ctr, unsigned int target, unsigned int* abort) { return gb_barrier(ctr, target, abort); }
 
 // Reflector of a column held in LDS (cn[r0 - 1 .. n - 1], cn[r0 - 1] the diagonal entry): the formulas of td_step_dev.  Every
 // workgroup runs this on the same data in the same order, so v and tau are bit-identical everywhere without a broadcast.
@@ -252,9 +251,12 @@ __device__ inline double td_p_reflector(const double* cn, double* vs, int n, int
   return tv;
 }
 
+// HIER: the hierarchical grid barrier (gridbar.h gbh_barrier; state block bar.st, zeroed by the host before the launch); otherwise the
+// one-counter barrier on bar.st[0] (ISLE_TD_FLATBAR=1: kept to time one against the other)
+template <bool HIER>
 __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
                                                         double* __restrict__ tau, double* __restrict__ xbuf /* 2 x (p | next column), 4 n */,
-                                                        unsigned int* __restrict__ ctr, unsigned int* __restrict__ abort) {
+                                                        const GbHierArgs bar, unsigned int* __restrict__ abort) {
   extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n
   __shared__ double sh[16];
   const int G = (int)gridDim.x;
@@ -294,9 +296,17 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       const double* col = slab + (size_t)(r0 / G) * n;
       for (int i = r0 + t; i < n; i += TD_P_T) td_st(cbuf + i, col[i]);
     }
-    if (!td_grid_barrier(ctr, ++phase * (unsigned int)G, abort)) return;
+    ++phase;
+    if (!(HIER ? gbh_barrier(bar, phase, abort) : gb_barrier(bar.st, phase * (unsigned int)G, abort))) return;
     if (cj % G == g)  // the reflector where td_back_k (a later launch) reads it
       for (int i = r0 + t; i < n; i += TD_P_T) A[(size_t)cj * n + i] = vs[i];
+    // the next column as published (read below, behind two block-wide sums): asked for now, its round trip to memory runs beside that of p
+    double cb[TD_P_MAXPT];
+#pragma unroll
+    for (int q = 0; q < TD_P_MAXPT; ++q) {
+      const int i = r0 + t + q * TD_P_T;
+      cb[q] = i < n ? td_ld(cbuf + i) : 0.0;
+    }
     // ---- w = p - tau/2 (p.v) v  (redundantly, same order everywhere)
     double dot = 0.0;
     for (int i = r0 + t; i < n; i += TD_P_T) {
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
 #pragma unroll
       for (int q = 0; q < TD_P_MAXPT; ++q) {
         const int i = r0 + t + q * TD_P_T;
-        cnr[q] = i < n ? td_ld(cbuf + i) - (vs[i] * wr + ws[i] * vr) : 0.0;
+        cnr[q] = i < n ? cb[q] - (vs[i] * wr + ws[i] * vr) : 0.0;
       }
     }
     // ---- rank-2 update of the owned columns
@@ -605,7 +615,8 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   const int ncb_max = (n + CB - 1) / CB;
   // workspace (doubles): A | part | w | d | e | tau | lam | Dp | Lf | Z ; then the check word
   const int nrb_max = TD_NRB;
-  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8 + 4 * (size_t)n + 8;
+  const size_t need = nn + (size_t)ncb_max * n + 7 * (size_t)n + 3 * (size_t)n * nvec + 16 + ((size_t)n * nrb_max + 1) / 2 + 8 + 4 * (size_t)n + 8 +
+                      (GBH_STATE_WORDS + GBH_LINE) / 2;  // + the persistent form's barrier state (128-byte aligned)
   HIPCHK(c, c->jacW.reserve(need));
   double* A = c->jacW.p;
   double* part = A + nn;
@@ -623,6 +634,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   unsigned int* tickets_rb = tickets + n + 2;
   // persistent form: 2 x (p | next column) behind the counters, rounded up to a double boundary
   double* pv = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tickets_rb + (size_t)n * nrb_max + 2) + 7) & ~(uintptr_t)7);
+  unsigned int* bar_state = reinterpret_cast<unsigned int*>((reinterpret_cast<uintptr_t>(pv + 4 * (size_t)n) + 127) & ~(uintptr_t)127);
   ISLECHK(isle_max_lds(c, (const void*)td_back_k<8>, TD_NMAX_BACK * 8 * (int)sizeof(double)));
   ISLECHK(isle_max_lds(c, (const void*)td_back_k<4>, TD_NMAX_BACK * 4 * (int)sizeof(double)));
   const bool small = n <= TD_ROWS * 4;
@@ -653,9 +665,18 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
     HIPCHK(c, hipMemsetAsync(worst, 0, ((size_t)n + 4 + (size_t)n * nrb_max + 4) * sizeof(unsigned int), c->stream));
     // ---- 1. tridiagonalisation
     if (persist) {
-      // one launch, matrix resident in LDS, two grid barriers per column (td_persist_k); tickets[0] = barrier counter, [1] = abort
-      ISLECHK(isle_max_lds(c, (const void*)td_persist_k, (int)TD_P_LDS));
-      hipLaunchKernelGGL(td_persist_k, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, tickets, tickets + 1);
+      // one launch, matrix resident in LDS, one grid barrier per column (td_persist_k); bar_state = the barrier's counters (zeroed per
+      // launch: all bases 0), tickets[1] = abort
+      GbHierArgs bar = {};
+      bar.st = bar_state;
+      HIPCHK(c, hipMemsetAsync(bar_state, 0, GBH_STATE_WORDS * sizeof(unsigned int), c->stream));
+      if (c->knob_on(KN_TD_FLATBAR)) {
+        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<false>, (int)TD_P_LDS));
+        hipLaunchKernelGGL(td_persist_k<false>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
+      } else {
+        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<true>, (int)TD_P_LDS));
+        hipLaunchKernelGGL(td_persist_k<true>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
+      }
       HIPCHK(c, hipGetLastError());
       if (const char* fb = c->knob(KN_TD_FORCE_BAIL_RANK)) {  // test hook: this rank behaves as if its barrier had timed out
         if (atoi(fb) == c->rank) {

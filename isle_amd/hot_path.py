@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import IsleHipError, load_library
 
 TIMING_FAMILIES = ["gram_pass1", "gram_pass2", "ortho", "qr", "evd", "rotate", "project", "kmpp", "lloyd_proj",
-                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post", "ingest", "infer"]
+                   "sparse_assign", "sparse_update", "op_build", "comm", "threshold", "post", "ingest", "infer", "lift"]
 
 BLOCK_KS_MAX_ITERS = 100      # include/hyperparams.h:38
 BLOCK_KS_BLOCK_SIZE = 10      # include/hyperparams.h:39
@@ -35,6 +35,29 @@ def catchword_rank(num_docs, num_topics, sample_rate=None):
 def model_rank_threshold(num_docs, num_topics):
     """rank_threshold of SparseMatrix::construct_topic_model (src/sparseMatrix.cpp:720)."""
     return int(EPS3_C * W0_C * float(np.float32(num_docs)) / (float(np.float32(num_topics)) * 2.0))
+
+
+EDGE_TOPIC_MIN_DOCS = 1            # include/hyperparams.h:77
+EDGE_TOPIC_PRIMARY_RATIO = 0.7     # include/hyperparams.h:79
+
+
+def select_edge_pairs(top1, top2, max_edge_topics, min_docs=EDGE_TOPIC_MIN_DOCS):
+    """Pair selection of ISLETrainer::construct_edge_topics_v2 (src/trainer.cpp:1116-1145), the host half of the edge-topic stage as
+    isle_amd/host/fpsparse_hip.h runs it: the documents' (top topic, second topic) pairs are counted, pairs with >= min_docs documents
+    are candidates, the max_edge_topics most frequent are kept (ties in the count by (primary, secondary) ascending — the reference's
+    sort is unstable there).  top1 / top2: int32 per document of A, -1 where the document has no such topic (construct_topic_model,
+    src/sparseMatrix.cpp:687-708).  -> int64 (n, 3): primary, secondary, documents."""
+    t1 = np.asarray(top1, np.int64)
+    t2 = np.asarray(top2, np.int64)
+    ok = (t1 >= 0) & (t2 >= 0)
+    if not ok.any():
+        return np.zeros((0, 3), np.int64)
+    base = int(max(t1.max(), t2.max())) + 1
+    key, cnt = np.unique(t1[ok] * base + t2[ok], return_counts=True)  # ascending (primary, secondary)
+    keep = cnt >= min_docs
+    key, cnt = key[keep], cnt[keep]
+    order = np.argsort(-cnt, kind="stable")[:max(int(max_edge_topics), 0)]
+    return np.stack([key[order] // base, key[order] % base, cnt[order]], axis=1).astype(np.int64)
 
 
 def _p(a):

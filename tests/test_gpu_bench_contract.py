@@ -11,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAMILIES = ["gram", "ortho", "project", "kmpp", "lloyd_proj", "sparse", "rotate", "lift"]
 KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
         "config", "roofline"]
 
@@ -26,6 +27,14 @@ def _check(stdout, n_gpus, steps):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # every kernel family with a SURVEY 8(d) figure carries its own roofline: algorithmic bytes / flops x the counts the run executed
+    fam = d["roofline_by_family"]
+    for f in FAMILIES:
+        assert f in fam, (f, sorted(fam))
+        v = fam[f]
+        assert v["bound"] in ("hbm", "mfma") and v["unit"] == ("GB/s" if v["bound"] == "hbm" else "TFLOP/s")
+        assert v["device_ms_per_step"] > 0 and v["achieved"] >= 0 and abs(v["frac"] - v["achieved"] / v["peak"]) < 2e-3
+    assert abs(fam["gram"]["frac"] - r["frac"]) < 0.05 + 0.5 * r["frac"]  # two measurements of one kernel (timed region / the extra pass)
     return d
 
 
@@ -74,3 +83,28 @@ def test_plain_gpus_2_without_two_gpus_fails_loudly():
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "needs 2 GPUs" in r.stderr
+
+
+def test_config4_flow_line():
+    """`--workload c4`'s flow at a size a test can run: A on the device, importance sampling there (checked against the CPU port bit for
+    bit inside bench.py — a difference ends the run), the hot path on the kept documents, docs/sec quoted on the documents of A."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4small", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 1, 1)
+    st = d["other_stages"]["input"]
+    assert all(st["identical_to_cpu_port"].values()) and st["docs_A"] == 200_000 and 20_000 <= st["docs_kept"] <= 20_001
+    assert "sample=1 sample_rate=0.10" in d["config"]["workload"]
+    assert abs(d["value"] - 200_000 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]  # the metric counts the documents of the input
+
+
+def test_config5_flow_line():
+    """`--workload c5`'s flow: device thresholding (sample = 0), hot path, then catchwords + topic model + edge topics as an other_stages leg
+    whose pair selection and edge columns bench.py holds against the CPU restatement."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5small", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, 1, 1)
+    e = d["other_stages"]["edge_topics"]
+    assert e["pairs_identical_to_oracle"] and 0 < e["num_edge_topics"] <= 300 and e["edge_columns_worst_rel_err"] <= 1e-5
+    assert all(d["other_stages"]["input"]["identical_to_cpu_port"].values())

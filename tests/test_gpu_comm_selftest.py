@@ -106,3 +106,15 @@ def test_a_collective_that_does_not_complete_becomes_an_error():
     env["ISLE_TEST_STALL_MS"] = "1500"
     r = subprocess.run([sys.executable, "-c", STALL], capture_output=True, text=True, env=env, timeout=300)
     assert "NO ERROR" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_comm_selftest_over_rccl_at_world_size_one():
+    """ISLE_COMM_SELFTEST=1 on the forced 1-rank RCCL communicator: every (operation, datatype, size class) the step issues runs once over
+    RCCL itself — ncclAllReduce sum / max and ncclAllGather on f32 / f64 / i32 / u32 / u64 from one element to 16 M — and is checked against
+    its closed-form result; the rank logs its device and PCI bus id.  (With more than one rank the self-test runs by default.)"""
+    env = dict(os.environ, ISLE_FORCE_COMM="1", ISLE_COMM_SELFTEST="1")
+    env.pop("ISLE_TEST_STALL_MS", None)
+    r = subprocess.run([sys.executable, "-c", STALL], capture_output=True, text=True, env=env, timeout=300)
+    assert "NO ERROR" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "rank 0 of 1: device 0 (PCI " in r.stderr and "RCCL " in r.stderr, r.stderr[-1500:]
+    assert "communicator self-test: 72 collectives" in r.stderr and "correct in" in r.stderr

@@ -79,10 +79,15 @@ def _default_route_against_the_oracle(hp, B, V, k, U, g, lp):
 
 
 def _run(hp, V, D, k, seed, n_pairs, n_sample):
-    from oracle.oracle import OracleCsc, lift
     from tools.synth import make_B
     B = make_B(V, D, k, seed)
     hp.upload_csc(V, B["vals"], B["rows"], B["offs"])
+    return _checks(hp, B, V, k, n_pairs, n_sample)
+
+
+def _checks(hp, B, V, k, n_pairs, n_sample):
+    """hp holds B (uploaded, or built on the device); B also on the host with B["planted"]."""
+    from oracle.oracle import OracleCsc, lift
     r = hp.compute_block_ks(k, seed=1, allow_noconv=True)
     assert r["rc"] == 0 and r["nconv"] == k and hp.operator_form() == 1
     U = hp.get_U(k)
@@ -217,3 +222,111 @@ def test_config3_at_its_own_size(hp, monkeypatch):
     assert agree >= 0.99999, agree
     # ... and the default route, step by step, against the oracle's arg-min (the k-means++ hand-over, a bounded iteration, the product through the projection)
     _default_route_against_the_oracle(hp, B, V, k, U, g, lp)
+
+
+def _need_host_memory(gb):
+    import psutil
+    if psutil.virtual_memory().available < gb * 1e9:
+        pytest.skip("needs ~%d GB of host memory" % gb)
+
+
+def test_config4_at_its_own_size(hp):
+    """BASELINE configs[3]: sample = 1, sample_rate = 0.1 on the 10 M-document corpus of configs[2].  The count matrix A (1.1 B entries) goes
+    to the device, normalize_docs + compute_thresholds + sampled_threshold_and_copy (src/trainer.cpp:430-485, src/sparseMatrix.cpp:1365-1435)
+    run there: the weights' prefix, 10 M keys rand_fraction()^(1/w), the pivot = the floor(0.1 D)-th largest key, original_cols of the kept
+    documents.  Under asserts: B, the kept-document map and the thresholds equal the CPU port's (tools/synth_corpus.cpp) bit for bit; then the
+    hot path on that B (about 1 M heavy documents, k = 1000) through every check of _checks — sigma bound through the oracle's operator, the
+    default route step by step against the oracle's arg-min, sample parity from injected seeds."""
+    _need_host_memory(50)
+    from tools.synth import Corpus
+    V, D, k, seed = 100_000, 10_000_000, 1000, 31337
+    corp = Corpus(V, D, k, seed)
+    cnt, rows, offs = corp.A_views()
+    nnz_A = int(cnt.shape[0])
+    assert nnz_A > 1_000_000_000  # beyond 2^30 entries
+    hp.upload_counts(V, cnt, rows, offs)
+    info = hp.threshold(k, sample_rate=0.1, sample_seed=seed)
+    B = hp.get_B()
+    del cnt, rows, offs
+    planted_all = corp.planted()
+    Bc = corp.threshold(k, free_A=True, sample_rate=0.1, sample_seed=seed)
+    assert info["docs_kept"] == Bc["D"] == B["D"] and info["nnz_kept"] == Bc["nnz"] == B["nnz"]
+    assert D // 10 <= B["D"] <= D // 10 + 1
+    for x in ("original_cols", "offs", "rows", "vals", "zetas"):
+        assert np.array_equal(B[x], Bc[x]), x
+    oc = B["original_cols"].astype(np.int64)
+    assert (np.diff(oc) > 0).all() and oc[-1] > 0.99 * D  # the kept documents in ascending order, drawn from the whole corpus
+    # importance sampling favours the heavy documents: the kept documents hold more entries each than the corpus's documents do before
+    # thresholding (at 200 000 documents: 106 against 105, and 96 in the unsampled B)
+    assert B["nnz"] / B["D"] > nnz_A / D, (B["nnz"] / B["D"], nnz_A / D)
+    del Bc, corp
+    B["planted"] = planted_all[oc]
+    r = _checks(hp, B, V, k, n_pairs=32, n_sample=15_000)
+    assert r["napplies"] == 200 + 100 * r["restarts"] and r["restarts"] <= 3
+
+
+def test_config5_at_its_own_size(hp):
+    """BASELINE configs[4]: edge_topics = 1, max_edge_topics = 5000 behind a config-3 hot path (src/trainer.cpp:673-685, :1116-1167;
+    top_topic_pairs from construct_topic_model, src/sparseMatrix.cpp:687-708) — at its own size: A on the device, B built there (equal to the
+    CPU port's bit for bit), one hot-path step at 10 M documents, then catchwords, the topic model (top-two topics of 10 M documents), the
+    pair selection over up to 10 M (top1, top2, doc) triples and the V x 5000 edge model (2 GB).  Checker oracle/isle_post_oracle.cpp:
+    catchword thresholds and catchwords bit for bit at full size, the pair selection (all pairs), the edge columns of the 64 most frequent
+    pairs, and the topic model with the top-two topics at full size."""
+    _need_host_memory(90)
+    from isle_amd.hot_path import select_edge_pairs
+    from oracle import oracle as O
+    from tools.synth import Corpus
+    V, D, k, seed = 100_000, 10_000_000, 1000, 31337
+    corp = Corpus(V, D, k, seed)
+    cnt, rows, offs = corp.A()  # copies: the CPU restatement of the downstream stage reads A after the port's thresholding has freed its own
+    hp.upload_counts(V, cnt, rows, offs)
+    info = hp.threshold(k)
+    B = hp.get_B()
+    Bc = corp.threshold(k, free_A=True)
+    for x in ("original_cols", "offs", "rows", "vals", "zetas"):
+        assert np.array_equal(B[x], Bc[x]), x
+    del Bc, corp
+    r = hp.compute_block_ks(k, seed=1, allow_noconv=True)
+    assert r["rc"] == 0 and r["nconv"] == k
+    g = hp.kmeans_init_on_projected_space(k, rng_seed=1)
+    lp = hp.run_lloyds_on_projected_space(k, g["C_lowd"])
+    hp.left_multiply_by_U(lp["C_lowd"], fetch=False)
+    ls = hp.run_lloyds(k, fetch_centers=False)
+    rk, rank_thr = O.catchword_rank(D, k), O.model_rank_threshold(D, k)
+    assert rk >= 1 and rank_thr >= 1
+    got = hp.find_catchwords(k, rk)  # the resident partition
+    tm = hp.construct_topic_model(k, rank_thr, D, fetch_sums=False)
+    pairs = select_edge_pairs(tm["top1"], tm["top2"], 5000)
+    assert pairs.shape[0] == 5000 and (pairs[:-1, 2] >= pairs[1:, 2]).all()
+    E = hp.edge_topics(pairs[:, :2])
+    assert E.shape == (V, 5000)
+    # --- the CPU restatement
+    cl = np.full(D, -1, np.int32)
+    cl[B["original_cols"].astype(np.int64)] = ls["assign"].astype(np.int32)
+    del B
+    nv = O.post_normalize(offs, cnt, info["avg_doc_sz"])
+    thr = O.post_catch_thresholds(V, offs, rows, nv, cl, k, rk)
+    np.testing.assert_array_equal(got["thresholds"], thr)
+    ct = O.post_find_catchwords(thr)
+    np.testing.assert_array_equal(got["catch_topic"], ct)
+    assert got["num_catchwords"] == int((ct >= 0).sum()) and got["num_catchwords"] > 5 * k
+    del thr, got
+    ref_pairs, ref_edge = O.post_edge_topics(tm["model"], tm["top1"], tm["top2"], 5000, want_edge=False)
+    np.testing.assert_array_equal(pairs, ref_pairs)
+    head_pairs, head_edge = O.post_edge_topics(tm["model"], tm["top1"], tm["top2"], 64)
+    np.testing.assert_array_equal(head_pairs, pairs[:64])
+    ok = np.isfinite(head_edge)
+    assert np.array_equal(np.isfinite(E[:, :64]), ok)
+    np.testing.assert_allclose(E[:, :64][ok], head_edge[ok], rtol=3e-7, atol=1e-12)
+    for t_ in (100, 2500, 4999):  # and columns beyond the oracle's head, by the formula of src/trainer.cpp:1152-1159
+        want = np.float32(0.7) * tm["model"][:, pairs[t_, 0]] + np.float32(1.0 - 0.7) * tm["model"][:, pairs[t_, 1]]
+        okc = np.isfinite(want)
+        np.testing.assert_allclose(E[okc, t_], want[okc], rtol=3e-7, atol=1e-12)
+    del E, head_edge
+    ref = O.post_topic_model(V, offs, rows, nv, cl, ct, k, rank_thr)
+    np.testing.assert_array_equal(tm["model_threshold"], ref["model_threshold"])
+    np.testing.assert_array_equal(tm["top1"], ref["top1"])
+    np.testing.assert_array_equal(tm["top2"], ref["top2"])
+    okm = np.isfinite(ref["model"])
+    assert np.array_equal(np.isfinite(tm["model"]), okm)
+    np.testing.assert_allclose(tm["model"][okm], ref["model"][okm], rtol=2e-5, atol=1e-9)  # fp32 sums in another order (tests/test_gpu_post.py)

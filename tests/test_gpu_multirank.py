@@ -27,11 +27,17 @@ from conftest import corpus
 from isle_amd import HotPath
 from tools.synth import Corpus
 
-hp = HotPath(0)
+rccl = os.environ.get("ISLE_TEST_RCCL") == "1"   # one GPU per rank and the product's own transport (needs `world` GPUs)
+hp = HotPath(rank if rccl else 0)
 if world > 1:
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% port, rank=rank, world_size=world)
-    hp.comm_init_host(world, rank, HotPath.gloo_exchange(dist, world, rank))
+    if rccl:
+        uid = [HotPath.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        hp.comm_init(world, rank, uid[0])
+    else:
+        hp.comm_init_host(world, rank, HotPath.gloo_exchange(dist, world, rank))
 res = {}
 
 # ---- thresholding on document shards: global statistics, B placed in the global column numbering
@@ -120,6 +126,7 @@ def _run(world, tmp, env=None, tag=""):
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "world %d rank %d failed:\n%s" % (world, r, (outs[r] if r < len(outs) else "")[-3000:])
+    _run.last_outputs = outs
     return [np.load(os.path.join(tmp, "w%d%s_r%d.npz" % (world, tag, r))) for r in range(world)]
 
 
@@ -141,6 +148,10 @@ def test_n_ranks_reproduce_one_rank(single, world, rowshard):
     GPU through the host-staged transport; over RCCL a collective that never completes ends in ISLE_E_COMM: test_gpu_comm_selftest.py.)"""
     tmp, one = single
     rs = _run(world, tmp, env={"ISLE_KS_ROWSHARD": rowshard} if rowshard else None, tag="rs" + str(rowshard))
+    _compare_with_one_rank(rs, one, world)
+
+
+def _compare_with_one_rank(rs, one, world):
     # replicated results: bit-identical on every rank
     for name in ("fro", "Z", "Z25", "evals", "restarts", "U", "free_seeds", "kmpp_C", "lp_C", "lp_it", "ls_cen", "ls_it", "thr_meta"):
         for r in rs[1:]:
@@ -195,3 +206,35 @@ def test_one_rank_bailing_out_of_the_persistent_evd_takes_all_ranks_along(single
     assert np.max(np.abs(rs[0]["evals"] - one["evals"]) / one["evals"]) <= 1e-5
     assert rs[0]["lp_it"][0] == one["lp_it"][0] and rs[0]["ls_it"][0] == one["ls_it"][0]
     assert (np.concatenate([r["ls_assign"] for r in rs]) == one["ls_assign"]).mean() >= 0.999
+
+
+def test_comm_selftest_through_the_host_transport(single):
+    """ISLE_COMM_SELFTEST=1: behind the communicator's creation every rank runs sum / max / all-gather of every (datatype, size class) the
+    step issues on patterns with known results and logs rank, device and PCI bus id (api.cpp comm_selftest; default on over RCCL with
+    more than one rank).  Here through the host-staged transport at two ranks: the same call sites, the same checks, and the run behind it
+    still reproduces the single-rank one."""
+    tmp, one = single
+    rs = _run(2, tmp, env={"ISLE_COMM_SELFTEST": "1"}, tag="selftest")
+    for r, o in enumerate(_run.last_outputs):
+        assert "rank %d of 2" % r in o and "communicator self-test: 72 collectives" in o and "correct in" in o, o[-1500:]
+        assert "host-staged test transport" in o
+    assert np.array_equal(rs[0]["U"], rs[1]["U"])
+    assert np.max(np.abs(rs[0]["evals"] - one["evals"]) / one["evals"]) <= 1e-5
+
+
+@pytest.mark.parametrize("rowshard", [None, "0"])
+def test_two_ranks_over_rccl(single, rowshard):
+    """The same comparison with the product's own transport: two ranks, one GPU each, RCCL all-reduce / all-gather (the communicator
+    self-test runs first, by default).  Needs two GPUs — the pool's boxes have one, where this test is skipped; until a box with two has
+    run it, the row-sharded orthogonalisation and the split EVD (the multi-rank defaults) are verified over the host-staged transport only
+    (DESIGN.md section 6 states that)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    tmp, one = single
+    env = {"ISLE_TEST_RCCL": "1", "ISLE_COMM_TIMEOUT_S": "60"}
+    if rowshard:
+        env["ISLE_KS_ROWSHARD"] = rowshard
+    rs = _run(2, tmp, env=env, tag="rccl" + str(rowshard))
+    _compare_with_one_rank(rs, one, 2)
+    assert all("communicator self-test: 72 collectives" in o for o in _run.last_outputs)

@@ -623,23 +623,6 @@ def test_operator_is_bitwise_reproducible_across_builds(hp, small50):
     assert np.array_equal(r1["evals"].view(np.uint32), r2["evals"].view(np.uint32))
 
 
-def test_persistent_panel_qr_gives_the_bits_of_the_five_kernel_form(hp, small50, monkeypatch):
-    """The panel QR of an expansion step runs as one persistent launch (pqr_fused_k: rows resident in LDS, two grid barriers) when
-    the panel has at most 512 x #CUs rows, else — or after a lost residency — as five kernels.  Ranks of a multi-GPU job may take
-    different forms, so both must produce identical bits: same slab partition, same summation orders, same formulas."""
-    B = small50
-    upload(hp, B)
-    monkeypatch.setenv("ISLE_QR_FUSED", "0")
-    r0 = hp.compute_block_ks(50, seed=7)
-    U0 = hp.get_U(50)
-    monkeypatch.setenv("ISLE_QR_FUSED", "1")
-    r1 = hp.compute_block_ks(50, seed=7)
-    U1 = hp.get_U(50)
-    assert r0["napplies"] == r1["napplies"] and r0["restarts"] == r1["restarts"]
-    assert np.array_equal(r0["evals"].view(np.uint32), r1["evals"].view(np.uint32))
-    assert np.array_equal(U0.view(np.uint32), U1.view(np.uint32))
-
-
 def test_kmeanspp_dice_thrown_on_the_device_pick_the_hosts_seeds(hp, small50, monkeypatch):
     """One rank: a round's dice are total x (host-drawn fraction); search_frac_k forms that product on the device, where the total
     lives, and searches it in the same launch (one host round trip per round).  The IEEE double product is the same on both sides,

@@ -99,6 +99,18 @@ class Corpus:
         return (_arr(L.synth_A_counts(self._h), self.nnz_A, np.float32), _arr(L.synth_A_rows(self._h), self.nnz_A, np.uint32),
                 _arr(L.synth_A_offs(self._h), self.D + 1, np.int64))
 
+    def A_views(self):
+        """The same three arrays WITHOUT copies: views onto the generator's buffers, valid while this object lives and A has not been freed
+        (threshold(free_A=True)).  For handing a 10 M-document A to the device without a second 9 GB host copy."""
+        L = _lib()
+
+        def view(ptr, n, dtype):
+            if n == 0:
+                return np.zeros(0, dtype)
+            return np.frombuffer((C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype, count=n)
+        return (view(L.synth_A_counts(self._h), self.nnz_A, np.float32), view(L.synth_A_rows(self._h), self.nnz_A, np.uint32),
+                view(L.synth_A_offs(self._h), self.D + 1, np.int64))
+
     def tdf_bytes(self):
         """The corpus as tdf text ("<doc> <word> <count>\\n", 1-based ids) in a uint8 array."""
         L = _lib()
