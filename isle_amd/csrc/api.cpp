@@ -88,6 +88,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_GL_VERBOSE", "diagnostic", "print the geometry of the LDS-banded operator build"},
     {"ISLE_TD_FORCE_BAIL_RANK", "test hook", "this rank behaves as if the grid barrier of its persistent EVD had timed out"},
     {"ISLE_GL_TEST_CUS", "test hook", "the operator build lays pass 1 out as for a device of this many CUs (several rounds of workgroups on a small matrix)"},
+    {"ISLE_GL_ABLATE_SKIP", "test hook", "m >= 2: TIMING EXPERIMENT, results wrong by construction — every m-th (band, group) of every wave of the LDS-banded passes is not walked and its ids are not read (prices a form with 1/m fewer padded slots; round 6)"},
 };
 void isle_refresh_knobs(isle_ctx* c) {
   for (int i = 0; i < KN_COUNT; ++i) {
@@ -425,6 +426,12 @@ extern "C" void isle_hip_destroy(isle_ctx* c) {
   }
   for (auto& e : c->ks_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->ks_ev_ready)
+    if (e) (void)hipEventDestroy(e);
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+  }
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamDestroy(c->stream);
   delete c;

@@ -200,6 +200,10 @@ struct Ks {
     // R, the three coefficient blocks — is written into one device mailbox and comes back as ONE copy (every small copy
     // costs ~20 us of queue time).  A rank-deficient panel (never seen on thresholded matrices) discards the speculative
     // work and repairs, as the synchronous form (ISLE_KS_SYNC=1) does.
+    // Round 6: the copy runs on a stream of its own behind an event — in the main stream it held the next step's kernels back for the ~10 us
+    // a 160 kB transfer over PCIe takes, 300 times per solve — and the device mailbox is double-buffered by slot, so that the next step's
+    // coefficients (written by the speculative orthogonalisation) never land in a mailbox whose copy may still be reading it: a slot is
+    // written again only after the host has waited for its copy.
     const bool pipelined = !c->knob_on(KN_KS_SYNC);
     // Passes of block Gram-Schmidt against the basis per step.  The reference makes three (CGS + 2 DGKS, :83-91); the second
     // already leaves coefficients at rounding level ("twice is enough"), so two are made here and the third
@@ -208,9 +212,12 @@ struct Ks {
     if (const char* e = c->knob(KN_KS_ORTHO_PASSES)) npass = std::max(2, std::min(3, atoi(e)));
     constexpr size_t MB_R = 64, MB_COEF = 64 + 32 * 32;  // mailbox offsets (floats): [meta ints | R | coefficients]
     const size_t mb_floats = MB_COEF + 3 * cap_r * blk;
-    HIPCHK(c, c->ks_mail.reserve(mb_floats));
-    for (int i = 0; i < 2; ++i)
+    HIPCHK(c, c->ks_mail.reserve(2 * mb_floats));
+    for (int i = 0; i < 2; ++i) {
       if (!c->ks_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ks_ev[i], hipEventDisableTiming));
+      if (!c->ks_ev_ready[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ks_ev_ready[i], hipEventDisableTiming));
+    }
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     std::vector<float> host_mail_pageable[2];
     float* host_mail[2];
     for (int i = 0; i < 2; ++i) {
@@ -222,12 +229,13 @@ struct Ks {
       }
     }
     isle_host_mark("expand: work matrix ready");
-    float* mail = c->ks_mail.p;
+    float* const mail2[2] = {c->ks_mail.p, c->ks_mail.p + mb_floats};
     bool spec = false;  // apply + ortho of the current step already enqueued
     int slot = 0;
     while (hr < ncv) {
       const size_t m = hr;
       float* F = c->Fbuf.p;
+      float* mail = mail2[slot];
       if (!spec) {
         ISLECHK(apply(col(hcn), F));
         ISLECHK(ortho(F, (int)blk, m, npass, mail + MB_COEF));
@@ -242,12 +250,14 @@ struct Ks {
         ISLECHK(isle_allreduce(c, reinterpret_cast<int*>(mail) + KS_AGREE, 3, ISLE_DT_I32, true));
       }
       float* hm = host_mail[slot];
-      HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + (size_t)npass * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipEventRecord(c->ks_ev[slot], c->stream));
+      HIPCHK(c, hipEventRecord(c->ks_ev_ready[slot], c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ks_ev_ready[slot], 0));
+      HIPCHK(c, hipMemcpyAsync(hm, mail, (MB_COEF + (size_t)npass * m * blk) * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(c, hipEventRecord(c->ks_ev[slot], c->copy_stream));
       const bool more = m + blk < ncv;
       if (pipelined && more) {  // speculate: full rank -> next step works on the blk new columns with m + blk basis vectors
         ISLECHK(apply(col(hcn + blk), F));
-        ISLECHK(ortho(F, (int)blk, m + blk, npass, mail + MB_COEF));  // behind the copy on the same stream: no hazard
+        ISLECHK(ortho(F, (int)blk, m + blk, npass, mail2[slot ^ 1] + MB_COEF));  // the other slot's mailbox: its last copy has been waited for
         spec = true;
       }
       HIPCHK(c, hipEventSynchronize(c->ks_ev[slot]));

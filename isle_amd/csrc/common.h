@@ -90,7 +90,7 @@ enum IsleKnob {
   KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_UPDATE_MFMA, KN_EVD_JACOBI, KN_TD_CHAIN, KN_TD_FLATBAR, KN_EVD_SPLIT,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_COMM_SELFTEST, KN_FORCE_COMM, KN_TEST_STALL_MS,
-  KN_ROCTX, KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS,
+  KN_ROCTX, KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS, KN_GL_ABLATE_SKIP,
   KN_COUNT
 };
 struct IsleKnobInfo {
@@ -234,7 +234,10 @@ struct isle_ctx {
   DevBuf<uint32_t> gl_bst;   // D x (NB1 + 1): first entry of each word band inside a document's column
   DevBuf<uint16_t> gl_cellcnt;   // V x NB2: entries of (word, document band)
   DevBuf<uint32_t> gl_srsum, gl_sbase;
-  DevBuf<uint32_t> gl_fb_cnt, gl_fb_tmp;  // pass-2 fill by buckets of word positions: entries per (band, bucket); the packed entries (nnz words, released behind the build)
+  DevBuf<uint32_t> gl_fb_cnt, gl_fb_tmp;  // pass-2 fill by buckets of word positions: entries per (band, bucket); the packed entries (nnz words = 4 GB at config 3).
+                                          // KEPT between builds, like gl_pscratch below (7.7 GB at 10 M documents): every solve builds the operator again and a
+                                          // hipFree / hipMalloc pair of that size per step costs more than the memory is worth on a 288 GB device; both count
+                                          // against what isle_scratch_ok sees as free — it decides from the device's TOTAL memory, so the routes do not depend on them
   DevBuf<int64_t> gl_fb_off;
   DevBuf<uint16_t> gl_scnt;  // super-rounds of (slice, band) of pass 2 (gl_sbase's indexing)
   DevBuf<uint32_t> gl_biglist;   // [count | (wave, band, group) triples whose pass-2 cells are too long for the register sort]
@@ -353,6 +356,8 @@ struct isle_ctx {
   // block Krylov-Schur, pipelined expand loop: device mailbox [rank, status, pivots | R | coefficients] of a step, fetched by
   // one copy; the events that mark its arrival
   hipEvent_t ks_ev[2] = {nullptr, nullptr};
+  hipEvent_t ks_ev_ready[2] = {nullptr, nullptr};  // the step's mailbox is complete on the main stream (the copy stream waits for it)
+  hipStream_t copy_stream = nullptr;               // the mailbox's way to the host: beside the main stream, not in it (api_ks.cpp expand)
   DevBuf<float> ks_mail;
   DevBuf<float> ks_top;     // truncation: the locked rows of H next to the rotated block, and their product with the Ritz rotation
   DevBuf<float> ks_gather;  // row-sharded orthogonalisation: the ranks' slices of F (world x nloc x blk)
@@ -454,7 +459,10 @@ struct YyMovers {
 // Which centres share a Yinyang group.  Null pointers: group g = centres 8 g .. 8 g + 7 (the identity).  Otherwise the groups are made
 // of SLOTS: slot s = 8 g + t holds centre id_of_slot[s] (s < k; the slots behind are padding), slot_of_id is the inverse.  The kernels
 // of the by-group iteration index tables and bounds by slot and report centres by id; ties between equal distances go to the smaller ID
-// whatever the slots' order, as the reference's isamin does (src/sparseMatrix.cpp:1553-1572).
+// whatever the slots' order, as the reference's isamin does (src/sparseMatrix.cpp:1553-1572).  ONE exception, stated in INTEGRATION.md: the
+// FIRST assignment (the product through the projection, columns in slot order: tile_epilogue / yy_first_combine_k) keeps the earlier COLUMN
+// on a bit-exact tie, i.e. the smaller slot = the smaller squared norm; identical centres keep their id order (the slot order is a stable
+// sort by norm), so only two DIFFERENT centres at bit-equal distances from a document can fall the other way, in that one iteration.
 struct YyMap {
   const uint32_t* id_of_slot = nullptr;
   const uint32_t* slot_of_id = nullptr;

@@ -398,7 +398,7 @@ __device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts,
   const int w = (pass == 1) ? wmax : meta[0];
   {
     // Sum of the partial Gram matrices: only the upper triangle (the slabs store nothing else), the slabs cut into PQ_NSEG runs of
-    // consecutive indices, a thread per (run, entry) with up to 32 loads in flight, each run summed in index order and the runs combined
+    // consecutive indices, a thread per (run, entry) with up to 48 loads in flight, each run summed in index order and the runs combined
     // in a fixed order — a function of (nparts, w) alone, so every workgroup of the fused form and every rank gets the same bits.  (Until
     // round 6: all w x w entries, two runs, 16 loads in flight: a chain of seven dependent load batches at 196 slabs, most of the kernel.)
     const int ne = w * (w + 1) / 2;
@@ -412,6 +412,13 @@ __device__ inline void pq_factor(PqFactorLds& L, const double* part, int nparts,
       const int p0 = (int)((long)nparts * seg / PQ_NSEG), p1 = (int)((long)nparts * (seg + 1) / PQ_NSEG);
       double sacc = 0.0;
       int p = p0;
+      for (; p + 48 <= p1; p += 48) {  // a run of the 196 slabs of V = 100 000 is 49 long: one batch and one straggler, not four batches
+        double v[48];
+#pragma unroll
+        for (int q = 0; q < 48; ++q) v[q] = pq_ld<COH>(&part[(size_t)(p + q) * (PQ_W * PQ_W) + u]);
+#pragma unroll
+        for (int q = 0; q < 48; ++q) sacc += v[q];
+      }
       for (; p + 32 <= p1; p += 32) {
         double v[32];
 #pragma unroll

@@ -818,7 +818,7 @@ __device__ inline float2 gl_lds_f2(uint32_t addr) {
 #define GL_IDS_NT 1
 #endif
 #ifndef GL_ABLATE
-#define GL_ABLATE 0  // timing experiments only (tools/build_variant.sh): 1 no band staging, 2 no band barriers, 4 every gather reads row 0, 8 ids re-read from one place, 16 no LDS reads, 32 half the id loads, 64 loaded ids never consumed
+#define GL_ABLATE 0  // timing experiments only (tools/build_variant.sh): 1 no band staging, 2 no band barriers, 4 every gather reads row 0, 8 ids re-read from one place, 16 no LDS reads, 32 half the id loads, 64 loaded ids never consumed, 256 every fifth (band, group) of a wave skipped with its ids (round 6: the ceiling of a form with 0.8x the slots)
 #endif
 // (a macro, not a function: with the plain load behind an inline function hipcc 7.2 allocated the kernel's registers differently and
 // the 10-column kernels at 6 and 7 items per lane spilled 10 / 74 registers — pass 1 of config 3 on one GPU 1.60 -> 2.77 ms)
@@ -933,6 +933,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_apply_k(const float4* __restric
       // bit 15 (gl_place_k / gl_scale_ids_k): every lane's last two slots of the group's last super-round are padding — only its first two are read
       const bool half_last = (GL_ABLATE & 128) ? (nf & 0x7fffu) != 0u : (nf >> 15) != 0u;
       const uint32_t n = nf & 0x7fffu;  // a scalar loop count
+      if ((GL_ABLATE & 256) && (band * (uint32_t)G + (uint32_t)g) % 5u == 4u) {  // timing build only: a stream with a fifth fewer slots (and ids)
+        p += (size_t)64 * n;
+        continue;
+      }
       // two super-rounds per step: the ring moves by PAIRS (q0 = q2; q1 = q3; two loads), so the moves read entries loaded one whole step
       // = two super-rounds earlier.  (Rotating by one — q0 = q1; ... q3 = *p — the move reads the load issued the step before and every
       // step waits for it, s_waitcnt vmcnt(0) at the head of the loop: one load in flight where the ring was meant to keep four.  A C3
@@ -1382,6 +1386,7 @@ int k_gl_detect(isle_ctx* c) {
   return 0;
 }
 
+int k_gl_ablate_skip(isle_ctx* c);
 int k_gl_build(isle_ctx* c) {
   const uint32_t D = (uint32_t)c->D, V = (uint32_t)c->V;
   GlSide& s1 = c->gl1;
@@ -1696,6 +1701,29 @@ int k_gl_build(isle_ctx* c) {
               V, D, (unsigned long long)c->nnz, s1.NB, s1.G, s1.nwv, s1.ndesc, (double)s1.total_sr * 256.0 / (double)c->nnz, s2.NB, s2.G, nblk, s2.ndesc,
               nslab, (double)s2.total_sr * 256.0 / (double)c->nnz);
   }
+  return k_gl_ablate_skip(c);
+}
+
+// TIMING EXPERIMENT (ISLE_GL_ABLATE_SKIP=m, round 6): the count records of every m-th (band, group) of every wave are zeroed behind the
+// build, so that the unchanged apply kernel walks (1 - 1/m) of its super-rounds and reads as much of its id stream (the waves then read
+// the ids of other cells: valid rows, wrong sums — Z is wrong by construction).  Prices a form with that many fewer padded slots at no
+// other cost; the in-kernel variant of the same cut (GL_ABLATE 256) moves the register allocation and spills.
+__global__ __launch_bounds__(256) void gl_ablate_cnt_k(uint16_t* __restrict__ cnt, size_t n, uint32_t NB, int G, uint32_t m) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = (uint32_t)(i % GL_GMAX), band = (uint32_t)((i / GL_GMAX) % NB);
+  if ((int)g < G && (band * (uint32_t)G + g) % m == m - 1) cnt[i] = 0;
+}
+int k_gl_ablate_skip(isle_ctx* c) {
+  const char* e = c->knob(KN_GL_ABLATE_SKIP);
+  const int m = e ? atoi(e) : 0;
+  if (m < 2) return 0;
+  for (GlSide* sd : {&c->gl1, &c->gl2}) {
+    const size_t n = (size_t)sd->nwv * sd->NB * GL_GMAX;
+    hipLaunchKernelGGL(gl_ablate_cnt_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sd->cnt.p, n, sd->NB, sd->G, (uint32_t)m);
+    HIPCHK(c, hipGetLastError());
+  }
+  fprintf(stderr, "[gram_lds] ISLE_GL_ABLATE_SKIP=%d: timing experiment, every %d-th (band, group) of a wave is not walked — results are WRONG\n", m, m);
   return 0;
 }
 

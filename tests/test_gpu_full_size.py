@@ -251,7 +251,9 @@ def test_config4_at_its_own_size(hp):
     planted_all = corp.planted()
     Bc = corp.threshold(k, free_A=True, sample_rate=0.1, sample_seed=seed)
     assert info["docs_kept"] == Bc["D"] == B["D"] and info["nnz_kept"] == Bc["nnz"] == B["nnz"]
-    assert D // 10 <= B["D"] <= D // 10 + 1
+    # every document whose key reaches the pivot is kept (src/sparseMatrix.cpp:1409-1421): floor(0.1 D) + 1 of them, plus the documents whose
+    # keys TIE with the pivot — rand() has 2^31 values and the keys are rounded to fp32, so a few dozen of 10 M do (first seen: 1 000 038)
+    assert D // 10 + 1 <= B["D"] <= D // 10 + 200, B["D"]
     for x in ("original_cols", "offs", "rows", "vals", "zetas"):
         assert np.array_equal(B[x], Bc[x]), x
     oc = B["original_cols"].astype(np.int64)
@@ -329,4 +331,6 @@ def test_config5_at_its_own_size(hp):
     np.testing.assert_array_equal(tm["top2"], ref["top2"])
     okm = np.isfinite(ref["model"])
     assert np.array_equal(np.isfinite(tm["model"]), okm)
-    np.testing.assert_allclose(tm["model"][okm], ref["model"][okm], rtol=2e-5, atol=1e-9)  # fp32 sums in another order (tests/test_gpu_post.py)
+    # fp32 sums in another order (atomics): 2e-5 holds on the reduced shapes of tests/test_gpu_post.py; a topic vector of config 3 adds ~10 000
+    # documents, where 287 of the 10^8 entries were seen beyond it (the largest at 2.4e-5)
+    np.testing.assert_allclose(tm["model"][okm], ref["model"][okm], rtol=6e-5, atol=1e-9)
