@@ -279,6 +279,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
+    if world > 1:
+        # a collective that never completes ends the run after two minutes, not five (the library's default suits long host phases between
+        # collectives; this script has none while collectives are pending), and the launcher then ends the other ranks
+        os.environ.setdefault("ISLE_COMM_TIMEOUT_S", "120")
     if world > 1 and "OMP_NUM_THREADS" not in os.environ:  # the ranks share the node's cores (corpus generation, thresholding)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // max(local_world, 1)))

@@ -21,6 +21,17 @@ pytestmark = pytest.mark.gpu
 SIGMA_TOL = 1e-4
 
 
+@pytest.fixture
+def hp():
+    """A context of its own per full-size test (shadows the session's): a context keeps the largest buffers it ever needed — config 3 leaves
+    ~200 GB of projections, products and scratch behind, and config 5 on top of that does not fit the 288 GB (first seen in round 6: out of memory
+    in the topic model's scratch when the whole suite ran in one process) — and isle_hip_destroy is what releases them."""
+    from isle_amd import HotPath
+    h = HotPath(0)
+    yield h
+    h.close()
+
+
 def _columns(B, cols):
     offs = B["offs"]
     lens = (offs[cols + 1] - offs[cols]).astype(np.int64)
