@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ V
 // 16 MFMAs on two alternating accumulators.  fp32 inside a chunk, fp64 across chunks (vtf_reduce_k).  The fp64 Gram
 // matrix of the panel QR keeps the fp64 VALU kernel above.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+// (Round 6 tried twice the loads in flight per lane in this kernel and in update_mfma_k — two 64-row groups / two 128-column tiles per trip, the
+// MFMAs in the same order, bit-equal sums: 132 -> 143 ms of orthogonalisation per step at a C3 shard.  The registers it takes cost more
+// occupancy than the deeper queue buys; removed.)
 constexpr int VM_RC = 1024;
 __global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, uint64_t ld, int m, const float* __restrict__ F, int b,
                                                    int BT, double* __restrict__ part /*[chunk][m][BT]*/) {
