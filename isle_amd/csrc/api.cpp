@@ -561,6 +561,20 @@ extern "C" int isle_hip_plan_shards(uint64_t num_docs, const int64_t* offs, int 
 // ------------------------------------------------------------------------------------------
 // upload
 // ------------------------------------------------------------------------------------------
+// A context keeps its buffers at the largest size it ever needed (no allocation inside a solve).  Six of them scale with D x k or nnz and
+// reach 40 GB each at config 3; when a matrix arrives for which they could never be needed at that size (k <= 2048, so the projection is at
+// most 2048 D floats, ...) they are released, so that a context that has held config 3 can go on to another large corpus without running
+// out of the 288 GB (round 6: the topic model of config 5 behind config 3 in one process).  Their contents are void at this point anyway.
+void isle_trim_derived(isle_ctx* c, uint64_t D, uint64_t nnz) {
+  const size_t d = (size_t)std::max<uint64_t>(D, 1), z = (size_t)std::max<uint64_t>(nnz, 1);
+  if (c->P.cap > 2048 * d) c->P.release();
+  if (c->Pt.cap > 2048 * d) c->Pt.release();
+  if (c->Pt2.cap > 512 * d) c->Pt2.release();        // 16-byte units: 4 k D bytes
+  if (c->dotsT.cap > 2048 * d) c->dotsT.release();
+  if (c->gl_pscratch.cap > 512 * d) c->gl_pscratch.release();  // sixteen slabs of 12 floats per document + norm partials
+  if (c->gl_fb_tmp.cap > 2 * z) c->gl_fb_tmp.release();
+}
+
 static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, const float* vals, const uint32_t* rows32,
                          const int64_t* offs, uint64_t doc_offset, uint64_t docs_global) {
   if (!c) return ISLE_E_ARG;
@@ -586,6 +600,7 @@ static int upload_common(isle_ctx* c, uint64_t V, uint64_t D, uint64_t nnz, cons
   c->p_model_ready = false;
   c->b_from_threshold = false;
   c->kmpp_track_k = 0;
+  isle_trim_derived(c, D, nnz);
   c->V = V;
   c->D = D;
   c->nnz = nnz;

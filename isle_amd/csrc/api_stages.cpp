@@ -242,6 +242,7 @@ extern "C" int isle_hip_threshold(isle_ctx* c, uint64_t num_topics, double sampl
     }
   }
 
+  isle_trim_derived(c, Db, bnnz);
   c->V = V;
   c->D = Db;
   c->nnz = bnnz;

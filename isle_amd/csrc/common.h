@@ -377,6 +377,9 @@ struct isle_ctx {
 };
 
 int isle_fail(isle_ctx* c, int code, const char* fmt, ...);
+// A new matrix of D documents and nnz entries replaces the context's: the largest derived buffers (projection and its copies, product scratch,
+// build scratch) are released where they are sized for a far larger matrix — everything derived from the old one is void anyway (api.cpp)
+void isle_trim_derived(isle_ctx* c, uint64_t D, uint64_t nnz);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context = device, kernel, size): api.cpp
 int isle_max_lds(isle_ctx* c, const void* fn, int bytes);
 bool isle_scratch_ok(isle_ctx* c, size_t have_elems, double bytes);
