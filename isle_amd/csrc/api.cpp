@@ -52,7 +52,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_UPDATE_MFMA", "form", "0: the orthogonalisation's update F -= V H by FMA chains with the coefficients read from LDS (update_k) instead of on the matrix cores (same sums in another order)"},
     {"ISLE_EVD_JACOBI", "form", "small symmetric EVD by block Jacobi instead of tridiagonalisation"},
     {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},
-    {"ISLE_TD_FLATBAR", "tuning", "1: the persistent tridiagonalisation crosses its grid barriers on one counter (gb_barrier) instead of the hierarchical barrier (gbh_barrier, gridbar.h); same bits"},
+    {"ISLE_TD_BAR", "tuning", "flat | hier: the persistent tridiagonalisation crosses its grid barriers on one counter (gb_barrier) or through the hierarchical barrier (gbh_barrier) instead of the sharded counters polled together (gbs_barrier, gridbar.h; round 6: 36.4 / 37.0 / 40.7 ms per EVD at n = 2000 sharded / hier / flat); same bits"},
     {"ISLE_EVD_SPLIT", "form", "0: with several ranks every rank computes all eigenvectors of the small EVD (default: rank r the vectors [r kc, (r + 1) kc) — eigenvectors of the tridiagonal matrix and their back-transformation — followed by an all-gather; the same bits on every rank)"},
     {"ISLE_KMPP_HOST_DICE", "form", "k-means++ dice scaled and searched through the host round trip (the multi-rank form) on one rank too"},
     {"ISLE_KMPP_SPARSE", "form", "0 / 1: k-means++ rounds on the projection / through thin products of B (default: by cost)"},

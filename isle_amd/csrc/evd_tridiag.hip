@@ -251,9 +251,9 @@ __device__ inline double td_p_reflector(const double* cn, double* vs, int n, int
   return tv;
 }
 
-// HIER: the hierarchical grid barrier (gridbar.h gbh_barrier; state block bar.st, zeroed by the host before the launch); otherwise the
-// one-counter barrier on bar.st[0] (ISLE_TD_FLATBAR=1: kept to time one against the other)
-template <bool HIER>
+// The grid barrier (gridbar.h; state block bar.st, zeroed by the host before the launch): sharded counters polled together by default,
+// ISLE_TD_BAR=hier the hierarchical form, ISLE_TD_BAR=flat the one-counter form on bar.st[0] (kept to time one against the other)
+template <int BAR>  // 0: one counter (gb_barrier), 1: hierarchical (gbh_barrier), 2: sharded counters polled together (gbs_barrier)
 __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, int n, double* __restrict__ d, double* __restrict__ e,
                                                         double* __restrict__ tau, double* __restrict__ xbuf /* 2 x (p | next column), 4 n */,
                                                         const GbHierArgs bar, unsigned int* __restrict__ abort) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       for (int i = r0 + t; i < n; i += TD_P_T) td_st(cbuf + i, col[i]);
     }
     ++phase;
-    if (!(HIER ? gbh_barrier(bar, phase, abort) : gb_barrier(bar.st, phase * (unsigned int)G, abort))) return;
+    if (!(BAR == 1 ? gbh_barrier(bar, phase, abort) : BAR == 2 ? gbs_barrier(bar, phase, abort) : gb_barrier(bar.st, phase * (unsigned int)G, abort))) return;
     if (cj % G == g)  // the reflector where td_back_k (a later launch) reads it
       for (int i = r0 + t; i < n; i += TD_P_T) A[(size_t)cj * n + i] = vs[i];
     // the next column as published (read below, behind two block-wide sums): asked for now, its round trip to memory runs beside that of p
@@ -670,12 +670,16 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
       GbHierArgs bar = {};
       bar.st = bar_state;
       HIPCHK(c, hipMemsetAsync(bar_state, 0, GBH_STATE_WORDS * sizeof(unsigned int), c->stream));
-      if (c->knob_on(KN_TD_FLATBAR)) {
-        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<false>, (int)TD_P_LDS));
-        hipLaunchKernelGGL(td_persist_k<false>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
+      const char* bk = c->knob(KN_TD_BAR);
+      if (bk && !strcmp(bk, "flat")) {
+        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<0>, (int)TD_P_LDS));
+        hipLaunchKernelGGL(td_persist_k<0>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
+      } else if (bk && !strcmp(bk, "hier")) {
+        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<1>, (int)TD_P_LDS));
+        hipLaunchKernelGGL(td_persist_k<1>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
       } else {
-        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<true>, (int)TD_P_LDS));
-        hipLaunchKernelGGL(td_persist_k<true>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
+        ISLECHK(isle_max_lds(c, (const void*)td_persist_k<2>, (int)TD_P_LDS));
+        hipLaunchKernelGGL(td_persist_k<2>, dim3(pG), dim3(TD_P_T), p_lds, c->stream, A, n, d, e, tau, pv, bar, tickets + 1);
       }
       HIPCHK(c, hipGetLastError());
       if (const char* fb = c->knob(KN_TD_FORCE_BAIL_RANK)) {  // test hook: this rank behaves as if its barrier had timed out

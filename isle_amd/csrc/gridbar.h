@@ -1,8 +1,10 @@
 // isle_amd/csrc/gridbar.h — grid-wide barriers for persistent kernels whose workgroups are all resident (grid <= number of CUs,
 // one workgroup per CU at most), and the device-scope accesses for the data that crosses workgroups between barriers.
 //
-// Two forms, same contract (every thread of every workgroup calls it; false = gave up, *abort raised):
-//   gb_barrier   one monotonic counter.  For kernels that cross a handful of barriers, and td_persist_k under ISLE_TD_FLATBAR=1.
+// Three forms, same contract (every thread of every workgroup calls it; false = gave up, *abort raised); td_persist_k (one barrier per column,
+// thousands per launch) takes gbs_barrier, the others under ISLE_TD_BAR = flat | hier.  EVD at n = 2000 / n = 400, round 6:
+// gbs 36.4 / 3.50 ms, gbh 37.0 / 3.93, gb 40.7 / 3.69 (profiles/r06_j_evd_probe_three_barriers.log).
+//   gb_barrier   one monotonic counter: release once, poll relaxed, acquire once (until round 6 it polled with ACQUIRE loads: an invalidate per poll).
 //   gbh_barrier  hierarchical (MI355X_MICROARCH.md, price table row "barrier-xcd": 4.1 us at 256 workgroups against 7.4 for one counter
 //                polled with relaxed loads and 13.2 polled with acquire loads — what gb_barrier did until round 6): the workgroups form eight
 //                groups by blockIdx % 8 — the dispatcher deals workgroups round-robin over the eight XCDs, so a group is one XCD's
@@ -10,8 +12,8 @@
 //                group adds to the top counter, the last of those publishes the top generation, every group's last arriver then publishes
 //                its group's generation.  At most 32 pollers per line instead of 256.  Correctness does not rest on the round-robin
 //                placement: EVERY workgroup's lane 0 makes its own agent-scope release fence before it arrives and its own agent-scope
-//                acquire fence after the release (a group that straddles XCDs only polls a line that is further away).  For kernels that
-//                cross thousands of barriers (td_persist_k: one per column).
+//                acquire fence after the release (a group that straddles XCDs only polls a line that is further away).
+//   gbs_barrier  sharded (at the end of this file): the eight arrival counters without the two extra hops.
 // All counters only grow (signed differences: they may wrap); a launch gets its starting counts from the host (GbHierArgs), or starts
 // from a zeroed state block with all bases 0.
 #pragma once
@@ -104,4 +106,46 @@ __device__ inline bool gbh_barrier(const GbHierArgs& a, unsigned int j, unsigned
   }
   __syncthreads();
   return gbh_ok != 0;
+}
+
+// ---- sharded form (the default of td_persist_k since round 6) ------------------------------------------------------------------------
+// The arrival counters of the hierarchical form without its two extra hops: a workgroup adds to its group's counter (at most 32 adders per
+// line) and then polls ALL eight counters at once — lane g of wave 0 polls counter g — until every group has reached its target.  Two round
+// trips (add, poll) instead of four (add, top add, top generation, group generation), at the price of 256 pollers per line again (loads, not
+// atomics).  Same state block (only the first eight lines are used), same fences, same contract.
+__device__ inline bool gbs_barrier(const GbHierArgs& a, unsigned int j, unsigned int* abort) {
+  __shared__ unsigned int gbs_ok;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x < 64) {  // wave 0
+    const unsigned int G = gridDim.x, lane = threadIdx.x;
+    const unsigned int mine = blockIdx.x % GBH_GROUPS;
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(a.st + mine * GBH_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");
+    const unsigned int g = lane < (unsigned)GBH_GROUPS ? lane : 0u;
+    const unsigned int target = a.cnt_base[g] + j * gbh_group_size(G, g);
+    unsigned int* cnt = a.st + g * GBH_LINE;
+    unsigned int spins = 0;
+    bool good = true;
+    for (;;) {
+      const bool there = (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+      if (__all(there)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 0x3ffu) == 0 && (spins > GB_SPIN_LIMIT || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = false;
+        break;
+      }
+    }
+    asm volatile("" ::: "memory");
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      gbs_ok = good ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  return gbs_ok != 0;
 }

@@ -23,7 +23,7 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "pqr_factor_k": ("qr", "sum of the slab Grams, Cholesky with column dropping, triangular inverse (one workgroup; wave 0 since round 6)", "latency"),
     "pqr_apply_gram_k": ("qr", "Q1 = F T and the slab Grams of Q1 in one sweep", "latency"),
     "pqr_apply_k": ("qr", "Q = Q1 T2", "latency"),
-    "td_persist_k": ("evd", "Householder tridiagonalisation, matrix resident in LDS, one hierarchical grid barrier per column (round 6)", "latency chain: n x ~10 us"),
+    "td_persist_k": ("evd", "Householder tridiagonalisation, matrix resident in LDS, one grid barrier on sharded counters per column (round 6)", "latency chain: n x ~10 us"),
     "td_back_k": ("evd", "Z = Q Z_T, reflectors applied in reverse to 4 / 8 eigenvector columns per workgroup", "LDS / latency"),
     "td_bisect_k": ("evd", "eigenvalues by 64-way multisection on the Sturm count", "latency"),
     "td_vectors_k": ("evd", "eigenvectors of T by twisted factorisation, a thread per vector", "latency"),

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, first GPU call: hierarchical grid barrier and wave-0 panel-QR factor — timing (EVD probe both barriers, C3-shard bench, QR forms) and the GPU suite
+# (the switch was ISLE_TD_FLATBAR when this ran; it is ISLE_TD_BAR = flat | hier since, the sharded form being the default)
 set -o pipefail
 O=gpurun_out/r06_a; mkdir -p $O
 cd "$GRAFT_REPO_ROOT"
