@@ -7,9 +7,9 @@ import csv
 import sys
 
 INFO = {  # kernel (prefix) -> (family, what, bound)
-    "gl_apply_k<3, true": ("gram / project / kmpp", "LDS-banded pass, 10-column panel (pass 1 and the wide / thin products; pass 2 at the other G)", "LDS issue + HBM ids"),
-    "gl_apply_k<2": ("project / kmpp / sparse", "the same pass on 6- / 8-column panels (last panel of a wide product, thin products)", "LDS issue + HBM ids"),
-    "gl_apply_k<1": ("kmpp / movers", "the same pass on 2- / 4-column panels (thin products of few centres)", "LDS issue + HBM ids"),
+    "gl_apply_k<3, true": ("gram / project / kmpp", "LDS-banded pass, 10-column panel (both Gram passes, the wide / thin products)", "LDS issue + HBM ids"),
+    "gl_apply_k<2": ("project / kmpp / sparse", "the same pass on 6- / 8-column panels", "LDS issue + HBM ids"),
+    "gl_apply_k<1": ("kmpp / movers", "the same pass on 2- / 4-column panels", "LDS issue + HBM ids"),
     "gl_apply_k<3, false": ("project", "12-column panel", "LDS issue + HBM ids"),
     "gl_reduce_cm_k": ("gram", "pass 2's slabs summed in fixed order, scaled by s_w, written column-major", "HBM"),
     "gl_pack_scale_k": ("gram", "diag(s) X packed as the planar band image", "launch"),
@@ -20,10 +20,10 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "vtf_partial_k": ("ortho", "H = V^T F for narrow bases (FMA form)", "HBM"),
     "update_mfma_k": ("ortho", "F -= V H on the matrix cores, coefficients from cache", "HBM (reads the basis)"),
     "pqr_gram_k": ("qr", "slab Gram matrices of the panel (fp64)", "latency"),
-    "pqr_factor_k": ("qr", "sum of the slab Grams, Cholesky with column dropping, triangular inverse (one workgroup; wave 0 since round 6)", "latency"),
+    "pqr_factor_k": ("qr", "sum of the slab Grams, Cholesky with column dropping, triangular inverse (one workgroup; wave 0)", "latency"),
     "pqr_apply_gram_k": ("qr", "Q1 = F T and the slab Grams of Q1 in one sweep", "latency"),
     "pqr_apply_k": ("qr", "Q = Q1 T2", "latency"),
-    "td_persist_k": ("evd", "Householder tridiagonalisation, matrix resident in LDS, one grid barrier on sharded counters per column (round 6)", "latency chain: n x ~10 us"),
+    "td_persist_k": ("evd", "Householder tridiagonalisation, matrix resident in LDS, one grid barrier per column", "latency chain: n x ~10 us"),
     "td_back_k": ("evd", "Z = Q Z_T, reflectors applied in reverse to 4 / 8 eigenvector columns per workgroup", "LDS / latency"),
     "td_bisect_k": ("evd", "eigenvalues by 64-way multisection on the Sturm count", "latency"),
     "td_vectors_k": ("evd", "eigenvectors of T by twisted factorisation, a thread per vector", "latency"),
@@ -32,7 +32,7 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "isle_gemm::gemm_f32_k<isle_gemm::Cfg<2, 2, 4, 4, 16, 4>": ("rotate / lift", "plain f32 GEMM 256x256 tiles, v_mfma_f32_32x32x2_f32 (Ritz rotation, lift)", "MFMA f32"),
     "isle_gemm::gemm_f32_k<isle_gemm::Cfg<2, 1": ("kmpp / movers", "thin f32 GEMM (W = U C_new^T)", "MFMA f32 / HBM"),
     "isle_gemm::gemm_f32_k": ("dense", "plain f32 GEMM, other tile shapes", "MFMA f32"),
-    "isle_gemm3::gemm_bf16x2_dma_k<isle_gemm3::CfgDma<2, 16>, YyGroupEpi": ("sparse", "first assignment of Lloyd on B: D x k x k product on two bf16 terms by LDS-DMA, Yinyang group epilogue", "MFMA bf16"),
+    "isle_gemm3::gemm_bf16x2_dma_k<isle_gemm3::CfgDma<2, 16>, YyGroupEpi": ("sparse", "first assignment of Lloyd on B: D x k x k on two bf16 terms by LDS-DMA, Yinyang group epilogue", "MFMA bf16"),
     "isle_gemm3::gemm_bf16x2_dma_k<isle_gemm3::CfgDma<2, 16>, TileEpi": ("lloyd_proj", "full assignment pass of Lloyd in span(U), same product, tile-bound epilogue", "MFMA bf16"),
     "isle_gemm3::gemm_bf16x3_k<isle_gemm3::Cfg<2, 2, 4, 4, 4, 16, 2>": ("lloyd_proj", "two-term product on the gathered rows of the active documents", "MFMA bf16"),
     "isle_gemm3::gemm_bf16x3_k<isle_gemm3::Cfg<2, 2, 4, 4, 4, 16, 3>": ("lloyd_proj / sparse", "three-term product on the rows the two-term pass left open", "MFMA bf16"),
@@ -51,13 +51,13 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "proj_segsum_k": ("lloyd_proj", "centroid sums over member lists in fixed order", "HBM"),
     "proj_delta_sum_k": ("lloyd_proj", "centroid sums kept up to date by the documents that moved", "HBM"),
     "proj_changed_k": ("lloyd_proj", "documents that changed centre", "HBM"),
-    "kmpp_min_dots_track_k": ("kmpp", "running minimum of the distances to the new seeds, nearest seed and tile minima kept", "HBM"),
+    "kmpp_min_dots_track_k": ("kmpp", "running minimum of the distances to the new seeds, nearest seed / tile minima kept", "HBM"),
     "kmpp_to_tiles_k": ("kmpp", "hand-over of the tracked state to Lloyd's tile bounds", "HBM"),
     "isle_scan::scan": ("kmpp", "fp64 prefix sums of D^2 (reduce / final)", "HBM"),
     "colnorm_partial_k": ("ortho / qr", "column norms (residual rule, rank repair)", "HBM"),
     "rownorms_k": ("kmeans", "squared norms of centre rows", "launch"),
     "scale_centers_k": ("lloyd_proj / sparse", "sums -> means", "launch"),
-    "cc_hist_k": ("sparse_update", "word histogram of 2048 member-list entries in LDS, one integer atomic per word present", "LDS integer atomics"),
+    "cc_hist_k": ("sparse_update", "word histogram of 2048 member entries in LDS, one integer atomic per word present", "LDS integer atomics"),
     "cc_centers_k": ("sparse_update", "count table -> row-major centres", "HBM"),
     "cc_moved_k": ("sparse_update", "counts updated by the documents that moved", "HBM"),
     "doc_norms_k": ("sparse", "squared norms of the documents", "HBM"),
@@ -77,7 +77,7 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "transpose_k": ("dense", "tiled transposition", "HBM"),
     "fetch_rows_k": ("kmpp", "seed rows of P", "launch"),
     "member_keys_k": ("kmeans", "member-list keys", "HBM"),
-    "__amd_rocclr_copyBuffer": ("runtime", "hipMemcpyAsync: the expand loop's mailbox (since round 6 on the copy stream, BESIDE the next application: its duration here is mostly its wait for a free CU, off the critical path), small D2D copies", "PCIe latency"),
+    "__amd_rocclr_copyBuffer": ("runtime", "hipMemcpyAsync: the expand loop's mailbox (round 6: on the copy stream beside the next application — its duration here is its wait for a free CU, off the critical path), small copies", "PCIe latency"),
     "__amd_rocclr_fillBufferAligned": ("runtime", "hipMemsetAsync", "launch"),
 }
 
