@@ -487,7 +487,8 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         del cntA, rowsA, offsA
     else:
         B = corp.threshold(k, free_A=True, allreduce=allreduce_np if dist is not None else None)
-    planted = planted_all[B["original_cols"].astype(np.int64)]  # dominant planted topic of every column of B (local numbering)
+    # dominant planted topic of every column of B (the device numbers B's columns by their GLOBAL document, the port by the rank's own)
+    planted = planted_all[B["original_cols"].astype(np.int64) - (doc_base if device_stage else 0)]
     t_thr_cpu = time.time() - t_thr0
     del corp, planted_all
     t_gen = time.time() - t0

@@ -16,14 +16,14 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "config", "roofline"]
 
 
-def _check(stdout, n_gpus, steps):
+def _check(stdout, n_gpus, steps, scaling="weak"):
     lines = stdout.splitlines()
     assert len(lines) == 1, stdout[-2000:]
     d = json.loads(lines[0])
     for k in KEYS:
         assert k in d, k
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["unit"] == "docs/sec" and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    assert d["scaling"] == scaling and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] > 0 and d["ms_per_step"] > 0
@@ -108,3 +108,20 @@ def test_config5_flow_line():
     e = d["other_stages"]["edge_topics"]
     assert e["pairs_identical_to_oracle"] and 0 < e["num_edge_topics"] <= 300 and e["edge_columns_worst_rel_err"] <= 1e-5
     assert all(d["other_stages"]["input"]["identical_to_cpu_port"].values())
+
+
+def test_config4_flow_on_two_ranks():
+    """The same flow on document shards (two ranks sharing GPU 0 through the rehearsal transport): every rank uploads its share of A, the
+    thresholds come from all-reduced statistics, the sampling pivot from the all-gathered keys — the shards keep what the one-rank run keeps."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["ISLE_BENCH_REHEARSE"] = "1"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4small", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4small", "--steps", "1", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr[-1500:], two.stderr[-3000:])
+    d1, d2 = _check(one.stdout, 1, 1), _check(two.stdout, 2, 1, scaling="strong")  # one corpus split over the ranks
+    assert "REHEARSAL" in d2["config"]["parallelism"]
+    k1 = d1["other_stages"]["input"]["docs_kept"]
+    assert "B keeps %d of the 200000 documents" % k1 in d2["config"]["workload"]  # the ranks' kept documents add up to the one-rank count
+    assert d2["accuracy"]["gate"]["passed"] and d2["config"]["kmeans"]["nonempty_clusters"] == 100
