@@ -115,18 +115,23 @@ def info(k):
     return INFO[best] if best else ("?", "", "")
 
 
-a, sa, b, sb = sys.argv[1], float(sys.argv[2]), sys.argv[3], float(sys.argv[4])
-N = int(sys.argv[5]) if len(sys.argv) > 5 else 40
-A, Bm = load(a, sa), load(b, sb)
-top = sorted(A, key=lambda k: -A[k])[:N]
-for k in sorted(Bm, key=lambda k: -Bm[k])[:12]:  # the shard's own heaviest kernels, where they are not among config 3's
-    if k not in top:
-        top.append(k)
-print("| kernel | family | computes | bound by | ms / step, config 3 | ms / step, C3 shard |")
-print("|---|---|---|---|---|---|")
-for k in top:
-    f, w, bd = info(k)
-    name = k.replace("isle_gemm3::", "").replace("isle_gemm::", "").replace("|", "\\|")
-    print("| `%s` | %s | %s | %s | %s | %s |" % (name[:70], f, w, bd, ("%.1f" % A[k]) if k in A else "—", ("%.2f" % Bm[k]) if k in Bm else "—"))
-print()
-print("Sum over all kernels: config 3 %.0f ms per step, C3 shard %.0f ms per step." % (sum(A.values()), sum(Bm.values())))
+def main():
+    a, sa, b, sb = sys.argv[1], float(sys.argv[2]), sys.argv[3], float(sys.argv[4])
+    N = int(sys.argv[5]) if len(sys.argv) > 5 else 40
+    A, Bm = load(a, sa), load(b, sb)
+    top = sorted(A, key=lambda k: -A[k])[:N]
+    for k in sorted(Bm, key=lambda k: -Bm[k])[:12]:  # the shard's own heaviest kernels, where they are not among config 3's
+        if k not in top:
+            top.append(k)
+    print("| kernel | family | computes | bound by | ms / step, config 3 | ms / step, C3 shard |")
+    print("|---|---|---|---|---|---|")
+    for k in top:
+        f, w, bd = info(k)
+        name = k.replace("isle_gemm3::", "").replace("isle_gemm::", "").replace("|", "\\|")
+        print("| `%s` | %s | %s | %s | %s | %s |" % (name[:70], f, w, bd, ("%.1f" % A[k]) if k in A else "—", ("%.2f" % Bm[k]) if k in Bm else "—"))
+    print()
+    print("Sum over all kernels: config 3 %.0f ms per step, C3 shard %.0f ms per step." % (sum(A.values()), sum(Bm.values())))
+
+
+if __name__ == "__main__":
+    main()
