@@ -127,7 +127,10 @@ def family_rooflines(V, D, nnz, k, b, ncv, restarts, applies, kmpp_rounds, lp_it
     put("kmpp", "hbm", sum(min(4.0 * k * D, 8.0 * nnz + 8.0 * (D + 1) + 4.0 * V * c) + 8.0 * D for c in draws), device_ms.get("kmpp", 0.0),
         "%d rounds x (min(4 k D, 8 nnz + 8 (D+1) + 4 V c) + 8 D), c = the round's draws" % len(draws))
     put("lloyd_proj", "mfma", lp_iters * 2.0 * D * k * k, device_ms.get("lloyd_proj", 0.0),
-        "%d iterations x 2 D k^2 (the dense formulation SURVEY 8(d) scores; bounded iterations skip part of it)" % lp_iters)
+        "%d iterations x 2 D k^2 (the dense formulation SURVEY 8(d) scores).  Above 1 where the exact distance bounds skip most dense passes and the "
+        "passes that run use the bf16 matrix cores (operands split in two / three bf16 terms): see frac_of_bf16_dense_peak" % lp_iters)
+    if "lloyd_proj" in out:
+        out["lloyd_proj"]["frac_of_bf16_dense_peak"] = round(out["lloyd_proj"]["achieved"] / 2500.0, 4)  # MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16
     put("sparse", "hbm", ls_iters * (16.0 * nnz + 8.0 * V * k), device_ms.get("sparse_assign", 0.0) + device_ms.get("sparse_update", 0.0),
         "%d iterations of Lloyd on B x (2 (8 nnz) + 2*4 V k)" % ls_iters)
     put("rotate", "mfma", (restarts + 1) * 2.0 * V * (ncv - b) * k, device_ms.get("rotate", 0.0),
