@@ -152,6 +152,23 @@ def gram_kernel_sha16():
         return None
 
 
+def library_sources_sha16():
+    """sha256 (first 16 hex digits) over the library's sources (isle_amd/csrc/*.hip, *.h, *.cpp, sorted by name): the key under which the
+    whole-step counter pass profiles/r06_step_traffic_by_family.json stays valid."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "isle_amd", "csrc")
+    try:
+        for fn in sorted(os.listdir(d)):
+            if fn.endswith((".hip", ".h", ".cpp")):
+                h.update(fn.encode())
+                with open(os.path.join(d, fn), "rb") as f:
+                    h.update(f.read())
+        return h.hexdigest()[:16]
+    except Exception:
+        return None
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher's environment: start N fresh rank processes of this script (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1) and wait for them.  The parent makes no torch or HIP
@@ -619,6 +636,20 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         if traffic_note is None:
             traffic_note = ("profiles/pmc_traffic.json['%s'] (kernel source %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py at "
                             "this size" % (pmc_key, sha) if traffic is not None else "no counter pass committed for workload '%s'" % pmc_key)
+    # HBM bytes of a whole step by kernel family, from the counter pass over one config-3 step (tools/r06_steppmc.sh), while it describes this build
+    step_traffic = None
+    if workload in ("c3", "c3full") and world == 1:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_step_traffic_by_family.json")) as f:
+                st = json.load(f)
+            if st.get("library_sources_sha16") == library_sources_sha16():
+                step_traffic = {"hbm_bytes_per_step_by_family": st["hbm_bytes_per_step_by_family"], "source": "profiles/r06_step_traffic_by_family.json "
+                                "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one step, separate passes; sources %s)" % st["library_sources_sha16"]}
+            else:
+                step_traffic = {"hbm_bytes_per_step_by_family": None, "source": "profiles/r06_step_traffic_by_family.json was collected on library sources %s, "
+                                "this build is %s: stale, not reported" % (st.get("library_sources_sha16"), library_sources_sha16())}
+        except Exception:
+            pass
     roofline = {"bound": "hbm", "kernel": "gram_apply (Z = B(B^T X), b=%d) = %s" % (b, form_kernels),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -680,6 +711,7 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         "config": cfg,
         "roofline": roofline,
         "roofline_by_family": by_family,
+        "step_traffic": step_traffic,
         "device_ms_per_step": device_ms,
         "timed_scopes_per_step": scopes_per_step,
         "host_wall_ms_per_step": {n: round(v * 1e3 / steps, 3) for n, v in phase_wall.items()},
