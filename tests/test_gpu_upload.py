@@ -45,3 +45,36 @@ def test_upload_refuses_bad_matrices_and_then_takes_a_good_one(hp):
     Bm = sp.csc_matrix((vals.astype(np.float64), rows, offs), shape=(V, len(offs) - 1))
     ref = Bm @ (Bm.T @ X.astype(np.float64))
     assert np.linalg.norm(Z - ref) <= 1e-5 * np.linalg.norm(ref)
+
+
+def test_a_smaller_matrix_after_a_large_one_releases_and_recomputes():
+    """Uploading a far smaller matrix releases the derived buffers sized for the large one (isle_trim_derived, api.cpp: the projection and
+    its copies, product and build scratch — here 250 000 x 12 floats of projection against the 2048 x 1000 a 1000-document matrix could ever
+    need); nothing computed afterwards may see stale contents: the whole chain on the small matrix equals a fresh context's bit for bit, and
+    going back to the large matrix reproduces its first run."""
+    import isle_amd
+    from tools.synth import make_B
+    big, small = make_B(2000, 250_000, 10, 3), make_B(2000, 1000, 10, 4)
+
+    def chain(h, B, k=10):
+        h.upload_csc(B["V"], B["vals"], B["rows"], B["offs"])
+        r = h.compute_block_ks(k, seed=2)
+        g = h.kmeans_init_on_projected_space(k, rng_seed=5)
+        lp = h.run_lloyds_on_projected_space(k, g["C_lowd"])
+        h.left_multiply_by_U(lp["C_lowd"], fetch=False)
+        ls = h.run_lloyds(k)
+        return r["evals"], g["seeds"], g["C_lowd"], lp["assign"], ls["assign"], ls["centers"]
+
+    h1, h2 = isle_amd.HotPath(0), isle_amd.HotPath(0)
+    try:
+        big1 = chain(h1, big)
+        small_after_big = chain(h1, small)
+        small_fresh = chain(h2, small)
+        for a, b in zip(small_after_big, small_fresh):
+            assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+        big2 = chain(h1, big)
+        for a, b in zip(big1, big2):
+            assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    finally:
+        h1.close()
+        h2.close()
