@@ -495,3 +495,18 @@ def test_small_evd_at_the_sizes_the_restarts_meet(hp, monkeypatch, n, env):
     v = v.astype(np.float64)
     assert np.abs(v.T @ v - np.eye(n)).max() <= 2e-5
     assert np.abs(S.astype(np.float64) @ v - v * e).max() <= 3e-5 * scale
+
+
+@pytest.mark.parametrize("n", [400, 2000])
+def test_the_three_grid_barriers_of_the_persistent_tridiagonalisation_give_the_same_bits(hp, monkeypatch, n):
+    """td_persist_k crosses one grid barrier per column (gridbar.h): sharded counters polled together (default), the hierarchical form
+    (ISLE_TD_BAR=hier), one counter (ISLE_TD_BAR=flat).  A barrier orders the same loads and stores in every form, so eigenvalues and
+    eigenvectors must agree bit for bit — a form that let a workgroup through early would read a stale column and differ."""
+    S = ritz_like(n, n + 1)
+    e0, v0 = hp.eig_sym(S)
+    for form in ("hier", "flat"):
+        monkeypatch.setenv("ISLE_TD_BAR", form)
+        e, v = hp.eig_sym(S)
+        monkeypatch.delenv("ISLE_TD_BAR")
+        assert np.array_equal(e.view(np.uint32), e0.view(np.uint32)), form
+        assert np.array_equal(v.view(np.uint32), v0.view(np.uint32)), form
