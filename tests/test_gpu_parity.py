@@ -679,3 +679,22 @@ def test_grouped_projection_at_topic_counts_that_end_inside_a_group(hp, small50,
         lo, hi = B["offs"][d], B["offs"][d + 1]
         ref = (B["vals"][lo:hi].astype(np.float64)[:, None] * U64[B["rows"][lo:hi]]).sum(0)
         assert np.abs(res["grouped"][0][i] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_pipelined_expand_equals_the_synchronous_form(hp, small50, monkeypatch):
+    """The expand loop (api_ks.cpp) enqueues step i + 1 behind the panel QR of step i and fetches step i's mailbox on a copy stream of its own
+    (round 6: double-buffered device mailbox); ISLE_KS_SYNC=1 runs one step at a time with a host synchronisation each.  Same kernels on the same
+    data in the same order: eigenvalues, U and the work counts must agree bit for bit — a mailbox read before its step had finished writing it,
+    or a coefficient block landing in a mailbox whose copy was still in flight, would show here."""
+    upload(hp, small50)
+    r0 = hp.compute_block_ks(50, seed=11)
+    U0 = hp.get_U(50)
+    monkeypatch.setenv("ISLE_KS_SYNC", "1")
+    r1 = hp.compute_block_ks(50, seed=11)
+    U1 = hp.get_U(50)
+    monkeypatch.delenv("ISLE_KS_SYNC")
+    r2 = hp.compute_block_ks(50, seed=11)
+    assert r0["napplies"] == r1["napplies"] == r2["napplies"] and r0["restarts"] == r1["restarts"]
+    assert np.array_equal(r0["evals"].view(np.uint32), r1["evals"].view(np.uint32))
+    assert np.array_equal(r0["evals"].view(np.uint32), r2["evals"].view(np.uint32))
+    assert np.array_equal(U0.view(np.uint32), U1.view(np.uint32))
