@@ -721,12 +721,14 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   }
   // ---- 2. eigenvalues, 3. eigenvectors of T, 4. back-transformation, 5. check
   hipLaunchKernelGGL(td_bisect_k, dim3((nvec + 3) / 4), dim3(256), 2 * (size_t)n * sizeof(double), c->stream, d, e, n, nvec, lam);
-  // Several ranks (round 5): the eigenvectors are independent of each other from here on — a thread per vector in td_vectors_k, a workgroup per
-  // 8 (4) vectors in td_back_k — so rank r computes the vectors [r kc, (r + 1) kc) only and the columns are all-gathered: every rank
-  // holds the same bits, whoever computed them (the replicated restart decisions stay in step), and the 5 - 8 ms of this stage at n = 2010
-  // divide by the number of ranks.  ISLE_EVD_SPLIT=0 keeps every rank computing every vector.
+  // Several ranks, ISLE_EVD_SPLIT=1 (round 5; opt-in since round 6): the eigenvectors are independent of each other from here on — a thread per
+  // vector in td_vectors_k, a workgroup per 8 (4) vectors in td_back_k — so rank r computes the vectors [r kc, (r + 1) kc) only and the columns
+  // are all-gathered: every rank holds the same bits, whoever computed them.  Round 5 made it the default expecting the stage's 5 - 8 ms at
+  // n = 2010 to divide by the number of ranks; they do not: both kernels are chains of n dependent steps (a reflector / a row per step) whose
+  // length does not depend on how many vectors a rank holds — 250 workgroups or 32, td_back_k takes its 4.2 ms — so the split buys an idle GPU and
+  // costs an 8 MB all-gather per EVD that has never run over RCCL.  Default: every rank computes every vector.
   int v0 = 0, v1 = nvec, kc = 0;
-  if (c->multi() && !c->knob_zero(KN_EVD_SPLIT)) {
+  if (c->multi() && c->knob_on(KN_EVD_SPLIT) && !c->knob_zero(KN_EVD_SPLIT)) {
     kc = ((nvec + c->world - 1) / c->world + 7) & ~7;
     if ((size_t)kc * c->world <= (size_t)n) {  // the gathered block fits the caller's n x n array
       v0 = std::min(nvec, c->rank * kc);

@@ -141,13 +141,15 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-@pytest.mark.parametrize("world,rowshard", [(2, "0"), (2, None), (3, None), (4, None)])
+@pytest.mark.parametrize("world,rowshard", [(2, "0"), (2, None), (3, None), (4, None), (2, "split"), (4, "split")])
 def test_n_ranks_reproduce_one_rank(single, world, rowshard):
     """rowshard: ISLE_KS_ROWSHARD — unset (the default with several ranks since round 5) has rank r orthogonalise its row slice of the Krylov
     block (all-reduced coefficients, all-gathered block); "0" keeps the orthogonalisation replicated on every rank.  (This test shares one
     GPU through the host-staged transport; over RCCL a collective that never completes ends in ISLE_E_COMM: test_gpu_comm_selftest.py.)"""
     tmp, one = single
-    rs = _run(world, tmp, env={"ISLE_KS_ROWSHARD": rowshard} if rowshard else None, tag="rs" + str(rowshard))
+    # "split": the opt-in column split of the small EVD's eigenvector stage (ISLE_EVD_SPLIT=1) on top of the defaults
+    env = {"ISLE_EVD_SPLIT": "1"} if rowshard == "split" else {"ISLE_KS_ROWSHARD": rowshard} if rowshard else None
+    rs = _run(world, tmp, env=env, tag="rs" + str(rowshard))
     _compare_with_one_rank(rs, one, world)
 
 
