@@ -469,6 +469,10 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
         uid = [HotPath.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         hp.comm_init(world, rank, uid[0])
+    elif os.environ.get("ISLE_FORCE_COMM") == "1":
+        # one GPU, 1-rank RCCL communicator: this process has torch's bundled librccl / libamdhip64 mapped (they win the soname lookup when
+        # libisle_hip.so is loaded after `import torch`), which is the pair an N > 1 run of this script uses — exercised here on one GPU
+        hp.comm_init(1, 0, HotPath.comm_unique_id())
 
     stage_in = None
     D_A_total = WORKLOADS[workload][1] * (1 if strong else world)  # documents of A over all ranks (the metric's numerator)

@@ -47,6 +47,26 @@ def test_single_gpu_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "docs/sec"
 
 
+def test_single_gpu_line_over_a_one_rank_rccl_communicator():
+    """bench.py's process maps torch's bundled librccl.so / libamdhip64.so before libisle_hip.so is loaded, so the library's RCCL calls bind
+    to THAT build (an N > 1 run of the script does the same).  A forced 1-rank communicator with the communicator self-test runs every
+    collective of the step through it on one GPU; the line must equal the communicator-free one."""
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "1"],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return _check(r.stdout, 1, 1), r.stderr
+    plain, _ = run({})
+    forced, err = run({"ISLE_FORCE_COMM": "1", "ISLE_COMM_SELFTEST": "1"})
+    assert "communicator self-test: 72 collectives" in err and "correct in" in err, err[-1500:]
+    assert "RCCL " in err
+    a, b = plain["accuracy"], forced["accuracy"]
+    assert b["gate"]["passed"] and a["gate"]["passed"]
+    assert b["planted_topic_agreement"] == a["planted_topic_agreement"]
+    assert b["sigma_rel_err_bound"] == pytest.approx(a["sigma_rel_err_bound"], rel=0.5, abs=1e-7)
+
+
 def test_two_rank_line_through_the_launcher():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
