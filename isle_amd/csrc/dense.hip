@@ -68,50 +68,89 @@ __global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ V
 
 // Matrix-core variant for the orthogonalisation coefficients (b <= 16): v_mfma_f32_16x16x4_f32 with basis columns
 // on the MFMA row index, panel columns on the MFMA column index and the V rows as the contraction index.  A wave owns
-// 16 basis columns of a 1024-row chunk; per 64 rows every lane loads four float4 of its basis column and four of its
-// panel column (MFMA step s pairs element s of both operands, so any row order inside a group is consistent) and issues
+// 16 basis columns of a 1024-row chunk; per 64 rows every lane loads four float4 of its basis column from memory and four of its
+// panel column from LDS (MFMA step s pairs element s of both operands, so any row order inside a group is consistent) and issues
 // 16 MFMAs on two alternating accumulators.  fp32 inside a chunk, fp64 across chunks (vtf_reduce_k).  The fp64 Gram
 // matrix of the panel QR keeps the fp64 VALU kernel above.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-// (Round 6 tried twice the loads in flight per lane in this kernel and in update_mfma_k — two 64-row groups / two 128-column tiles per trip, the
-// MFMAs in the same order, bit-equal sums: 132 -> 143 ms of orthogonalisation per step at a C3 shard.  The registers it takes cost more
-// occupancy than the deeper queue buys; removed.)
+// What bounds it (round 6, profiles/r06_u_ortho_kernels.txt): not the loads in flight per wave (2, 8 or 16 float4: the same time) and not the
+// occupancy — the vector L1's tag path.  A load of this shape is 16 column pieces of 64 bytes = 16 tag look-ups for 1 KB.
 constexpr int VM_RC = 1024;
-__global__ __launch_bounds__(256) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, uint64_t ld, int m, const float* __restrict__ F, int b,
-                                                   int BT, double* __restrict__ part /*[chunk][m][BT]*/) {
+constexpr int VM_WAVES = 8;           // waves (16 basis columns each) of a workgroup: they share the staged panel chunk
+#ifndef VM_NG_V
+#define VM_NG_V 2
+#endif
+constexpr int VM_NG = VM_NG_V;        // 64-row groups per trip of the main loop
+constexpr int VM_FS = VM_RC + 4;      // floats between the panel's columns in LDS: the 16 columns of a ds_read_b128 quarter lie 16 bytes apart mod 256
+// The panel chunk (b columns x 1024 rows, 41 KB at b = 10) is staged in LDS once per workgroup (round 6).  Read from global memory by every wave it
+// doubled the wave's load instructions, and a load instruction of this shape — 16 columns x 64 bytes — is 16 tag look-ups in the vector L1
+// (≈ 4 clk each: 64 clk for 1 KB, ≈ 4.9 TB/s chip-wide for the basis when the panel takes half of them; the kernel ran at 4.6).  Same MFMAs on the same
+// operands in the same order as before: same bits.
+__global__ __launch_bounds__(64 * VM_WAVES) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, uint64_t ld, int m, const float* __restrict__ F, int b,
+                                                            int BT, double* __restrict__ part /*[chunk][m][BT]*/) {
+  extern __shared__ float vm_fs[];  // [b][VM_FS], rows beyond the chunk's end are zeros
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int col0 = (blockIdx.y * 4 + wave) * 16;
-  if (col0 >= m) return;
   const uint64_t r0 = (uint64_t)blockIdx.x * VM_RC;
   const uint64_t r1 = min(n, r0 + VM_RC);
+  const bool aligned = (ld & 3) == 0 && (((uintptr_t)Vb | (uintptr_t)F) & 15) == 0;  // columns are 16-byte aligned
+  for (int idx = threadIdx.x; idx < b * (VM_RC / 4); idx += 64 * VM_WAVES) {
+    const int j = idx / (VM_RC / 4), q4 = idx - j * (VM_RC / 4);
+    const uint64_t rr = r0 + 4 * (uint64_t)q4;
+    const float* src = F + (uint64_t)j * ld + rr;
+    float4 v;
+    if (aligned && rr + 4 <= r1) v = *(const float4*)src;
+    else {
+      v.x = rr < r1 ? src[0] : 0.f;
+      v.y = rr + 1 < r1 ? src[1] : 0.f;
+      v.z = rr + 2 < r1 ? src[2] : 0.f;
+      v.w = rr + 3 < r1 ? src[3] : 0.f;
+    }
+    *(float4*)(vm_fs + (size_t)j * VM_FS + 4 * q4) = v;
+  }
+  __syncthreads();
+  const int col0 = (blockIdx.y * VM_WAVES + wave) * 16;
+  if (col0 >= m) return;
   const float* va = Vb + (uint64_t)min(col0 + l15, m - 1) * ld;  // clamped: rows of H beyond m are not written
-  const float* fb = F + (uint64_t)min(l15, b - 1) * ld;
-  const float bmask = (l15 < b) ? 1.f : 0.f;
+  // (lanes l15 >= b read column b - 1 again: column j of the B operand only reaches column j of the tile, and those are never read)
+  const float* fs = vm_fs + (size_t)min(l15, b - 1) * VM_FS;
   floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   uint64_t r = r0;
-  if ((ld & 3) == 0 && (((uintptr_t)Vb | (uintptr_t)F) & 15) == 0) {  // columns are 16-byte aligned
-    for (; r + 64 <= r1; r += 64) {
-      float4 av[4], fv[4];
+  if (aligned) {
+    // VM_NG groups of 64 rows per trip: all their basis loads are issued before the first MFMA (the compiler, left alone, keeps two in flight
+    // per wave: with 24 waves a CU that is 12 MB in flight chip-wide, one memory latency at 5.4 TB/s)
+    for (; r + 64 * VM_NG <= r1; r += 64 * VM_NG) {
+      float4 av[4 * VM_NG];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        av[u] = *(const float4*)(va + r + 16 * u + 4 * g);
-        fv[u] = *(const float4*)(fb + r + 16 * u + 4 * g);
+      for (int u = 0; u < 4 * VM_NG; ++u) av[u] = *(const float4*)(va + r + 16 * u + 4 * g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4 * VM_NG; ++u) {
+        const float4 fv = *(const float4*)(fs + (r - r0) + 16 * u + 4 * g);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, fv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, fv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, fv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, fv.w, acc1, 0, 0, 0);
       }
+    }
+    for (; r + 64 <= r1; r += 64) {  // the groups a trip does not fill
+      float4 av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[u] = *(const float4*)(va + r + 16 * u + 4 * g);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, fv[u].x * bmask, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, fv[u].y * bmask, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, fv[u].z * bmask, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, fv[u].w * bmask, acc1, 0, 0, 0);
+        const float4 fv = *(const float4*)(fs + (r - r0) + 16 * u + 4 * g);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, fv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, fv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, fv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, fv.w, acc1, 0, 0, 0);
       }
     }
   }
   for (; r < r1; r += 4) {  // tail / unaligned: 4 rows per MFMA, rows beyond the end contribute zeros
     const uint64_t rr = r + g;
-    const float inr = (rr < r1) ? 1.f : 0.f;
-    const float a = va[min(rr, n - 1)] * inr;
-    const float f = fb[min(rr, n - 1)] * (inr * bmask);
+    const float a = rr < r1 ? va[rr] : 0.f;
+    const float f = fs[min(rr, r1 - 1) - r0];
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f, acc0, 0, 0, 0);
   }
   // C/D layout of the 16x16 tile: column j = lane & 15, row i = 4 * (lane >> 4) + reg
@@ -171,7 +210,9 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
     const int BT = bt_of(b);
     const int nch = cdiv(n, VM_RC);
     HIPCHK(c, c->part.reserve((size_t)nch * m * BT));
-    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 64)), dim3(256), 0, c->stream, Vb, n, ld, m, F, b, BT, c->part.p);
+    const size_t lds = (size_t)b * VM_FS * sizeof(float);
+    ISLECHK(isle_max_lds(c, (const void*)vtf_mfma_k, (int)lds));
+    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 16 * VM_WAVES)), dim3(64 * VM_WAVES), lds, c->stream, Vb, n, ld, m, F, b, BT, c->part.p);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(vtf_reduce_k<float>, dim3(cdiv((long)m * BT, 256)), dim3(256), 0, c->stream, c->part.p, nch, m, BT, b, coef);
     HIPCHK(c, hipGetLastError());
@@ -232,10 +273,15 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
 // The same update on the matrix cores (round 5; b <= 16, columns 16-byte aligned).  update_k reads three ds_read_b128 of coefficients for
 // every float of the basis it loads (137 us a call at config 3); here (94 us) a wave takes 64 rows: a lane loads FOUR consecutive rows of a
 // basis column as one float4 (a wave instruction = 4 columns x 256 bytes), component c of the 16 lanes of a quarter is the A operand of
-// tile c (rows r0 + 4 i + c, i < 16), the coefficients are the B operand (one cached 4-byte load per four MFMAs), v_mfma_f32_16x16x4_f32 (exact
+// tile c (rows r0 + 4 i + c, i < 16), the coefficients are the B operand (one cached 16-byte load per sixteen MFMAs since round 6), v_mfma_f32_16x16x4_f32 (exact
 // f32 products and sums).  The four waves of a workgroup take the basis columns i = 32 q .. 32 q + 31 of every 128-column tile, eight
-// float4 loads in flight each, and their sums are added in the order q = 0 .. 3: deterministic, other rounding than update_k's chains.
+// float4 loads in flight each (UM_SETS = 1: four; the same time), and their sums are added in the order q = 0 .. 3: deterministic, other
+// rounding than update_k's chains.
 constexpr int UM_TILE = 128;
+#ifndef UM_SETS_V
+#define UM_SETS_V 2
+#endif
+constexpr int UM_SETS = UM_SETS_V;  // sets of 16 columns whose loads a wave issues together (1 or 2)
 __global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint64_t n, uint64_t ld, int b, const float* __restrict__ Vb, int m,
                                                       const float* __restrict__ coef /*m x b col-major*/) {
   __shared__ float red[4][64][17];
@@ -248,28 +294,40 @@ __global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint
   // m x b block — no staging in LDS, no barrier in the loop, the waves run free like vtf_mfma_k's (with the coefficients staged per 128 columns behind two barriers:
   // 128 us a call at config 3; this form: 94)
   const float* cf = coef + (size_t)min(l15, b - 1) * m;
-  const float bmask = l15 < b ? 1.f : 0.f;
+  // (lanes l15 >= b read column b - 1 again: column j of the B operand only reaches column j of the tiles, and those are never stored)
   floatx4 acc[4];
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) acc[c4] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // A trip = the wave's 32 columns of a 128-column tile, two sets of 16; in a set, MFMA step s takes the columns base + 4 g + s (g = the lane's quarter):
+  // a lane's four coefficients of a set are CONSECUTIVE in its column of coef, one 16-byte load per 16 MFMAs (round 6; until then the step
+  // took the columns base + 4 s + g and every MFMA quadruple had a dword load of its own — a wave instruction over 16 cache lines, 64 clk of
+  // tag look-ups in the vector L1 beside the 32 clk of the basis load it fed: 4.25 TB/s).  All loads of a trip are issued before its first MFMA.
   for (int i0 = 0; i0 < m; i0 += UM_TILE) {
     const int kb = i0 + q * (UM_TILE / 4);
     if (kb < m) {  // wave-uniform
-      float4 av[8];
-      float bq[8];
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        const int kk = min(kb + 4 * s8 + g, m - 1);  // clamped: a column past the basis meets a zero coefficient
-        av[s8] = *reinterpret_cast<const float4*>(Vb + (uint64_t)kk * ld + rb);
-        bq[s8] = cf[kk];
-      }
+      for (int h0 = 0; h0 < 2; h0 += UM_SETS) {  // UM_SETS sets' loads in flight together
+        float4 av[4 * UM_SETS], bq[UM_SETS];
 #pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        const float bb = kb + 4 * s8 + g < m ? bq[s8] * bmask : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].x, bb, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].y, bb, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].z, bb, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s8].w, bb, acc[3], 0, 0, 0);
+        for (int h = 0; h < UM_SETS; ++h) {
+          const int k0 = kb + 16 * (h0 + h) + 4 * g;  // the lane's four columns of this set
+#pragma unroll
+          for (int s = 0; s < 4; ++s) av[4 * h + s] = *reinterpret_cast<const float4*>(Vb + (uint64_t)min(k0 + s, m - 1) * ld + rb);  // clamped: meets a zero
+          if (k0 + 3 < m) __builtin_memcpy(&bq[h], cf + k0, 16);  // (4-byte aligned: m need not be a multiple of 4)
+          else bq[h] = float4{k0 < m ? cf[k0] : 0.f, k0 + 1 < m ? cf[k0 + 1] : 0.f, k0 + 2 < m ? cf[k0 + 2] : 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < UM_SETS; ++h) {
+          const float bb[4] = {bq[h].x, bq[h].y, bq[h].z, bq[h].w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * h + s].x, bb[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * h + s].y, bb[s], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * h + s].z, bb[s], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * h + s].w, bb[s], acc[3], 0, 0, 0);
+          }
+        }
       }
     }
   }
