@@ -7,8 +7,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-C3 = os.path.join(ROOT, "profiles", "r06_g_c3full_kernel_stats.csv")
-SHARD = os.path.join(ROOT, "profiles", "r06_d_c3shard_kernel_stats.csv")
+C3 = os.path.join(ROOT, "profiles", "r06_v_c3full_kernel_stats.csv")
+SHARD = os.path.join(ROOT, "profiles", "r06_v_c3shard_kernel_stats.csv")
 
 
 def test_design_is_short_and_covers_the_profiles_top_40():

@@ -15,10 +15,10 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "gl_pack_scale_k": ("gram", "diag(s) X packed as the planar band image", "launch"),
     "gl_pack_panel_k": ("project / kmpp", "a panel of a wide operand packed as the band image", "launch"),
     "gl_wide_assemble_k": ("project", "16 panels' position-ordered rows -> document-major rows of P, norms, the bf16 split copy", "HBM"),
-    "vtf_mfma_k": ("ortho", "H = V^T F, v_mfma_f32_16x16x4_f32, fp64 across row chunks", "HBM (reads the basis)"),
+    "vtf_mfma_k": ("ortho", "H = V^T F, v_mfma_f32_16x16x4_f32, panel chunk staged in LDS per 8-wave workgroup, fp64 across row chunks", "HBM (reads the basis at 5.4 TB/s; before round 6: the vector L1 tag path)"),
     "vtf_reduce_k": ("ortho", "row-chunk partials of H summed in fixed order", "launch"),
     "vtf_partial_k": ("ortho", "H = V^T F for narrow bases (FMA form)", "HBM"),
-    "update_mfma_k": ("ortho", "F -= V H on the matrix cores, coefficients from cache", "HBM (reads the basis)"),
+    "update_mfma_k": ("ortho", "F -= V H on the matrix cores, a 16-byte coefficient load per 16 MFMAs", "HBM (reads the basis)"),
     "pqr_gram_k": ("qr", "slab Gram matrices of the panel (fp64)", "latency"),
     "pqr_factor_k": ("qr", "sum of the slab Grams, Cholesky with column dropping, triangular inverse (one workgroup; wave 0)", "latency"),
     "pqr_apply_gram_k": ("qr", "Q1 = F T and the slab Grams of Q1 in one sweep", "latency"),
