@@ -352,6 +352,23 @@ def test_block_ks_medium(hp, small50):
     assert (np.diff(r["evals"]) <= 1e-3 * r["evals"][0]).all()  # descending
 
 
+def test_block_ks_on_a_vocabulary_that_is_not_a_multiple_of_four(hp):
+    """V = 3001: the basis columns are not 16-byte aligned, so the orthogonalisation's matrix-core kernels (vtf_mfma_k with its panel chunk
+    staged in LDS, update_mfma_k) take their element-wise paths at every basis width, the last 1024-row chunk holds 953 rows, and the
+    panel QR and the rotation see an odd leading dimension.  k = 40: ncv = 90, basis widths 10 ... 90 on both sides of the 64-column switch."""
+    from conftest import corpus
+    B, k = corpus(3001, 9000, 40, 11), 40
+    upload(hp, B)
+    r = hp.compute_block_ks(k, allow_noconv=True)
+    o = B["oracle"].block_ks(k)
+    sig, sig_o = np.sqrt(r["evals"]), np.sqrt(o["evals"])
+    assert np.max(np.abs(sig - sig_o) / sig_o) <= 1e-4, (sig, sig_o)
+    U = hp.get_U(k)
+    assert np.abs(U.astype(np.float64).T @ U - np.eye(k)).max() <= 1e-4
+    AU = B["oracle"].gram_apply(U)
+    assert np.abs(AU - U * r["evals"]).max() <= 2e-3 * r["evals"][0]
+
+
 def _kmeans_setup(hp, B, k):
     upload(hp, B)
     o = B["oracle"].block_ks(k)
