@@ -75,27 +75,28 @@ __global__ __launch_bounds__(256) void vtf_partial_k(const float* __restrict__ V
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 // What bounds it (round 6, profiles/r06_u_ortho_kernels.txt): not the loads in flight per wave (2, 8 or 16 float4: the same time) and not the
 // occupancy — the vector L1's tag path.  A load of this shape is 16 column pieces of 64 bytes = 16 tag look-ups for 1 KB.
-constexpr int VM_RC = 1024;
+constexpr int VM_RC = 1024;           // most rows of a chunk; a short panel (a rank's row slice: V / N rows) takes 512 or 256 (vm_rows_per_chunk)
 constexpr int VM_WAVES = 8;           // waves (16 basis columns each) of a workgroup: they share the staged panel chunk
 #ifndef VM_NG_V
 #define VM_NG_V 2
 #endif
 constexpr int VM_NG = VM_NG_V;        // 64-row groups per trip of the main loop
-constexpr int VM_FS = VM_RC + 4;      // floats between the panel's columns in LDS: the 16 columns of a ds_read_b128 quarter lie 16 bytes apart mod 256
+// floats between the panel's columns in LDS = rows per chunk + 4: the 16 columns of a ds_read_b128 quarter lie 16 bytes apart mod 256
 // The panel chunk (b columns x 1024 rows, 41 KB at b = 10) is staged in LDS once per workgroup (round 6).  Read from global memory by every wave it
 // doubled the wave's load instructions, and a load instruction of this shape — 16 columns x 64 bytes — is 16 tag look-ups in the vector L1
 // (≈ 4 clk each: 64 clk for 1 KB, ≈ 4.9 TB/s chip-wide for the basis when the panel takes half of them; the kernel ran at 4.6).  Same MFMAs on the same
 // operands in the same order as before: same bits.
 __global__ __launch_bounds__(64 * VM_WAVES) void vtf_mfma_k(const float* __restrict__ Vb, uint64_t n, uint64_t ld, int m, const float* __restrict__ F, int b,
-                                                            int BT, double* __restrict__ part /*[chunk][m][BT]*/) {
-  extern __shared__ float vm_fs[];  // [b][VM_FS], rows beyond the chunk's end are zeros
+                                                            int BT, double* __restrict__ part /*[chunk][m][BT]*/, int rc /*rows per chunk*/) {
+  extern __shared__ float vm_fs[];  // [b][rc + 4], rows beyond the chunk's end are zeros
+  const int VM_FS = rc + 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const uint64_t r0 = (uint64_t)blockIdx.x * VM_RC;
-  const uint64_t r1 = min(n, r0 + VM_RC);
+  const uint64_t r0 = (uint64_t)blockIdx.x * rc;
+  const uint64_t r1 = min(n, r0 + rc);
   const bool aligned = (ld & 3) == 0 && (((uintptr_t)Vb | (uintptr_t)F) & 15) == 0;  // columns are 16-byte aligned
-  for (int idx = threadIdx.x; idx < b * (VM_RC / 4); idx += 64 * VM_WAVES) {
-    const int j = idx / (VM_RC / 4), q4 = idx - j * (VM_RC / 4);
+  for (int idx = threadIdx.x; idx < b * (rc / 4); idx += 64 * VM_WAVES) {
+    const int j = idx / (rc / 4), q4 = idx - j * (rc / 4);
     const uint64_t rr = r0 + 4 * (uint64_t)q4;
     const float* src = F + (uint64_t)j * ld + rr;
     float4 v;
@@ -208,11 +209,17 @@ int k_vtf(isle_ctx* c, const float* Vb, uint64_t n, int m, const float* F, int b
   }
   if (b <= 16 && m >= 64) {  // matrix-core path (enough columns to fill the chip)
     const int BT = bt_of(b);
-    const int nch = cdiv(n, VM_RC);
+    // Rows per chunk: 1024, or — a rank's row slice under the row-sharded step, V / N rows — 512 / 256 while that leaves at most 128 chunks
+    // (vtf_reduce_k walks them one after another) and the grid would not reach two workgroups per CU otherwise.  At n = 12 500 (N = 8) the
+    // 1024-row chunks gave 13 x 16 workgroups of eight dependent trips each: the call took as long as at n = 100 000 / 3 (round 6,
+    // tools/ortho_slice_probe.py).  One GPU at V = 100 000: 1024 at every basis width, as before.
+    int rc = VM_RC;
+    while (rc > 256 && cdiv(n, rc / 2) <= 128 && (long)cdiv(n, rc) * cdiv(m, 16 * VM_WAVES) < 2L * c->num_cus) rc /= 2;
+    const int nch = cdiv(n, rc);
     HIPCHK(c, c->part.reserve((size_t)nch * m * BT));
-    const size_t lds = (size_t)b * VM_FS * sizeof(float);
+    const size_t lds = (size_t)b * (rc + 4) * sizeof(float);
     ISLECHK(isle_max_lds(c, (const void*)vtf_mfma_k, (int)lds));
-    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 16 * VM_WAVES)), dim3(64 * VM_WAVES), lds, c->stream, Vb, n, ld, m, F, b, BT, c->part.p);
+    hipLaunchKernelGGL(vtf_mfma_k, dim3(nch, cdiv(m, 16 * VM_WAVES)), dim3(64 * VM_WAVES), lds, c->stream, Vb, n, ld, m, F, b, BT, c->part.p, rc);
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(vtf_reduce_k<float>, dim3(cdiv((long)m * BT, 256)), dim3(256), 0, c->stream, c->part.p, nch, m, BT, b, coef);
     HIPCHK(c, hipGetLastError());
@@ -277,14 +284,16 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
 // f32 products and sums).  The four waves of a workgroup take the basis columns i = 32 q .. 32 q + 31 of every 128-column tile, eight
 // float4 loads in flight each (UM_SETS = 1: four; the same time), and their sums are added in the order q = 0 .. 3: deterministic, other
 // rounding than update_k's chains.
-constexpr int UM_TILE = 128;
+constexpr int UM_TILE = 128;  // columns of a tile of the four-wave form (32 per wave)
 #ifndef UM_SETS_V
 #define UM_SETS_V 2
 #endif
 constexpr int UM_SETS = UM_SETS_V;  // sets of 16 columns whose loads a wave issues together (1 or 2)
-__global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint64_t n, uint64_t ld, int b, const float* __restrict__ Vb, int m,
-                                                      const float* __restrict__ coef /*m x b col-major*/) {
-  __shared__ float red[4][64][17];
+template <int NQ>  // waves of a workgroup (4; 8 / 16 on a short panel: a rank's row slice), each takes 32 of every 32 NQ basis columns
+__global__ __launch_bounds__(64 * NQ) void update_mfma_k(float* __restrict__ F, uint64_t n, uint64_t ld, int b, const float* __restrict__ Vb, int m,
+                                                         const float* __restrict__ coef /*m x b col-major*/) {
+  extern __shared__ float um_red[];  // [NQ][64][17]
+  float (*red)[64][17] = reinterpret_cast<float (*)[64][17]>(um_red);
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const uint64_t r0 = (uint64_t)blockIdx.x * 64;
@@ -302,8 +311,8 @@ __global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint
   // a lane's four coefficients of a set are CONSECUTIVE in its column of coef, one 16-byte load per 16 MFMAs (round 6; until then the step
   // took the columns base + 4 s + g and every MFMA quadruple had a dword load of its own — a wave instruction over 16 cache lines, 64 clk of
   // tag look-ups in the vector L1 beside the 32 clk of the basis load it fed: 4.25 TB/s).  All loads of a trip are issued before its first MFMA.
-  for (int i0 = 0; i0 < m; i0 += UM_TILE) {
-    const int kb = i0 + q * (UM_TILE / 4);
+  for (int i0 = 0; i0 < m; i0 += 32 * NQ) {
+    const int kb = i0 + 32 * q;
     if (kb < m) {  // wave-uniform
 #pragma unroll
       for (int h0 = 0; h0 < 2; h0 += UM_SETS) {  // UM_SETS sets' loads in flight together
@@ -339,7 +348,12 @@ __global__ __launch_bounds__(256) void update_mfma_k(float* __restrict__ F, uint
   __syncthreads();
   const uint64_t r = r0 + lane;
   if (r < n)
-    for (int j = q; j < b; j += 4) F[(uint64_t)j * ld + r] -= ((red[0][lane][j] + red[1][lane][j]) + red[2][lane][j]) + red[3][lane][j];
+    for (int j = q; j < b; j += NQ) {
+      float s = red[0][lane][j];
+#pragma unroll
+      for (int qq = 1; qq < NQ; ++qq) s += red[qq][lane][j];  // q = 0, 1, ...: the order of the four-wave form's ((r0 + r1) + r2) + r3
+      F[(uint64_t)j * ld + r] -= s;
+    }
 }
 
 int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, const float* coef, uint64_t ld) {
@@ -349,7 +363,19 @@ int k_update(isle_ctx* c, float* F, uint64_t n, int b, const float* Vb, int m, c
   const int BT = bt_of(b);
   dim3 g(cdiv(n, 64)), blk(256);
   if (b <= 16 && m >= 32 && (ld & 3) == 0 && (((uintptr_t)Vb | (uintptr_t)F) & 15) == 0 && !c->knob_zero(KN_UPDATE_MFMA)) {
-    hipLaunchKernelGGL(update_mfma_k, g, blk, 0, c->stream, F, n, ld, b, Vb, m, coef);
+    // waves per workgroup: a workgroup is 64 rows, so a short panel (a rank's row slice) leaves CUs empty and every wave a long chain of
+    // dependent trips (n = 12 500: 196 workgroups x 16 trips at m = 2010) — there the columns are dealt over 8 or 16 waves instead of 4
+    const long wgs = cdiv(n, 64);
+    const int nq = wgs <= c->num_cus ? 16 : wgs <= 2L * c->num_cus ? 8 : 4;
+    const size_t lds = (size_t)nq * 64 * 17 * sizeof(float);
+    switch (nq) {
+      case 16:
+        ISLECHK(isle_max_lds(c, (const void*)update_mfma_k<16>, (int)lds));
+        hipLaunchKernelGGL(update_mfma_k<16>, g, dim3(1024), lds, c->stream, F, n, ld, b, Vb, m, coef);
+        break;
+      case 8: hipLaunchKernelGGL(update_mfma_k<8>, g, dim3(512), lds, c->stream, F, n, ld, b, Vb, m, coef); break;
+      default: hipLaunchKernelGGL(update_mfma_k<4>, g, blk, lds, c->stream, F, n, ld, b, Vb, m, coef); break;
+    }
     HIPCHK(c, hipGetLastError());
     return 0;
   }
