@@ -622,7 +622,9 @@ def run(args, workload, rank, world, local_rank, dist, torch, steps, warmup, ful
     # (profiles/pmc_traffic.json, collected by tools/pmc_probe.py under rocprofv3 --pmc in passes of their own), or null with the reason
     traffic, traffic_note = None, None
     pmc_key = {"c3": "c3full"}.get(workload, workload)
-    if world > 1:
+    if world == 8 and workload in ("c3", "c3full") and WORKLOADS["c3shard"][1] * 8 == WORKLOADS[workload][1]:
+        pmc_key = "c3shard"  # rank 0 of eight holds the documents of the c3shard workload (thresholded there on their own statistics): same launches within 0.1 %
+    if world > 1 and pmc_key != "c3shard":
         traffic_note = "no counter pass exists for a %d-rank shard" % world
     elif form != 1:
         traffic_note = "profiles/pmc_traffic.json holds the LDS-banded form's counters; this run used the gather form"
