@@ -53,6 +53,7 @@ const IsleKnobInfo isle_knob_table[KN_COUNT] = {
     {"ISLE_EVD_JACOBI", "form", "small symmetric EVD by block Jacobi instead of tridiagonalisation"},
     {"ISLE_TD_CHAIN", "form", "tridiagonalisation as a launch chain instead of the persistent kernel"},
     {"ISLE_TD_BAR", "tuning", "flat | hier: the persistent tridiagonalisation crosses its grid barriers on one counter (gb_barrier) or through the hierarchical barrier (gbh_barrier) instead of the sharded counters polled together (gbs_barrier, gridbar.h; round 6: 36.4 / 37.0 / 40.7 ms per EVD at n = 2000 sharded / hier / flat); same bits"},
+    {"ISLE_TD_BACK", "form", "seq: the eigenvectors' back-transformation applies the reflectors one by one (td_back_k) instead of by blocks of four in compact WY form"},
     {"ISLE_EVD_SPLIT", "form", "1: with several ranks rank r computes the eigenvectors [r kc, (r + 1) kc) of the small EVD and the columns are all-gathered (same bits on every rank; default since round 6: every rank computes all of them — the stage's kernels are chains of n steps whatever the number of vectors, the split saves no time)"},
     {"ISLE_KMPP_HOST_DICE", "form", "k-means++ dice scaled and searched through the host round trip (the multi-rank form) on one rank too"},
     {"ISLE_KMPP_SPARSE", "form", "0 / 1: k-means++ rounds on the projection / through thin products of B (default: by cost)"},

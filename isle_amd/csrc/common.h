@@ -87,7 +87,7 @@ struct DevBuf {
 // ------------------------------------------------------------------------------------------
 enum IsleKnob {
   KN_GRAM_LDS, KN_GL_G1, KN_GL_G2, KN_GL_PLACE, KN_GL_FILL_BUCKETS, KN_GL_ROUNDS, KN_GL_COLUMNS, KN_GL_PANEL, KN_GL_WIDE_GROUPED, KN_WIDE_GATHER, KN_WIDE_LDS,
-  KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_UPDATE_MFMA, KN_EVD_JACOBI, KN_TD_CHAIN, KN_TD_BAR, KN_EVD_SPLIT,
+  KN_KS_ROWSHARD, KN_KS_SYNC, KN_KS_ORTHO_PASSES, KN_UPDATE_MFMA, KN_EVD_JACOBI, KN_TD_CHAIN, KN_TD_BAR, KN_TD_BACK, KN_EVD_SPLIT,
   KN_KMPP_HOST_DICE, KN_KMPP_SPARSE, KN_KMPP_TRACK, KN_NO_HAMERLY, KN_KMEANS_BOUNDS, KN_PROJ_BOUNDS, KN_PROJ_FULL, KN_FIRST_ASSIGN, KN_GEMM_BF16X3, KN_GEMM_EPILOGUE, KN_GEMM_TERMS, KN_GEMM_DMA, KN_YY_MODE, KN_YY_FUSED, KN_YY_MOVERS, KN_YY_REGROUP, KN_YY_ORDER, KN_PT_SORT, KN_PROJ_ACTIVE, KN_PROJ_SUMS, KN_CENTERS_FRESH,
   KN_INFER_CAP_ROWS, KN_CHUNK_COLS, KN_COMM_TIMEOUT, KN_COMM_SELFTEST, KN_FORCE_COMM, KN_TEST_STALL_MS,
   KN_ROCTX, KN_HOST_TRACE, KN_DEBUG_HAMERLY, KN_DEBUG_EVD, KN_GL_VERBOSE, KN_TD_FORCE_BAIL_RANK, KN_GL_TEST_CUS, KN_GL_ABLATE_SKIP,

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void update_k(float* __restrict__ F, uint64_t 
 // f32 products and sums).  The four waves of a workgroup take the basis columns i = 32 q .. 32 q + 31 of every 128-column tile, eight
 // float4 loads in flight each (UM_SETS = 1: four; the same time), and their sums are added in the order q = 0 .. 3: deterministic, other
 // rounding than update_k's chains.
-constexpr int UM_TILE = 128;  // columns of a tile of the four-wave form (32 per wave)
+
 #ifndef UM_SETS_V
 #define UM_SETS_V 2
 #endif

@@ -570,6 +570,182 @@ __global__ __launch_bounds__(TD_B_T) void td_back_k(const double* __restrict__ A
     for (int i = rl; i < n; i += RL) out[(size_t)(c0 + c) * n + i] = (float)zs[i * NC + c];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same back-transformation by blocks of four reflectors in compact WY form (round 6): H_j0 H_j1 H_j2 H_j3 = I - V T V^T
+// (T upper triangular 4 x 4, LAPACK dlarft 'forward, columnwise'), so a step is  S = V^T Z,  Y = T S,  Z -= V Y  — one reduction and two
+// workgroup barriers per FOUR reflectors, and the block's reflector entries are loaded once, all at once (td_back_k: 2.1 us per reflector,
+// of which most is the dependent load of the reflector and the reduction: 4.3 ms per call at n = 2010).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TD_WY = 4;
+// T of every block: Tb[b][r][s], r <= s.  One workgroup per block: the six inner products of its reflectors, then the recurrence
+//   T[i][i] = tau_i,  T[0:i, i] = -tau_i T[0:i, 0:i] (V[:, 0:i]^T v_i).
+__global__ __launch_bounds__(256) void td_wy_T_k(const double* __restrict__ A, const double* __restrict__ tau, int n, double* __restrict__ Tb) {
+  __shared__ double sh[4][6];
+  const int b = blockIdx.x, j0 = TD_WY * b, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nref = n - 2;  // reflectors 0 .. n - 3
+  double g[6] = {0, 0, 0, 0, 0, 0};  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+  for (int i = j0 + 2 + t; i < n; i += 256) {  // row i carries reflector j iff i >= j + 1
+    double v[TD_WY];
+#pragma unroll
+    for (int r = 0; r < TD_WY; ++r) v[r] = (j0 + r < nref && i >= j0 + r + 1) ? A[(size_t)(j0 + r) * n + i] : 0.0;
+    g[0] = fma(v[0], v[1], g[0]);
+    g[1] = fma(v[0], v[2], g[1]);
+    g[2] = fma(v[0], v[3], g[2]);
+    g[3] = fma(v[1], v[2], g[3]);
+    g[4] = fma(v[1], v[3], g[4]);
+    g[5] = fma(v[2], v[3], g[5]);
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g[q] += __shfl_xor(g[q], off);
+    if (lane == 0) sh[wave][q] = g[q];
+  }
+  __syncthreads();
+  if (t != 0) return;
+  double G[TD_WY][TD_WY] = {};
+  const int idx[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+  for (int q = 0; q < 6; ++q) G[idx[q][0]][idx[q][1]] = (sh[0][q] + sh[1][q]) + (sh[2][q] + sh[3][q]);
+  double T[TD_WY][TD_WY] = {};
+  for (int i = 0; i < TD_WY; ++i) {
+    const double ti = j0 + i < nref ? tau[j0 + i] : 0.0;
+    double w[TD_WY];
+    for (int r = 0; r < i; ++r) w[r] = -ti * G[r][i];
+    for (int r = 0; r < i; ++r) {
+      double s = 0.0;
+      for (int q = r; q < i; ++q) s = fma(T[r][q], w[q], s);
+      T[r][i] = s;
+    }
+    T[i][i] = ti;
+  }
+  for (int r = 0; r < TD_WY; ++r)
+    for (int s = 0; s < TD_WY; ++s) Tb[(size_t)b * 16 + r * 4 + s] = T[r][s];
+}
+
+template <int NC, bool KEEPV, bool DMA>  // eigenvectors per workgroup (as td_back_k); a thread owns column c = t % NC of the rows rl, rl + RL, ... (RL = 1024 / NC):
+                   // its entries of Z stay in registers from the first load to the store; KEEPV: so do a block's reflector entries between the
+                   // two phases of a step (NC = 4: 8 rows x 4 doubles; at NC = 8 they would spill and are read again, from L2)
+__global__ __launch_bounds__(TD_B_T) void td_back_wy_k(const double* __restrict__ A, const double* __restrict__ Tb, int n, const double* __restrict__ Z, int nvec,
+                                                       float* __restrict__ out, int v0, int v1 /*the vectors [v0, v1) of the nvec*/) {
+  constexpr int NWV = TD_B_T / 64;
+  constexpr int RL = TD_B_T / NC;                              // row lanes
+  constexpr int RPT = (TD_NMAX_BACK + RL - 1) / RL;            // rows per thread at most (8 at NC = 4)
+  __shared__ double red[NWV][TD_WY][NC], ys[TD_WY][NC];
+  // two images of a block's four reflector columns (rows 0 .. nrow - 1 of each, nrow = n rounded up to 128 = 1 KiB pieces): block b - 1 is
+  // staged by LDS-DMA while block b is worked on, so no step waits for memory (even n: the pieces are 16-byte aligned; odd n reads memory directly)
+  extern __shared__ double vb[];
+  const int nrow = (n + 127) & ~127;
+  constexpr bool dma = DMA;  // even n: the pieces are 16-byte aligned
+  const int c0 = v0 + (int)blockIdx.x * NC;
+  const int t = threadIdx.x, c = t & (NC - 1), rl = t / NC, lane = t & 63, wave = t >> 6;
+  const bool live = c0 + c < v1;
+  const int nref0 = n - 2;
+  auto stage = [&](int b, int buf) {  // this wave's 1-KiB pieces of block b: piece = (reflector r, chunk ch)
+    const int npiece = TD_WY * (nrow / 128);
+    for (int pc = wave; pc < npiece; pc += NWV) {
+      const int r = pc / (nrow / 128), ch = pc - r * (nrow / 128);
+      if (TD_WY * b + r < nref0) {  // wave-uniform
+        const char* gp = reinterpret_cast<const char*>(A + (size_t)(TD_WY * b + r) * n) + (size_t)ch * 1024 + (size_t)lane * 16;
+        char* lp = reinterpret_cast<char*>(vb + ((size_t)buf * TD_WY + r) * nrow) + (size_t)ch * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+      }
+    }
+  };
+  double z[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int i = rl + q * RL;
+    z[q] = (live && i < n) ? Z[(size_t)i * nvec + c0 + c] : 0.0;
+  }
+  const int nref = n - 2, nblk = (nref + TD_WY - 1) / TD_WY;
+  if (dma) {
+    stage(nblk - 1, (nblk - 1) & 1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+  }
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int j0 = TD_WY * b;
+    // the next block's image: its buffer was last read before the previous step's first barrier
+    if (dma && b > 0) stage(b - 1, (b - 1) & 1);
+    const double* vcur = vb + (size_t)(b & 1) * TD_WY * nrow;
+    // the block's reflector entries of this thread's rows (rows above a reflector's support: zero), from the image in LDS
+    // the block's T (uniform address: scalar loads), asked for before the reflector entries so that it is there when wave 0 needs it
+    double Tr[TD_WY][TD_WY];
+#pragma unroll
+    for (int r = 0; r < TD_WY; ++r)
+#pragma unroll
+      for (int q = r; q < TD_WY; ++q) Tr[r][q] = Tb[(size_t)b * 16 + r * 4 + q];
+    auto ldv = [&](int q, int r) {
+      const int i = rl + q * RL;
+      return (i < n && j0 + r < nref && i >= j0 + r + 1) ? (dma ? vcur[(size_t)r * nrow + i] : A[(size_t)(j0 + r) * n + i]) : 0.0;
+    };
+    double v[KEEPV ? RPT : 1][TD_WY];
+    double s[TD_WY] = {0.0, 0.0, 0.0, 0.0};
+    if (KEEPV) {
+#pragma unroll
+      for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int r = 0; r < TD_WY; ++r) v[q][r] = ldv(q, r);
+#pragma unroll
+      for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int r = 0; r < TD_WY; ++r) s[r] = fma(v[q][r], z[q], s[r]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int r = 0; r < TD_WY; ++r) s[r] = fma(ldv(q, r), z[q], s[r]);
+    }
+    // the row lanes of a column inside the wave by butterflies, the waves in LDS: a fixed order
+#pragma unroll
+    for (int r = 0; r < TD_WY; ++r) {
+#pragma unroll
+      for (int off = NC; off < 64; off <<= 1) s[r] += __shfl_xor(s[r], off);
+      if (lane < NC) red[wave][r][lane] = s[r];
+    }
+    __syncthreads();
+    if (t < TD_WY * NC) {  // thread (r, c') of wave 0: S[r][c'] over the waves ...
+      const int r = t / NC, cc = t - r * NC;
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWV; w += 4) tot += (red[w][r][cc] + red[w + 1][r][cc]) + (red[w + 2][r][cc] + red[w + 3][r][cc]);
+      red[0][r][cc] = tot;  // (only this thread reads red[.][r][cc])
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t < NC) {  // ... then Y = T S, a column per thread
+      double S[TD_WY];
+#pragma unroll
+      for (int r = 0; r < TD_WY; ++r) S[r] = red[0][r][t];
+#pragma unroll
+      for (int r = 0; r < TD_WY; ++r) {
+        double y = 0.0;
+#pragma unroll
+        for (int q = r; q < TD_WY; ++q) y = fma(Tr[r][q], S[q], y);
+        ys[r][t] = y;
+      }
+    }
+    if (dma) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of the next block have landed (they had the whole step to)
+    __syncthreads();
+    double y[TD_WY];
+#pragma unroll
+    for (int r = 0; r < TD_WY; ++r) y[r] = ys[r][c];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+      for (int r = 0; r < TD_WY; ++r) z[q] = fma(-(KEEPV ? v[q][r] : ldv(q, r)), y[r], z[q]);
+    // (the next block's first barrier stands between these reads of ys / red[0] and their next writes)
+  }
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = rl + q * RL;
+      if (i < n) out[(size_t)(c0 + c) * n + i] = (float)z[q];
+    }
+  }
+}
+
 // max over vectors of | <z_c, z_{c+q}> | (q = 1..4) and | |z_c|^2 - 1 |, as the bits of a non-negative float
 __global__ __launch_bounds__(256) void td_check_k(const float* __restrict__ Zc, int n, int nvec, unsigned int* __restrict__ worst) {
   __shared__ double sh[16];
@@ -637,6 +813,7 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   unsigned int* bar_state = reinterpret_cast<unsigned int*>((reinterpret_cast<uintptr_t>(pv + 4 * (size_t)n) + 127) & ~(uintptr_t)127);
   ISLECHK(isle_max_lds(c, (const void*)td_back_k<8>, TD_NMAX_BACK * 8 * (int)sizeof(double)));
   ISLECHK(isle_max_lds(c, (const void*)td_back_k<4>, TD_NMAX_BACK * 4 * (int)sizeof(double)));
+  ISLECHK(isle_max_lds(c, (const void*)td_back_wy_k<4, true, true>, 2 * TD_WY * TD_NMAX_BACK * (int)sizeof(double)));
   const bool small = n <= TD_ROWS * 4;
   // persistent form: G workgroups, each with its columns (ncl of them) plus v and w in LDS
   int pG = TD_P_GSMALL;
@@ -740,10 +917,23 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   const int nv = v1 - v0;
   if (nv > 0) {
     hipLaunchKernelGGL(td_vectors_k, dim3((nv + 63) / 64), dim3(64), 0, c->stream, d, e, n, lam, nvec, Dp, Lf, Z, v0, v1);
-    if ((nvec + 7) / 8 > c->num_cus / 2 && !kc)
-      hipLaunchKernelGGL(td_back_k<8>, dim3((nv + 7) / 8), dim3(TD_B_T), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev, v0, v1);
-    else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread (two per workgroup measured no better)
-      hipLaunchKernelGGL(td_back_k<4>, dim3((nv + 3) / 4), dim3(TD_B_T), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev, v0, v1);
+    // back-transformation by blocks of four reflectors (compact WY): the T factors first (the buffer of the launch chain's partial sums is free by now);
+    // ISLE_TD_BACK=seq: reflector by reflector (td_back_k)
+    const char* e_back = c->knob(KN_TD_BACK);
+    if (e_back && e_back[0] == 's') {
+      if ((nvec + 7) / 8 > c->num_cus / 2 && !kc)
+        hipLaunchKernelGGL(td_back_k<8>, dim3((nv + 7) / 8), dim3(TD_B_T), (size_t)n * 8 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev, v0, v1);
+      else  // few eigenvectors: four per workgroup, twice the workgroups, half the rows per thread (two per workgroup measured no better)
+        hipLaunchKernelGGL(td_back_k<4>, dim3((nv + 3) / 4), dim3(TD_B_T), (size_t)n * 4 * sizeof(double), c->stream, A, tau, n, Z, nvec, vecs_dev, v0, v1);
+    } else {
+      const int nblk = (n - 2 + TD_WY - 1) / TD_WY;
+      double* Tb = part;
+      hipLaunchKernelGGL(td_wy_T_k, dim3(nblk), dim3(256), 0, c->stream, A, tau, n, Tb);
+      // four eigenvectors per workgroup whatever their number (eight would spill the block's reflector entries: beyond 4 x 256 vectors the
+      // workgroups run in two rounds, still ahead of the eight-column sequential form)
+      if (n & 1) hipLaunchKernelGGL((td_back_wy_k<4, true, false>), dim3((nv + 3) / 4), dim3(TD_B_T), 0, c->stream, A, Tb, n, Z, nvec, vecs_dev, v0, v1);
+      else hipLaunchKernelGGL((td_back_wy_k<4, true, true>), dim3((nv + 3) / 4), dim3(TD_B_T), (size_t)2 * TD_WY * ((n + 127) & ~127) * sizeof(double), c->stream, A, Tb, n, Z, nvec, vecs_dev, v0, v1);
+    }
   }
   HIPCHK(c, hipGetLastError());
   if (kc) {

@@ -510,3 +510,24 @@ def test_the_three_grid_barriers_of_the_persistent_tridiagonalisation_give_the_s
         monkeypatch.delenv("ISLE_TD_BAR")
         assert np.array_equal(e.view(np.uint32), e0.view(np.uint32)), form
         assert np.array_equal(v.view(np.uint32), v0.view(np.uint32)), form
+
+
+@pytest.mark.parametrize("n", [399, 400, 1212, 2010])
+def test_back_transformation_by_blocks_of_four_reflectors_equals_the_sequential_one(hp, monkeypatch, n):
+    """The eigenvectors' back-transformation Z <- H_0 ... H_{n-3} Z runs by blocks of four reflectors in compact WY form (td_wy_T_k + td_back_wy_k:
+    S = V^T Z, Y = T S, Z -= V Y; the block's reflector columns staged by LDS-DMA one block ahead when n is even); ISLE_TD_BACK=seq applies the
+    reflectors one by one (td_back_k).  Same eigenvalues bit for bit (the back-transformation does not touch them), eigenvectors equal to
+    rounding, both orthonormal and both satisfying S v = lambda v.  n = 399: the element-wise path and a last block of one reflector;
+    n = 2010 with all vectors: 503 workgroups, two rounds; n = 1212: rows per thread that do not fill the unrolled eight."""
+    S = ritz_like(n, n + 7)
+    e1, v1 = hp.eig_sym(S)
+    monkeypatch.setenv("ISLE_TD_BACK", "seq")
+    e0, v0 = hp.eig_sym(S)
+    monkeypatch.delenv("ISLE_TD_BACK")
+    assert np.array_equal(e1.view(np.uint32), e0.view(np.uint32))
+    assert np.abs(v1.astype(np.float64) - v0).max() <= 2e-6
+    S64 = S.astype(np.float64)
+    for v in (v1, v0):
+        V = v.astype(np.float64)
+        assert np.abs(V.T @ V - np.eye(n)).max() <= 2e-6
+        assert np.abs(S64 @ V - V * e1.astype(np.float64)).max() <= 2e-6 * np.abs(e1).max()

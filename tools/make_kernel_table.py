@@ -24,7 +24,9 @@ INFO = {  # kernel (prefix) -> (family, what, bound)
     "pqr_apply_gram_k": ("qr", "Q1 = F T and the slab Grams of Q1 in one sweep", "latency"),
     "pqr_apply_k": ("qr", "Q = Q1 T2", "latency"),
     "td_persist_k": ("evd", "Householder tridiagonalisation, matrix resident in LDS, one grid barrier per column", "latency chain: n x ~10 us"),
-    "td_back_k": ("evd", "Z = Q Z_T, reflectors applied in reverse to 4 / 8 eigenvector columns per workgroup", "LDS / latency"),
+    "td_back_k": ("evd", "Z = Q Z_T, reflectors applied one by one (ISLE_TD_BACK=seq)", "latency: 2 barriers per reflector"),
+    "td_back_wy_k": ("evd", "Z = Q Z_T by blocks of four reflectors in compact WY form, the block's columns staged by LDS-DMA one block ahead", "latency: 2 barriers per four reflectors"),
+    "td_wy_T_k": ("evd", "the 4 x 4 T factors of the reflector blocks", "launch"),
     "td_bisect_k": ("evd", "eigenvalues by 64-way multisection on the Sturm count", "latency"),
     "td_vectors_k": ("evd", "eigenvectors of T by twisted factorisation, a thread per vector", "latency"),
     "td_check_k": ("evd", "orthogonality of neighbouring vectors", "launch"),

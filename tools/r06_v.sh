@@ -11,4 +11,4 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 f=$(find $O/prof_shard -name "*kernel_stats.csv" | head -1); cp "$f" $O/c3shard_kernel_stats.csv
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 head -8 $O/c3full_kernel_stats.csv | cut -c1-160
-bash tools/r06_steppmc.sh
+
