@@ -19,8 +19,8 @@ def switches():
     out = ["| switch | kind | effect |", "|---|---|---|"]
     for name, kind, what in rows:
         what = what.replace('\\"', '"').replace("|", "\\|")
-        if len(what) > 112:  # the full text: isle_hip_switch_info / api.cpp
-            cut = what[:112]
+        if len(what) > 100:  # the full text: isle_hip_switch_info / api.cpp
+            cut = what[:100]
             what = cut[:cut.rfind(" ")] + " …"
         out.append("| `%s` | %s | %s |" % (name, kind, what))
     return "\n".join(out)
