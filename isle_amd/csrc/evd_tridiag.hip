@@ -216,6 +216,26 @@ __global__ __launch_bounds__(TD_ROWS) void td_update_symv_k(double* __restrict__
 // gives up after a bounded spin and raises `abort` (a workgroup that is not resident would otherwise hang the GPU); the host
 // then runs the launch chain instead.
 // ---------------------------------------------------------------------------------------------------------------
+// Block sum with ONE barrier: the waves' partial sums go to 16 slots that nobody writes again before another barrier has been crossed
+// (td_persist_k has a set per sum), so the barrier in front of the write that td_block_sum needs can go.  Same order of additions.
+__device__ inline double td_block_sum1(double v, double* sh16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if (lane == 0) sh16[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int nw = (int)(blockDim.x >> 6);
+  for (int w = 0; w < nw; ++w) s += sh16[w];  // fixed order
+  return s;
+}
+
+#ifdef TD_STAMPS
+__device__ unsigned long long td_stamps[16];
+#define TD_ST(k) if (g == 0 && t == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); td_stamps[k] += now_ - st_; st_ = now_; }
+#else
+#define TD_ST(k)
+#endif
 constexpr int TD_P_GSMALL = 32;   // workgroups for n <= 512 (more only add barrier latency)
 constexpr int TD_P_T = 1024;  // 16 waves: the length-n vector phases every workgroup repeats per column are latency chains (256 threads: 35 -> 28 ms at n = 2010)
 constexpr int TD_P_MAXPT = TD_NMAX_BACK / TD_P_T;  // column entries per thread
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
                                                         double* __restrict__ tau, double* __restrict__ xbuf /* 2 x (p | next column), 4 n */,
                                                         const GbHierArgs bar, unsigned int* __restrict__ abort) {
   extern __shared__ double lds[];  // slab: ncl columns of n | vs n | ws n
-  __shared__ double sh[16];
+  __shared__ double sh[16], shd[16], shn[18], shr[4];  // sh: the first reflector; shd / shn: the two sums of a column (shn[16]: alpha); shr: beta, tau, scale
   const int G = (int)gridDim.x;
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ncl = (n + G - 1) / G;
@@ -275,6 +295,9 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
   __syncthreads();
   double tj = td_p_reflector(ws, vs, n, 0, g == 0, d, e, tau, sh);
   unsigned int phase = 0;
+#ifdef TD_STAMPS
+  unsigned long long st_ = __builtin_readcyclecounter();
+#endif
   for (int cj = 0; cj < n - 1; ++cj) {
     const int r0 = cj + 1;  // first row / column of the trailing block
     double* pbuf = xbuf + (size_t)(cj & 1) * 2 * n;  // double-buffered: a fast workgroup writes step cj + 1 while a slow one still reads step cj
@@ -286,6 +309,7 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       if (c >= r0 && c < n) {  // wave-uniform
         const double* col = slab + (size_t)lc * n;
         double s = 0.0;
+#pragma unroll 4
         for (int i = r0 + lane; i < n; i += 64) s = fma(col[i], vs[i], s);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -296,8 +320,10 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       const double* col = slab + (size_t)(r0 / G) * n;
       for (int i = r0 + t; i < n; i += TD_P_T) td_st(cbuf + i, col[i]);
     }
+    TD_ST(0)  // symv + publish
     ++phase;
     if (!(BAR == 1 ? gbh_barrier(bar, phase, abort) : BAR == 2 ? gbs_barrier(bar, phase, abort) : gb_barrier(bar.st, phase * (unsigned int)G, abort))) return;
+    TD_ST(1)  // grid barrier
     if (cj % G == g)  // the reflector where td_back_k (a later launch) reads it
       for (int i = r0 + t; i < n; i += TD_P_T) A[(size_t)cj * n + i] = vs[i];
     // the next column as published (read below, behind two block-wide sums): asked for now, its round trip to memory runs beside that of p
@@ -314,12 +340,14 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       ws[i] = p;
       dot = fma(p, vs[i], dot);
     }
-    dot = td_block_sum(dot, sh);
+    TD_ST(2)  // loads of p, cb + dot partial
+    dot = td_block_sum1(dot, shd);
+    TD_ST(3)  // dot block sum
     const double a2 = -0.5 * tj * dot;
+    for (int i = r0 + t; i < n; i += TD_P_T) ws[i] = fma(a2, vs[i], ws[i]);  // (the entries this thread wrote above: no barrier in between)
     __syncthreads();
-    for (int i = r0 + t; i < n; i += TD_P_T) ws[i] = fma(a2, vs[i], ws[i]);
-    __syncthreads();
-    // ---- column r0 of the updated matrix, by everybody (registers: it replaces w once the update has used w)
+    TD_ST(4)  // w + barrier
+    // ---- column r0 of the updated matrix, by everybody, in registers: the input of the next reflector
     double cnr[TD_P_MAXPT];
     {
       const double vr = vs[r0], wr = ws[r0];  // v[r0] = 1
@@ -335,18 +363,59 @@ __global__ __launch_bounds__(TD_P_T) void td_persist_k(double* __restrict__ A, i
       if (c >= r0 && c < n) {
         double* col = slab + (size_t)lc * n;
         const double vc = vs[c], wc = ws[c];
+#pragma unroll 4
         for (int i = r0 + lane; i < n; i += 64) col[i] -= vs[i] * wc + ws[i] * vc;
       }
     }
-    __syncthreads();
+    TD_ST(5)  // cnr + rank-2 update
+    // ---- the next reflector straight from the registers (round 6: the column used to go through LDS behind two barriers, and the sum of its
+    // squares had two barriers of its own: eleven workgroup barriers of 16 waves per column, now six).  The formulas of td_p_reflector; thread 0
+    // holds the diagonal entry (row r0), thread 1 alpha (row r0 + 1); the sum runs over the rows from r0 + 2.
+    if (r0 < n - 1) {
+      double nrm2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < TD_P_MAXPT; ++q) {
-      const int i = r0 + t + q * TD_P_T;
-      if (i < n) ws[i] = cnr[q];
+      for (int q = 0; q < TD_P_MAXPT; ++q) {
+        const int i = r0 + t + q * TD_P_T;
+        if (i >= r0 + 2 && i < n) nrm2 = fma(cnr[q], cnr[q], nrm2);
+      }
+      if (t == 1) shn[16] = cnr[0];
+      nrm2 = td_block_sum1(nrm2, shn);
+      TD_ST(7)  // its barrier also stands between everybody's reads of v, w above and the new v below
+      // the square root and the two divisions by ONE wave: sixteen waves doing them side by side share four SIMDs, and the fp64 sequences
+      // of the other three waves of a SIMD were 1.5 us of a column's 10.6 (cycle stamps, round 6)
+      if (wave == 0) {
+        const double alpha = shn[16];
+        double beta = alpha, tv = 0.0, scale = 0.0;
+        if (nrm2 > 0.0) {
+          beta = -copysign(sqrt(fma(alpha, alpha, nrm2)), alpha);
+          tv = (beta - alpha) / beta;
+          scale = 1.0 / (alpha - beta);
+        }
+        if (lane == 0) {
+          shr[0] = beta;
+          shr[1] = tv;
+          shr[2] = scale;
+        }
+      }
+      __syncthreads();
+      TD_ST(8)
+      const double beta = shr[0], tv = shr[1], scale = shr[2];
+      if (r0 % G == g && t == 0) {
+        d[r0] = cnr[0];
+        e[r0] = beta;
+        tau[r0] = tv;
+      }
+#pragma unroll
+      for (int q = 0; q < TD_P_MAXPT; ++q) {
+        const int i = r0 + t + q * TD_P_T;
+        if (i >= r0 + 1 && i < n) vs[i] = (i == r0 + 1) ? 1.0 : cnr[q] * scale;
+      }
+      __syncthreads();
+      tj = tv;
+    } else if (r0 % G == g && t == 0) {
+      d[n - 1] = cnr[0];
     }
-    __syncthreads();
-    if (r0 < n - 1) tj = td_p_reflector(ws, vs, n, r0, r0 % G == g, d, e, tau, sh);
-    else if (r0 % G == g && t == 0) d[n - 1] = ws[n - 1];
+    TD_ST(6)  // reflector
   }
 }
 
@@ -950,6 +1019,15 @@ int k_tridiag_eig(isle_ctx* c, const float* S_host, int n, float* evals_host, fl
   float dev;
   static_assert(sizeof(dev) == sizeof(wbits), "");
   memcpy(&dev, &wbits, sizeof dev);
+#ifdef TD_STAMPS
+  {
+    unsigned long long hs[16];
+    hipMemcpyFromSymbol(hs, HIP_SYMBOL(td_stamps), sizeof hs);
+    fprintf(stderr, "[td_stamps n=%d] cycles per column: symv %.0f | barrier %.0f | loads+dot %.0f | dot sum %.0f | w %.0f | cnr+rank2 %.0f | reflector: sum %.0f math+barrier %.0f rest %.0f\n", n, hs[0] / (double)n, hs[1] / (double)n, hs[2] / (double)n, hs[3] / (double)n, hs[4] / (double)n, hs[5] / (double)n, hs[7] / (double)n, hs[8] / (double)n, hs[6] / (double)n);
+    unsigned long long z[16] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(td_stamps), z, sizeof z);
+  }
+#endif
   if (c->knob_on(KN_DEBUG_EVD)) fprintf(stderr, "[evd n=%d] tridiagonal solver: nvec %d, worst orthogonality defect %.3g\n", n, nvec, (double)dev);
   if (!(dev <= 1e-6f)) return 1;
   for (int i = 0; i < n; ++i) evals_host[i] = (float)ev[i];
