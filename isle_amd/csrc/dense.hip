@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void vtf_reduce_k(const double* __restrict__ p
   const int slab = m * BT;
   if (idx >= slab) return;
   double s = 0.0;
-#pragma unroll 8
+  // 32 chunks' loads in flight per batch (98 chunks at V = 100 000: four dependent batches instead of thirteen of 8; the additions keep their order)
+#pragma unroll 32
   for (int ch = 0; ch < nchunks; ++ch) s += part[(size_t)ch * slab + idx];
   const int i = idx / BT, j = idx - i * BT;
   if (j < b) coef[(size_t)j * m + i] = (Tout)s;
