@@ -1541,19 +1541,28 @@ int k_colnorms_rm(isle_ctx* c, const float* Mrm, uint64_t rows, int k, int ldk, 
 }
 
 // centre /= cluster size, true division, empty clusters stay zero (src/sparseMatrix.cpp:1641-1646)
-__global__ void scale_centers_k(float* __restrict__ Crm, uint64_t rows, int k, int ldk, const int* __restrict__ counts) {
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * (uint64_t)ldk) return;
-  const int cc = (int)(idx % ldk);
-  if (cc < k) {
-    const float div = (float)counts[cc];
-    if (div > 0.0f) Crm[idx] /= div;
+// (round 6: four rows per workgroup, a float4 per thread and trip — the flat form spent a 64-bit modulo per element: 316 us for 0.8 GB at k = 1000)
+__global__ __launch_bounds__(256) void scale_centers_k(float* __restrict__ Crm, uint64_t rows, int k, int ldk, const int* __restrict__ counts) {
+  const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* r = Crm + row * (uint64_t)ldk;
+  for (int c4 = (int)(threadIdx.x & 63) * 4; c4 < ldk; c4 += 256) {  // ldk is a multiple of 4
+    float4 v = *reinterpret_cast<float4*>(r + c4);
+    float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c4 + j < k) {
+        const float div = (float)counts[c4 + j];
+        if (div > 0.0f) e[j] /= div;
+      }
+    *reinterpret_cast<float4*>(r + c4) = v;
   }
 }
 int k_scale_centers(isle_ctx* c, float* Crm, uint64_t rows, int k, int ldk, const int* counts) {
   TimeScope ts(c, ISLE_T_SPARSE_UPDATE);
-  const uint64_t n = rows * (uint64_t)ldk;
-  hipLaunchKernelGGL(scale_centers_k, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, Crm, rows, k, ldk, counts);
+  if (rows == 0) return 0;
+  if ((ldk & 3) != 0 || ((uintptr_t)Crm & 15) != 0) return isle_fail(c, ISLE_E_ARG, "scale_centers: leading dimension %d not a multiple of 4", ldk);
+  hipLaunchKernelGGL(scale_centers_k, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, c->stream, Crm, rows, k, ldk, counts);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

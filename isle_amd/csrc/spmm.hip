@@ -1416,27 +1416,38 @@ __global__ __launch_bounds__(256) void yy_scan_k(const float* __restrict__ vals,
 //       the upper bound and the bounds of the scanned groups exactly as yy_scan_k leaves them.
 // Per (document, group) the distances are the same sums in the same order as yy_scan_k's (yy_group_dists).
 // ------------------------------------------------------------------------------------------
+// Cg[(g * V + w) * 2 + q] = the centres of slots 8 g + 4 q .. + 3 at word w (regrouped: centre id_of_slot[slot]; else column = slot, zero beyond ld).
+// Round 6: a workgroup takes YYP_W = 16 words — their rows (4 kB each) go to LDS by coalesced float4 loads, and the group-major image leaves as
+// runs of 512 bytes (a group's 16 words x 32 bytes).  The thread-per-float4 form wrote every 16-byte piece to a line of its own (consecutive
+// threads = consecutive groups, V x 32 bytes apart): 456 us for 0.8 GB at k = 1000.
+constexpr int YYP_W = 16;
 __global__ __launch_bounds__(256) void yy2_pack_k(const float* __restrict__ Crm, uint32_t V, int ld, int G, float4* __restrict__ Cg, int k,
                                                    const uint32_t* __restrict__ id_of_slot /*nullable*/) {
-  // Cg[(g * V + w) * 2 + q] = Crm[w * ld + 8 g + 4 q .. + 3] (zero beyond ld); consecutive threads read consecutive float4 of a row.
-  // Regrouped: the four slots' centres are gathered from the row (a 4 KB row is read by its 2 G threads: the lines come from cache)
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int nq = 2 * G;
-  if (i >= (size_t)V * nq) return;
-  const uint32_t w = (uint32_t)(i / nq);
-  const int gq = (int)(i - (size_t)w * nq);
-  const int col = 4 * gq;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (id_of_slot) {
-    const float* row = Crm + (size_t)w * ld;
-    if (col < k) v.x = row[id_of_slot[col]];
-    if (col + 1 < k) v.y = row[id_of_slot[col + 1]];
-    if (col + 2 < k) v.z = row[id_of_slot[col + 2]];
-    if (col + 3 < k) v.w = row[id_of_slot[col + 3]];
-  } else if (col < ld) {
-    v = *reinterpret_cast<const float4*>(Crm + (size_t)w * ld + col);
+  extern __shared__ float yyp_rows[];  // YYP_W x ld
+  const uint32_t w0 = blockIdx.x * YYP_W;
+  const uint32_t nw = min((uint32_t)YYP_W, V - w0);
+  const int q4 = ld / 4;  // ld is a multiple of 4 (launcher)
+  for (int i = threadIdx.x; i < (int)nw * q4; i += 256) {
+    const int r = i / q4, c4 = i - r * q4;
+    reinterpret_cast<float4*>(yyp_rows)[(size_t)r * q4 + c4] = reinterpret_cast<const float4*>(Crm + (size_t)(w0 + r) * ld)[c4];
   }
-  Cg[((size_t)(gq >> 1) * V + w) * 2 + (gq & 1)] = v;
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * 2 * YYP_W; i += 256) {
+    const int g = i / (2 * YYP_W), rem = i - g * (2 * YYP_W), wl = rem >> 1, q = rem & 1;
+    if ((uint32_t)wl >= nw) continue;
+    const int col = 8 * g + 4 * q;
+    const float* row = yyp_rows + (size_t)wl * ld;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id_of_slot) {
+      if (col < k) v.x = row[id_of_slot[col]];
+      if (col + 1 < k) v.y = row[id_of_slot[col + 1]];
+      if (col + 2 < k) v.z = row[id_of_slot[col + 2]];
+      if (col + 3 < k) v.w = row[id_of_slot[col + 3]];
+    } else if (col < ld) {
+      v = *reinterpret_cast<const float4*>(row + col);
+    }
+    Cg[((size_t)g * V + w0 + wl) * 2 + q] = v;
+  }
 }
 
 struct YyRes {  // top two of one group scan
@@ -1780,8 +1791,10 @@ int k_yy_pack_groups(isle_ctx* c, const float* Crm, int ld, int G, const YyMap& 
   TimeScope ts(c, ISLE_T_SPARSE_ASSIGN);
   const uint32_t V = (uint32_t)c->V;
   HIPCHK(c, c->yy_cg.reserve((size_t)V * 8 * G));
-  const size_t n = (size_t)V * 2 * G;
-  hipLaunchKernelGGL(yy2_pack_k, dim3(cdiv((long)n, 256)), dim3(256), 0, c->stream, Crm, V, ld, G, (float4*)c->yy_cg.p, c->centers_k, map.id_of_slot);
+  if ((ld & 3) != 0 || ((uintptr_t)Crm & 15) != 0) return isle_fail(c, ISLE_E_ARG, "yy_pack_groups: leading dimension %d not a multiple of 4", ld);
+  const size_t lds = (size_t)YYP_W * ld * sizeof(float);
+  ISLECHK(isle_max_lds(c, (const void*)yy2_pack_k, (int)lds));
+  hipLaunchKernelGGL(yy2_pack_k, dim3(cdiv(V, YYP_W)), dim3(256), lds, c->stream, Crm, V, ld, G, (float4*)c->yy_cg.p, c->centers_k, map.id_of_slot);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
